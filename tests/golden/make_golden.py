@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by executing the REFERENCE's own Python, unmodified, in the build
+container (needs /root/reference; never runs on the GPU box).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+TensorFlow and h5py are not installed here, so the reference modules are imported under the
+NumPy stand-in in tf_numpy_standin.py (this repo's code).  What is executed from the reference:
+
+  lrgnet_*.npz    learn_region_grow_util.LrgNet.__init__  (graph wiring: layer order, pooling,
+                  tile/concat order, heads, loss/accuracy) -> per-layer activations and logits
+  greedy_*.npz    the whole of test_region_grow.py   (runpy, argv ``--area 5``) on one synthetic
+                  room: stdout region lines, final labels, features, metrics
+  restart_*.npz   the whole of test_random_restart.py (``--area 5 --scoring np``, NUM_RESTARTS=10)
+
+Only data (inputs, expected outputs) is stored; weights are regenerated from their seed by
+learn_region_grow_amd.synthetic.make_synthetic_weights and pinned by a SHA-256 digest.
+"""
+import contextlib
+import hashlib
+import io
+import os
+import runpy
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+import tf_numpy_standin as standin  # noqa: E402
+from learn_region_grow_amd import synthetic  # noqa: E402
+
+WEIGHT_KW = dict(seed=0, gain=2.0, bias_std=0.2, add_bias_shift=0.0, rmv_bias_shift=-3.0)
+
+
+def weights_digest(w):
+    h = hashlib.sha256()
+    for k in sorted(w):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(w[k]).tobytes())
+    return h.hexdigest()
+
+
+def golden_lrgnet(lite, feature_size, n_in, n_nb, batch, seed):
+    standin.install()
+    sys.path.insert(0, REF)
+    sys.modules.pop('learn_region_grow_util', None)
+    import learn_region_grow_util as util   # the reference module, unmodified
+    tf = sys.modules['tensorflow']
+    tf.compat.v1.reset_default_graph()
+    net = util.LrgNet(batch, 1, n_in, n_nb, feature_size, lite)
+    w = synthetic.make_synthetic_weights(feature_size=feature_size, lite=lite, **WEIGHT_KW)
+    standin.RESTORE_WEIGHTS.clear()
+    standin.RESTORE_WEIGHTS.update(w)
+    tf.compat.v1.train.Saver().restore(None, 'synthetic')
+    rs = np.random.RandomState(seed)
+    inlier = rs.randn(batch, n_in, feature_size).astype(np.float32)
+    neighbor = rs.randn(batch, n_nb, feature_size).astype(np.float32)
+    add_mask = rs.randint(0, 2, (batch, n_nb)).astype(np.int32)
+    rmv_mask = rs.randint(0, 2, (batch, n_in)).astype(np.int32)
+    sess = tf.compat.v1.Session()
+    fetch = [net.add_output, net.remove_output, net.loss, net.add_acc, net.remove_acc, net.pooled_feature] \
+        + list(net.conv) + list(net.neighbor_conv) + list(net.add_conv[:-1]) + list(net.remove_conv[:-1])
+    out = sess.run(fetch, {net.inlier_pl: inlier, net.neighbor_pl: neighbor,
+                           net.add_mask_pl: add_mask, net.remove_mask_pl: rmv_mask})
+    nc = len(net.conv)
+    nh = len(net.add_conv) - 1
+    d = dict(lite=np.int32(-1 if lite is None else lite), feature_size=np.int32(feature_size),
+             inlier=inlier, neighbor=neighbor, add_mask=add_mask, rmv_mask=rmv_mask,
+             add_output=out[0], remove_output=out[1], loss=np.float32(out[2]), add_acc=np.float32(out[3]),
+             remove_acc=np.float32(out[4]), pooled=out[5], weights_digest=weights_digest(w))
+    k = 6
+    for i in range(nc):
+        d['conv%d' % i] = out[k + i]
+        d['neighbor_conv%d' % i] = out[k + nc + i]
+    k += 2 * nc
+    for i in range(nh):
+        d['add_conv%d' % i] = out[k + i]
+        d['remove_conv%d' % i] = out[k + nh + i]
+    name = 'lrgnet_lite%s_f%d_n%d_b%d.npz' % ('N' if lite is None else lite, feature_size, n_in, batch)
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print('wrote', name)
+
+
+def run_reference_script(script, argv, raw_room, tag):
+    """Execute a reference top-level script unmodified on ONE synthetic room."""
+    standin.install()
+    for m in ('learn_region_grow_util', 'class_util'):
+        sys.modules.pop(m, None)
+    w = synthetic.make_synthetic_weights(**WEIGHT_KW)
+    standin.RESTORE_WEIGHTS.clear()
+    standin.RESTORE_WEIGHTS.update(w)
+    standin.H5_FILES.clear()
+    standin.H5_FILES['data/s3dis_area5.h5'] = {'points': raw_room.astype(np.float32),
+                                               'count_room': np.array([len(raw_room)], dtype=np.int32)}
+    old_argv, old_cwd, old_path = sys.argv, os.getcwd(), list(sys.path)
+    buf = io.StringIO()
+    try:
+        os.chdir(REF)                     # the script reads data/s3dis_sampled.txt relative to cwd
+        sys.path.insert(0, REF)
+        sys.argv = [script] + argv
+        with contextlib.redirect_stdout(buf):
+            g = runpy.run_path(os.path.join(REF, script), run_name='__main__')
+    finally:
+        sys.argv = old_argv
+        os.chdir(old_cwd)
+        sys.path[:] = old_path
+    lines = buf.getvalue().split('\n')
+    region_lines = [l for l in lines if l.startswith('room ')]
+    d = dict(raw_room=raw_room.astype(np.float32),
+             points=g['points'], obj_id=np.asarray(g['obj_id']), cls_id=np.asarray(g['cls_id']),
+             curvatures=g['curvatures'], order=np.asarray(g['order'] if 'order' in g else np.argsort(g['curvatures'])),
+             filled_label=np.asarray(g['cluster_label']),
+             region_lines=np.array(region_lines),
+             metrics=np.array([g['agg_nmi'][0], g['agg_ami'][0], g['agg_ars'][0], g['agg_prc'][0], g['agg_rcl'][0],
+                               g['agg_iou'][0]]),
+             weights_digest=weights_digest(w), weight_kw=repr(WEIGHT_KW))
+    np.savez_compressed(os.path.join(HERE, tag + '.npz'), **d)
+    print('wrote %s.npz: %d points, %d region lines' % (tag, len(g['points']), len(region_lines)))
+    print('\n'.join(lines[-4:]))
+
+
+def main():
+    which = sys.argv[1:] or ['net', 'greedy', 'restart']
+    if 'net' in which:
+        golden_lrgnet(0, 13, 32, 32, 2, seed=11)
+        golden_lrgnet(None, 13, 24, 40, 1, seed=12)     # LITE=None as test_region_grow.py passes it; Ni != Nn
+        golden_lrgnet(1, 13, 32, 32, 2, seed=13)
+        golden_lrgnet(2, 13, 32, 32, 2, seed=14)
+        golden_lrgnet(0, 9, 32, 32, 1, seed=15)         # feature-size variant (test_region_grow.py:72-77)
+    if 'greedy' in which:
+        room = synthetic.generate_room_points(1500, seed=100).astype(np.float32)
+        run_reference_script('test_region_grow.py', ['--area', '5'], room, 'greedy_room100')
+        room = synthetic.area5_shaped_room(1800, seed=101, n_furniture=6).astype(np.float32)
+        run_reference_script('test_region_grow.py', ['--area', '5'], room, 'greedy_room101')
+    if 'restart' in which:
+        room = synthetic.generate_room_points(1000, seed=103).astype(np.float32)
+        run_reference_script('test_random_restart.py', ['--area', '5', '--scoring', 'np'], room, 'restart_room103')
+
+
+if __name__ == '__main__':
+    main()
