@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- region-grow throughput on synthetic S3DIS-Area-5-shaped rooms (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one lock-step iteration of the batched grow loop (lrg_grow_step) over all rooms in flight: every
+in-flight room takes one region-grow step (one LrgNet evaluation on 512+512 points + neighbour query, median,
+sampling, mask update).  The workload is the 68-room Area-5-shaped set (BASELINE.json configs[1]) with all rooms
+in flight; a room that finishes is replaced at once (the set is cycled) so the batch stays full.  Inputs
+(13-D room features, weights) are resident in HBM before the timed region.
+For N > 1 every rank runs its own 68-room set (weak scaling, no collective inside the loop) and the final
+label gather goes over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+BYTES_PER_INSTANCE_STEP = 10297344      # layer-streamed algorithmic HBM bytes of one LrgNet evaluation
+FLOPS_PER_INSTANCE_STEP = 271712256     # hoisted-head FLOPs of one LrgNet evaluation
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+FP32_MATRIX_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: fp32-input MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=1500)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--rooms', type=int, default=68, help='rooms in flight per GPU (the Area-5 set has 68)')
+    ap.add_argument('--restarts', type=int, default=1)
+    ap.add_argument('--policy', default='net', choices=['net', 'gt', 'threshold'])
+    ap.add_argument('--fuse-pool', type=int, default=0)
+    ap.add_argument('--advance-rounds', type=int, default=2)
+    ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
+    return ap.parse_args()
+
+
+def cpu_baseline(rooms, weights, seconds):
+    """The oracle (faithful NumPy restatement of test_region_grow.py:175-316, per-point Python voxel-set loop,
+    un-hoisted head) on this box's host cores, for a bounded sample: steps of the median-size room."""
+    from oracle import grow_ref, rng_ref      # CPU baseline leg only
+    order = np.argsort([len(r['points']) for r in rooms])
+    room = rooms[int(order[len(order) // 2])]
+    t0 = time.time()
+    count = [0]
+
+    class Stop(Exception):
+        pass
+
+    def hook(d):
+        count[0] += 1
+        if time.time() - t0 > seconds:
+            raise Stop()
+    try:
+        grow_ref.grow_room(room['points'], room['obj_id'], room['order'], weights, rng_ref.LegacyStream(0), faithful=True,
+                           hook=hook, fill=False)
+    except Stop:
+        pass
+    dt = time.time() - t0
+    return dict(value=count[0] / dt, unit='instance-steps/s', cores=os.cpu_count(), kind='port',
+                sample='%d grow steps of one %d-point Area-5-shaped room, oracle.grow_ref (faithful=True), %.1f s'
+                       % (count[0], len(room['points']), dt))
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from learn_region_grow_amd import synthetic, workloads, dist as lrg_dist
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    from learn_region_grow_amd.grow import RegionGrower
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    weights = synthetic.make_synthetic_weights(seed=0)
+    rooms = workloads.area5_rooms(args.rooms, seed_base=1000 + 100 * rank, cache_dir=args.cache)
+    net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, fuse_pool=bool(args.fuse_pool)).load_weights(weights)
+    gr = RegionGrower(net, rooms_in_flight=len(rooms), restarts=args.restarts, rng='counter', seed=rank,
+                      policy=args.policy, advance_rounds=args.advance_rounds)
+    gr.load_rooms(rooms)
+    for g in range(gr.n_groups):
+        gr.bind(g, g)
+
+    def iterate(k):
+        for _ in range(k):
+            gr.enqueue_iteration()
+            for g in gr.poll_done():          # finished rooms restart at once: the set is cycled
+                r = gr.group_room[g]
+                gr.reset_room(r)
+                gr.bind(g, r)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    iterate(args.warmup)
+    barrier()
+    s0 = gr.d_stats[:3].cpu().numpy().copy()
+    t0 = time.perf_counter()
+    iterate(args.steps)
+    barrier()
+    t1 = time.perf_counter()
+    s1 = gr.d_stats[:3].cpu().numpy().copy()
+    elapsed = lrg_dist.allreduce_max(t1 - t0, device=dev)
+    inst_steps, rooms_done, seeds = lrg_dist.allreduce_sum([float(s1[2] - s0[2]), float(s1[1] - s0[1]), float(s1[0] - s0[0])],
+                                                           device=dev)
+
+    # ---- roofline of the LrgNet evaluation (the dominant kernels), HIP events on the launch stream ----
+    S = gr.S
+    reps = 20
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    net.forward(gr.b_inl, gr.b_nbr, gr.b_add, gr.b_rmv)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        net.forward(gr.b_inl, gr.b_nbr, gr.b_add, gr.b_rmv)
+    ev1.record()
+    torch.cuda.synchronize()
+    fwd_ms = ev0.elapsed_time(ev1) / reps
+    achieved = S * BYTES_PER_INSTANCE_STEP / (fwd_ms * 1e-3) / 1e9
+    tflops = S * FLOPS_PER_INSTANCE_STEP / (fwd_ms * 1e-3) / 1e12
+
+    # ---- final label gather over RCCL (the only collective of the path) ----
+    if world > 1:
+        labs = [gr.d_label[int(gr.room_off[r]):int(gr.room_off[r]) + gr.room_n[r]].cpu().numpy() for r in range(2)]
+        lrg_dist.gather_room_labels([rank * 2, rank * 2 + 1], labs, 2 * world, device=dev)
+
+    if rank == 0:
+        out = {
+            'metric': 'region-grow steps/sec (rooms/sec alongside), S3DIS Area-5 shape',
+            'value': inst_steps / elapsed,
+            'unit': 'instance-steps/s',
+            'rooms_per_sec': rooms_done / elapsed,
+            'regions_per_sec': seeds / elapsed,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'S3DIS Area-5-shaped synthetic rooms (68-room set per GPU, all in flight, cycled), '
+                                   'greedy test_region_grow.py loop' if args.restarts == 1 else
+                                   'Area-5-shaped rooms, random restarts x%d' % args.restarts,
+                       'rooms_in_flight_per_gpu': len(rooms), 'slots_per_gpu': S, 'policy': args.policy,
+                       'restarts': args.restarts, 'points': '512 inlier + 512 neighbour x 13 features',
+                       'rng': 'counter (Philox) stream', 'weights': 'synthetic, seed 0',
+                       'active_fraction': inst_steps / (args.steps * S * world)},
+            'roofline': {'bound': 'hbm', 'kernel': 'lrg_forward (all launches of one LrgNet evaluation batch)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'ms_per_launch': fwd_ms, 'instances_per_launch': S,
+                         'bytes_per_instance': BYTES_PER_INSTANCE_STEP,
+                         'fp32_matrix_tflops': tflops, 'fp32_matrix_frac': tflops / FP32_MATRIX_PEAK_TFLOPS},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out['cpu_baseline'] = cpu_baseline(rooms, weights, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,276 @@
+/* lrg_hip.h -- C-ABI of liblrg_hip.so: the MI355X (gfx950) LRGNet region-grow hot path.
+ *
+ * Conventions (all entry points):
+ *   - pointers are DEVICE pointers unless a parameter is documented as host; buffers are caller-owned;
+ *   - tensors are dense row-major; kernels of the network are [Cin,Cout] row-major, i.e. the TF
+ *     variable of shape [1,Cin,Cout] (learn_region_grow_util.py:107) with the leading 1 dropped;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream) and the
+ *     call returns without synchronising; no entry point allocates or frees device memory;
+ *   - return value: 0 on success, -(hipError_t) on a HIP failure, LRG_EINVAL (-1000 - n) on a bad
+ *     argument; re-entrant, no global state.
+ *
+ * Every entry point names the reference interface it replaces (file:line under the reference repo).
+ */
+#ifndef LRG_HIP_H
+#define LRG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRG_ABI_VERSION 1
+#define LRG_EINVAL (-1000)
+
+#define LRG_MAX_CONV 5 /* branch layers: lite=0 -> 5, lite=1 -> 2, lite=2 -> 3  (learn_region_grow_util.py:77-85) */
+#define LRG_MAX_HEAD 3 /* head layers incl. the final 2-wide one: lite=0 -> 3, lite=1 -> 2, lite=2 -> 3        */
+
+int lrg_abi_version(void);
+/* Name of the code object's target ("gfx950"); a build sanity hook for the loader. */
+const char *lrg_target_arch(void);
+/* sizeof() of the ABI structs as compiled (0 LrgWeights, 1 LrgRoom, 2 LrgSlot, 3 LrgGrowParams), so that a
+ * foreign-language binding can verify its mirror of the layout at load time. */
+size_t lrg_struct_size(int which);
+
+/* ------------------------------------------------------------------------------------------------
+ * LrgNet forward   (replaces: sess.run([net.add_output, net.remove_output], ...) at
+ * test_region_grow.py:257-258 on the graph built by learn_region_grow_util.py:75-162)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct LrgWeights {
+    int32_t feature_size;            /* F: 13 (6/9/12 variants, test_region_grow.py:72-77)                 */
+    int32_t n_conv;                  /* branch layers                                                       */
+    int32_t n_head;                  /* head layers including the final [C,2] layer                         */
+    int32_t reserved;
+    int32_t conv_ch[LRG_MAX_CONV];   /* CONV_CHANNELS                                                       */
+    int32_t head_ch[LRG_MAX_HEAD];   /* CONV2_CHANNELS followed by 2                                        */
+    const float *inlier_w[LRG_MAX_CONV];   /* lrg_kernel{i}          [Cin,Cout]   :107                      */
+    const float *inlier_b[LRG_MAX_CONV];   /* lrg_bias{i}            [Cout]       :108                      */
+    const float *neighbor_w[LRG_MAX_CONV]; /* lrg_neighbor_kernel{i}              :115                      */
+    const float *neighbor_b[LRG_MAX_CONV]; /* lrg_neighbor_bias{i}                :116                      */
+    const float *add_w[LRG_MAX_HEAD];      /* lrg_add_kernel{j}; j=0 is [2*C_last + conv_ch[1], C]  :139,:145 */
+    const float *add_b[LRG_MAX_HEAD];      /* lrg_add_bias{j}                                       :140,:146 */
+    const float *rmv_w[LRG_MAX_HEAD];      /* lrg_remove_kernel{j}                                  :152,:158 */
+    const float *rmv_b[LRG_MAX_HEAD];      /* lrg_remove_bias{j}                                    :153,:159 */
+} LrgWeights;
+
+#define LRG_FWD_FUSE_POOL 1u /* fold the max-pool (:122-123) into the last branch layer's epilogue */
+
+/* Bytes of scratch lrg_forward needs for a batch of B instances (host-side arithmetic only). */
+size_t lrg_forward_workspace_bytes(const LrgWeights *w, int B, int n_inlier, int n_neighbor);
+
+/* inlier [B,n_inlier,F], neighbor [B,n_neighbor,F] -> add_logits [B,n_neighbor,2] (net.add_output :149),
+ * rmv_logits [B,n_inlier,2] (net.remove_output :162).  `w` is a HOST struct holding device pointers. */
+int lrg_forward(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
+                int n_neighbor, float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes,
+                unsigned flags, void *stream);
+
+/* Workspace introspection for layer-by-layer parity tests: float offset / element count of a named
+ * intermediate inside `workspace`.  kind: 0 conv[i] (inlier), 1 neighbor_conv[i], 2 pooled [B,2*C_last],
+ * 3 add head hidden[i], 4 remove head hidden[i].  Returns 0, or LRG_EINVAL. */
+int lrg_forward_workspace_view(const LrgWeights *w, int B, int n_inlier, int n_neighbor, int kind, int index,
+                               size_t *offset_floats, size_t *count_floats);
+
+/* One per-point layer  y = act(x @ w + bias)   (tf.nn.conv1d k=1 + bias_add + relu, :109-111).
+ * x [rows,cin] (row stride ldx), w [cin,cout] (row stride ldw), y [rows,cout].
+ * bias is [cout], or -- when rows_per_instance > 0 and bias_instance_stride > 0 -- one bias row per
+ * instance: bias[(row / rows_per_instance) * bias_instance_stride + col] (the hoisted pooled-feature
+ * product of the heads, :128-141).  pool_out (nullable, needs relu) receives
+ * max over each instance's rows: pool_out[(row / rows_per_instance) * pool_stride + col]; it must be
+ * zero-filled by the caller beforehand. */
+int lrg_pointwise_layer(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y, long rows,
+                        int cin, int cout, int relu, int rows_per_instance, int bias_instance_stride,
+                        float *pool_out, int pool_stride, void *stream);
+
+/* Column max over each instance's rows: out[b*out_stride + c] = max_r x[b,r,c]   (tf.reduce_max axis=1, :122-123) */
+int lrg_segmax(const float *x, float *out, int B, int rows, int C, int out_stride, void *stream);
+
+/* Hoisted pooled-feature product of a head's first layer:
+ * hb[b, c] = bias[c] + sum_k pooled[b,k] * w[k,c],  k < P   (the tiled part of the concat at :128-135) */
+int lrg_head_pool_gemv(const float *pooled, const float *w, int ldw, const float *bias, float *hb, int B, int P,
+                       int C, void *stream);
+
+/* Final head layer, no ReLU: logits[r, 0..1] = h[r,:] @ w[C,2] + bias[2]   (:145-149, :158-162) */
+int lrg_head_final(const float *h, const float *w, const float *bias, float *logits, long rows, int C, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Region-grow loop state (replaces the module-level state of test_region_grow.py:175-205)
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+    LRG_IDLE = 0,            /* slot not bound to work                                                     */
+    LRG_ACTIVE = 1,          /* region growing                                                             */
+    LRG_STOP_NONEIGHBOR = 2, /* test_region_grow.py:233-235                                                */
+    LRG_STOP_NOEXPAND = 3,   /* :304-306                                                                   */
+    LRG_STOP_STUCK = 4,      /* :294-297                                                                   */
+    LRG_STOP_EMPTY = 5,      /* mask became empty; the reference raises at :292 -- defined as a stop here  */
+    LRG_STOP_MAXSTEPS = 6,   /* optional safety cap (off when max_region_steps <= 0)                        */
+    LRG_DONE = 7,            /* the slot's room has no unvisited seed left                                  */
+    LRG_WAIT = 8             /* finished its restarts, waiting for its group; also the state a host binds a
+                                fresh group in (with seed = -1) so that lrg_advance picks the first seed    */
+};
+
+/* One room, device-resident.  Arrays are per equalised point (n of them). */
+typedef struct LrgRoom {
+    const float *points;     /* [n,F] features as stacked at test_region_grow.py:165-172                    */
+    const int32_t *voxels;   /* [n,3] rint(xyz/resolution)  (:175)                                          */
+    const int32_t *obj_id;   /* [n] ground-truth instance id (:116), only for the GT flags (:230-231)        */
+    const int32_t *order;    /* [n] seed order = argsort(curvatures) (:183)                                  */
+    uint8_t *visited;        /* [n] (:178)                                                                  */
+    int32_t *label;          /* [n] cluster_label before fill-in (:176)                                      */
+    const uint64_t *hash_keys; /* voxel hash table (open addressing), hash_mask+1 entries                    */
+    const int32_t *hash_vals;
+    int32_t *region_log;     /* [n,6] per committed seed: seed, steps, points, reason, labeled, restart      */
+    int32_t n;
+    int32_t hash_mask;
+    int32_t next_cluster_id; /* (:177)                                                                      */
+    int32_t seed_cursor;     /* position in `order` of the next candidate seed (:186-188)                    */
+    int32_t n_regions;
+    int32_t done;
+    int32_t room_id;         /* RNG stream key and log tag                                                   */
+    int32_t pad;
+} LrgRoom;
+
+/* One growing region instance.  A *group* of `group_size` consecutive slots shares one room and one seed
+ * (random restarts, test_random_restart.py:169-197); greedy growing is group_size = 1, restarts = 1. */
+typedef struct LrgSlot {
+    uint8_t *cur;            /* [cap] currentMask (:197)                                                    */
+    uint8_t *best;           /* [cap] best restart mask so far (restart :175-177); unused when restarts==1   */
+    int32_t *cur_idx;        /* [cap] compacted indices of current points, index order (:221)                */
+    int32_t *cand_idx;       /* [cap] compacted indices of expand candidates (:229)                          */
+    int32_t room;            /* index into rooms[], -1 = none                                                */
+    int32_t status;
+    int32_t seed;            /* seed point (:186)                                                            */
+    int32_t restart;         /* restart ordinal of the grow in progress                                      */
+    int32_t step;            /* steps of the grow in progress (RNG counter)                                  */
+    int32_t steps_total;     /* `steps` of the reference: never reset between restarts of a seed             */
+    int32_t stuck;           /* (:204)                                                                       */
+    int32_t nc;              /* len(currentPoints)                                                           */
+    int32_t ne;              /* len(expandPoints)                                                            */
+    int32_t updated;         /* (:278)                                                                       */
+    int32_t count;           /* sum(currentMask) after the last update                                       */
+    int32_t best_count;      /* restart_score of `best` (--scoring np), -1 = none                            */
+    int32_t best_restart;
+    int32_t last_reason;
+    int32_t mn[3], mx[3];    /* minDims / maxDims (:199-200)                                                 */
+    int32_t seq_mn[3], seq_mx[3]; /* seqMinDims / seqMaxDims (:201-202)                                      */
+    int32_t target;          /* obj_id[seed] (:190)                                                          */
+    int32_t pad;
+} LrgSlot;
+
+typedef struct LrgGrowParams {
+    float resolution;        /* 0.1 (test_region_grow.py:27)                                                 */
+    int32_t feature_size;
+    int32_t n_inlier;        /* NUM_INLIER_POINT   (:22)                                                     */
+    int32_t n_neighbor;      /* NUM_NEIGHBOR_POINT (:23)                                                     */
+    int32_t cluster_threshold; /* 10 (:30)                                                                   */
+    int32_t restarts;        /* NUM_RESTARTS; 1 = greedy                                                     */
+    int32_t group_size;      /* slots per group; restarts are dealt round-robin over the group's slots       */
+    int32_t max_region_steps;/* <= 0: no cap                                                                 */
+    uint32_t rng_seed;       /* counter-stream key word 0 (key word 1 = room_id)                             */
+    int32_t policy;          /* 0 net (:266-267), 1 threshold (:264-265), 2 ground truth (:268-269)          */
+} LrgGrowParams;
+
+/* voxels[i,0..2] = rint(points[i,0..2] / resolution)   (test_region_grow.py:175) */
+int lrg_voxelize(const float *points, int n, int F, float resolution, int32_t *voxels, void *stream);
+
+/* Build the room's voxel -> point-index table (replaces the tuple sets of :273,:277,:283-286).
+ * keys must hold hash_mask+1 entries; *dup_flag (device int, zeroed by the caller) is set when two points
+ * share a voxel (the path assumes an equalised room, :125-134). */
+int lrg_voxel_hash_build(const int32_t *voxels, int n, uint64_t *keys, int32_t *vals, int hash_mask,
+                         int32_t *dup_flag, void *stream);
+
+/* Stop / bounding-box bookkeeping of the step just taken (:291-306), for every ACTIVE slot that has taken a
+ * mask update (slot.updated >= 0). */
+int lrg_bbox_stop(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, void *stream);
+
+/* Commit finished seeds (:210-217 / restart :169-197), pick the next unvisited seed (:186-188) and reset
+ * the group's slots (:197-204).  stats (device, LRG_STATS_WORDS x int64, nullable): see LrgStepBuffers. */
+int lrg_advance(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams *params, int64_t *stats,
+                void *stream);
+
+/* Dilated voxel-box neighbour query + ordered compaction (:221-235): fills cur_idx/nc, cand_idx/ne; a slot
+ * with ne == 0 stops with LRG_STOP_NONEIGHBOR. */
+int lrg_box_query(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, void *stream);
+
+/* center[s, c] = median over the slot's current points of channel c for c in {0,1} U [6,F), 0 elsewhere
+ * (numpy.median, :241; only those channels are used, :243-247).  center is [n_slots,16]. */
+int lrg_median(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
+               void *stream);
+
+/* Counter-stream subset sampling (:237-240, :249-252): positions into cur_idx / cand_idx,
+ * sample_in [n_slots,n_inlier], sample_nb [n_slots,n_neighbor]. */
+int lrg_sample(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params,
+               int32_t *sample_in, int32_t *sample_nb, void *stream);
+
+/* Gather + centre (:242-254): inlier [n_slots,n_inlier,F], neighbor [n_slots,n_neighbor,F];
+ * gt_remove / gt_add (nullable) receive input_remove / input_add (:248,:254). */
+int lrg_gather_center(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params,
+                      const int32_t *sample_in, const int32_t *sample_nb, const float *center, float *inlier,
+                      float *neighbor, int32_t *gt_remove, int32_t *gt_add, void *stream);
+
+/* Confidence + Bernoulli masks + voxel-set mask update (:262-288).
+ * add_mask / rmv_mask (nullable, uint8 [n_slots,n]) : host-decided masks (reference-order RNG);
+ * when NULL the masks are drawn on the device from the counter stream against
+ * softmax(logits)[:,1].  Sets slot.updated, increments slot.step / steps_total and, when stats is
+ * non-NULL, stats[2] (instance-steps taken). */
+int lrg_mask_update(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params,
+                    const float *inlier, const float *neighbor, const float *center, const float *add_logits,
+                    const float *rmv_logits, const int32_t *gt_remove, const int32_t *gt_add,
+                    const uint8_t *add_mask, const uint8_t *rmv_mask, int64_t *stats, void *stream);
+
+/* Device buffers of one lock-step iteration over n_slots slots (all caller-owned). */
+typedef struct LrgStepBuffers {
+    float *center;        /* [n_slots,16]                 */
+    int32_t *sample_in;   /* [n_slots,n_inlier]           */
+    int32_t *sample_nb;   /* [n_slots,n_neighbor]         */
+    float *inlier;        /* [n_slots,n_inlier,F]         */
+    float *neighbor;      /* [n_slots,n_neighbor,F]       */
+    int32_t *gt_remove;   /* [n_slots,n_inlier]           */
+    int32_t *gt_add;      /* [n_slots,n_neighbor]         */
+    float *add_logits;    /* [n_slots,n_neighbor,2]       */
+    float *rmv_logits;    /* [n_slots,n_inlier,2]         */
+    void *workspace;      /* lrg_forward scratch          */
+    size_t workspace_bytes;
+    int64_t *stats;       /* LRG_STATS_WORDS x int64      */
+} LrgStepBuffers;
+
+/* stats layout: [0] committed seeds, [1] rooms finished, [2] instance-steps taken, [3] reserved,
+ * [4 + k % LRG_DONE_RING] = first slot of the k-th finished group (ring written by lrg_advance). */
+#define LRG_DONE_RING 1020
+#define LRG_STATS_WORDS (4 + LRG_DONE_RING)
+
+/* One whole lock-step iteration with device-side (counter-stream) randomness -- the body of the
+ * `while True` loop at test_region_grow.py:208-306 for every slot at once:
+ *   lrg_bbox_stop; advance_rounds x (lrg_advance; lrg_box_query); lrg_median; lrg_sample;
+ *   lrg_gather_center; lrg_forward; lrg_mask_update.
+ * `weights` and `buffers` are HOST structs of device pointers. */
+int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams *params, const LrgWeights *weights,
+                  const LrgStepBuffers *buffers, int advance_rounds, unsigned forward_flags, void *stream);
+
+/* 1-NN fill-in of unlabeled points in all F feature dims, first-min ties (:308-316). */
+int lrg_nn1_fill(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * tf_ops/grouping replacements.  Same argument order as the reference launchers
+ * (tf_ops/grouping/tf_grouping_g.cu:125-141) plus a trailing stream; extern "C"; int return.
+ * ---------------------------------------------------------------------------------------------- */
+/* queryBallPointLauncher (tf_grouping_g.cu:125; kernel :3-36).  Rows with no hit are zero-filled. */
+int lrg_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                         int *idx, int *pts_cnt, void *stream);
+/* selectionSortLauncher (tf_grouping_g.cu:129; kernel :83-123): full [b,m,n] outputs, first k sorted. */
+int lrg_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream);
+/* groupPointLauncher (tf_grouping_g.cu:133; kernel :40-57) */
+int lrg_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,
+                    void *stream);
+/* groupPointGradLauncher (tf_grouping_g.cu:137; kernel :61-78); grad_points must be zeroed by the caller
+ * (the reference op does cudaMemset at tf_grouping.cpp:204). */
+int lrg_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                         float *grad_points, void *stream);
+/* dist[b,m,n] = sum_c (xyz1[b,n,c]-xyz2[b,m,c])^2 -- the matrix knn_point builds at tf_grouping.py:62-65 */
+int lrg_pairwise_sqdist(int b, int n, int m, int c, const float *xyz1, const float *xyz2, float *dist, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRG_HIP_H */

@@ -1,0 +1,161 @@
+"""ctypes binding of liblrg_hip.so (include/lrg_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an exception is raised.
+``build()`` compiles the HIP sources in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_PATH = os.path.join(HERE, 'liblrg_hip.so')
+SOURCES = ['lrg_net.hip', 'lrg_grow.hip', 'lrg_grouping.hip']
+
+LRG_MAX_CONV = 5
+LRG_MAX_HEAD = 3
+LRG_FWD_FUSE_POOL = 1
+
+(LRG_IDLE, LRG_ACTIVE, LRG_STOP_NONEIGHBOR, LRG_STOP_NOEXPAND, LRG_STOP_STUCK, LRG_STOP_EMPTY, LRG_STOP_MAXSTEPS,
+ LRG_DONE, LRG_WAIT) = range(9)
+REASON_NAMES = {LRG_STOP_NONEIGHBOR: 'noneighbor', LRG_STOP_NOEXPAND: 'noexpand', LRG_STOP_STUCK: 'stuck',
+                LRG_STOP_EMPTY: 'empty', LRG_STOP_MAXSTEPS: 'maxsteps'}
+
+_fp = ctypes.c_void_p
+
+
+class LrgWeights(ctypes.Structure):
+    _fields_ = [('feature_size', ctypes.c_int32), ('n_conv', ctypes.c_int32), ('n_head', ctypes.c_int32),
+                ('reserved', ctypes.c_int32),
+                ('conv_ch', ctypes.c_int32 * LRG_MAX_CONV), ('head_ch', ctypes.c_int32 * LRG_MAX_HEAD),
+                ('inlier_w', _fp * LRG_MAX_CONV), ('inlier_b', _fp * LRG_MAX_CONV),
+                ('neighbor_w', _fp * LRG_MAX_CONV), ('neighbor_b', _fp * LRG_MAX_CONV),
+                ('add_w', _fp * LRG_MAX_HEAD), ('add_b', _fp * LRG_MAX_HEAD),
+                ('rmv_w', _fp * LRG_MAX_HEAD), ('rmv_b', _fp * LRG_MAX_HEAD)]
+
+
+class LrgRoom(ctypes.Structure):
+    _fields_ = [('points', _fp), ('voxels', _fp), ('obj_id', _fp), ('order', _fp), ('visited', _fp), ('label', _fp),
+                ('hash_keys', _fp), ('hash_vals', _fp), ('region_log', _fp),
+                ('n', ctypes.c_int32), ('hash_mask', ctypes.c_int32), ('next_cluster_id', ctypes.c_int32),
+                ('seed_cursor', ctypes.c_int32), ('n_regions', ctypes.c_int32), ('done', ctypes.c_int32),
+                ('room_id', ctypes.c_int32), ('pad', ctypes.c_int32)]
+
+
+class LrgSlot(ctypes.Structure):
+    _fields_ = [('cur', _fp), ('best', _fp), ('cur_idx', _fp), ('cand_idx', _fp),
+                ('room', ctypes.c_int32), ('status', ctypes.c_int32), ('seed', ctypes.c_int32),
+                ('restart', ctypes.c_int32), ('step', ctypes.c_int32), ('steps_total', ctypes.c_int32),
+                ('stuck', ctypes.c_int32), ('nc', ctypes.c_int32), ('ne', ctypes.c_int32),
+                ('updated', ctypes.c_int32), ('count', ctypes.c_int32), ('best_count', ctypes.c_int32),
+                ('best_restart', ctypes.c_int32), ('last_reason', ctypes.c_int32),
+                ('mn', ctypes.c_int32 * 3), ('mx', ctypes.c_int32 * 3),
+                ('seq_mn', ctypes.c_int32 * 3), ('seq_mx', ctypes.c_int32 * 3),
+                ('target', ctypes.c_int32), ('pad', ctypes.c_int32)]
+
+
+class LrgGrowParams(ctypes.Structure):
+    _fields_ = [('resolution', ctypes.c_float), ('feature_size', ctypes.c_int32), ('n_inlier', ctypes.c_int32),
+                ('n_neighbor', ctypes.c_int32), ('cluster_threshold', ctypes.c_int32), ('restarts', ctypes.c_int32),
+                ('group_size', ctypes.c_int32), ('max_region_steps', ctypes.c_int32), ('rng_seed', ctypes.c_uint32),
+                ('policy', ctypes.c_int32)]
+
+
+class LrgStepBuffers(ctypes.Structure):
+    _fields_ = [('center', _fp), ('sample_in', _fp), ('sample_nb', _fp), ('inlier', _fp), ('neighbor', _fp),
+                ('gt_remove', _fp), ('gt_add', _fp), ('add_logits', _fp), ('rmv_logits', _fp), ('workspace', _fp),
+                ('workspace_bytes', ctypes.c_size_t), ('stats', _fp)]
+
+
+LRG_DONE_RING = 1020
+LRG_STATS_WORDS = 4 + LRG_DONE_RING
+
+
+class LrgHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """hipcc --offload-arch=gfx950 -> learn_region_grow_amd/liblrg_hip.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in ('lrg_common.h', 'lrg_rng.h')] + \
+        [os.path.join(os.path.dirname(HERE), 'include', 'lrg_hip.h')]
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB_PATH] + srcs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_SIGS = {
+    'lrg_abi_version': (ctypes.c_int, []),
+    'lrg_target_arch': (ctypes.c_char_p, []),
+    'lrg_struct_size': (ctypes.c_size_t, [ctypes.c_int]),
+    'lrg_forward_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(LrgWeights), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'lrg_forward': (ctypes.c_int, [ctypes.POINTER(LrgWeights), _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp,
+                                   _fp, ctypes.c_size_t, ctypes.c_uint, _fp]),
+    'lrg_forward_workspace_view': (ctypes.c_int, [ctypes.POINTER(LrgWeights), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                                                  ctypes.POINTER(ctypes.c_size_t)]),
+    'lrg_pointwise_layer': (ctypes.c_int, [_fp, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, ctypes.c_long, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]),
+    'lrg_segmax': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
+    'lrg_head_pool_gemv': (ctypes.c_int, [_fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
+    'lrg_head_final': (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_long, ctypes.c_int, _fp]),
+    'lrg_voxelize': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _fp, _fp]),
+    'lrg_voxel_hash_build': (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, _fp]),
+    'lrg_bbox_stop': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp]),
+    'lrg_advance': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp]),
+    'lrg_box_query': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp]),
+    'lrg_median': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp]),
+    'lrg_sample': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp]),
+    'lrg_gather_center': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp,
+                                         _fp, _fp, _fp]),
+    'lrg_mask_update': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp,
+                                       _fp, _fp, _fp, _fp, _fp, _fp]),
+    'lrg_grow_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgWeights),
+                                     ctypes.POINTER(LrgStepBuffers), ctypes.c_int, ctypes.c_uint, _fp]),
+    'lrg_nn1_fill': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
+    'lrg_query_ball_point': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _fp,
+                                            _fp, _fp, _fp, _fp]),
+    'lrg_selection_sort': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
+    'lrg_group_point': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp,
+                                       _fp, _fp]),
+    'lrg_group_point_grad': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
+                                            _fp, _fp, _fp]),
+    'lrg_pairwise_sqdist': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
+}
+
+EXPORTS = sorted(_SIGS)
+_lib = None
+
+
+def load():
+    """Load liblrg_hip.so and bind every declared entry point; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LrgHipError('%s not found: run `python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950). '
+                          'There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lrg_abi_version() != 1:
+        raise LrgHipError('ABI version mismatch')
+    for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams)):
+        if lib.lrg_struct_size(which) != ctypes.sizeof(st):
+            raise LrgHipError('struct layout mismatch for %s: C %d vs ctypes %d' %
+                              (st.__name__, lib.lrg_struct_size(which), ctypes.sizeof(st)))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise LrgHipError('%s failed with code %d' % (what, rc))

@@ -1,0 +1,59 @@
+// Shared helpers for the liblrg_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include <math.h>
+#include "../../include/lrg_hip.h"
+
+#define LRG_HIP_CHECK(expr)                                 \
+    do {                                                    \
+        hipError_t _e = (expr);                             \
+        if (_e != hipSuccess) return -(int)_e;              \
+    } while (0)
+
+#define LRG_LAUNCH_CHECK()                                  \
+    do {                                                    \
+        hipError_t _e = hipGetLastError();                  \
+        if (_e != hipSuccess) return -(int)_e;              \
+    } while (0)
+
+static inline size_t lrg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+__device__ __forceinline__ int lrg_lane() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float lrg_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ uint64_t lrg_fmix64(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return k;
+}
+
+#define LRG_VOX_OFF (1 << 20)
+#define LRG_HASH_EMPTY 0xFFFFFFFFFFFFFFFFULL
+
+// Packed voxel key; returns LRG_HASH_EMPTY when a coordinate is outside the 21-bit window.
+__device__ __forceinline__ uint64_t lrg_pack_voxel(int x, int y, int z) {
+    unsigned ux = (unsigned)(x + LRG_VOX_OFF), uy = (unsigned)(y + LRG_VOX_OFF), uz = (unsigned)(z + LRG_VOX_OFF);
+    if ((ux | uy | uz) >> 21) return LRG_HASH_EMPTY;
+    return ((uint64_t)ux << 42) | ((uint64_t)uy << 21) | (uint64_t)uz;
+}
+
+__device__ __forceinline__ int lrg_hash_lookup(const uint64_t *keys, const int32_t *vals, int mask, uint64_t key) {
+    if (key == LRG_HASH_EMPTY) return -1;
+    unsigned h = (unsigned)lrg_fmix64(key) & (unsigned)mask;
+    for (int probe = 0; probe <= mask; ++probe) {
+        uint64_t k = keys[h];
+        if (k == key) return vals[h];
+        if (k == LRG_HASH_EMPTY) return -1;
+        h = (h + 1) & (unsigned)mask;
+    }
+    return -1;
+}
+
+// rint(x / res) exactly as numpy.round(float32 / float32) (test_region_grow.py:175): IEEE divide, half-to-even.
+__device__ __forceinline__ int lrg_voxel_of(float x, float res) { return (int)rintf(__fdiv_rn(x, res)); }

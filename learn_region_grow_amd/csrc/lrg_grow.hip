@@ -1,0 +1,715 @@
+// Region-grow loop kernels (gfx950): the per-step bookkeeping around the LrgNet forward.
+//
+// Reference: test_region_grow.py:175-316 (greedy) and test_random_restart.py:141-303 (restarts).
+// The reference runs ONE region of ONE room per step on the host; here S "slots" (region instances)
+// advance in lock-step, one workgroup per slot (or per slot group), all state device-resident.
+#include "lrg_common.h"
+#include "lrg_rng.h"
+
+#define LRG_SCAN_THREADS 1024
+
+__device__ __forceinline__ bool lrg_is_stop(int st) { return st >= LRG_STOP_NONEIGHBOR && st <= LRG_STOP_MAXSTEPS; }
+
+// ------------------------------------------------------------------------------------------------
+// voxelise + voxel hash
+// ------------------------------------------------------------------------------------------------
+__global__ void lrg_voxelize_kernel(const float *points, int n, int F, float res, int32_t *vox) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vox[3 * i + 0] = lrg_voxel_of(points[(long)i * F + 0], res);
+    vox[3 * i + 1] = lrg_voxel_of(points[(long)i * F + 1], res);
+    vox[3 * i + 2] = lrg_voxel_of(points[(long)i * F + 2], res);
+}
+
+__global__ void lrg_hash_build_kernel(const int32_t *vox, int n, uint64_t *keys, int32_t *vals, int mask, int32_t *dup) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t key = lrg_pack_voxel(vox[3 * i], vox[3 * i + 1], vox[3 * i + 2]);
+    if (key == LRG_HASH_EMPTY) { atomicOr(dup, 2); return; }
+    unsigned h = (unsigned)lrg_fmix64(key) & (unsigned)mask;
+    for (int probe = 0; probe <= mask; ++probe) {
+        unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&keys[h]),
+                                            (unsigned long long)LRG_HASH_EMPTY, (unsigned long long)key);
+        if (prev == LRG_HASH_EMPTY) { vals[h] = i; return; }
+        if (prev == key) { atomicOr(dup, 1); return; }
+        h = (h + 1) & (unsigned)mask;
+    }
+    atomicOr(dup, 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block helpers (1024 threads = 16 waves)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lrg_block_min(int v, int *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    __syncthreads();
+    if (lrg_lane() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int nw = blockDim.x >> 6;
+    int r = red[0];
+    for (int i = 1; i < nw; ++i) r = min(r, red[i]);
+    return r;
+}
+__device__ __forceinline__ int lrg_block_max(int v, int *red) { return -lrg_block_min(-v, red); }
+__device__ __forceinline__ int lrg_block_sum(int v, int *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lrg_lane() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int nw = blockDim.x >> 6;
+    int r = 0;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stop / bbox bookkeeping of the step just taken   (test_region_grow.py:291-306)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_bbox_stop_kernel(LrgSlot *slots, const LrgRoom *rooms,
+                                                                          LrgGrowParams prm) {
+    __shared__ int red[16];
+    LrgSlot *S = &slots[blockIdx.x];
+    if (S->status != LRG_ACTIVE || S->updated < 0 || S->room < 0) return;
+    const LrgRoom *R = &rooms[S->room];
+    const int n = R->n;
+    const uint8_t *cur = S->cur;
+    const int32_t *vox = R->voxels;
+    int cnt = 0;
+    int mn0 = INT_MAX, mn1 = INT_MAX, mn2 = INT_MAX, mx0 = INT_MIN, mx1 = INT_MIN, mx2 = INT_MIN;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (cur[i]) {
+            ++cnt;
+            int a = vox[3 * i], b = vox[3 * i + 1], c = vox[3 * i + 2];
+            mn0 = min(mn0, a); mn1 = min(mn1, b); mn2 = min(mn2, c);
+            mx0 = max(mx0, a); mx1 = max(mx1, b); mx2 = max(mx2, c);
+        }
+    }
+    cnt = lrg_block_sum(cnt, red);
+    mn0 = lrg_block_min(mn0, red); mn1 = lrg_block_min(mn1, red); mn2 = lrg_block_min(mn2, red);
+    mx0 = lrg_block_max(mx0, red); mx1 = lrg_block_max(mx1, red); mx2 = lrg_block_max(mx2, red);
+    if (threadIdx.x != 0) return;
+    const int updated = S->updated;
+    S->updated = -1;
+    S->count = cnt;
+    if (!updated) { S->status = LRG_STOP_NOEXPAND; S->last_reason = LRG_STOP_NOEXPAND; return; }   // :304-306
+    if (cnt == 0) { S->status = LRG_STOP_EMPTY; S->last_reason = LRG_STOP_EMPTY; return; }          // :292 would raise
+    S->mn[0] = mn0; S->mn[1] = mn1; S->mn[2] = mn2;                                                  // :292-293
+    S->mx[0] = mx0; S->mx[1] = mx1; S->mx[2] = mx2;
+    bool grew = mn0 < S->seq_mn[0] || mn1 < S->seq_mn[1] || mn2 < S->seq_mn[2] ||
+                mx0 > S->seq_mx[0] || mx1 > S->seq_mx[1] || mx2 > S->seq_mx[2];                     // :294
+    if (!grew) {
+        if (S->stuck >= 1) { S->status = LRG_STOP_STUCK; S->last_reason = LRG_STOP_STUCK; return; }  // :295-297
+        S->stuck += 1;                                                                               // :299
+    } else {
+        S->stuck = 0;                                                                                // :301
+    }
+    S->seq_mn[0] = min(S->seq_mn[0], mn0); S->seq_mn[1] = min(S->seq_mn[1], mn1); S->seq_mn[2] = min(S->seq_mn[2], mn2);
+    S->seq_mx[0] = max(S->seq_mx[0], mx0); S->seq_mx[1] = max(S->seq_mx[1], mx1); S->seq_mx[2] = max(S->seq_mx[2], mx2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// commit / next seed / reset     (test_region_grow.py:186-217, test_random_restart.py:169-197)
+// One workgroup per group of `group_size` slots sharing a room and a seed.
+// ------------------------------------------------------------------------------------------------
+__device__ void lrg_reset_slot(LrgSlot *S, const LrgRoom *R, int seed, int restart) {
+    // cooperative: clear the mask, set the seed (:197-204)
+    for (int i = threadIdx.x; i < R->n; i += blockDim.x) S->cur[i] = (i == seed) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        S->seed = seed;
+        S->restart = restart;
+        S->step = 0;
+        S->stuck = 0;
+        S->updated = -1;
+        S->nc = 1; S->ne = 0; S->count = 1;
+        for (int d = 0; d < 3; ++d) {
+            int v = R->voxels[3 * seed + d];
+            S->mn[d] = v; S->mx[d] = v; S->seq_mn[d] = v; S->seq_mx[d] = v;
+        }
+        S->target = R->obj_id ? R->obj_id[seed] : 0;
+        S->status = LRG_ACTIVE;
+    }
+}
+
+__global__ __launch_bounds__(256) void lrg_advance_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
+                                                           LrgGrowParams prm, int64_t *stats) {
+    __shared__ int sh_next;
+    __shared__ int sh_flag;
+    const int G = prm.group_size, RST = prm.restarts;
+    const int g0 = blockIdx.x * G;
+    if (g0 >= n_slots) return;
+    LrgSlot *S0 = &slots[g0];
+    if (S0->room < 0) return;
+    LrgRoom *R = &rooms[S0->room];
+    const int n = R->n;
+    if (S0->status == LRG_DONE || S0->status == LRG_IDLE) return;
+
+    // ---- phase 1: bank finished grows, start the slot's next restart (restart :173-175,:187-197) ----
+    for (int s = 0; s < G && g0 + s < n_slots; ++s) {
+        LrgSlot *S = &slots[g0 + s];
+        int st = S->status;   // uniform across the block
+        if (!lrg_is_stop(st)) continue;
+        if (RST > 1) {
+            bool better = S->best_count < 0 || S->count > S->best_count;   // first max wins (numpy.argmax, :177)
+            if (better) {
+                for (int i = threadIdx.x; i < n; i += blockDim.x) S->best[i] = S->cur[i];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0 && better) { S->best_count = S->count; S->best_restart = S->restart; }
+        }
+        int next_restart = S->restart + G;
+        __syncthreads();
+        if (RST > 1 && next_restart < RST) {
+            lrg_reset_slot(S, R, S->seed, next_restart);
+        } else if (threadIdx.x == 0) {
+            S->status = LRG_WAIT;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: when every slot of the group waits, commit the seed ----
+    if (threadIdx.x == 0) {
+        int all_wait = 1;
+        for (int s = 0; s < G && g0 + s < n_slots; ++s)
+            if (slots[g0 + s].status != LRG_WAIT) all_wait = 0;
+        sh_flag = all_wait;
+    }
+    __syncthreads();
+    if (!sh_flag) return;
+
+    if (S0->seed >= 0) {
+        // winner: max score, earliest restart ordinal (restart :177); greedy: the slot's own mask
+        int win = 0, wcount = -1, wrest = INT_MAX, steps = 0;
+        for (int s = 0; s < G && g0 + s < n_slots; ++s) {
+            const LrgSlot *S = &slots[g0 + s];
+            steps += S->steps_total;
+            int c = RST > 1 ? S->best_count : S->count;
+            int r = RST > 1 ? S->best_restart : S->restart;
+            if (c < 0) continue;
+            if (c > wcount || (c == wcount && r < wrest)) { win = s; wcount = c; wrest = r; }
+        }
+        const LrgSlot *W = &slots[g0 + win];
+        const uint8_t *mask = RST > 1 ? W->best : W->cur;
+        const int labeled = wcount > prm.cluster_threshold;                       // :213
+        const int cid = R->next_cluster_id;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            if (mask[i]) {
+                R->visited[i] = 1;                                                // :212
+                if (labeled) R->label[i] = cid;                                   // :214
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // reason printed by the reference is that of the call completing the seed: restart ordinal RST-1
+            int last_slot = (RST - 1) % G;
+            if (g0 + last_slot >= n_slots) last_slot = 0;
+            int32_t *log = R->region_log + 6 * (long)R->n_regions;
+            log[0] = S0->seed; log[1] = steps; log[2] = wcount; log[3] = slots[g0 + last_slot].last_reason;
+            log[4] = labeled; log[5] = wrest;
+            R->n_regions += 1;
+            if (labeled) R->next_cluster_id = cid + 1;                            // :215
+            if (stats) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), 1ULL);
+        }
+        __syncthreads();
+    }
+
+    // ---- next unvisited seed in curvature order (:186-188) ----
+    int cursor = R->seed_cursor;
+    int found = -1;
+    while (cursor < n) {
+        int pos = cursor + threadIdx.x;
+        int cand = INT_MAX;
+        if (pos < n && !R->visited[R->order[pos]]) cand = pos;
+        if (threadIdx.x == 0) sh_next = INT_MAX;
+        __syncthreads();
+        if (cand != INT_MAX) atomicMin(&sh_next, cand);
+        __syncthreads();
+        int best = sh_next;
+        __syncthreads();
+        if (best != INT_MAX) { found = best; break; }
+        cursor += blockDim.x;
+    }
+    if (found < 0) {
+        if (threadIdx.x == 0) {
+            R->seed_cursor = n;
+            R->done = 1;
+            for (int s = 0; s < G && g0 + s < n_slots; ++s) slots[g0 + s].status = LRG_DONE;
+            if (stats) {
+                unsigned long long k = atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), 1ULL);
+                stats[4 + (k % LRG_DONE_RING)] = g0;
+            }
+        }
+        return;
+    }
+    const int seed = R->order[found];
+    __syncthreads();
+    if (threadIdx.x == 0) R->seed_cursor = found + 1;
+    for (int s = 0; s < G && g0 + s < n_slots; ++s) {
+        LrgSlot *S = &slots[g0 + s];
+        if (threadIdx.x == 0) { S->steps_total = 0; S->best_count = -1; S->best_restart = INT_MAX; S->last_reason = 0; }
+        if (s < RST) {
+            lrg_reset_slot(S, R, seed, s);
+        } else if (threadIdx.x == 0) {
+            S->seed = seed; S->status = LRG_WAIT; S->count = -1;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dilated voxel-box query + ordered compaction   (test_region_grow.py:221-235)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_query_kernel(LrgSlot *slots, const LrgRoom *rooms,
+                                                                          LrgGrowParams prm) {
+    __shared__ int wtot_c[16], wtot_e[16];
+    LrgSlot *S = &slots[blockIdx.x];
+    if (S->status != LRG_ACTIVE || S->room < 0) return;
+    const LrgRoom *R = &rooms[S->room];
+    const int n = R->n;
+    const uint8_t *cur = S->cur;
+    const uint8_t *visited = R->visited;
+    const int32_t *vox = R->voxels;
+    const int lo0 = S->mn[0] - 1, lo1 = S->mn[1] - 1, lo2 = S->mn[2] - 1;     // :222-225
+    const int hi0 = S->mx[0] + 1, hi1 = S->mx[1] + 1, hi2 = S->mx[2] + 1;
+    const int lane = lrg_lane(), wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    int base_c = 0, base_e = 0;
+    for (int i0 = 0; i0 < n; i0 += LRG_SCAN_THREADS) {
+        int i = i0 + threadIdx.x;
+        bool c = false, e = false;
+        if (i < n) {
+            c = cur[i] != 0;
+            if (!c && !visited[i]) {                                           // :227-228
+                int a = vox[3 * i], b = vox[3 * i + 1], d = vox[3 * i + 2];
+                e = a >= lo0 && a <= hi0 && b >= lo1 && b <= hi1 && d >= lo2 && d <= hi2;   // :226
+            }
+        }
+        unsigned long long mc = __ballot(c), me = __ballot(e);
+        if (lane == 0) { wtot_c[wave] = __popcll(mc); wtot_e[wave] = __popcll(me); }
+        __syncthreads();
+        int off_c = 0, off_e = 0, tot_c = 0, tot_e = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            int tc = wtot_c[w], te = wtot_e[w];
+            if (w < wave) { off_c += tc; off_e += te; }
+            tot_c += tc; tot_e += te;
+        }
+        if (c) S->cur_idx[base_c + off_c + __popcll(mc & lt)] = i;
+        if (e) S->cand_idx[base_e + off_e + __popcll(me & lt)] = i;
+        base_c += tot_c; base_e += tot_e;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        S->nc = base_c;
+        S->ne = base_e;
+        if (base_e == 0) {                                                      // :233-235
+            S->status = LRG_STOP_NONEIGHBOR; S->last_reason = LRG_STOP_NONEIGHBOR; S->count = base_c;
+        } else if (prm.max_region_steps > 0 && S->step >= prm.max_region_steps) {
+            S->status = LRG_STOP_MAXSTEPS; S->last_reason = LRG_STOP_MAXSTEPS; S->count = base_c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-channel median of the current points   (numpy.median, test_region_grow.py:241)
+// one workgroup per (slot, channel); radix select on order-preserving keys
+// ------------------------------------------------------------------------------------------------
+#define LRG_MED_CAP 8192
+__device__ __forceinline__ uint32_t lrg_f2key(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float lrg_key2f(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);
+}
+
+// k-th smallest (0-based) key among nc values; values come from LDS (cached) or are re-gathered.
+__device__ uint32_t lrg_radix_select(const uint32_t *cache, bool cached, const float *pts, const int32_t *idx, int F,
+                                     int ch, int nc, int k, int *hist, int *sh) {
+    uint32_t prefix = 0, mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < nc; j += blockDim.x) {
+            uint32_t key = cached ? cache[j] : lrg_f2key(pts[(long)idx[j] * F + ch]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int cum = 0, b = 0;
+            for (; b < 256; ++b) {
+                if (cum + hist[b] > k) break;
+                cum += hist[b];
+            }
+            sh[0] = b; sh[1] = k - cum;
+        }
+        __syncthreads();
+        prefix |= (uint32_t)sh[0] << shift;
+        mask |= 255u << shift;
+        k = sh[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+__global__ __launch_bounds__(256) void lrg_median_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
+                                                          float *center) {
+    __shared__ uint32_t cache[LRG_MED_CAP];
+    __shared__ int hist[256];
+    __shared__ int sh[2];
+    const int s = blockIdx.x, ch = blockIdx.y;
+    const LrgSlot *S = &slots[s];
+    const int F = prm.feature_size;
+    const bool centred = (ch < 2 || ch >= 6) && ch < F;                         // :243-247
+    if (!centred || S->status != LRG_ACTIVE || S->room < 0) {
+        if (threadIdx.x == 0) center[s * 16 + ch] = 0.f;
+        return;
+    }
+    const LrgRoom *R = &rooms[S->room];
+    const int nc = S->nc;
+    const bool cached = nc <= LRG_MED_CAP;
+    if (cached) {
+        for (int j = threadIdx.x; j < nc; j += blockDim.x) cache[j] = lrg_f2key(R->points[(long)S->cur_idx[j] * F + ch]);
+        __syncthreads();
+    }
+    const int k2 = nc >> 1;
+    float hi = lrg_key2f(lrg_radix_select(cache, cached, R->points, S->cur_idx, F, ch, nc, k2, hist, sh));
+    float med = hi;
+    if ((nc & 1) == 0) {
+        float lo = lrg_key2f(lrg_radix_select(cache, cached, R->points, S->cur_idx, F, ch, nc, k2 - 1, hist, sh));
+        med = __fmul_rn(__fadd_rn(lo, hi), 0.5f);       // numpy.mean of the two middle float32 values
+    }
+    if (threadIdx.x == 0) center[s * 16 + ch] = med;
+}
+
+// ------------------------------------------------------------------------------------------------
+// counter-stream subset sampling   (test_region_grow.py:237-240, :249-252)
+// ------------------------------------------------------------------------------------------------
+__global__ void lrg_sample_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm, int32_t *sample_in,
+                                  int32_t *sample_nb) {
+    const int s = blockIdx.x;
+    const LrgSlot *S = &slots[s];
+    if (S->status != LRG_ACTIVE || S->room < 0) return;
+    const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)rooms[S->room].room_id;
+    const int side = blockIdx.y;
+    const int k = side == 0 ? prm.n_inlier : prm.n_neighbor;
+    const int n = side == 0 ? S->nc : S->ne;
+    int32_t *out = (side == 0 ? sample_in + (long)s * prm.n_inlier : sample_nb + (long)s * prm.n_neighbor);
+    for (int j = threadIdx.x; j < k; j += blockDim.x)
+        out[j] = (int32_t)lrg_sample_position((uint32_t)j, (uint32_t)n, (uint32_t)k,
+                                               side == 0 ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
+                                               (uint32_t)S->seed, (uint32_t)S->restart, (uint32_t)S->step, k0, k1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather + centre   (test_region_grow.py:242-254)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lrg_gather_center_kernel(const LrgSlot *slots, const LrgRoom *rooms,
+                                                                 LrgGrowParams prm, const int32_t *sample_in,
+                                                                 const int32_t *sample_nb, const float *center,
+                                                                 float *inlier, float *neighbor, int32_t *gt_remove,
+                                                                 int32_t *gt_add) {
+    const int s = blockIdx.x, side = blockIdx.y;
+    const LrgSlot *S = &slots[s];
+    if (S->status != LRG_ACTIVE || S->room < 0) return;
+    const LrgRoom *R = &rooms[S->room];
+    const int F = prm.feature_size;
+    const int k = side == 0 ? prm.n_inlier : prm.n_neighbor;
+    const int32_t *samp = side == 0 ? sample_in + (long)s * prm.n_inlier : sample_nb + (long)s * prm.n_neighbor;
+    const int32_t *list = side == 0 ? S->cur_idx : S->cand_idx;
+    float *out = side == 0 ? inlier + (long)s * prm.n_inlier * F : neighbor + (long)s * prm.n_neighbor * F;
+    const float *c = center + s * 16;
+    const int chunk = (int)(blockDim.x * gridDim.z);
+    for (int e = blockIdx.z * blockDim.x + threadIdx.x; e < k * F; e += chunk) {
+        int j = e / F, f = e - j * F;
+        int src = list[samp[j]];
+        float v = R->points[(long)src * F + f];
+        out[e] = __fsub_rn(v, c[f]);       // center[] is 0 on the channels the reference leaves alone (z, room xyz)
+        if (f == 0) {
+            if (side == 0 && gt_remove) gt_remove[(long)s * prm.n_inlier + j] = R->obj_id ? (R->obj_id[src] != S->target) : 0;   // :231,:248
+            if (side == 1 && gt_add) gt_add[(long)s * prm.n_neighbor + j] = R->obj_id ? (R->obj_id[src] == S->target) : 0;      // :230,:254
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// confidence, Bernoulli masks, voxel-set update   (test_region_grow.py:262-288)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lrg_conf(const float *logit2) {
+    // scipy.special.softmax(x)[1] in float32: exp(x - max) / sum
+    float l0 = logit2[0], l1 = logit2[1];
+    float m = fmaxf(l0, l1);
+    float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    return __fdiv_rn(e1, __fadd_rn(e0, e1));
+}
+
+__global__ __launch_bounds__(512) void lrg_mask_update_kernel(LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
+                                                               const float *inlier, const float *neighbor,
+                                                               const float *center, const float *add_logits,
+                                                               const float *rmv_logits, const int32_t *gt_remove,
+                                                               const int32_t *gt_add, const uint8_t *add_mask,
+                                                               const uint8_t *rmv_mask, int64_t *stats) {
+    __shared__ int sh_upd;
+    const int s = blockIdx.x;
+    LrgSlot *S = &slots[s];
+    if (S->status != LRG_ACTIVE || S->room < 0) return;
+    const LrgRoom *R = &rooms[S->room];
+    const int F = prm.feature_size;
+    const float res = prm.resolution;
+    const float c0 = center[s * 16 + 0], c1 = center[s * 16 + 1];
+    const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
+    uint8_t *cur = S->cur;
+    if (threadIdx.x == 0) sh_upd = 0;
+    __syncthreads();
+    // ---- add pass (:266,:270-273,:283-285) ----
+    for (int j = threadIdx.x; j < prm.n_neighbor; j += blockDim.x) {
+        bool take;
+        const long o = (long)s * prm.n_neighbor + j;
+        if (prm.policy == 2) take = gt_add[o] != 0;
+        else if (add_mask) take = add_mask[o] != 0;
+        else {
+            float conf = lrg_conf(add_logits + 2 * o);
+            if (prm.policy == 1) take = conf > 0.5f;
+            else take = lrg_uniform01(lrg_rng_word((uint32_t)j, LRG_PURPOSE_ADD, (uint32_t)S->seed, (uint32_t)S->restart,
+                                                   (uint32_t)S->step, k0, k1)) < conf;
+        }
+        if (take) {
+            const float *p = neighbor + o * F;
+            int vx = lrg_voxel_of(__fadd_rn(p[0], c0), res);      // :271-272: un-centre x,y then rint(/res)
+            int vy = lrg_voxel_of(__fadd_rn(p[1], c1), res);
+            int vz = lrg_voxel_of(p[2], res);
+            int idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(vx, vy, vz));
+            if (idx >= 0 && !cur[idx]) { cur[idx] = 1; sh_upd = 1; }
+        }
+    }
+    __syncthreads();
+    // ---- remove pass (:267,:274-277,:286-287) ----
+    for (int j = threadIdx.x; j < prm.n_inlier; j += blockDim.x) {
+        bool take;
+        const long o = (long)s * prm.n_inlier + j;
+        if (prm.policy == 2) take = gt_remove[o] != 0;
+        else if (rmv_mask) take = rmv_mask[o] != 0;
+        else {
+            float conf = lrg_conf(rmv_logits + 2 * o);
+            if (prm.policy == 1) take = conf > 0.5f;
+            else take = lrg_uniform01(lrg_rng_word((uint32_t)j, LRG_PURPOSE_RMV, (uint32_t)S->seed, (uint32_t)S->restart,
+                                                   (uint32_t)S->step, k0, k1)) < conf;
+        }
+        if (take) {
+            const float *p = inlier + o * F;
+            int vx = lrg_voxel_of(__fadd_rn(p[0], c0), res);
+            int vy = lrg_voxel_of(__fadd_rn(p[1], c1), res);
+            int vz = lrg_voxel_of(p[2], res);
+            int idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(vx, vy, vz));
+            if (idx >= 0) cur[idx] = 0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S->updated = sh_upd;
+        S->step += 1;
+        S->steps_total += 1;                                                    // :288
+        if (stats) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[2]), 1ULL);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1-NN fill-in of unlabeled points   (test_region_grow.py:308-316)
+// distance = numpy.sum((P - p)**2, axis=1) in float32 with NumPy's pairwise order; first minimum wins
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lrg_np_sqdist(const float *a, const float *b, int F) {
+    float t[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+        if (l < F) {
+            float d = __fsub_rn(a[l], b[l]);
+            t[l] = __fmul_rn(d, d);
+        } else t[l] = 0.f;
+    }
+    if (F < 8) {
+        float s = t[0];
+        for (int l = 1; l < F; ++l) s = __fadd_rn(s, t[l]);
+        return s;
+    }
+    float s = __fadd_rn(__fadd_rn(__fadd_rn(t[0], t[1]), __fadd_rn(t[2], t[3])),
+                        __fadd_rn(__fadd_rn(t[4], t[5]), __fadd_rn(t[6], t[7])));
+    for (int l = 8; l < F; ++l) s = __fadd_rn(s, t[l]);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void lrg_nn1_fill_kernel(const float *points, int n, int F, const int32_t *label_in,
+                                                            int32_t *label_out) {
+    __shared__ float me[16];
+    __shared__ float rd[4];
+    __shared__ int rj[4];
+    const int i = blockIdx.x;
+    const int li = label_in[i];
+    if (li != 0) { if (threadIdx.x == 0) label_out[i] = li; return; }
+    if (threadIdx.x < 16) me[threadIdx.x] = threadIdx.x < F ? points[(long)i * F + threadIdx.x] : 0.f;
+    __syncthreads();
+    float best = INFINITY; int bj = INT_MAX;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        if (label_in[j] == 0) continue;
+        float d = lrg_np_sqdist(points + (long)j * F, me, F);
+        if (d < best || (d == best && j < bj) || bj == INT_MAX) { best = d; bj = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float od = __shfl_xor(best, o); int oj = __shfl_xor(bj, o);
+        if (oj != INT_MAX && (bj == INT_MAX || od < best || (od == best && oj < bj))) { best = od; bj = oj; }
+    }
+    if (lrg_lane() == 0) { rd[threadIdx.x >> 6] = best; rj[threadIdx.x >> 6] = bj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (rj[w] != INT_MAX && (bj == INT_MAX || rd[w] < best || (rd[w] == best && rj[w] < bj))) { best = rd[w]; bj = rj[w]; }
+        label_out[i] = bj == INT_MAX ? 0 : label_in[bj];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int lrg_voxelize(const float *points, int n, int F, float resolution, int32_t *voxels, void *stream) {
+    if (!points || !voxels || n < 0 || F < 3 || !(resolution > 0.f)) return LRG_EINVAL - 1;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(lrg_voxelize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, points, n, F,
+                       resolution, voxels);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_voxel_hash_build(const int32_t *voxels, int n, uint64_t *keys, int32_t *vals, int hash_mask, int32_t *dup_flag,
+                         void *stream) {
+    if (!voxels || !keys || !vals || !dup_flag || n < 0 || hash_mask < 0 || ((hash_mask + 1) & hash_mask) != 0 ||
+        hash_mask + 1 < n)
+        return LRG_EINVAL - 1;
+    LRG_HIP_CHECK(hipMemsetAsync(keys, 0xFF, (size_t)(hash_mask + 1) * sizeof(uint64_t), (hipStream_t)stream));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(lrg_hash_build_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, voxels, n, keys,
+                       vals, hash_mask, dup_flag);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+static int check_params(const LrgGrowParams *p) {
+    if (!p || p->feature_size < 3 || p->feature_size > 16 || p->n_inlier <= 0 || p->n_neighbor <= 0 ||
+        p->restarts < 1 || p->group_size < 1 || !(p->resolution > 0.f) || p->policy < 0 || p->policy > 2)
+        return LRG_EINVAL - 20;
+    return 0;
+}
+
+int lrg_bbox_stop(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || n_slots <= 0) return LRG_EINVAL - 1;
+    hipLaunchKernelGGL(lrg_bbox_stop_kernel, dim3(n_slots), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream, slots, rooms,
+                       *params);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_advance(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams *params, int64_t *stats, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || n_slots <= 0 || n_slots % params->group_size != 0) return LRG_EINVAL - 1;
+    hipLaunchKernelGGL(lrg_advance_kernel, dim3(n_slots / params->group_size), dim3(256), 0, (hipStream_t)stream, slots,
+                       rooms, n_slots, *params, stats);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_box_query(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || n_slots <= 0) return LRG_EINVAL - 1;
+    hipLaunchKernelGGL(lrg_box_query_kernel, dim3(n_slots), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream, slots, rooms,
+                       *params);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_median(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
+               void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || !center || n_slots <= 0) return LRG_EINVAL - 1;
+    hipLaunchKernelGGL(lrg_median_kernel, dim3(n_slots, 16), dim3(256), 0, (hipStream_t)stream, slots, rooms, *params,
+                       center);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_sample(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, int32_t *sample_in,
+               int32_t *sample_nb, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || !sample_in || !sample_nb || n_slots <= 0) return LRG_EINVAL - 1;
+    hipLaunchKernelGGL(lrg_sample_kernel, dim3(n_slots, 2), dim3(256), 0, (hipStream_t)stream, slots, rooms, *params,
+                       sample_in, sample_nb);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_gather_center(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params,
+                      const int32_t *sample_in, const int32_t *sample_nb, const float *center, float *inlier,
+                      float *neighbor, int32_t *gt_remove, int32_t *gt_add, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || !sample_in || !sample_nb || !center || !inlier || !neighbor || n_slots <= 0)
+        return LRG_EINVAL - 1;
+    hipLaunchKernelGGL(lrg_gather_center_kernel, dim3(n_slots, 2, 4), dim3(256), 0, (hipStream_t)stream, slots, rooms,
+                       *params, sample_in, sample_nb, center, inlier, neighbor, gt_remove, gt_add);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_mask_update(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, const float *inlier,
+                    const float *neighbor, const float *center, const float *add_logits, const float *rmv_logits,
+                    const int32_t *gt_remove, const int32_t *gt_add, const uint8_t *add_mask, const uint8_t *rmv_mask,
+                    int64_t *stats, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || !inlier || !neighbor || !center || n_slots <= 0) return LRG_EINVAL - 1;
+    if (params->policy == 2 && (!gt_remove || !gt_add)) return LRG_EINVAL - 2;
+    if (params->policy != 2 && ((add_mask == nullptr) != (rmv_mask == nullptr))) return LRG_EINVAL - 3;
+    if (params->policy != 2 && !add_mask && (!add_logits || !rmv_logits)) return LRG_EINVAL - 4;
+    hipLaunchKernelGGL(lrg_mask_update_kernel, dim3(n_slots), dim3(512), 0, (hipStream_t)stream, slots, rooms, *params,
+                       inlier, neighbor, center, add_logits, rmv_logits, gt_remove, gt_add, add_mask, rmv_mask, stats);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams *params, const LrgWeights *weights,
+                  const LrgStepBuffers *b, int advance_rounds, unsigned forward_flags, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || !weights || !b || n_slots <= 0 || advance_rounds < 1) return LRG_EINVAL - 1;
+    if (weights->feature_size != params->feature_size) return LRG_EINVAL - 2;
+    if ((rc = lrg_bbox_stop(slots, rooms, n_slots, params, stream))) return rc;
+    for (int r = 0; r < advance_rounds; ++r) {
+        if ((rc = lrg_advance(slots, rooms, n_slots, params, b->stats, stream))) return rc;
+        if ((rc = lrg_box_query(slots, rooms, n_slots, params, stream))) return rc;
+    }
+    if ((rc = lrg_median(slots, rooms, n_slots, params, b->center, stream))) return rc;
+    if ((rc = lrg_sample(slots, rooms, n_slots, params, b->sample_in, b->sample_nb, stream))) return rc;
+    if ((rc = lrg_gather_center(slots, rooms, n_slots, params, b->sample_in, b->sample_nb, b->center, b->inlier,
+                                b->neighbor, b->gt_remove, b->gt_add, stream))) return rc;
+    if ((rc = lrg_forward(weights, b->inlier, b->neighbor, n_slots, params->n_inlier, params->n_neighbor, b->add_logits,
+                          b->rmv_logits, b->workspace, b->workspace_bytes, forward_flags, stream))) return rc;
+    return lrg_mask_update(slots, rooms, n_slots, params, b->inlier, b->neighbor, b->center, b->add_logits,
+                           b->rmv_logits, b->gt_remove, b->gt_add, nullptr, nullptr, b->stats, stream);
+}
+
+int lrg_nn1_fill(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *stream) {
+    if (!points || !label_in || !label_out || n < 0 || F < 1 || F > 16) return LRG_EINVAL - 1;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(lrg_nn1_fill_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, points, n, F, label_in,
+                       label_out);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

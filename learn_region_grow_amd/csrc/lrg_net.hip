@@ -1,0 +1,546 @@
+// LrgNet forward on gfx950: per-point layers on the fp32 matrix cores, max-pool, hoisted heads.
+//
+// Reference graph: learn_region_grow_util.py:106-162 (two 5-layer per-point branches, max-pool over the
+// 512 rows of each, [pooled | conv[1]] concat, two 3-layer heads).  Restated here as
+//   lrg_pointwise_mfma_kernel  y = relu(x @ W + b)  -- v_mfma_f32_32x32x2_f32 (exact fp32, == fmaf chain)
+//   lrg_segmax_kernel          column max over an instance's rows
+//   lrg_head_gemv_kernel       pooled @ W0[:2*C_last] + b0  once per instance (the tiled concat is never built)
+//   lrg_head_final_kernel      [C] -> 2 logits
+#include "lrg_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LRG_BM 64
+#define LRG_BN 64
+#define LRG_BK 64
+#define LRG_LDA (LRG_BK + 4)   // +4 floats: conflict-free ds_read_b128 of A fragments, rows stay 16-B aligned
+#define LRG_LDB (LRG_BN)
+
+struct LrgLayerProb {
+    const float *x;
+    const float *w;
+    const float *bias;
+    float *y;
+    float *pool;
+    long rows;
+    int rows_per_inst;
+    int pad;
+};
+
+struct LrgLayerArgs {
+    LrgLayerProb p[2];
+    int ldx, ldw, K, N;
+    int relu, bias_inst_stride, pool_stride, ncol;
+    int vec_x, vec_w;
+};
+
+// One 64x64 output tile per 256-thread workgroup (4 waves as 2x2 of 32x32), K streamed through LDS in
+// chunks of 64.  Row tiles are dealt to XCDs (block b runs on XCD b%8) so that all column tiles of one row
+// tile hit the same per-XCD L2.
+__global__ __launch_bounds__(256) void lrg_pointwise_mfma_kernel(LrgLayerArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[LRG_BM * LRG_LDA + LRG_BK * LRG_LDB];
+    float *As = smem;
+    float *Bs = smem + LRG_BM * LRG_LDA;
+
+    const LrgLayerProb P = a.p[blockIdx.y];
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int rt = (q / a.ncol) * 8 + xcd;
+    const int ct = q % a.ncol;
+    const long r0 = (long)rt * LRG_BM;
+    if (r0 >= P.rows) return;
+    const int n0 = ct * LRG_BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    const int K = a.K;
+    for (int k0 = 0; k0 < K; k0 += LRG_BK) {
+        const int kw = min(LRG_BK, K - k0);
+        const int kwp = (kw + 7) & ~7;
+        // ---- stage A (rows of x) ----
+        if (a.vec_x) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                int idx = tid + it * 256;
+                int row = idx >> 4, c4 = idx & 15;
+                int kk = k0 + 4 * c4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r0 + row < P.rows && kk < K) v = *reinterpret_cast<const float4 *>(P.x + (r0 + row) * a.ldx + kk);
+                *reinterpret_cast<float4 *>(&As[row * LRG_LDA + 4 * c4]) = v;
+            }
+        } else {
+            for (int idx = tid; idx < LRG_BM * kwp; idx += 256) {
+                int row = idx / kwp, c = idx - row * kwp;
+                float v = 0.f;
+                if (r0 + row < P.rows && c < kw) v = P.x[(r0 + row) * a.ldx + k0 + c];
+                As[row * LRG_LDA + c] = v;
+            }
+        }
+        // ---- stage B (rows of W) ----
+        if (a.vec_w) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                int idx = tid + it * 256;
+                int kr = idx >> 4, c4 = idx & 15;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kr < kw) v = *reinterpret_cast<const float4 *>(P.w + (long)(k0 + kr) * a.ldw + n0 + 4 * c4);
+                *reinterpret_cast<float4 *>(&Bs[kr * LRG_LDB + 4 * c4]) = v;
+            }
+        } else {
+            for (int idx = tid; idx < kwp * LRG_BN; idx += 256) {
+                int kr = idx >> 6, c = idx & 63;
+                float v = 0.f;
+                if (kr < kw) v = P.w[(long)(k0 + kr) * a.ldw + n0 + c];
+                Bs[kr * LRG_LDB + c] = v;
+            }
+        }
+        __syncthreads();
+        // ---- 32x32x2 fp32 MFMA: lane half h feeds logical k = 8g + 4h + s of both operands ----
+        const float *ap = &As[(wm * 32 + li) * LRG_LDA + 4 * lh];
+        const float *bp = &Bs[(4 * lh) * LRG_LDB + wn * 32 + li];
+        const int ng = kwp >> 3;
+        for (int g = 0; g < ng; ++g) {
+            float4 av = *reinterpret_cast<const float4 *>(ap + 8 * g);
+            float b0 = bp[(8 * g + 0) * LRG_LDB];
+            float b1 = bp[(8 * g + 1) * LRG_LDB];
+            float b2 = bp[(8 * g + 2) * LRG_LDB];
+            float b3 = bp[(8 * g + 3) * LRG_LDB];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+    const int col = n0 + wn * 32 + li;
+    const long rbase = r0 + wm * 32 + 4 * lh;
+    const bool inst_bias = a.bias_inst_stride > 0 && P.rows_per_inst > 0;
+    float bias0 = 0.f;
+    if (P.bias && !inst_bias) bias0 = P.bias[col];
+    float cmax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        long row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < P.rows) {
+            float bv = bias0;
+            if (inst_bias) bv = P.bias[(row / P.rows_per_inst) * a.bias_inst_stride + col];
+            float v = acc[r] + bv;
+            if (a.relu) v = fmaxf(v, 0.f);
+            P.y[row * a.N + col] = v;
+            cmax = fmaxf(cmax, v);
+        }
+    }
+    if (P.pool) {   // host guarantees relu and rows_per_inst % 64 == 0: the whole tile is one instance
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        if (lh == 0) atomicMax(reinterpret_cast<int *>(P.pool + (r0 / P.rows_per_inst) * a.pool_stride + col),
+                               __float_as_int(cmax));
+    }
+}
+
+// Any-shape fallback (cout not a multiple of 64): one thread per output element.
+__global__ void lrg_pointwise_naive_kernel(LrgLayerArgs a) {
+    const LrgLayerProb P = a.p[blockIdx.y];
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.rows * a.N) return;
+    long row = e / a.N;
+    int col = (int)(e - row * a.N);
+    float s = 0.f;
+    for (int k = 0; k < a.K; ++k) s = fmaf(P.x[row * a.ldx + k], P.w[(long)k * a.ldw + col], s);
+    float bv = 0.f;
+    if (P.bias) bv = (a.bias_inst_stride > 0 && P.rows_per_inst > 0)
+                         ? P.bias[(row / P.rows_per_inst) * a.bias_inst_stride + col] : P.bias[col];
+    s += bv;
+    if (a.relu) s = fmaxf(s, 0.f);
+    P.y[row * a.N + col] = s;
+    if (P.pool) atomicMax(reinterpret_cast<int *>(P.pool + (row / P.rows_per_inst) * a.pool_stride + col), __float_as_int(s));
+}
+
+static int launch_layer(const LrgLayerArgs &a0, int nprob, hipStream_t st) {
+    LrgLayerArgs a = a0;
+    long maxrows = a.p[0].rows;
+    if (nprob > 1 && a.p[1].rows > maxrows) maxrows = a.p[1].rows;
+    if (maxrows <= 0) return 0;
+    if (a.N % LRG_BN == 0) {
+        a.ncol = a.N / LRG_BN;
+        long nrt = (maxrows + LRG_BM - 1) / LRG_BM;
+        long nrt8 = (nrt + 7) / 8 * 8;
+        dim3 grid((unsigned)(nrt8 * a.ncol), nprob, 1);
+        hipLaunchKernelGGL(lrg_pointwise_mfma_kernel, grid, dim3(256), 0, st, a);
+    } else {
+        long tot = maxrows * a.N;
+        dim3 grid((unsigned)((tot + 255) / 256), nprob, 1);
+        hipLaunchKernelGGL(lrg_pointwise_naive_kernel, grid, dim3(256), 0, st, a);
+    }
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+static void fill_vec_flags(LrgLayerArgs &a, int nprob) {
+    a.vec_x = (a.ldx % 4 == 0) && (a.K % 4 == 0);
+    a.vec_w = (a.ldw % 4 == 0);
+    for (int i = 0; i < nprob; ++i) {
+        if (((uintptr_t)a.p[i].x & 15) != 0) a.vec_x = 0;
+        if (((uintptr_t)a.p[i].w & 15) != 0) a.vec_w = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column max over an instance's rows
+// ------------------------------------------------------------------------------------------------
+struct LrgSegmaxArgs {
+    const float *x[2];
+    float *out[2];
+    int rows[2];
+    int C, out_stride;
+};
+
+__global__ __launch_bounds__(256) void lrg_segmax_kernel(LrgSegmaxArgs a) {
+    __shared__ float red[16][65];
+    const int z = blockIdx.z;
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 columns x 4 row groups, 256-B rows per wave
+    const int rows = a.rows[z];
+    const float *x = a.x[z] + (long)b * rows * a.C;
+    float m = -INFINITY;
+    if (c0 + tx < a.C)
+        for (int r = ty; r < rows; r += 4) m = fmaxf(m, x[(long)r * a.C + c0 + tx]);
+    red[ty][tx] = m;
+    __syncthreads();
+    if (ty == 0 && c0 + tx < a.C) {
+        m = fmaxf(fmaxf(red[0][tx], red[1][tx]), fmaxf(red[2][tx], red[3][tx]));
+        a.out[z][(long)b * a.out_stride + c0 + tx] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hoisted pooled-feature product: hb[b,c] = bias[c] + sum_k pooled[b,k] w[k,c]
+// ------------------------------------------------------------------------------------------------
+#define LRG_GEMV_TB 4
+struct LrgGemvArgs {
+    const float *pooled;
+    const float *w[2];
+    const float *bias[2];
+    float *hb[2];
+    int ldw, B, P, C;
+};
+
+__global__ __launch_bounds__(256) void lrg_head_gemv_kernel(LrgGemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float pl[];   // [TB][P]
+    const int z = blockIdx.z;
+    const int b0 = blockIdx.y * LRG_GEMV_TB;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int nb = min(LRG_GEMV_TB, a.B - b0);
+    for (int i = threadIdx.x; i < LRG_GEMV_TB * a.P; i += 256) {
+        int bi = i / a.P;
+        pl[i] = bi < nb ? a.pooled[(long)(b0 + bi) * a.P + (i - bi * a.P)] : 0.f;
+    }
+    __syncthreads();
+    if (c >= a.C) return;
+    float acc[LRG_GEMV_TB];
+#pragma unroll
+    for (int i = 0; i < LRG_GEMV_TB; ++i) acc[i] = 0.f;
+    const float *w = a.w[z] + c;
+#pragma unroll 4
+    for (int k = 0; k < a.P; ++k) {
+        float wv = w[(long)k * a.ldw];
+#pragma unroll
+        for (int i = 0; i < LRG_GEMV_TB; ++i) acc[i] = fmaf(pl[i * a.P + k], wv, acc[i]);
+    }
+    float bv = a.bias[z] ? a.bias[z][c] : 0.f;
+    for (int i = 0; i < nb; ++i) a.hb[z][(long)(b0 + i) * a.C + c] = acc[i] + bv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// final head layer: [rows,C] @ [C,2] + b, no ReLU.  16 lanes per row, float4 loads.
+// ------------------------------------------------------------------------------------------------
+struct LrgFinalArgs {
+    const float *h[2];
+    const float *w[2];
+    const float *bias[2];
+    float *out[2];
+    long rows[2];
+    int C;
+};
+
+__global__ __launch_bounds__(256) void lrg_head_final_kernel(LrgFinalArgs a) {
+    const int z = blockIdx.y;
+    const int sub = threadIdx.x & 15;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool valid = row < a.rows[z];
+    float s0 = 0.f, s1 = 0.f;
+    if (valid) {
+        const float *h = a.h[z] + row * a.C;
+        const float *w = a.w[z];
+        for (int k = 4 * sub; k < a.C; k += 64) {
+            float4 hv = *reinterpret_cast<const float4 *>(h + k);
+            float4 w01 = *reinterpret_cast<const float4 *>(w + 2 * k);       // w[k][0],w[k][1],w[k+1][0],w[k+1][1]
+            float4 w23 = *reinterpret_cast<const float4 *>(w + 2 * k + 4);
+            s0 = fmaf(hv.x, w01.x, s0); s1 = fmaf(hv.x, w01.y, s1);
+            s0 = fmaf(hv.y, w01.z, s0); s1 = fmaf(hv.y, w01.w, s1);
+            s0 = fmaf(hv.z, w23.x, s0); s1 = fmaf(hv.z, w23.y, s1);
+            s0 = fmaf(hv.w, w23.z, s0); s1 = fmaf(hv.w, w23.w, s1);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+    }
+    if (valid && sub == 0) {
+        a.out[z][row * 2 + 0] = s0 + a.bias[z][0];
+        a.out[z][row * 2 + 1] = s1 + a.bias[z][1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout
+// ------------------------------------------------------------------------------------------------
+struct LrgFwdLayout {
+    size_t conv[2][LRG_MAX_CONV];   // float offsets
+    size_t pooled;
+    size_t hb[2];                   // 0 add, 1 remove
+    size_t hid[2][LRG_MAX_HEAD];
+    size_t total;
+    int P;                          // 2*C_last
+};
+
+static int fwd_layout(const LrgWeights *w, int B, int ni, int nn, LrgFwdLayout *L) {
+    if (!w || B <= 0 || ni <= 0 || nn <= 0) return LRG_EINVAL - 1;
+    if (w->n_conv < 2 || w->n_conv > LRG_MAX_CONV || w->n_head < 2 || w->n_head > LRG_MAX_HEAD) return LRG_EINVAL - 2;
+    if (w->head_ch[w->n_head - 1] != 2) return LRG_EINVAL - 3;
+    size_t off = 0;
+    const long rows[2] = {(long)B * ni, (long)B * nn};
+    for (int br = 0; br < 2; ++br)
+        for (int i = 0; i < w->n_conv; ++i) {
+            L->conv[br][i] = off;
+            off = lrg_align_up(off + (size_t)rows[br] * w->conv_ch[i], 64);
+        }
+    L->P = 2 * w->conv_ch[w->n_conv - 1];
+    L->pooled = off;
+    off = lrg_align_up(off + (size_t)B * L->P, 64);
+    for (int hd = 0; hd < 2; ++hd) {
+        L->hb[hd] = off;
+        off = lrg_align_up(off + (size_t)B * w->head_ch[0], 64);
+    }
+    // head 0 = add head on the neighbour rows, head 1 = remove head on the inlier rows
+    for (int hd = 0; hd < 2; ++hd)
+        for (int i = 0; i < w->n_head - 1; ++i) {
+            L->hid[hd][i] = off;
+            off = lrg_align_up(off + (size_t)rows[hd == 0 ? 1 : 0] * w->head_ch[i], 64);
+        }
+    L->total = off;
+    return 0;
+}
+
+extern "C" {
+
+int lrg_abi_version(void) { return LRG_ABI_VERSION; }
+const char *lrg_target_arch(void) { return "gfx950"; }
+size_t lrg_struct_size(int which) {
+    switch (which) {
+    case 0: return sizeof(LrgWeights);
+    case 1: return sizeof(LrgRoom);
+    case 2: return sizeof(LrgSlot);
+    case 3: return sizeof(LrgGrowParams);
+    }
+    return 0;
+}
+
+size_t lrg_forward_workspace_bytes(const LrgWeights *w, int B, int n_inlier, int n_neighbor) {
+    LrgFwdLayout L;
+    if (fwd_layout(w, B, n_inlier, n_neighbor, &L) != 0) return 0;
+    return L.total * sizeof(float);
+}
+
+int lrg_forward_workspace_view(const LrgWeights *w, int B, int n_inlier, int n_neighbor, int kind, int index,
+                               size_t *offset_floats, size_t *count_floats) {
+    LrgFwdLayout L;
+    int rc = fwd_layout(w, B, n_inlier, n_neighbor, &L);
+    if (rc) return rc;
+    if (!offset_floats || !count_floats) return LRG_EINVAL - 4;
+    switch (kind) {
+    case 0: case 1:
+        if (index < 0 || index >= w->n_conv) return LRG_EINVAL - 5;
+        *offset_floats = L.conv[kind][index];
+        *count_floats = (size_t)B * (kind == 0 ? n_inlier : n_neighbor) * w->conv_ch[index];
+        return 0;
+    case 2:
+        *offset_floats = L.pooled; *count_floats = (size_t)B * L.P; return 0;
+    case 3: case 4:
+        if (index < 0 || index >= w->n_head - 1) return LRG_EINVAL - 5;
+        *offset_floats = L.hid[kind - 3][index];
+        *count_floats = (size_t)B * (kind == 3 ? n_neighbor : n_inlier) * w->head_ch[index];
+        return 0;
+    }
+    return LRG_EINVAL - 6;
+}
+
+int lrg_pointwise_layer(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y, long rows,
+                        int cin, int cout, int relu, int rows_per_instance, int bias_instance_stride,
+                        float *pool_out, int pool_stride, void *stream) {
+    if (!x || !w || !y || rows < 0 || cin <= 0 || cout <= 0 || ldx < cin || ldw < cout) return LRG_EINVAL - 1;
+    if (pool_out && (!relu || rows_per_instance <= 0 || (cout % LRG_BN == 0 && rows_per_instance % LRG_BM != 0)))
+        return LRG_EINVAL - 2;
+    LrgLayerArgs a = {};
+    a.p[0].x = x; a.p[0].w = w; a.p[0].bias = bias; a.p[0].y = y; a.p[0].pool = pool_out;
+    a.p[0].rows = rows; a.p[0].rows_per_inst = rows_per_instance;
+    a.ldx = ldx; a.ldw = ldw; a.K = cin; a.N = cout; a.relu = relu;
+    a.bias_inst_stride = bias_instance_stride; a.pool_stride = pool_stride;
+    fill_vec_flags(a, 1);
+    return launch_layer(a, 1, (hipStream_t)stream);
+}
+
+int lrg_segmax(const float *x, float *out, int B, int rows, int C, int out_stride, void *stream) {
+    if (!x || !out || B <= 0 || rows <= 0 || C <= 0) return LRG_EINVAL - 1;
+    LrgSegmaxArgs a = {};
+    a.x[0] = x; a.out[0] = out; a.rows[0] = rows; a.C = C; a.out_stride = out_stride;
+    hipLaunchKernelGGL(lrg_segmax_kernel, dim3((C + 63) / 64, B, 1), dim3(256), 0, (hipStream_t)stream, a);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_head_pool_gemv(const float *pooled, const float *w, int ldw, const float *bias, float *hb, int B, int P,
+                       int C, void *stream) {
+    if (!pooled || !w || !hb || B <= 0 || P <= 0 || C <= 0 || ldw < C) return LRG_EINVAL - 1;
+    LrgGemvArgs a = {};
+    a.pooled = pooled; a.w[0] = w; a.bias[0] = bias; a.hb[0] = hb; a.ldw = ldw; a.B = B; a.P = P; a.C = C;
+    size_t sh = (size_t)LRG_GEMV_TB * P * sizeof(float);
+    hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C + 255) / 256, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 1), dim3(256),
+                       sh, (hipStream_t)stream, a);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_head_final(const float *h, const float *w, const float *bias, float *logits, long rows, int C, void *stream) {
+    if (!h || !w || !bias || !logits || rows < 0 || C <= 0 || C % 4 != 0) return LRG_EINVAL - 1;
+    if (rows == 0) return 0;
+    LrgFinalArgs a = {};
+    a.h[0] = h; a.w[0] = w; a.bias[0] = bias; a.out[0] = logits; a.rows[0] = rows; a.C = C;
+    hipLaunchKernelGGL(lrg_head_final_kernel, dim3((unsigned)((rows + 15) / 16), 1, 1), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_forward(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
+                int n_neighbor, float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes,
+                unsigned flags, void *stream) {
+    LrgFwdLayout L;
+    int rc = fwd_layout(w, B, n_inlier, n_neighbor, &L);
+    if (rc) return rc;
+    if (!inlier || !neighbor || !add_logits || !rmv_logits || !workspace) return LRG_EINVAL - 7;
+    if (workspace_bytes < L.total * sizeof(float)) return LRG_EINVAL - 8;
+    if (((uintptr_t)workspace & 255) != 0) return LRG_EINVAL - 9;
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    const long rows[2] = {(long)B * n_inlier, (long)B * n_neighbor};
+    const int rpi[2] = {n_inlier, n_neighbor};
+    const int nc = w->n_conv, nh = w->n_head;
+    const int Clast = w->conv_ch[nc - 1];
+    bool fuse_pool = (flags & LRG_FWD_FUSE_POOL) && (Clast % LRG_BN == 0) && (n_inlier % LRG_BM == 0) &&
+                     (n_neighbor % LRG_BM == 0);
+    if (fuse_pool) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
+
+    // ---- branches (:106-119): both branches in one launch per layer ----
+    for (int i = 0; i < nc; ++i) {
+        LrgLayerArgs a = {};
+        const int cin = i == 0 ? w->feature_size : w->conv_ch[i - 1];
+        for (int br = 0; br < 2; ++br) {
+            a.p[br].x = i == 0 ? (br == 0 ? inlier : neighbor) : ws + L.conv[br][i - 1];
+            a.p[br].w = br == 0 ? w->inlier_w[i] : w->neighbor_w[i];
+            a.p[br].bias = br == 0 ? w->inlier_b[i] : w->neighbor_b[i];
+            a.p[br].y = ws + L.conv[br][i];
+            a.p[br].rows = rows[br];
+            a.p[br].rows_per_inst = rpi[br];
+            a.p[br].pool = (fuse_pool && i == nc - 1) ? ws + L.pooled + (br == 0 ? 0 : Clast) : nullptr;
+        }
+        a.ldx = cin; a.ldw = w->conv_ch[i]; a.K = cin; a.N = w->conv_ch[i]; a.relu = 1;
+        a.pool_stride = L.P;
+        fill_vec_flags(a, 2);
+        rc = launch_layer(a, 2, st);
+        if (rc) return rc;
+    }
+    // ---- max-pool + concat (:122-125): pooled = [max(inlier) | max(neighbour)] ----
+    if (!fuse_pool) {
+        LrgSegmaxArgs s = {};
+        for (int br = 0; br < 2; ++br) {
+            s.x[br] = ws + L.conv[br][nc - 1];
+            s.out[br] = ws + L.pooled + (br == 0 ? 0 : Clast);
+            s.rows[br] = rpi[br];
+        }
+        s.C = Clast; s.out_stride = L.P;
+        hipLaunchKernelGGL(lrg_segmax_kernel, dim3((Clast + 63) / 64, B, 2), dim3(256), 0, st, s);
+        LRG_LAUNCH_CHECK();
+    }
+    // ---- heads (:128-162).  head 0 = add on neighbour rows, head 1 = remove on inlier rows.
+    // x @ W0 = pooled @ W0[:P] (once per instance) + conv[1] @ W0[P:]  -- the tile/concat is never materialised.
+    const int C0 = w->head_ch[0];
+    const int Cloc = w->conv_ch[1];
+    {
+        LrgGemvArgs g = {};
+        g.pooled = ws + L.pooled;
+        g.w[0] = w->add_w[0]; g.w[1] = w->rmv_w[0];
+        g.bias[0] = w->add_b[0]; g.bias[1] = w->rmv_b[0];
+        g.hb[0] = ws + L.hb[0]; g.hb[1] = ws + L.hb[1];
+        g.ldw = C0; g.B = B; g.P = L.P; g.C = C0;
+        size_t sh = (size_t)LRG_GEMV_TB * L.P * sizeof(float);
+        hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C0 + 255) / 256, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 2),
+                           dim3(256), sh, st, g);
+        LRG_LAUNCH_CHECK();
+    }
+    const int hbr[2] = {1, 0};   // branch feeding each head
+    for (int i = 0; i < nh - 1; ++i) {
+        LrgLayerArgs a = {};
+        for (int hd = 0; hd < 2; ++hd) {
+            const int br = hbr[hd];
+            const float *W = hd == 0 ? w->add_w[i] : w->rmv_w[i];
+            if (i == 0) {
+                a.p[hd].x = ws + L.conv[br][1];
+                a.p[hd].w = W + (size_t)L.P * C0;          // rows P.. of W0: the conv[1] part of the concat
+                a.p[hd].bias = ws + L.hb[hd];
+            } else {
+                a.p[hd].x = ws + L.hid[hd][i - 1];
+                a.p[hd].w = W;
+                a.p[hd].bias = hd == 0 ? w->add_b[i] : w->rmv_b[i];
+            }
+            a.p[hd].y = ws + L.hid[hd][i];
+            a.p[hd].rows = rows[br];
+            a.p[hd].rows_per_inst = rpi[br];
+        }
+        const int cin = i == 0 ? Cloc : w->head_ch[i - 1];
+        a.ldx = cin; a.ldw = w->head_ch[i]; a.K = cin; a.N = w->head_ch[i]; a.relu = 1;
+        a.bias_inst_stride = i == 0 ? C0 : 0;
+        fill_vec_flags(a, 2);
+        rc = launch_layer(a, 2, st);
+        if (rc) return rc;
+    }
+    {
+        LrgFinalArgs f = {};
+        const int C = w->head_ch[nh - 2];
+        if (C % 4 != 0) return LRG_EINVAL - 10;
+        for (int hd = 0; hd < 2; ++hd) {
+            f.h[hd] = ws + L.hid[hd][nh - 2];
+            f.w[hd] = hd == 0 ? w->add_w[nh - 1] : w->rmv_w[nh - 1];
+            f.bias[hd] = hd == 0 ? w->add_b[nh - 1] : w->rmv_b[nh - 1];
+            f.out[hd] = hd == 0 ? add_logits : rmv_logits;
+            f.rows[hd] = rows[hbr[hd]];
+        }
+        f.C = C;
+        long mr = rows[0] > rows[1] ? rows[0] : rows[1];
+        hipLaunchKernelGGL(lrg_head_final_kernel, dim3((unsigned)((mr + 15) / 16), 2, 1), dim3(256), 0, st, f);
+        LRG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+"""Multi-GPU: rooms are independent units (test_region_grow.py:110-183 re-derives all state per room), so they
+shard across ranks with no collective inside the grow loop; the only exchange is the final gather of per-room
+labels.  One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" on CPU).
+The reference has no multi-GPU path at all; this is new design.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_rooms_lpt(sizes, world_size):
+    """Longest-processing-time-first assignment of rooms to ranks by equalised point count.
+    Returns a list (per rank) of room indices; deterministic, every room assigned exactly once."""
+    order = sorted(range(len(sizes)), key=lambda i: (-sizes[i], i))
+    load = [0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        shards[r].append(i)
+        load[r] += sizes[i]
+    return [sorted(s) for s in shards]
+
+
+def gather_room_labels(local_ids, local_labels, n_rooms, device=None, group=None):
+    """All ranks end up with the labels of all rooms: one all_gather of (room id, size) tables and one
+    all_gather of a flat int32 label buffer padded to the largest shard.  `local_labels[i]` is the int array of
+    room `local_ids[i]`.  Returns a list of n_rooms arrays (None for rooms nobody owned)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        out = [None] * n_rooms
+        for i, lab in zip(local_ids, local_labels):
+            out[i] = np.asarray(lab, dtype=np.int32)
+        return out
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    meta = torch.full((n_rooms, 2), -1, dtype=torch.int64, device=device)
+    for k, (i, lab) in enumerate(zip(local_ids, local_labels)):
+        meta[k, 0], meta[k, 1] = i, len(lab)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    totals = [int(m[:, 1].clamp(min=0).sum()) for m in metas]
+    flat = torch.zeros(max(max(totals), 1), dtype=torch.int32, device=device)
+    if local_labels:
+        cat = np.concatenate([np.asarray(l, dtype=np.int32) for l in local_labels]) if totals[dist.get_rank(group)] else np.zeros(0, np.int32)
+        flat[:len(cat)] = torch.from_numpy(cat).to(device)
+    flats = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(flats, flat, group=group)
+    out = [None] * n_rooms
+    for m, f in zip(metas, flats):
+        m, f = m.cpu().numpy(), f.cpu().numpy()
+        o = 0
+        for i, n in m:
+            if i < 0:
+                continue
+            out[int(i)] = f[o:o + int(n)].copy()
+            o += int(n)
+    return out
+
+
+def allreduce_sum(values, device=None, group=None):
+    """Sum a small list of numbers over ranks (throughput accounting)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return list(values)
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().tolist()
+
+
+def allreduce_max(value, device=None, group=None):
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return value
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

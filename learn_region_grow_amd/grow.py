@@ -1,0 +1,395 @@
+"""RegionGrower -- the region-grow loop of test_region_grow.py / test_random_restart.py, batched.
+
+The reference (test_region_grow.py:175-316) grows ONE region of ONE room per ``sess.run``; here
+many rooms are in flight, each contributing one group of slots (one slot for greedy growing,
+several for random restarts, test_random_restart.py:169-197), and every lock-step iteration is
+one pass of HIP kernels over all slots (include/lrg_hip.h).  All loop state lives on the GPU.
+
+Two sources of randomness:
+  rng='counter'  device-side counter stream (Philox keyed by room / seed point / restart / step);
+                 no host round trip inside an iteration (``lrg_grow_step``)        -- throughput
+  rng='legacy'   the reference's own order: one legacy ``numpy.random.RandomState`` per room,
+                 consumed choice / choice / random / random per step (:238-267); sampling
+                 positions and Bernoulli masks are decided on the host from the GPU's logits
+                 exactly as the reference does (scipy-style softmax, float64 uniforms)    -- parity
+"""
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LRG_ACTIVE, LRG_DONE, LRG_WAIT, LRG_IDLE,
+                   LRG_STATS_WORDS, LRG_DONE_RING, REASON_NAMES)
+from .lrgnet import _ptr, _stream_ptr
+
+POLICIES = {'net': 0, 'threshold': 1, 'gt': 2}
+
+
+def _softmax_conf(logits):
+    """scipy.special.softmax(x, axis=-1)[:, 1] in float32 (test_region_grow.py:262-263)."""
+    m = logits.max(axis=-1, keepdims=True)
+    e = np.exp(logits - m)
+    return (e / e.sum(axis=-1, keepdims=True))[..., 1]
+
+
+class RoomResult:
+    def __init__(self, room_id, cluster_label, filled_label, regions):
+        self.room_id = room_id
+        self.cluster_label = cluster_label      # before fill-in (test_region_grow.py:176,:214)
+        self.filled_label = filled_label        # after fill-in (:308-316)
+        self.regions = regions                  # dicts: seed, steps, points, reason, labeled, restart
+
+    @property
+    def total_steps(self):
+        return sum(r['steps'] for r in self.regions)
+
+
+class RegionGrower:
+    def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
+                 resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=2, pipeline_depth=4):
+        self.lib = _lib.load()
+        self.net = net
+        self.dev = net.device
+        self.rng = rng
+        assert rng in ('counter', 'legacy')
+        if group_size is None:
+            group_size = restarts if rng == 'counter' else 1
+        if rng == 'legacy' and group_size != 1:
+            raise ValueError("rng='legacy' replays the reference's sequential stream: group_size must be 1")
+        self.G = int(group_size)
+        self.n_groups = int(rooms_in_flight)
+        self.S = self.n_groups * self.G
+        self.advance_rounds = int(advance_rounds)
+        self.depth = int(pipeline_depth)
+        self.seed = seed
+        p = LrgGrowParams()
+        p.resolution = resolution
+        p.feature_size = net.feature_size
+        p.n_inlier = net.num_inlier_points
+        p.n_neighbor = net.num_neighbor_points
+        p.cluster_threshold = cluster_threshold
+        p.restarts = restarts
+        p.group_size = self.G
+        p.max_region_steps = max_region_steps
+        p.rng_seed = seed & 0xFFFFFFFF
+        p.policy = POLICIES[policy]
+        self.params = p
+        self.policy = policy
+        self.debug_hook = None      # tests: called once per active slot per legacy iteration with the step's data
+        self._rooms_loaded = False
+
+    # ------------------------------------------------------------------------------------------
+    def load_rooms(self, rooms):
+        """rooms: list of dicts with points [n,F] float32, obj_id [n], order [n] (= argsort(curvatures),
+        test_region_grow.py:183) and optional room_id.  Uploads them, voxelises (:175) and builds the
+        per-room voxel tables."""
+        dev, F, S = self.dev, self.net.feature_size, self.S
+        ns = [int(len(r['points'])) for r in rooms]
+        offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+        tot = int(offs[-1])
+        self.room_n, self.room_off, self.n_rooms = ns, offs, len(rooms)
+        pts = np.concatenate([np.ascontiguousarray(r['points'], dtype=np.float32) for r in rooms], axis=0)
+        assert pts.shape[1] == F
+        self.d_points = torch.from_numpy(pts).to(dev)
+        self.d_obj = torch.from_numpy(np.concatenate([np.asarray(r['obj_id']).astype(np.int32) for r in rooms])).to(dev)
+        self.d_order = torch.from_numpy(np.concatenate([np.asarray(r['order']).astype(np.int32) for r in rooms])).to(dev)
+        self.d_vox = torch.empty((tot, 3), dtype=torch.int32, device=dev)
+        self.d_visited = torch.zeros(tot, dtype=torch.uint8, device=dev)
+        self.d_label = torch.zeros(tot, dtype=torch.int32, device=dev)
+        self.d_filled = torch.zeros(tot, dtype=torch.int32, device=dev)
+        self.d_rlog = torch.zeros((tot, 6), dtype=torch.int32, device=dev)
+        caps = [max(16, 1 << int(np.ceil(np.log2(2 * n + 1)))) for n in ns]
+        hoffs = np.concatenate([[0], np.cumsum(caps)]).astype(np.int64)
+        self.d_hkeys = torch.empty(int(hoffs[-1]), dtype=torch.int64, device=dev)
+        self.d_hvals = torch.zeros(int(hoffs[-1]), dtype=torch.int32, device=dev)
+        self.d_dup = torch.zeros(1, dtype=torch.int32, device=dev)
+        st = _stream_ptr()
+        _lib.check(self.lib.lrg_voxelize(_ptr(self.d_points), tot, F, ctypes.c_float(self.params.resolution),
+                                         _ptr(self.d_vox), st), 'lrg_voxelize')
+        self.h_rooms = (LrgRoom * len(rooms))()
+        for r, room in enumerate(rooms):
+            o, n, ho = int(offs[r]), ns[r], int(hoffs[r])
+            R = self.h_rooms[r]
+            R.points = self.d_points.data_ptr() + o * F * 4
+            R.voxels = self.d_vox.data_ptr() + o * 12
+            R.obj_id = self.d_obj.data_ptr() + o * 4
+            R.order = self.d_order.data_ptr() + o * 4
+            R.visited = self.d_visited.data_ptr() + o
+            R.label = self.d_label.data_ptr() + o * 4
+            R.hash_keys = self.d_hkeys.data_ptr() + ho * 8
+            R.hash_vals = self.d_hvals.data_ptr() + ho * 4
+            R.region_log = self.d_rlog.data_ptr() + o * 24
+            R.n = n
+            R.hash_mask = caps[r] - 1
+            R.next_cluster_id = 1
+            R.seed_cursor = 0
+            R.n_regions = 0
+            R.done = 0
+            R.room_id = int(room.get('room_id', r))
+            _lib.check(self.lib.lrg_voxel_hash_build(ctypes.c_void_p(R.voxels), n, ctypes.c_void_p(R.hash_keys),
+                                                     ctypes.c_void_p(R.hash_vals), R.hash_mask, _ptr(self.d_dup), st),
+                       'lrg_voxel_hash_build')
+        dup = int(self.d_dup.item())
+        if dup:
+            raise _lib.LrgHipError('room voxels are not unique / out of range (flag %d): rooms must be equalised at '
+                                   'the grow resolution (test_region_grow.py:125-134)' % dup)
+        self.room_ids = [int(self.h_rooms[r].room_id) for r in range(len(rooms))]
+        self.d_rooms = torch.from_numpy(np.frombuffer(bytes(self.h_rooms), dtype=np.uint8).copy()).to(dev)
+        # ---- slots ----
+        cap = max(ns)
+        self.cap = cap
+        self.d_cur = torch.zeros((S, cap), dtype=torch.uint8, device=dev)
+        self.d_best = torch.zeros((S, cap), dtype=torch.uint8, device=dev)
+        self.d_curidx = torch.zeros((S, cap), dtype=torch.int32, device=dev)
+        self.d_candidx = torch.zeros((S, cap), dtype=torch.int32, device=dev)
+        self.h_slots = (LrgSlot * S)()
+        for s in range(S):
+            sl = self.h_slots[s]
+            sl.cur = self.d_cur.data_ptr() + s * cap
+            sl.best = self.d_best.data_ptr() + s * cap
+            sl.cur_idx = self.d_curidx.data_ptr() + s * cap * 4
+            sl.cand_idx = self.d_candidx.data_ptr() + s * cap * 4
+            sl.room = -1
+            sl.status = LRG_IDLE
+            sl.seed = -1
+        self.d_slots = torch.from_numpy(np.frombuffer(bytes(self.h_slots), dtype=np.uint8).copy()).to(dev)
+        # ---- step buffers ----
+        Ni, Nn = self.net.num_inlier_points, self.net.num_neighbor_points
+        self.b_center = torch.zeros((S, 16), dtype=torch.float32, device=dev)
+        self.b_sin = torch.zeros((S, Ni), dtype=torch.int32, device=dev)
+        self.b_snb = torch.zeros((S, Nn), dtype=torch.int32, device=dev)
+        self.b_inl = torch.zeros((S, Ni, F), dtype=torch.float32, device=dev)
+        self.b_nbr = torch.zeros((S, Nn, F), dtype=torch.float32, device=dev)
+        self.b_gtr = torch.zeros((S, Ni), dtype=torch.int32, device=dev)
+        self.b_gta = torch.zeros((S, Nn), dtype=torch.int32, device=dev)
+        self.b_add = torch.zeros((S, Nn, 2), dtype=torch.float32, device=dev)
+        self.b_rmv = torch.zeros((S, Ni, 2), dtype=torch.float32, device=dev)
+        self.b_amask = torch.zeros((S, Nn), dtype=torch.uint8, device=dev)
+        self.b_rmask = torch.zeros((S, Ni), dtype=torch.uint8, device=dev)
+        self.d_stats = torch.zeros(LRG_STATS_WORDS, dtype=torch.int64, device=dev)
+        ws = self.net._workspace(S)
+        sb = LrgStepBuffers()
+        sb.center, sb.sample_in, sb.sample_nb = self.b_center.data_ptr(), self.b_sin.data_ptr(), self.b_snb.data_ptr()
+        sb.inlier, sb.neighbor = self.b_inl.data_ptr(), self.b_nbr.data_ptr()
+        sb.gt_remove, sb.gt_add = self.b_gtr.data_ptr(), self.b_gta.data_ptr()
+        sb.add_logits, sb.rmv_logits = self.b_add.data_ptr(), self.b_rmv.data_ptr()
+        sb.workspace, sb.workspace_bytes = ws.data_ptr(), ws.numel()
+        sb.stats = self.d_stats.data_ptr()
+        self.step_buffers = sb
+        self.h_stats = [torch.zeros(LRG_STATS_WORDS, dtype=torch.int64).pin_memory() for _ in range(self.depth)]
+        self.ev = [torch.cuda.Event() for _ in range(self.depth)]
+        self.group_room = [-1] * self.n_groups
+        self.iterations = 0
+        self._seen_done = 0
+        self._rooms_loaded = True
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    def reset_room(self, r):
+        """Return room r to its pristine state (visited / labels cleared, cursor at 0)."""
+        o, n = int(self.room_off[r]), self.room_n[r]
+        self.d_visited[o:o + n].zero_()
+        self.d_label[o:o + n].zero_()
+        R = self.h_rooms[r]
+        R.next_cluster_id, R.seed_cursor, R.n_regions, R.done = 1, 0, 0, 0
+        sz = ctypes.sizeof(LrgRoom)
+        buf = np.frombuffer(bytes(R), dtype=np.uint8).copy()
+        self.d_rooms[r * sz:(r + 1) * sz].copy_(torch.from_numpy(buf))
+
+    def bind(self, group, r):
+        """Bind slot group `group` to room r: every slot waits with seed -1, so the next lrg_advance
+        picks the room's first seed (:186-188)."""
+        sz = ctypes.sizeof(LrgSlot)
+        for s in range(group * self.G, (group + 1) * self.G):
+            sl = self.h_slots[s]
+            sl.room = r
+            sl.status = LRG_WAIT if r >= 0 else LRG_IDLE
+            sl.seed = -1
+            sl.restart = sl.step = sl.steps_total = sl.stuck = 0
+            sl.updated = -1
+            sl.count = -1
+            sl.best_count = -1
+        a, b = group * self.G, (group + 1) * self.G
+        buf = np.frombuffer(bytes(self.h_slots), dtype=np.uint8)[a * sz:b * sz].copy()
+        self.d_slots[a * sz:b * sz].copy_(torch.from_numpy(buf))
+        self.group_room[group] = r
+
+    def fill(self, r):
+        o, n = int(self.room_off[r]), self.room_n[r]
+        F = self.net.feature_size
+        _lib.check(self.lib.lrg_nn1_fill(ctypes.c_void_p(self.d_points.data_ptr() + o * F * 4), n, F,
+                                         ctypes.c_void_p(self.d_label.data_ptr() + o * 4),
+                                         ctypes.c_void_p(self.d_filled.data_ptr() + o * 4), _stream_ptr()), 'lrg_nn1_fill')
+
+    # ------------------------------------------------------------------------------------------
+    def enqueue_iteration(self):
+        """One lock-step iteration, device-side randomness (no host sync)."""
+        flags = _lib.LRG_FWD_FUSE_POOL if self.net.fuse_pool else 0
+        rc = self.lib.lrg_grow_step(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, ctypes.byref(self.params),
+                                    ctypes.byref(self.net._w), ctypes.byref(self.step_buffers), self.advance_rounds,
+                                    flags, _stream_ptr())
+        _lib.check(rc, 'lrg_grow_step')
+        k = self.iterations % self.depth
+        self.h_stats[k].copy_(self.d_stats, non_blocking=True)
+        self.ev[k].record()
+        self.iterations += 1
+
+    def poll_done(self, wait=False):
+        """Groups whose room finished, as seen `depth-1` iterations ago (or now, if wait)."""
+        if self.iterations == 0:
+            return []
+        k = (self.iterations - 1) % self.depth if wait else self.iterations % self.depth
+        if not wait and self.iterations < self.depth:
+            return []
+        self.ev[k].synchronize()
+        st = self.h_stats[k]
+        done_total = int(st[1])
+        out = []
+        if done_total - self._seen_done > LRG_DONE_RING:
+            raise _lib.LrgHipError('done ring overflow')
+        for j in range(self._seen_done, done_total):
+            out.append(int(st[4 + (j % LRG_DONE_RING)]) // self.G)
+        self._seen_done = done_total
+        self.last_stats = (int(st[0]), int(st[1]), int(st[2]))
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def _legacy_iteration(self, streams):
+        lib, st, P = self.lib, _stream_ptr(), ctypes.byref(self.params)
+        S, Ni, Nn = self.S, self.net.num_inlier_points, self.net.num_neighbor_points
+        _lib.check(lib.lrg_bbox_stop(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, st), 'lrg_bbox_stop')
+        for _ in range(self.advance_rounds):
+            _lib.check(lib.lrg_advance(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.d_stats), st), 'lrg_advance')
+            _lib.check(lib.lrg_box_query(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, st), 'lrg_box_query')
+        slots = self._read_slots()
+        active = [s for s in range(S) if slots[s].status == LRG_ACTIVE]
+        if active:
+            sin = np.zeros((S, Ni), dtype=np.int32)
+            snb = np.zeros((S, Nn), dtype=np.int32)
+            for s in active:
+                rs = streams[self.group_room[s // self.G]]
+                nc, ne = slots[s].nc, slots[s].ne
+                # test_region_grow.py:237-240 / :249-252, same calls in the same order
+                sin[s] = rs.choice(nc, Ni, replace=False) if nc >= Ni else \
+                    list(range(nc)) + list(rs.choice(nc, Ni - nc, replace=True))
+                snb[s] = rs.choice(ne, Nn, replace=False) if ne >= Nn else \
+                    list(range(ne)) + list(rs.choice(ne, Nn - ne, replace=True))
+            self.b_sin.copy_(torch.from_numpy(sin))
+            self.b_snb.copy_(torch.from_numpy(snb))
+            _lib.check(lib.lrg_median(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.b_center), st), 'lrg_median')
+            _lib.check(lib.lrg_gather_center(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.b_sin),
+                                             _ptr(self.b_snb), _ptr(self.b_center), _ptr(self.b_inl), _ptr(self.b_nbr),
+                                             _ptr(self.b_gtr), _ptr(self.b_gta), st), 'lrg_gather_center')
+            self.net.forward(self.b_inl, self.b_nbr, self.b_add, self.b_rmv)
+            amask = rmask = None
+            need_logits = self.policy != 'gt'
+            if need_logits:
+                add = self.b_add.cpu().numpy()
+                rmv = self.b_rmv.cpu().numpy()
+            am = np.zeros((S, Nn), dtype=np.uint8)
+            rm = np.zeros((S, Ni), dtype=np.uint8)
+            for s in active:
+                rs = streams[self.group_room[s // self.G]]
+                u_add = rs.random_sample(Nn)                                                # :266
+                u_rmv = rs.random_sample(Ni)                                                # :267
+                if need_logits:
+                    add_conf, rmv_conf = _softmax_conf(add[s]), _softmax_conf(rmv[s])       # :262-263
+                    if self.policy == 'net':
+                        am[s], rm[s] = u_add < add_conf, u_rmv < rmv_conf
+                    else:
+                        am[s], rm[s] = add_conf > 0.5, rmv_conf > 0.5
+            if need_logits:
+                self.b_amask.copy_(torch.from_numpy(am))
+                self.b_rmask.copy_(torch.from_numpy(rm))
+                amask, rmask = self.b_amask, self.b_rmask
+            if self.debug_hook is not None:
+                center = self.b_center.cpu().numpy()
+                inl, nbr = self.b_inl.cpu().numpy(), self.b_nbr.cpu().numpy()
+                cur = self.d_cur.cpu().numpy()
+                for s in active:
+                    r = self.group_room[s // self.G]
+                    self.debug_hook(dict(slot=s, room=r, seed=slots[s].seed, restart=slots[s].restart, step=slots[s].step,
+                                         nc=slots[s].nc, ne=slots[s].ne, center=center[s].copy(), inlier=inl[s].copy(),
+                                         neighbor=nbr[s].copy(), subset_in=sin[s].copy(), subset_nb=snb[s].copy(),
+                                         add=add[s].copy() if need_logits else None,
+                                         rmv=rmv[s].copy() if need_logits else None,
+                                         add_mask=am[s].astype(bool), rmv_mask=rm[s].astype(bool),
+                                         mask_before=cur[s, :self.room_n[r]].astype(bool),
+                                         min_dims=np.array(slots[s].mn[:]), max_dims=np.array(slots[s].mx[:])))
+            prm = LrgGrowParams.from_buffer_copy(self.params)
+            if self.policy == 'threshold':
+                prm.policy = 0      # the masks were thresholded on the host
+            _lib.check(lib.lrg_mask_update(_ptr(self.d_slots), _ptr(self.d_rooms), S, ctypes.byref(prm), _ptr(self.b_inl),
+                                           _ptr(self.b_nbr), _ptr(self.b_center), _ptr(self.b_add), _ptr(self.b_rmv),
+                                           _ptr(self.b_gtr), _ptr(self.b_gta), _ptr(amask), _ptr(rmask),
+                                           _ptr(self.d_stats), st), 'lrg_mask_update')
+        self.iterations += 1
+        return slots
+
+    def _read_slots(self):
+        raw = self.d_slots.cpu().numpy().tobytes()
+        return (LrgSlot * self.S).from_buffer_copy(raw)
+
+    def _read_rooms(self):
+        raw = self.d_rooms.cpu().numpy().tobytes()
+        return (LrgRoom * self.n_rooms).from_buffer_copy(raw)
+
+    # ------------------------------------------------------------------------------------------
+    def run(self, rooms, fill=True, max_iterations=None, legacy_seeds=None):
+        """Grow every room once; returns a RoomResult per room (in input order)."""
+        self.load_rooms(rooms)
+        queue = list(range(self.n_rooms))
+        for g in range(self.n_groups):
+            self.bind(g, queue.pop(0) if queue else -1)
+        finished = 0
+        if self.rng == 'legacy':
+            seeds = legacy_seeds if legacy_seeds is not None else [self.room_ids[r] for r in range(self.n_rooms)]
+            streams = [np.random.RandomState(sd) for sd in seeds]
+            while finished < self.n_rooms:
+                slots = self._legacy_iteration(streams)
+                for g in range(self.n_groups):
+                    r = self.group_room[g]
+                    if r >= 0 and slots[g * self.G].status == LRG_DONE:
+                        if fill:
+                            self.fill(r)
+                        finished += 1
+                        self.bind(g, queue.pop(0) if queue else -1)
+                if max_iterations and self.iterations >= max_iterations:
+                    break
+        else:
+            while finished < self.n_rooms:
+                self.enqueue_iteration()
+                for g in self.poll_done():
+                    r = self.group_room[g]
+                    if fill:
+                        self.fill(r)
+                    finished += 1
+                    self.bind(g, queue.pop(0) if queue else -1)
+                if max_iterations and self.iterations >= max_iterations:
+                    break
+        torch.cuda.synchronize()
+        return self.collect(fill)
+
+    def collect(self, fill=True):
+        rooms = self._read_rooms()
+        label = self.d_label.cpu().numpy()
+        filled = self.d_filled.cpu().numpy() if fill else None
+        rlog = self.d_rlog.cpu().numpy()
+        out = []
+        for r in range(self.n_rooms):
+            o, n = int(self.room_off[r]), self.room_n[r]
+            regs = []
+            for k in range(rooms[r].n_regions):
+                row = rlog[o + k]
+                regs.append(dict(seed=int(row[0]), steps=int(row[1]), points=int(row[2]),
+                                 reason=REASON_NAMES.get(int(row[3]), str(int(row[3]))), labeled=bool(row[4]),
+                                 restart=int(row[5])))
+            out.append(RoomResult(self.room_ids[r], label[o:o + n].astype(np.int64),
+                                  filled[o:o + n].astype(np.int64) if fill else None, regs))
+        return out
+
+    @property
+    def instance_steps(self):
+        return int(self.d_stats[2].item())

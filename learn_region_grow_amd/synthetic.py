@@ -129,34 +129,42 @@ def _cuboid(rs, lo, size, n_pts, obj, xyz_noise):
     return pcd
 
 
-def area5_shaped_room(target_equalized_points, seed, n_furniture=None, resolution=0.1):
-    """Box room + cuboid furniture; density tuned so the equalised count ~= target.
-
-    Surfaces sampled at >= ~2 raw points per occupied voxel equalise to about
-    (surface area / resolution^2) points, so the room is scaled to the surface area the target
-    needs and then sampled densely enough to fill those voxels."""
-    rs = np.random.RandomState(seed)
-    wlh = room_dims(rs)
-    wlh[:2] = np.minimum(wlh[:2], 15.0)
-    if n_furniture is None:
-        n_furniture = int(rs.randint(10, 61))
-    sizes = rs.uniform(0.3, 1.5, size=(n_furniture, 3))
-    f_area = float(np.sum(2 * (sizes[:, 0] * sizes[:, 1] + sizes[:, 0] * sizes[:, 2] + sizes[:, 1] * sizes[:, 2])))
-    want_area = target_equalized_points * resolution ** 2 / 1.15   # voxelised planes cover ~1.15 voxels per res^2
-    box_area = max(want_area - f_area, 0.4 * want_area)
-    w, l, h = wlh
-    s = np.sqrt(box_area / (2 * (w * l + w * h + l * h)))
-    w, l = max(w * s, 1.2), max(l * s, 1.2)
-    h = float(np.clip(h * min(s, 1.0), 2.0, 4.0))
+def _area5_geometry(rs_seed, w, l, h, sizes, resolution):
+    rs = np.random.RandomState(rs_seed)
     raw_per_area = 2.5 / resolution ** 2
     density = float(np.sqrt(1.0 / raw_per_area))
     parts = [generate_room(w, l, h, rs, density=density)]
-    for k in range(n_furniture):
+    for k in range(len(sizes)):
         sz = np.minimum(sizes[k], [0.8 * w, 0.8 * l, 0.8 * h])
         lo = np.array([rs.uniform(0.05, w - sz[0] - 0.05), rs.uniform(0.05, l - sz[1] - 0.05), 0.0])
         a = 2 * (sz[0] * sz[1] + sz[0] * sz[2] + sz[1] * sz[2])
         parts.append(_cuboid(rs, lo, sz, max(8, int(a * raw_per_area)), 7 + k, 0.01))
     return np.vstack(parts)
+
+
+def area5_shaped_room(target_equalized_points, seed, n_furniture=None, resolution=0.1):
+    """Box room + cuboid furniture whose equalised (one point per `resolution` voxel) count is within a few
+    percent of the target: the floor plan is rescaled until the voxel count matches (surfaces are sampled at
+    ~2.5 raw points per voxel-sized patch so that equalisation fills them)."""
+    rs = np.random.RandomState(seed)
+    wlh = room_dims(rs)
+    w, l = float(min(wlh[0], 15.0)), float(min(wlh[1], 15.0))
+    h = float(np.clip(wlh[2], 2.2, 4.0))
+    if n_furniture is None:
+        n_furniture = int(rs.randint(10, 61))
+    sizes = rs.uniform(0.3, 1.5, size=(n_furniture, 3))
+    g = 1.0
+    room = None
+    for _ in range(6):
+        ww, ll = max(1.2, w * g), max(1.2, l * g)
+        fs = sizes * min(1.0, max(0.3, g))
+        room = _area5_geometry(seed + 7919, ww, ll, h, fs, resolution)
+        vox = np.round(room[:, :3].astype(np.float32) / np.float32(resolution)).astype(np.int64)
+        count = len(np.unique(vox, axis=0))
+        if abs(count - target_equalized_points) <= 0.03 * target_equalized_points:
+            break
+        g *= float(np.sqrt(target_equalized_points / count)) ** 1.15
+    return room
 
 
 def make_synthetic_weights(seed=0, feature_size=13, lite=0, gain=2.0, bias_std=0.2, add_bias_shift=0.0,

@@ -1,0 +1,39 @@
+"""Synthetic workloads of the shapes BASELINE.json names (no datasets are available offline).
+
+``area5_rooms`` -- "S3DIS Area-5 shape": 68 rooms whose 0.1 m-equalised point counts follow the reference's own
+Area-5 run (learn_region_grow_amd.synthetic.AREA5_POINTS), box rooms + cuboid furniture,
+preprocessed (P0) to the 13-feature layout the loop consumes.  Generation is seeded and cached as .npz.
+"""
+import os
+
+import numpy as np
+
+from . import preprocess, synthetic
+
+
+def make_room(target_points, seed, room_id, resolution=0.1):
+    raw = synthetic.area5_shaped_room(target_points, seed, resolution=resolution).astype(np.float32)
+    p = preprocess.preprocess_room(raw[:, :6], raw[:, 6].astype(int), raw[:, 7].astype(int), resolution=resolution)
+    return dict(points=p['points'], obj_id=p['obj_id'], order=p['order'].astype(np.int32), room_id=room_id)
+
+
+def area5_rooms(n_rooms=68, seed_base=1000, cache_dir=None, targets=None, scale=1.0):
+    targets = list(targets if targets is not None else synthetic.AREA5_POINTS)
+    rooms = []
+    cache = None
+    if cache_dir:
+        os.makedirs(cache_dir, exist_ok=True)
+        cache = os.path.join(cache_dir, 'lrg_area5_%d_%d_%g.npz' % (n_rooms, seed_base, scale))
+        if os.path.exists(cache):
+            z = np.load(cache)
+            return [dict(points=z['p%d' % i], obj_id=z['o%d' % i], order=z['s%d' % i], room_id=int(z['ids'][i]))
+                    for i in range(n_rooms)]
+    for i in range(n_rooms):
+        t = max(300, int(targets[i % len(targets)] * scale))
+        rooms.append(make_room(t, seed_base + i, seed_base + i))
+    if cache:
+        d = {'ids': np.array([r['room_id'] for r in rooms])}
+        for i, r in enumerate(rooms):
+            d['p%d' % i], d['o%d' % i], d['s%d' % i] = r['points'], r['obj_id'], r['order']
+        np.savez(cache, **d)
+    return rooms

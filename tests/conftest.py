@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+CLASSES_S3DIS = ['clutter', 'board', 'bookcase', 'beam', 'chair', 'column', 'door', 'sofa', 'table', 'window',
+                 'ceiling', 'floor', 'wall']   # class_util.py:5 of the reference (log-line tag only)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+@pytest.fixture(scope='session')
+def hip_lib():
+    """The in-tree C-ABI library, built on demand (hipcc cross-compiles without a GPU)."""
+    from learn_region_grow_amd import _lib
+    _lib.build()
+    return _lib.load()
+
+
+@pytest.fixture(scope='session')
+def cuda_device(hip_lib):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail('GPU test selected but no GPU is visible (there is no CPU fallback)')
+    return torch.device('cuda:0')

@@ -1,0 +1,59 @@
+"""CPU: the N>1 path (room sharding + final label gather) with world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from learn_region_grow_amd import dist as lrg_dist
+from learn_region_grow_amd.synthetic import AREA5_POINTS
+
+
+def test_lpt_sharding_is_a_balanced_partition():
+    for world in (1, 2, 4, 8):
+        shards = lrg_dist.shard_rooms_lpt(AREA5_POINTS, world)
+        assert sorted(i for s in shards for i in s) == list(range(len(AREA5_POINTS)))
+        loads = [sum(AREA5_POINTS[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(AREA5_POINTS)            # LPT bound
+        assert shards == lrg_dist.shard_rooms_lpt(AREA5_POINTS, world)   # deterministic
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sizes = [50, 7, 31, 12, 90]
+    shards = lrg_dist.shard_rooms_lpt(sizes, world)
+    mine = shards[rank]
+    labels = [np.arange(sizes[i], dtype=np.int32) + 1000 * i for i in mine]     # stand-in per-room labels
+    allrooms = lrg_dist.gather_room_labels(mine, labels, len(sizes))
+    ok = all(np.array_equal(allrooms[i], np.arange(sizes[i], dtype=np.int32) + 1000 * i) for i in range(len(sizes)))
+    tot = lrg_dist.allreduce_sum([len(mine), sum(sizes[i] for i in mine)])
+    mx = lrg_dist.allreduce_max(float(rank))
+    q.put((rank, ok, tot, mx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_world_size_2_gloo():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, tot, mx in res:
+        assert ok and tot == [5.0, 190.0] and mx == 1.0
+
+
+def test_single_process_gather_is_identity():
+    out = lrg_dist.gather_room_labels([1, 0], [np.array([5, 6]), np.array([7])], 3)
+    assert out[0].tolist() == [7] and out[1].tolist() == [5, 6] and out[2] is None

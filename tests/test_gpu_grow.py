@@ -1,0 +1,164 @@
+"""GPU: the batched region-grow loop (HIP kernels through the C-ABI) against the oracle and the goldens made
+by running the reference's own scripts.
+
+Decomposition: the network is checked to tolerance in test_gpu_net.py; here the oracle loop is
+driven with the SAME GPU network (net_fn) so that every integer / index / mask result must agree exactly."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from learn_region_grow_amd import synthetic, preprocess
+from oracle import grow_ref, rng_ref
+
+pytestmark = pytest.mark.gpu
+WEIGHT_KW = dict(seed=0, gain=2.0, bias_std=0.2, add_bias_shift=0.0, rmv_bias_shift=-3.0)
+
+
+@pytest.fixture(scope='module')
+def net(cuda_device):
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    return LrgNetHIP(1, 1, 512, 512, 13, 0, device=cuda_device).load_weights(synthetic.make_synthetic_weights(**WEIGHT_KW))
+
+
+def gpu_net_fn(net):
+    def fn(xi, xn):
+        _, add, _, rmv, _ = net.run(xi, xn)
+        return add, rmv
+    return fn
+
+
+def golden_room(name, room_id=0):
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    return dict(points=g['points'], obj_id=g['obj_id'], order=g['order'], room_id=room_id), g
+
+
+def small_room(seed, n_raw, furniture=0, room_id=0):
+    raw = (synthetic.area5_shaped_room(n_raw, seed, n_furniture=furniture) if furniture
+           else synthetic.generate_room_points(n_raw, seed)).astype(np.float32)
+    p = preprocess.preprocess_room(raw[:, :6], raw[:, 6].astype(int), raw[:, 7].astype(int))
+    return dict(points=p['points'], obj_id=p['obj_id'], order=p['order'], room_id=room_id)
+
+
+def same_regions(got, want):
+    g = [(r['seed'], r['steps'], r['points'], r['reason'], r['labeled']) for r in got]
+    w = [(r['seed'], r['steps'], r['points'], r['reason'], r['labeled']) for r in want]
+    assert g == w, 'first difference at region %d: %s vs %s' % (
+        next(i for i, (a, b) in enumerate(zip(g + [None], w + [None])) if a != b),
+        (g + [None])[next(i for i, (a, b) in enumerate(zip(g + [None], w + [None])) if a != b)],
+        (w + [None])[next(i for i, (a, b) in enumerate(zip(g + [None], w + [None])) if a != b)])
+
+
+def test_legacy_single_room_step_by_step(net):
+    """One room, reference-order RNG: every step's sampled sets, centre, stacked inputs, masks and the mask
+    itself equal the oracle's; final labels equal the oracle's and the reference script's own output."""
+    from learn_region_grow_amd.grow import RegionGrower
+    room, g = golden_room('greedy_room101')
+    want_steps = []
+    want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.LegacyStream(0),
+                              net_fn=gpu_net_fn(net), hook=want_steps.append)
+    got_steps = []
+    gr = RegionGrower(net, rooms_in_flight=1, rng='legacy', advance_rounds=1)
+    gr.debug_hook = got_steps.append
+    res = gr.run([room])[0]
+    n = min(len(got_steps), len(want_steps))
+    for i in range(n):
+        a, b = got_steps[i], want_steps[i]
+        ctx = 'step %d (seed %d)' % (i, b['seed'])
+        assert (a['seed'], a['step'], a['nc'], a['ne']) == (b['seed'], b['step'], b['nc'], b['ne']), ctx
+        np.testing.assert_array_equal(a['mask_before'], b['mask_before'], err_msg=ctx)
+        np.testing.assert_array_equal(a['min_dims'], b['min_dims'], err_msg=ctx)
+        np.testing.assert_array_equal(a['subset_in'], b['subset_in'], err_msg=ctx)
+        cen = b['center'].copy()
+        cen[2:6] = 0
+        np.testing.assert_array_equal(a['center'][:13], cen, err_msg=ctx)
+        np.testing.assert_array_equal(a['inlier'], b['inlier'][0], err_msg=ctx)
+        np.testing.assert_array_equal(a['neighbor'], b['neighbor'][0], err_msg=ctx)
+        np.testing.assert_array_equal(a['add'], b['add'][0], err_msg=ctx)
+        np.testing.assert_array_equal(a['add_mask'], b['add_mask'], err_msg=ctx)
+        np.testing.assert_array_equal(a['rmv_mask'], b['rmv_mask'], err_msg=ctx)
+    assert len(got_steps) == len(want_steps)
+    same_regions(res.regions, want.regions)
+    np.testing.assert_array_equal(res.cluster_label, want.cluster_label)
+    np.testing.assert_array_equal(res.filled_label, want.filled_label)
+    # against the reference script's output: identical unless a Bernoulli draw sits within fp32 noise of its
+    # confidence (oracle margin for this room: 1.4e-5)
+    np.testing.assert_array_equal(res.filled_label, g['filled_label'])
+
+
+@pytest.mark.parametrize('name,restarts', [('greedy_room100', 1), ('restart_room103', 10)])
+def test_legacy_matches_reference_script_output(net, name, restarts):
+    from learn_region_grow_amd.grow import RegionGrower
+    room, g = golden_room(name)
+    want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.LegacyStream(0),
+                              net_fn=gpu_net_fn(net), restarts=0 if restarts == 1 else restarts)
+    res = RegionGrower(net, rooms_in_flight=1, rng='legacy', restarts=restarts).run([room])[0]
+    same_regions(res.regions, want.regions)
+    np.testing.assert_array_equal(res.filled_label, want.filled_label)
+    if not np.array_equal(res.filled_label, g['filled_label']):
+        # the oracle itself (NumPy network) reproduces the golden exactly (tests/test_oracle_golden.py); a
+        # difference here can only come from a draw within fp32 noise of its confidence
+        assert want.min_margin < 1e-4, 'labels differ from the reference output without a near-tie'
+        pytest.xfail('near-tie Bernoulli draw (margin %.2e) flipped by fp32 rounding of the logits' % want.min_margin)
+
+
+def test_legacy_many_rooms_in_flight(net):
+    """Rooms are independent: 5 rooms through 2 slots (queue + refill) equal 5 separate oracle runs."""
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = [small_room(200 + i, 500 + 150 * i, room_id=i) for i in range(4)] + [small_room(300, 1500, furniture=4, room_id=4)]
+    res = RegionGrower(net, rooms_in_flight=2, rng='legacy').run(rooms)
+    for i, room in enumerate(rooms):
+        want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.LegacyStream(i),
+                                  net_fn=gpu_net_fn(net))
+        same_regions(res[i].regions, want.regions)
+        np.testing.assert_array_equal(res[i].filled_label, want.filled_label)
+
+
+@pytest.mark.parametrize('restarts,group', [(1, 1), (4, 4), (5, 2)])
+def test_counter_stream_matches_oracle(net, restarts, group):
+    """Device-side randomness (Philox counter stream), restarts batched over slot groups."""
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = [small_room(400 + i, 600 + 200 * i, room_id=10 + i) for i in range(3)]
+    res = RegionGrower(net, rooms_in_flight=2, rng='counter', seed=123, restarts=restarts, group_size=group).run(rooms)
+    for i, room in enumerate(rooms):
+        want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None,
+                                  rng_ref.CounterStream(123, room['room_id']), net_fn=gpu_net_fn(net),
+                                  restarts=0 if restarts == 1 else restarts)
+        if want.min_margin < 2e-6:
+            pytest.skip('near-tie draw in the oracle run (margin %.1e)' % want.min_margin)
+        same_regions(res[i].regions, want.regions)
+        np.testing.assert_array_equal(res[i].cluster_label, want.cluster_label)
+        np.testing.assert_array_equal(res[i].filled_label, want.filled_label)
+
+
+@pytest.mark.parametrize('policy', ['gt', 'threshold'])
+def test_policies_and_step_cap(net, policy):
+    from learn_region_grow_amd.grow import RegionGrower
+    room = small_room(500, 1200, furniture=3, room_id=7)
+    res = RegionGrower(net, rooms_in_flight=1, rng='counter', seed=5, policy=policy, max_region_steps=20).run([room])[0]
+    want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.CounterStream(5, 7),
+                              net_fn=gpu_net_fn(net), policy=policy, max_region_steps=20)
+    same_regions(res.regions, want.regions)
+    np.testing.assert_array_equal(res.filled_label, want.filled_label)
+
+
+def test_results_do_not_depend_on_batching(net):
+    """Counter-stream draws are a function of (room, seed point, restart, step): 1 or 3 rooms in flight, any order."""
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = [small_room(600 + i, 700, room_id=20 + i) for i in range(3)]
+    a = RegionGrower(net, rooms_in_flight=1, rng='counter', seed=9).run(rooms)
+    b = RegionGrower(net, rooms_in_flight=3, rng='counter', seed=9).run(rooms[::-1])[::-1]
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x.filled_label, y.filled_label)
+
+
+def test_unequalised_room_is_rejected(net):
+    from learn_region_grow_amd.grow import RegionGrower
+    from learn_region_grow_amd._lib import LrgHipError
+    room = small_room(700, 500)
+    room['points'] = np.concatenate([room['points'], room['points'][:1]])     # two points in one voxel
+    room['obj_id'] = np.concatenate([room['obj_id'], room['obj_id'][:1]])
+    room['order'] = np.arange(len(room['points']))
+    with pytest.raises(LrgHipError):
+        RegionGrower(net, rooms_in_flight=1).load_rooms([room])

@@ -1,0 +1,117 @@
+"""GPU: LrgNet forward through the C-ABI (HIP kernels) against the oracle and the reference-made goldens.
+Tolerance: |delta| <= 1e-4 + 1e-5*|x| relative to the activation scale of the layer."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from learn_region_grow_amd import synthetic
+from oracle import lrgnet_ref
+
+pytestmark = pytest.mark.gpu
+WEIGHT_KW = dict(seed=0, gain=2.0, bias_std=0.2, add_bias_shift=0.0, rmv_bias_shift=-3.0)
+
+
+def close(got, want, what):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = np.abs(got - want)
+    tol = 1e-4 * scale + 1e-5 * np.abs(want)
+    assert (err <= tol).all(), '%s: max err %.3e (scale %.3e) at %s' % (what, err.max(), scale, np.unravel_index(err.argmax(), err.shape))
+
+
+def make_net(cuda_device, lite, F, ni, nn, fuse_pool=False):
+    import torch
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    w = synthetic.make_synthetic_weights(feature_size=F, lite=lite, **WEIGHT_KW)
+    net = LrgNetHIP(1, 1, ni, nn, F, lite, device=cuda_device, fuse_pool=fuse_pool).load_weights(w)
+    return net, w
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'lrgnet_*.npz'))), ids=os.path.basename)
+@pytest.mark.parametrize('fuse_pool', [False, True])
+def test_forward_matches_reference_goldens_layer_by_layer(cuda_device, path, fuse_pool):
+    import torch
+    g = np.load(path)
+    lite = int(g['lite'])
+    lite = None if lite < 0 else lite
+    F = int(g['feature_size'])
+    B, ni = g['inlier'].shape[:2]
+    nn = g['neighbor'].shape[1]
+    net, w = make_net(cuda_device, lite, F, ni, nn, fuse_pool)
+    xi = torch.from_numpy(g['inlier']).to(cuda_device)
+    xn = torch.from_numpy(g['neighbor']).to(cuda_device)
+    add, rmv = net.forward(xi, xn)
+    torch.cuda.synchronize()
+    nc = len(net.conv_channels)
+    for i in range(nc):
+        close(net.intermediate('conv', i, B).cpu().numpy().reshape(g['conv%d' % i].shape), g['conv%d' % i], 'conv%d' % i)
+        close(net.intermediate('neighbor_conv', i, B).cpu().numpy().reshape(g['neighbor_conv%d' % i].shape),
+              g['neighbor_conv%d' % i], 'neighbor_conv%d' % i)
+    close(net.intermediate('pooled', 0, B).cpu().numpy().reshape(g['pooled'].shape), g['pooled'], 'pooled')
+    for i in range(len(net.conv2_channels)):
+        close(net.intermediate('add_hidden', i, B).cpu().numpy().reshape(g['add_conv%d' % i].shape), g['add_conv%d' % i], 'add_conv%d' % i)
+        close(net.intermediate('remove_hidden', i, B).cpu().numpy().reshape(g['remove_conv%d' % i].shape), g['remove_conv%d' % i], 'remove_conv%d' % i)
+    close(add.cpu().numpy(), g['add_output'], 'add_output')
+    close(rmv.cpu().numpy(), g['remove_output'], 'remove_output')
+    # the reference-shaped run() wrapper, with the logged scalars
+    loss, a, add_acc, r, rmv_acc = net.run(g['inlier'], g['neighbor'], g['add_mask'], g['rmv_mask'])
+    np.testing.assert_allclose(loss, g['loss'], rtol=1e-4)
+    assert abs(add_acc - g['add_acc']) <= 1.0 / nn + 1e-6 and abs(rmv_acc - g['remove_acc']) <= 1.0 / ni + 1e-6
+
+
+@pytest.mark.parametrize('B', [1, 3, 68])
+@pytest.mark.parametrize('fuse_pool', [False, True])
+def test_forward_full_size_against_oracle(cuda_device, B, fuse_pool):
+    """The shape the loop uses: 512 inliers + 512 neighbours x 13 features (test_region_grow.py:22-24)."""
+    import torch
+    net, w = make_net(cuda_device, 0, 13, 512, 512, fuse_pool)
+    rs = np.random.RandomState(B)
+    xi = (rs.randn(B, 512, 13) * 0.5).astype(np.float32)
+    xn = (rs.randn(B, 512, 13) * 0.5).astype(np.float32)
+    xi[:, 300:] = xi[:, :212]          # duplicated rows, as the padding rule produces (:240)
+    add, rmv = net.forward(torch.from_numpy(xi).to(cuda_device), torch.from_numpy(xn).to(cuda_device))
+    take = slice(0, min(B, 3))
+    wadd, wrmv = lrgnet_ref.forward(w, xi[take], xn[take], dtype=np.float64)
+    # instances are independent: the first few must equal the oracle run on them alone
+    close(add.cpu().numpy()[take], wadd, 'add')
+    close(rmv.cpu().numpy()[take], wrmv, 'rmv')
+    if B > 3:
+        wadd, wrmv = lrgnet_ref.forward(w, xi[-1:], xn[-1:], dtype=np.float64)
+        close(add.cpu().numpy()[-1:], wadd, 'add[-1]')
+        close(rmv.cpu().numpy()[-1:], wrmv, 'rmv[-1]')
+    # duplicate rows give identical logits; permuting rows permutes logits (max-pool is order-free)
+    r = rmv.cpu().numpy()
+    np.testing.assert_array_equal(r[:, 300:], r[:, :212])
+    perm = rs.permutation(512)
+    add2, rmv2 = net.forward(torch.from_numpy(xi[:, perm].copy()).to(cuda_device), torch.from_numpy(xn).to(cuda_device))
+    np.testing.assert_allclose(rmv2.cpu().numpy(), r[:, perm], rtol=0, atol=1e-4 * max(1, np.abs(r).max()))
+
+
+def test_single_layer_entry_points(cuda_device, hip_lib):
+    import ctypes
+    import torch
+    from learn_region_grow_amd.lrgnet import _ptr, _stream_ptr
+    from learn_region_grow_amd import _lib
+    rs = np.random.RandomState(3)
+    for rows, cin, cout in [(128, 13, 64), (200, 64, 128), (64, 128, 512), (77, 64, 2), (130, 12, 64)]:
+        x = rs.randn(rows, cin).astype(np.float32)
+        w = rs.randn(cin, cout).astype(np.float32)
+        b = rs.randn(cout).astype(np.float32)
+        dx, dw, db = [torch.from_numpy(a).to(cuda_device) for a in (x, w, b)]
+        dy = torch.empty((rows, cout), dtype=torch.float32, device=cuda_device)
+        _lib.check(hip_lib.lrg_pointwise_layer(_ptr(dx), cin, _ptr(dw), cout, _ptr(db), _ptr(dy), rows, cin, cout, 1, 0, 0,
+                                               None, 0, _stream_ptr()), 'lrg_pointwise_layer')
+        want = np.maximum(x.astype(np.float64) @ w.astype(np.float64) + b, 0)
+        close(dy.cpu().numpy(), want, 'layer %dx%dx%d' % (rows, cin, cout))
+    # segmax
+    x = rs.randn(5, 40, 96).astype(np.float32)
+    dx = torch.from_numpy(x).to(cuda_device)
+    out = torch.zeros((5, 200), dtype=torch.float32, device=cuda_device)
+    _lib.check(hip_lib.lrg_segmax(_ptr(dx), ctypes.c_void_p(out.data_ptr() + 4 * 100), 5, 40, 96, 200, _stream_ptr()), 'lrg_segmax')
+    np.testing.assert_array_equal(out.cpu().numpy()[:, 100:196], x.max(axis=1))
+    # bad arguments are rejected, not launched
+    assert hip_lib.lrg_pointwise_layer(None, 4, None, 4, None, None, 4, 4, 4, 1, 0, 0, None, 0, None) <= -1000

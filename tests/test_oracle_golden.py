@@ -1,0 +1,97 @@
+"""CPU: the oracle against golden vectors produced by the REFERENCE's own code
+(tests/golden/make_golden.py executes learn_region_grow_util.LrgNet.__init__,
+test_region_grow.py and test_random_restart.py unmodified)."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, CLASSES_S3DIS
+from learn_region_grow_amd import synthetic, preprocess
+from oracle import grow_ref, lrgnet_ref, metrics_ref, preprocess_ref, rng_ref
+
+WEIGHT_KW = dict(seed=0, gain=2.0, bias_std=0.2, add_bias_shift=0.0, rmv_bias_shift=-3.0)
+
+
+def digest(w):
+    h = hashlib.sha256()
+    for k in sorted(w):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(w[k]).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'lrgnet_*.npz'))), ids=os.path.basename)
+def test_lrgnet_forward_matches_reference_graph(path):
+    g = np.load(path)
+    lite = int(g['lite'])
+    lite = None if lite < 0 else lite
+    F = int(g['feature_size'])
+    w = synthetic.make_synthetic_weights(feature_size=F, lite=lite, **WEIGHT_KW)
+    assert digest(w) == str(g['weights_digest'])
+    assert {k: v.shape for k, v in w.items()} == lrgnet_ref.weight_shapes(F, lite)
+    add, rmv, acts = lrgnet_ref.forward(w, g['inlier'], g['neighbor'], lite=lite, return_acts=True)
+    np.testing.assert_array_equal(add, g['add_output'])
+    np.testing.assert_array_equal(rmv, g['remove_output'])
+    np.testing.assert_array_equal(acts['pooled'], g['pooled'])
+    for i, a in enumerate(acts['conv']):
+        np.testing.assert_array_equal(a, g['conv%d' % i])
+        np.testing.assert_array_equal(acts['neighbor_conv'][i], g['neighbor_conv%d' % i])
+    for i, a in enumerate(acts['add_hidden']):
+        np.testing.assert_array_equal(a, g['add_conv%d' % i])
+        np.testing.assert_array_equal(acts['remove_hidden'][i], g['remove_conv%d' % i])
+    loss, add_acc, rmv_acc = lrgnet_ref.logged_scalars(add, rmv, g['add_mask'], g['rmv_mask'])
+    np.testing.assert_allclose(loss, g['loss'], rtol=1e-6)
+    assert add_acc == g['add_acc'] and rmv_acc == g['remove_acc']
+    # float64 evaluation of the same graph stays within the stated fp32 tolerance
+    add64, rmv64 = lrgnet_ref.forward(w, g['inlier'], g['neighbor'], lite=lite, dtype=np.float64)
+    scale = max(1.0, float(np.abs(add64).max()))
+    assert np.abs(add - add64).max() <= 1e-4 * scale and np.abs(rmv - rmv64).max() <= 1e-4 * scale
+
+
+def test_confidence_is_scipy_softmax():
+    import scipy.special
+    x = np.random.RandomState(0).randn(512, 2).astype(np.float32) * 10
+    np.testing.assert_array_equal(lrgnet_ref.confidence(x), scipy.special.softmax(x, axis=-1)[:, 1])
+
+
+@pytest.mark.parametrize('name,restarts', [('greedy_room100', 0), ('greedy_room101', 0), ('restart_room103', 10)])
+def test_grow_loop_reproduces_reference_script(name, restarts):
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    w = synthetic.make_synthetic_weights(**WEIGHT_KW)
+    assert digest(w) == str(g['weights_digest'])
+    raw = g['raw_room']
+    # preprocessing: oracle loop and the product's vectorised version both equal the reference's output
+    for pre in (preprocess_ref.preprocess_room, preprocess.preprocess_room):
+        p = pre(raw[:, :6], raw[:, 6].astype(int), raw[:, 7].astype(int))
+        np.testing.assert_array_equal(p['points'], g['points'])
+        np.testing.assert_array_equal(p['obj_id'], g['obj_id'])
+        np.testing.assert_array_equal(np.argsort(p['curvatures']), g['order'])
+    r = grow_ref.grow_room(g['points'], g['obj_id'], g['order'], w, rng_ref.LegacyStream(0), cls_id=g['cls_id'],
+                           classes=CLASSES_S3DIS, restarts=restarts)
+    np.testing.assert_array_equal(r.filled_label, g['filled_label'])
+    assert list(r.lines) == [str(x) for x in g['region_lines']]
+    m = metrics_ref.room_metrics(g['obj_id'], r.filled_label)
+    np.testing.assert_allclose([m['nmi'], m['ami'], m['ars'], m['prc'], m['rcl'], m['iou']], g['metrics'], rtol=1e-9)
+
+
+def test_faithful_and_vectorised_mask_update_agree():
+    g = np.load(os.path.join(GOLDEN, 'greedy_room101.npz'))
+    w = synthetic.make_synthetic_weights(**WEIGHT_KW)
+    a = grow_ref.grow_room(g['points'], g['obj_id'], g['order'], w, rng_ref.LegacyStream(0), faithful=True)
+    np.testing.assert_array_equal(a.filled_label, g['filled_label'])
+    assert a.total_steps == sum(x['steps'] for x in a.regions)
+
+
+@pytest.mark.parametrize('policy', ['gt', 'threshold'])
+def test_other_policies_run(policy):
+    g = np.load(os.path.join(GOLDEN, 'greedy_room100.npz'))
+    w = synthetic.make_synthetic_weights(**WEIGHT_KW)
+    r = grow_ref.grow_room(g['points'], g['obj_id'], g['order'], w, rng_ref.CounterStream(1, 0), policy=policy,
+                           max_region_steps=50)
+    assert r.filled_label.min() >= 0 and len(r.regions) > 0
+    if policy == 'gt':     # ground-truth masks never mix instances: every labeled region is pure
+        for lab in range(1, int(r.cluster_label.max()) + 1):
+            assert len(set(g['obj_id'][r.cluster_label == lab].tolist())) == 1
