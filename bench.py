@@ -38,7 +38,11 @@ def parse():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--rooms', type=int, default=68, help='rooms in flight per GPU (the Area-5 set has 68)')
     ap.add_argument('--restarts', type=int, default=1)
-    ap.add_argument('--policy', default='net', choices=['net', 'gt', 'threshold'])
+    ap.add_argument('--policy', default='gt', choices=['net', 'gt', 'threshold'],
+                    help="mask policy: 'net' = the reference's Bernoulli draws against the network's confidence "
+                         "(test_region_grow.py:266-267); 'gt' = its commented-out ground-truth masks (:268-269). "
+                         "The network is evaluated every step either way; with synthetic weights only 'gt' gives "
+                         "Area-5-like region dynamics (regions per room, steps per region)")
     ap.add_argument('--fuse-pool', type=int, default=0)
     ap.add_argument('--advance-rounds', type=int, default=2)
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline sample (0 = skip)')
@@ -46,12 +50,11 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(rooms, weights, seconds):
+def cpu_baseline(rooms, weights, seconds, policy):
     """The oracle (faithful NumPy restatement of test_region_grow.py:175-316, per-point Python voxel-set loop,
     un-hoisted head) on this box's host cores, for a bounded sample: steps of the median-size room."""
     from oracle import grow_ref, rng_ref      # CPU baseline leg only
     order = np.argsort([len(r['points']) for r in rooms])
-    room = rooms[int(order[len(order) // 2])]
     t0 = time.time()
     count = [0]
 
@@ -62,15 +65,19 @@ def cpu_baseline(rooms, weights, seconds):
         count[0] += 1
         if time.time() - t0 > seconds:
             raise Stop()
+    sizes = []
     try:
-        grow_ref.grow_room(room['points'], room['obj_id'], room['order'], weights, rng_ref.LegacyStream(0), faithful=True,
-                           hook=hook, fill=False)
+        for k in range(len(rooms)):        # median-size room first, then outwards
+            room = rooms[int(order[(len(order) // 2 + (k + 1) // 2 * (1 if k % 2 else -1)) % len(order)])]
+            sizes.append(len(room['points']))
+            grow_ref.grow_room(room['points'], room['obj_id'], room['order'], weights, rng_ref.LegacyStream(k), faithful=True,
+                               hook=hook, fill=False, policy=policy)
     except Stop:
         pass
     dt = time.time() - t0
     return dict(value=count[0] / dt, unit='instance-steps/s', cores=os.cpu_count(), kind='port',
-                sample='%d grow steps of one %d-point Area-5-shaped room, oracle.grow_ref (faithful=True), %.1f s'
-                       % (count[0], len(room['points']), dt))
+                sample='%d grow steps over %d Area-5-shaped room(s) of %s points, oracle.grow_ref (faithful=True, policy=%s), '
+                       '%.1f s' % (count[0], len(sizes), sizes, policy, dt))
 
 
 def main():
@@ -171,7 +178,7 @@ def main():
                          'fp32_matrix_tflops': tflops, 'fp32_matrix_frac': tflops / FP32_MATRIX_PEAK_TFLOPS},
         }
         if world == 1 and args.cpu_seconds > 0:
-            out['cpu_baseline'] = cpu_baseline(rooms, weights, args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline(rooms, weights, args.cpu_seconds, args.policy)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

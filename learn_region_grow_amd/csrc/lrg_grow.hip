@@ -51,7 +51,17 @@ __device__ __forceinline__ int lrg_block_min(int v, int *red) {
     for (int i = 1; i < nw; ++i) r = min(r, red[i]);
     return r;
 }
-__device__ __forceinline__ int lrg_block_max(int v, int *red) { return -lrg_block_min(-v, red); }
+__device__ __forceinline__ int lrg_block_max(int v, int *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    __syncthreads();
+    if (lrg_lane() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int nw = blockDim.x >> 6;
+    int r = red[0];
+    for (int i = 1; i < nw; ++i) r = max(r, red[i]);
+    return r;
+}
 __device__ __forceinline__ int lrg_block_sum(int v, int *red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

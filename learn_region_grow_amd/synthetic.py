@@ -151,7 +151,7 @@ def area5_shaped_room(target_equalized_points, seed, n_furniture=None, resolutio
     w, l = float(min(wlh[0], 15.0)), float(min(wlh[1], 15.0))
     h = float(np.clip(wlh[2], 2.2, 4.0))
     if n_furniture is None:
-        n_furniture = int(rs.randint(10, 61))
+        n_furniture = int(rs.randint(40, 101))   # ~72 logged regions per Area-5 room
     sizes = rs.uniform(0.3, 1.5, size=(n_furniture, 3))
     g = 1.0
     room = None

@@ -39,6 +39,8 @@ class GrowResult:
         self.regions = []              # dicts: seed, target, steps, points, gt, iou, add_acc, rmv_acc, reason, labeled
         self.total_steps = 0           # LrgNet evaluations
         self.min_margin = np.inf       # min |u - conf| over all Bernoulli draws
+        self.min_safety = np.inf       # min |u - conf| / (1e-4*conf*(1-conf) + 1e-9): < 1 means a draw sits within
+                                       # fp32 noise of its confidence, so another fp32 network may flip it
         self.lines = []                # reference-format log lines (:217)
 
 
@@ -129,8 +131,10 @@ def grow_room(points, obj_id, order, weights, stream, *, cls_id=None, classes=No
                 if policy == 'net':
                     add_mask = u_add < add_conf
                     rmv_mask = u_rmv < rmv_conf
-                    res.min_margin = min(res.min_margin, float(np.abs(u_add - add_conf).min()),
-                                         float(np.abs(u_rmv - rmv_conf).min()))
+                    for u_, c_ in ((u_add, add_conf), (u_rmv, rmv_conf)):
+                        d_ = np.abs(np.asarray(u_, np.float64) - c_)
+                        res.min_margin = min(res.min_margin, float(d_.min()))
+                        res.min_safety = min(res.min_safety, float((d_ / (1e-4 * c_ * (1.0 - c_) + 1e-9)).min()))
                 elif policy == 'threshold':                                      # :264-265 (commented out upstream)
                     add_mask = add_conf > 0.5
                     rmv_mask = rmv_conf > 0.5

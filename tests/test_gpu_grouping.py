@@ -77,5 +77,6 @@ def test_nn1_fill(cuda_device, hip_lib, F):
     P[10] = P[20]
     lab = ((rs.rand(3000) < 0.3) * rs.randint(1, 9, 3000)).astype(np.int32)
     out = torch.zeros(3000, dtype=torch.int32, device=cuda_device)
-    _lib.check(hip_lib.lrg_nn1_fill(_ptr(dev(P, cuda_device)), 3000, F, _ptr(dev(lab, cuda_device)), _ptr(out), _stream_ptr()), 'nn1')
+    dP, dlab = dev(P, cuda_device), dev(lab, cuda_device)      # keep the device buffers alive across the launch
+    _lib.check(hip_lib.lrg_nn1_fill(_ptr(dP), 3000, F, _ptr(dlab), _ptr(out), _stream_ptr()), 'nn1')
     np.testing.assert_array_equal(out.cpu().numpy(), grow_ref.fill_unlabeled(P, lab.astype(np.int64)))
