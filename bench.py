@@ -44,6 +44,7 @@ def parse():
                          "The network is evaluated every step either way; with synthetic weights only 'gt' gives "
                          "Area-5-like region dynamics (regions per room, steps per region)")
     ap.add_argument('--fuse-pool', type=int, default=0)
+    ap.add_argument('--net-mode', default='fused', choices=['fused', 'streamed'])
     ap.add_argument('--advance-rounds', type=int, default=2)
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
@@ -101,7 +102,7 @@ def main():
 
     weights = synthetic.make_synthetic_weights(seed=0)
     rooms = workloads.area5_rooms(args.rooms, seed_base=1000 + 100 * rank, cache_dir=args.cache)
-    net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, fuse_pool=bool(args.fuse_pool)).load_weights(weights)
+    net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, fuse_pool=bool(args.fuse_pool), mode=args.net_mode).load_weights(weights)
     gr = RegionGrower(net, rooms_in_flight=len(rooms), restarts=args.restarts, rng='counter', seed=rank,
                       policy=args.policy, advance_rounds=args.advance_rounds)
     gr.load_rooms(rooms)
@@ -169,7 +170,7 @@ def main():
                                    'Area-5-shaped rooms, random restarts x%d' % args.restarts,
                        'rooms_in_flight_per_gpu': len(rooms), 'slots_per_gpu': S, 'policy': args.policy,
                        'restarts': args.restarts, 'points': '512 inlier + 512 neighbour x 13 features',
-                       'rng': 'counter (Philox) stream', 'weights': 'synthetic, seed 0',
+                       'rng': 'counter (Philox) stream', 'weights': 'synthetic, seed 0', 'net_mode': args.net_mode,
                        'active_fraction': inst_steps / (args.steps * S * world)},
             'roofline': {'bound': 'hbm', 'kernel': 'lrg_forward (all launches of one LrgNet evaluation batch)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

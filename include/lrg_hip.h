@@ -55,7 +55,10 @@ typedef struct LrgWeights {
     const float *rmv_b[LRG_MAX_HEAD];      /* lrg_remove_bias{j}                                    :153,:159 */
 } LrgWeights;
 
-#define LRG_FWD_FUSE_POOL 1u /* fold the max-pool (:122-123) into the last branch layer's epilogue */
+#define LRG_FWD_FUSE_POOL 1u /* layer-streamed path: fold the max-pool (:122-123) into the last branch layer's epilogue */
+#define LRG_FWD_FUSED 2u     /* whole branch / whole head per 64-row tile in one kernel each: activations stay in LDS,
+                                only conv[1], the pooled maxima and the logits reach HBM (3 launches per call)         */
+#define LRG_FWD_KEEP_ACTS 4u /* with LRG_FWD_FUSED: also copy every intermediate into the workspace (parity tests)     */
 
 /* Bytes of scratch lrg_forward needs for a batch of B instances (host-side arithmetic only). */
 size_t lrg_forward_workspace_bytes(const LrgWeights *w, int B, int n_inlier, int n_neighbor);
@@ -155,7 +158,7 @@ typedef struct LrgSlot {
     int32_t mn[3], mx[3];    /* minDims / maxDims (:199-200)                                                 */
     int32_t seq_mn[3], seq_mx[3]; /* seqMinDims / seqMaxDims (:201-202)                                      */
     int32_t target;          /* obj_id[seed] (:190)                                                          */
-    int32_t pad;
+    int32_t pad;             /* 1 while cur_idx / cand_idx describe the current mask and bbox (set by lrg_box_query)  */
 } LrgSlot;
 
 typedef struct LrgGrowParams {

@@ -10,11 +10,13 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(HERE, 'liblrg_hip.so')
-SOURCES = ['lrg_net.hip', 'lrg_grow.hip', 'lrg_grouping.hip']
+SOURCES = ['lrg_net.hip', 'lrg_fused.hip', 'lrg_grow.hip', 'lrg_grouping.hip']
 
 LRG_MAX_CONV = 5
 LRG_MAX_HEAD = 3
 LRG_FWD_FUSE_POOL = 1
+LRG_FWD_FUSED = 2
+LRG_FWD_KEEP_ACTS = 4
 
 (LRG_IDLE, LRG_ACTIVE, LRG_STOP_NONEIGHBOR, LRG_STOP_NOEXPAND, LRG_STOP_STUCK, LRG_STOP_EMPTY, LRG_STOP_MAXSTEPS,
  LRG_DONE, LRG_WAIT) = range(9)
@@ -78,7 +80,7 @@ class LrgHipError(RuntimeError):
 def build(verbose=False):
     """hipcc --offload-arch=gfx950 -> learn_region_grow_amd/liblrg_hip.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ('lrg_common.h', 'lrg_rng.h')] + \
+    deps = srcs + [os.path.join(CSRC, h) for h in ('lrg_common.h', 'lrg_rng.h', 'lrg_fused.h')] + \
         [os.path.join(os.path.dirname(HERE), 'include', 'lrg_hip.h')]
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
@@ -143,6 +145,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise LrgHipError('%s not found: run `python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950). '
                           'There is no CPU fallback.' % LIB_PATH)
+    # torch first: its bundled HIP runtime must be the one in the process (device memory and streams come from
+    # torch); loading this library before torch would bind it to a second copy of libamdhip64.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

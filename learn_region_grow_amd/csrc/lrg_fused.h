@@ -1,0 +1,35 @@
+// Internal interface between lrg_net.hip (lrg_forward) and lrg_fused.hip (fused stack kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define LRG_FUSED_MAXL 6
+#define LRG_FL_RELU 1
+#define LRG_FL_INST_BIAS 2   // bias is [instances, N]: the hoisted pooled-feature product of a head
+#define LRG_FL_POOL 4        // column max over the instance's rows -> pool
+#define LRG_FL_KEEP 8        // output stays in LDS as the next layer's input
+#define LRG_FL_INPLACE 16     // output overlays this layer's own input buffer (last layer, one column block)
+
+struct LrgFusedLayer {
+    const float *w;      // [K,N] row-major, row stride ldw
+    const float *bias;
+    float *gout;         // nullable: copy of the output in HBM, [rows,N]
+    int K, N, ldw, flags;
+};
+
+struct LrgFusedProb {
+    const float *x;      // [rows,Kin], row stride ldx
+    float *pool;         // pool[(row / rows_per_inst) * pool_stride + col], zero-filled by the caller
+    const float *fw;     // nullable: final [C,2] layer applied to the last LDS-resident activations
+    const float *fb;
+    float *fout;         // [rows,2]
+    long rows;
+    int ldx, Kin, rows_per_inst, pool_stride, nlayers, pad;
+    LrgFusedLayer L[LRG_FUSED_MAXL];
+};
+
+struct LrgFusedArgs {
+    LrgFusedProb p[2];
+};
+
+int lrg_fused_branches(const LrgFusedArgs &a, int nprob, hipStream_t st);
+int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st);

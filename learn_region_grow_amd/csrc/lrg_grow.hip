@@ -138,6 +138,7 @@ __device__ void lrg_reset_slot(LrgSlot *S, const LrgRoom *R, int seed, int resta
             S->mn[d] = v; S->mx[d] = v; S->seq_mn[d] = v; S->seq_mx[d] = v;
         }
         S->target = R->obj_id ? R->obj_id[seed] : 0;
+        S->pad = 0;
         S->status = LRG_ACTIVE;
     }
 }
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_query_kernel(LrgSlot
     __shared__ int wtot_c[16], wtot_e[16];
     LrgSlot *S = &slots[blockIdx.x];
     if (S->status != LRG_ACTIVE || S->room < 0) return;
+    if (S->pad == 1) return;      // lists still valid: nothing changed since the last query of this iteration
     const LrgRoom *R = &rooms[S->room];
     const int n = R->n;
     const uint8_t *cur = S->cur;
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_query_kernel(LrgSlot
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        S->pad = 1;
         S->nc = base_c;
         S->ne = base_e;
         if (base_e == 0) {                                                      // :233-235
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_query_kernel(LrgSlot
 // per-channel median of the current points   (numpy.median, test_region_grow.py:241)
 // one workgroup per (slot, channel); radix select on order-preserving keys
 // ------------------------------------------------------------------------------------------------
-#define LRG_MED_CAP 8192
+#define LRG_MED_CAP 16384
 __device__ __forceinline__ uint32_t lrg_f2key(float f) {
     uint32_t b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -335,40 +338,41 @@ __device__ __forceinline__ float lrg_key2f(uint32_t k) {
     return __uint_as_float(b);
 }
 
-// k-th smallest (0-based) key among nc values; values come from LDS (cached) or are re-gathered.
-__device__ uint32_t lrg_radix_select(const uint32_t *cache, bool cached, const float *pts, const int32_t *idx, int F,
-                                     int ch, int nc, int k, int *hist, int *sh) {
-    uint32_t prefix = 0, mask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
-        for (int j = threadIdx.x; j < nc; j += blockDim.x) {
-            uint32_t key = cached ? cache[j] : lrg_f2key(pts[(long)idx[j] * F + ch]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int cum = 0, b = 0;
-            for (; b < 256; ++b) {
-                if (cum + hist[b] > k) break;
-                cum += hist[b];
+// k-th smallest (0-based) keys for two ranks at once, by bitwise bisection on the key: the answer is the largest r
+// with #(key < r) <= k.  32 counting passes, no atomics, no sorting (regions of 1..10^4 points, test_region_grow.py:241).
+__device__ void lrg_select2(const uint32_t *cache, bool cached, const float *pts, const int32_t *idx, int F, int ch,
+                            int nc, int ka, int kb, int *sh, uint32_t *ra_out, uint32_t *rb_out) {
+    uint32_t ra = 0, rb = 0;
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nround = (nc + blockDim.x - 1) / blockDim.x;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t ca = ra | (1u << bit), cb = rb | (1u << bit);
+        int cnt_a = 0, cnt_b = 0;
+        for (int it = 0; it < nround; ++it) {
+            int j = it * blockDim.x + threadIdx.x;
+            bool la = false, lb = false;
+            if (j < nc) {
+                uint32_t key = cached ? cache[j] : lrg_f2key(pts[(long)idx[j] * F + ch]);
+                la = key < ca; lb = key < cb;
             }
-            sh[0] = b; sh[1] = k - cum;
+            cnt_a += (int)__popcll(__ballot(la));
+            cnt_b += (int)__popcll(__ballot(lb));
         }
+        if (lrg_lane() == 0) { sh[2 * wave] = cnt_a; sh[2 * wave + 1] = cnt_b; }
         __syncthreads();
-        prefix |= (uint32_t)sh[0] << shift;
-        mask |= 255u << shift;
-        k = sh[1];
+        int ta = 0, tb = 0;
+        for (int w = 0; w < nw; ++w) { ta += sh[2 * w]; tb += sh[2 * w + 1]; }
         __syncthreads();
+        if (ta <= ka) ra = ca;
+        if (tb <= kb) rb = cb;
     }
-    return prefix;
+    *ra_out = ra; *rb_out = rb;
 }
 
 __global__ __launch_bounds__(256) void lrg_median_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                           float *center) {
     __shared__ uint32_t cache[LRG_MED_CAP];
-    __shared__ int hist[256];
-    __shared__ int sh[2];
+    __shared__ int sh[8];
     const int s = blockIdx.x, ch = blockIdx.y;
     const LrgSlot *S = &slots[s];
     const int F = prm.feature_size;
@@ -385,12 +389,11 @@ __global__ __launch_bounds__(256) void lrg_median_kernel(const LrgSlot *slots, c
         __syncthreads();
     }
     const int k2 = nc >> 1;
-    float hi = lrg_key2f(lrg_radix_select(cache, cached, R->points, S->cur_idx, F, ch, nc, k2, hist, sh));
-    float med = hi;
-    if ((nc & 1) == 0) {
-        float lo = lrg_key2f(lrg_radix_select(cache, cached, R->points, S->cur_idx, F, ch, nc, k2 - 1, hist, sh));
-        med = __fmul_rn(__fadd_rn(lo, hi), 0.5f);       // numpy.mean of the two middle float32 values
-    }
+    const int k1 = (nc & 1) ? k2 : k2 - 1;
+    uint32_t ka, kb;
+    lrg_select2(cache, cached, R->points, S->cur_idx, F, ch, nc, k1, k2, sh, &ka, &kb);
+    float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
+    float med = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);   // numpy.mean of the two middle float32 values
     if (threadIdx.x == 0) center[s * 16 + ch] = med;
 }
 
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(512) void lrg_mask_update_kernel(LrgSlot *slots, co
     __syncthreads();
     if (threadIdx.x == 0) {
         S->updated = sh_upd;
+        S->pad = 0;
         S->step += 1;
         S->steps_total += 1;                                                    // :288
         if (stats) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[2]), 1ULL);

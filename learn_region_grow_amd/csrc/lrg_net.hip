@@ -7,6 +7,7 @@
 //   lrg_head_gemv_kernel       pooled @ W0[:2*C_last] + b0  once per instance (the tiled concat is never built)
 //   lrg_head_final_kernel      [C] -> 2 logits
 #include "lrg_common.h"
+#include "lrg_fused.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void lrg_segmax_kernel(LrgSegmaxArgs a) {
 // ------------------------------------------------------------------------------------------------
 // hoisted pooled-feature product: hb[b,c] = bias[c] + sum_k pooled[b,k] w[k,c]
 // ------------------------------------------------------------------------------------------------
-#define LRG_GEMV_TB 4
+#define LRG_GEMV_TB 2
 struct LrgGemvArgs {
     const float *pooled;
     const float *w[2];
@@ -234,30 +235,48 @@ struct LrgGemvArgs {
     int ldw, B, P, C;
 };
 
+// 64 output columns x TB instances per 256-thread block; the 4 waves split K and their partial sums are
+// combined through LDS in a fixed order (deterministic, no atomics).
 __global__ __launch_bounds__(256) void lrg_head_gemv_kernel(LrgGemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float pl[];   // [TB][P]
+    extern __shared__ __attribute__((aligned(16))) float pl[];   // [TB][P] pooled rows, then [4][TB][64] partials
     const int z = blockIdx.z;
     const int b0 = blockIdx.y * LRG_GEMV_TB;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     const int nb = min(LRG_GEMV_TB, a.B - b0);
     for (int i = threadIdx.x; i < LRG_GEMV_TB * a.P; i += 256) {
         int bi = i / a.P;
         pl[i] = bi < nb ? a.pooled[(long)(b0 + bi) * a.P + (i - bi * a.P)] : 0.f;
     }
     __syncthreads();
-    if (c >= a.C) return;
     float acc[LRG_GEMV_TB];
 #pragma unroll
     for (int i = 0; i < LRG_GEMV_TB; ++i) acc[i] = 0.f;
-    const float *w = a.w[z] + c;
-#pragma unroll 4
-    for (int k = 0; k < a.P; ++k) {
-        float wv = w[(long)k * a.ldw];
+    const int kq = (a.P + 3) / 4;
+    const int k0 = wave * kq, k1 = min(a.P, k0 + kq);
+    if (c < a.C) {
+        const float *w = a.w[z] + c;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) {
+            float wv = w[(long)k * a.ldw];
 #pragma unroll
-        for (int i = 0; i < LRG_GEMV_TB; ++i) acc[i] = fmaf(pl[i * a.P + k], wv, acc[i]);
+            for (int i = 0; i < LRG_GEMV_TB; ++i) acc[i] = fmaf(pl[i * a.P + k], wv, acc[i]);
+        }
     }
-    float bv = a.bias[z] ? a.bias[z][c] : 0.f;
-    for (int i = 0; i < nb; ++i) a.hb[z][(long)(b0 + i) * a.C + c] = acc[i] + bv;
+    float *part = pl + LRG_GEMV_TB * a.P;
+#pragma unroll
+    for (int i = 0; i < LRG_GEMV_TB; ++i) part[(wave * LRG_GEMV_TB + i) * 64 + lane] = acc[i];
+    __syncthreads();
+    if (wave == 0 && c < a.C) {
+        float bv = a.bias[z] ? a.bias[z][c] : 0.f;
+        for (int i = 0; i < nb; ++i) {
+            float s = part[(0 * LRG_GEMV_TB + i) * 64 + lane];
+            s += part[(1 * LRG_GEMV_TB + i) * 64 + lane];
+            s += part[(2 * LRG_GEMV_TB + i) * 64 + lane];
+            s += part[(3 * LRG_GEMV_TB + i) * 64 + lane];
+            a.hb[z][(long)(b0 + i) * a.C + c] = s + bv;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,6 +361,88 @@ static int fwd_layout(const LrgWeights *w, int B, int ni, int nn, LrgFwdLayout *
     return 0;
 }
 
+// Fused evaluation: 3 launches (both branches | pooled-feature GEMV | both heads).
+static int forward_fused(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
+                         int n_neighbor, float *add_logits, float *rmv_logits, float *ws, const LrgFwdLayout &L,
+                         bool keep_acts, hipStream_t st) {
+    const long rows[2] = {(long)B * n_inlier, (long)B * n_neighbor};
+    const int rpi[2] = {n_inlier, n_neighbor};
+    const int nc = w->n_conv, nh = w->n_head;
+    const int Clast = w->conv_ch[nc - 1];
+    LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
+    {
+        LrgFusedArgs a = {};
+        for (int br = 0; br < 2; ++br) {
+            LrgFusedProb &P = a.p[br];
+            P.x = br == 0 ? inlier : neighbor;
+            P.ldx = w->feature_size; P.Kin = w->feature_size;
+            P.rows = rows[br]; P.rows_per_inst = rpi[br];
+            P.pool = ws + L.pooled + (br == 0 ? 0 : Clast); P.pool_stride = L.P;
+            P.nlayers = nc;
+            for (int i = 0; i < nc; ++i) {
+                LrgFusedLayer &F = P.L[i];
+                F.w = br == 0 ? w->inlier_w[i] : w->neighbor_w[i];
+                F.bias = br == 0 ? w->inlier_b[i] : w->neighbor_b[i];
+                F.K = i == 0 ? w->feature_size : w->conv_ch[i - 1];
+                F.N = w->conv_ch[i]; F.ldw = F.N;
+                F.flags = LRG_FL_RELU | (i + 1 < nc ? LRG_FL_KEEP : LRG_FL_POOL);
+                F.gout = (i == 1 || keep_acts) ? ws + L.conv[br][i] : nullptr;      // conv[1] feeds the heads (:130,:134)
+            }
+        }
+        int rc = lrg_fused_branches(a, 2, st);
+        if (rc) return rc;
+    }
+    const int C0 = w->head_ch[0];
+    {
+        LrgGemvArgs g = {};
+        g.pooled = ws + L.pooled;
+        g.w[0] = w->add_w[0]; g.w[1] = w->rmv_w[0];
+        g.bias[0] = w->add_b[0]; g.bias[1] = w->rmv_b[0];
+        g.hb[0] = ws + L.hb[0]; g.hb[1] = ws + L.hb[1];
+        g.ldw = C0; g.B = B; g.P = L.P; g.C = C0;
+        size_t sh = ((size_t)LRG_GEMV_TB * L.P + 4 * LRG_GEMV_TB * 64) * sizeof(float);
+        hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C0 + 63) / 64, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 2),
+                           dim3(256), sh, st, g);
+        LRG_LAUNCH_CHECK();
+    }
+    {
+        const int hbr[2] = {1, 0};      // head 0 = add on the neighbour rows, head 1 = remove on the inlier rows
+        LrgFusedArgs a = {};
+        for (int hd = 0; hd < 2; ++hd) {
+            const int br = hbr[hd];
+            LrgFusedProb &P = a.p[hd];
+            P.x = ws + L.conv[br][1];
+            P.ldx = w->conv_ch[1]; P.Kin = w->conv_ch[1];
+            P.rows = rows[br]; P.rows_per_inst = rpi[br];
+            P.nlayers = nh - 1;
+            for (int i = 0; i < nh - 1; ++i) {
+                LrgFusedLayer &F = P.L[i];
+                const float *W = hd == 0 ? w->add_w[i] : w->rmv_w[i];
+                F.N = w->head_ch[i]; F.ldw = F.N;
+                if (i == 0) {
+                    F.w = W + (size_t)L.P * C0;      // rows 2*C_last.. of W0: the conv[1] part of the concat (:131,:135)
+                    F.bias = ws + L.hb[hd];
+                    F.K = w->conv_ch[1];
+                    F.flags = LRG_FL_RELU | LRG_FL_KEEP | LRG_FL_INST_BIAS;
+                } else {
+                    F.w = W;
+                    F.bias = hd == 0 ? w->add_b[i] : w->rmv_b[i];
+                    F.K = w->head_ch[i - 1];
+                    F.flags = LRG_FL_RELU | LRG_FL_KEEP;
+                    // the head kernel's odd buffer only holds the 64-wide input: a wider last hidden layer is
+                    // written over its own (dead) input instead
+                    if (i == nh - 2 && (i & 1) && F.N > 64) F.flags |= LRG_FL_INPLACE;
+                }
+                F.gout = keep_acts ? ws + L.hid[hd][i] : nullptr;
+            }
+            P.fw = hd == 0 ? w->add_w[nh - 1] : w->rmv_w[nh - 1];
+            P.fb = hd == 0 ? w->add_b[nh - 1] : w->rmv_b[nh - 1];
+            P.fout = hd == 0 ? add_logits : rmv_logits;
+        }
+        return lrg_fused_heads(a, 2, st);
+    }
+}
+
 extern "C" {
 
 int lrg_abi_version(void) { return LRG_ABI_VERSION; }
@@ -414,8 +515,8 @@ int lrg_head_pool_gemv(const float *pooled, const float *w, int ldw, const float
     if (!pooled || !w || !hb || B <= 0 || P <= 0 || C <= 0 || ldw < C) return LRG_EINVAL - 1;
     LrgGemvArgs a = {};
     a.pooled = pooled; a.w[0] = w; a.bias[0] = bias; a.hb[0] = hb; a.ldw = ldw; a.B = B; a.P = P; a.C = C;
-    size_t sh = (size_t)LRG_GEMV_TB * P * sizeof(float);
-    hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C + 255) / 256, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 1), dim3(256),
+    size_t sh = ((size_t)LRG_GEMV_TB * P + 4 * LRG_GEMV_TB * 64) * sizeof(float);
+    hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C + 63) / 64, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 1), dim3(256),
                        sh, (hipStream_t)stream, a);
     LRG_LAUNCH_CHECK();
     return 0;
@@ -449,6 +550,14 @@ int lrg_forward(const LrgWeights *w, const float *inlier, const float *neighbor,
     const int Clast = w->conv_ch[nc - 1];
     bool fuse_pool = (flags & LRG_FWD_FUSE_POOL) && (Clast % LRG_BN == 0) && (n_inlier % LRG_BM == 0) &&
                      (n_neighbor % LRG_BM == 0);
+    bool fused = (flags & LRG_FWD_FUSED) && (n_inlier % 64 == 0) && (n_neighbor % 64 == 0);
+    for (int i = 0; fused && i < nc; ++i)
+        if (w->conv_ch[i] % 64 != 0 || (i + 1 < nc && w->conv_ch[i] > 128)) fused = false;
+    for (int i = 0; fused && i < nh - 1; ++i)
+        if (w->head_ch[i] % 64 != 0 || w->head_ch[i] > ((i & 1) ? 128 : 256) ||
+            ((i & 1) && w->head_ch[i] > 64 && i != nh - 2)) fused = false;
+    if (fused) return forward_fused(w, inlier, neighbor, B, n_inlier, n_neighbor, add_logits, rmv_logits, ws, L,
+                                    (flags & LRG_FWD_KEEP_ACTS) != 0, st);
     if (fuse_pool) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
 
     // ---- branches (:106-119): both branches in one launch per layer ----
@@ -493,8 +602,8 @@ int lrg_forward(const LrgWeights *w, const float *inlier, const float *neighbor,
         g.bias[0] = w->add_b[0]; g.bias[1] = w->rmv_b[0];
         g.hb[0] = ws + L.hb[0]; g.hb[1] = ws + L.hb[1];
         g.ldw = C0; g.B = B; g.P = L.P; g.C = C0;
-        size_t sh = (size_t)LRG_GEMV_TB * L.P * sizeof(float);
-        hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C0 + 255) / 256, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 2),
+        size_t sh = ((size_t)LRG_GEMV_TB * L.P + 4 * LRG_GEMV_TB * 64) * sizeof(float);
+        hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C0 + 63) / 64, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 2),
                            dim3(256), sh, st, g);
         LRG_LAUNCH_CHECK();
     }

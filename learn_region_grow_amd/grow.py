@@ -211,6 +211,7 @@ class RegionGrower:
             sl.updated = -1
             sl.count = -1
             sl.best_count = -1
+            sl.pad = 0
         a, b = group * self.G, (group + 1) * self.G
         buf = np.frombuffer(bytes(self.h_slots), dtype=np.uint8)[a * sz:b * sz].copy()
         self.d_slots[a * sz:b * sz].copy_(torch.from_numpy(buf))
@@ -226,7 +227,7 @@ class RegionGrower:
     # ------------------------------------------------------------------------------------------
     def enqueue_iteration(self):
         """One lock-step iteration, device-side randomness (no host sync)."""
-        flags = _lib.LRG_FWD_FUSE_POOL if self.net.fuse_pool else 0
+        flags = self.net.forward_flags
         rc = self.lib.lrg_grow_step(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, ctypes.byref(self.params),
                                     ctypes.byref(self.net._w), ctypes.byref(self.step_buffers), self.advance_rounds,
                                     flags, _stream_ptr())

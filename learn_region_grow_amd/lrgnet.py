@@ -31,7 +31,10 @@ def _ptr(t):
 
 class LrgNetHIP:
     def __init__(self, batch_size, seq_len, num_inlier_points, num_neighbor_points, feature_size, lite=0,
-                 device='cuda:0', fuse_pool=False):
+                 device='cuda:0', fuse_pool=False, mode='fused', keep_acts=False):
+        """mode='fused': whole branch / whole head per 64-row tile in one kernel each (3 launches per evaluation);
+        mode='streamed': one launch per layer, every activation through HBM (the layer-by-layer formulation).
+        keep_acts: with 'fused', also copy every intermediate to the workspace so intermediate() works."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.LrgHipError('LrgNetHIP needs a GPU (no CPU fallback)')
@@ -44,6 +47,10 @@ class LrgNetHIP:
         self.conv_channels = CONV_CHANNELS[self.lite]
         self.conv2_channels = CONV2_CHANNELS[self.lite]
         self.fuse_pool = fuse_pool
+        assert mode in ('fused', 'streamed')
+        self.mode = mode
+        self.forward_flags = (_lib.LRG_FWD_FUSE_POOL if fuse_pool else 0) | (_lib.LRG_FWD_FUSED if mode == 'fused' else 0) | \
+            (_lib.LRG_FWD_KEEP_ACTS if keep_acts else 0)
         self.weights = {}          # name -> device tensor ([Cin,Cout] / [C])
         self._w = None             # LrgWeights (host struct of device pointers)
         self._ws = None
@@ -127,7 +134,7 @@ class LrgNetHIP:
             add_out = torch.empty((B, self.num_neighbor_points, 2), dtype=torch.float32, device=self.device)
         if rmv_out is None:
             rmv_out = torch.empty((B, self.num_inlier_points, 2), dtype=torch.float32, device=self.device)
-        flags = _lib.LRG_FWD_FUSE_POOL if self.fuse_pool else 0
+        flags = self.forward_flags
         rc = self.lib.lrg_forward(ctypes.byref(self._w), _ptr(inlier), _ptr(neighbor), B, self.num_inlier_points,
                                   self.num_neighbor_points, _ptr(add_out), _ptr(rmv_out), _ptr(ws), ws.numel(), flags,
                                   _stream_ptr())

@@ -132,6 +132,9 @@ def main():
         golden_lrgnet(1, 13, 32, 32, 2, seed=13)
         golden_lrgnet(2, 13, 32, 32, 2, seed=14)
         golden_lrgnet(0, 9, 32, 32, 1, seed=15)         # feature-size variant (test_region_grow.py:72-77)
+        golden_lrgnet(0, 13, 64, 128, 2, seed=16)       # 64-row multiples: the fused kernels' tile size
+        golden_lrgnet(1, 13, 64, 64, 1, seed=17)
+        golden_lrgnet(2, 12, 64, 64, 1, seed=18)
     if 'greedy' in which:
         room = synthetic.generate_room_points(1500, seed=100).astype(np.float32)
         run_reference_script('test_region_grow.py', ['--area', '5'], room, 'greedy_room100')

@@ -23,17 +23,21 @@ def close(got, want, what):
     assert (err <= tol).all(), '%s: max err %.3e (scale %.3e) at %s' % (what, err.max(), scale, np.unravel_index(err.argmax(), err.shape))
 
 
-def make_net(cuda_device, lite, F, ni, nn, fuse_pool=False):
+MODES = {'streamed': dict(mode='streamed'), 'streamed+pool': dict(mode='streamed', fuse_pool=True),
+         'fused': dict(mode='fused', keep_acts=True)}
+
+
+def make_net(cuda_device, lite, F, ni, nn, mode='streamed'):
     import torch
     from learn_region_grow_amd.lrgnet import LrgNetHIP
     w = synthetic.make_synthetic_weights(feature_size=F, lite=lite, **WEIGHT_KW)
-    net = LrgNetHIP(1, 1, ni, nn, F, lite, device=cuda_device, fuse_pool=fuse_pool).load_weights(w)
+    net = LrgNetHIP(1, 1, ni, nn, F, lite, device=cuda_device, **MODES[mode]).load_weights(w)
     return net, w
 
 
 @pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'lrgnet_*.npz'))), ids=os.path.basename)
-@pytest.mark.parametrize('fuse_pool', [False, True])
-def test_forward_matches_reference_goldens_layer_by_layer(cuda_device, path, fuse_pool):
+@pytest.mark.parametrize('mode', sorted(MODES))
+def test_forward_matches_reference_goldens_layer_by_layer(cuda_device, path, mode):
     import torch
     g = np.load(path)
     lite = int(g['lite'])
@@ -41,7 +45,9 @@ def test_forward_matches_reference_goldens_layer_by_layer(cuda_device, path, fus
     F = int(g['feature_size'])
     B, ni = g['inlier'].shape[:2]
     nn = g['neighbor'].shape[1]
-    net, w = make_net(cuda_device, lite, F, ni, nn, fuse_pool)
+    if mode == 'fused' and (ni % 64 or nn % 64):
+        pytest.skip('the fused kernels tile 64 rows; lrg_forward takes the layer-streamed path for this shape')
+    net, w = make_net(cuda_device, lite, F, ni, nn, mode)
     xi = torch.from_numpy(g['inlier']).to(cuda_device)
     xn = torch.from_numpy(g['neighbor']).to(cuda_device)
     add, rmv = net.forward(xi, xn)
@@ -64,11 +70,11 @@ def test_forward_matches_reference_goldens_layer_by_layer(cuda_device, path, fus
 
 
 @pytest.mark.parametrize('B', [1, 3, 68])
-@pytest.mark.parametrize('fuse_pool', [False, True])
-def test_forward_full_size_against_oracle(cuda_device, B, fuse_pool):
+@pytest.mark.parametrize('mode', sorted(MODES))
+def test_forward_full_size_against_oracle(cuda_device, B, mode):
     """The shape the loop uses: 512 inliers + 512 neighbours x 13 features (test_region_grow.py:22-24)."""
     import torch
-    net, w = make_net(cuda_device, 0, 13, 512, 512, fuse_pool)
+    net, w = make_net(cuda_device, 0, 13, 512, 512, mode)
     rs = np.random.RandomState(B)
     xi = (rs.randn(B, 512, 13) * 0.5).astype(np.float32)
     xn = (rs.randn(B, 512, 13) * 0.5).astype(np.float32)
@@ -115,3 +121,20 @@ def test_single_layer_entry_points(cuda_device, hip_lib):
     np.testing.assert_array_equal(out.cpu().numpy()[:, 100:196], x.max(axis=1))
     # bad arguments are rejected, not launched
     assert hip_lib.lrg_pointwise_layer(None, 4, None, 4, None, None, 4, 4, 4, 1, 0, 0, None, 0, None) <= -1000
+
+
+def test_fused_and_streamed_paths_agree(cuda_device):
+    """Same weights, same inputs: the 3-launch fused evaluation and the layer-streamed one give the same logits to
+    fp32 rounding (the k-order inside a dot product is the only difference)."""
+    import torch
+    rs = np.random.RandomState(5)
+    xi = torch.from_numpy((rs.randn(9, 512, 13) * 0.5).astype(np.float32)).to(cuda_device)
+    xn = torch.from_numpy((rs.randn(9, 512, 13) * 0.5).astype(np.float32)).to(cuda_device)
+    outs = {}
+    for mode in ('streamed', 'fused'):
+        net, _ = make_net(cuda_device, 0, 13, 512, 512, mode)
+        add, rmv = net.forward(xi, xn)
+        outs[mode] = (add.cpu().numpy(), rmv.cpu().numpy(), net.intermediate('pooled', 0, 9).cpu().numpy().copy())
+    close(outs['fused'][0], outs['streamed'][0], 'add')
+    close(outs['fused'][1], outs['streamed'][1], 'rmv')
+    close(outs['fused'][2], outs['streamed'][2], 'pooled')
