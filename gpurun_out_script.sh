@@ -1,4 +1,10 @@
 mkdir -p gpurun_out
+R=$(pwd)
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q --maxfail=40 --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
+tail -3 gpurun_out/pytest_gpu.log
 for B in 68 1088; do python tools/fwd_only.py $B fused 10; done 2>&1 | grep forward
-timeout 600 python -m pytest tests/test_gpu_net.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | grep -E "^E|passed|failed|FAILED" | head -20
+timeout 900 python bench.py --steps 1500 --warmup 100 --cpu-seconds 0 > gpurun_out/bench_gt.log 2>&1; tail -1 gpurun_out/bench_gt.log
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r1e -o bench --output-format csv -- python $R/bench.py --steps 300 --warmup 50 --cpu-seconds 0 > $R/gpurun_out/prof_bench.log 2>&1

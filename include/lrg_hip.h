@@ -69,6 +69,16 @@ int lrg_forward(const LrgWeights *w, const float *inlier, const float *neighbor,
                 int n_neighbor, float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes,
                 unsigned flags, void *stream);
 
+/* lrg_forward restricted to the leading rows of each instance.  rows_in / rows_nb ([B] device int32, both or
+ * neither NULL): only rows [0, rows_in[b]) of inlier[b] and [0, rows_nb[b]) of neighbor[b] are evaluated.  The caller
+ * guarantees that every later row is a copy of one of those (the reference pads small sets by duplication,
+ * test_region_grow.py:240,:252), so their logits equal the source row's bit for bit and the max-pool (:122-123) is
+ * unchanged; logits of rows that are not evaluated are left unwritten.  A count of 0 skips the instance.
+ * Needs LRG_FWD_FUSED (whole 64-row tiles are skipped). */
+int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
+                     int n_neighbor, const int32_t *rows_in, const int32_t *rows_nb, float *add_logits,
+                     float *rmv_logits, void *workspace, size_t workspace_bytes, unsigned flags, void *stream);
+
 /* Workspace introspection for layer-by-layer parity tests: float offset / element count of a named
  * intermediate inside `workspace`.  kind: 0 conv[i] (inlier), 1 neighbor_conv[i], 2 pooled [B,2*C_last],
  * 3 add head hidden[i], 4 remove head hidden[i].  Returns 0, or LRG_EINVAL. */
@@ -207,20 +217,26 @@ int lrg_sample(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const Lr
                int32_t *sample_in, int32_t *sample_nb, void *stream);
 
 /* Gather + centre (:242-254): inlier [n_slots,n_inlier,F], neighbor [n_slots,n_neighbor,F];
- * gt_remove / gt_add (nullable) receive input_remove / input_add (:248,:254). */
+ * gt_remove / gt_add (nullable) receive input_remove / input_add (:248,:254).
+ * rows_in / rows_nb (nullable, [n_slots]) receive the number of distinct leading rows of each stacked set:
+ * min(nc, n_inlier) / min(ne, n_neighbor) for an active slot (the rest are duplicates, :240,:252), 0 otherwise. */
 int lrg_gather_center(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params,
                       const int32_t *sample_in, const int32_t *sample_nb, const float *center, float *inlier,
-                      float *neighbor, int32_t *gt_remove, int32_t *gt_add, void *stream);
+                      float *neighbor, int32_t *gt_remove, int32_t *gt_add, int32_t *rows_in, int32_t *rows_nb,
+                      void *stream);
 
 /* Confidence + Bernoulli masks + voxel-set mask update (:262-288).
  * add_mask / rmv_mask (nullable, uint8 [n_slots,n]) : host-decided masks (reference-order RNG);
  * when NULL the masks are drawn on the device from the counter stream against
  * softmax(logits)[:,1].  Sets slot.updated, increments slot.step / steps_total and, when stats is
- * non-NULL, stats[2] (instance-steps taken). */
+ * non-NULL, stats[2] (instance-steps taken).
+ * sample_in / sample_nb (nullable): when given, logits were produced by lrg_forward_rows, i.e. only for the distinct
+ * leading rows; slot j of a set with fewer points than slots then reads the logits of row sample[j] (its source). */
 int lrg_mask_update(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params,
                     const float *inlier, const float *neighbor, const float *center, const float *add_logits,
                     const float *rmv_logits, const int32_t *gt_remove, const int32_t *gt_add,
-                    const uint8_t *add_mask, const uint8_t *rmv_mask, int64_t *stats, void *stream);
+                    const uint8_t *add_mask, const uint8_t *rmv_mask, const int32_t *sample_in,
+                    const int32_t *sample_nb, int64_t *stats, void *stream);
 
 /* Device buffers of one lock-step iteration over n_slots slots (all caller-owned). */
 typedef struct LrgStepBuffers {
@@ -236,6 +252,8 @@ typedef struct LrgStepBuffers {
     void *workspace;      /* lrg_forward scratch          */
     size_t workspace_bytes;
     int64_t *stats;       /* LRG_STATS_WORDS x int64      */
+    int32_t *rows_in;     /* [n_slots] rows to evaluate per slot (nullable pair: NULL = evaluate all 512+512 rows) */
+    int32_t *rows_nb;
 } LrgStepBuffers;
 
 /* stats layout: [0] committed seeds, [1] rooms finished, [2] instance-steps taken, [3] reserved,

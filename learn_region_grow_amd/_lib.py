@@ -66,7 +66,7 @@ class LrgGrowParams(ctypes.Structure):
 class LrgStepBuffers(ctypes.Structure):
     _fields_ = [('center', _fp), ('sample_in', _fp), ('sample_nb', _fp), ('inlier', _fp), ('neighbor', _fp),
                 ('gt_remove', _fp), ('gt_add', _fp), ('add_logits', _fp), ('rmv_logits', _fp), ('workspace', _fp),
-                ('workspace_bytes', ctypes.c_size_t), ('stats', _fp)]
+                ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('rows_in', _fp), ('rows_nb', _fp)]
 
 
 LRG_DONE_RING = 1020
@@ -101,6 +101,8 @@ _SIGS = {
     'lrg_forward_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(LrgWeights), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'lrg_forward': (ctypes.c_int, [ctypes.POINTER(LrgWeights), _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp,
                                    _fp, ctypes.c_size_t, ctypes.c_uint, _fp]),
+    'lrg_forward_rows': (ctypes.c_int, [ctypes.POINTER(LrgWeights), _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp,
+                                        _fp, _fp, _fp, ctypes.c_size_t, ctypes.c_uint, _fp]),
     'lrg_forward_workspace_view': (ctypes.c_int, [ctypes.POINTER(LrgWeights), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
                                                   ctypes.POINTER(ctypes.c_size_t)]),
@@ -117,9 +119,9 @@ _SIGS = {
     'lrg_median': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp]),
     'lrg_sample': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp]),
     'lrg_gather_center': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp,
-                                         _fp, _fp, _fp]),
+                                         _fp, _fp, _fp, _fp, _fp]),
     'lrg_mask_update': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp,
-                                       _fp, _fp, _fp, _fp, _fp, _fp]),
+                                       _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     'lrg_grow_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgWeights),
                                      ctypes.POINTER(LrgStepBuffers), ctypes.c_int, ctypes.c_uint, _fp]),
     'lrg_nn1_fill': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),

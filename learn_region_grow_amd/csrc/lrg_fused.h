@@ -22,6 +22,7 @@ struct LrgFusedProb {
     const float *fw;     // nullable: final [C,2] layer applied to the last LDS-resident activations
     const float *fb;
     float *fout;         // [rows,2]
+    const int *valid;    // nullable, [instances]: only the first valid[i] rows of instance i are evaluated (0 = skip)
     long rows;
     int ldx, Kin, rows_per_inst, pool_stride, nlayers, pad;
     LrgFusedLayer L[LRG_FUSED_MAXL];

@@ -102,8 +102,15 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
     float *poolbuf = smem + CAP0 + CAP1;      // [512] running column maxima of the pooled layer / final-layer weights
 
     const LrgFusedProb &P = args.p[blockIdx.y];
-    const long r0 = (long)blockIdx.x * FM;
-    if (r0 >= P.rows) return;
+    // Tile-major block order (instance fastest): block b runs on XCD b % 8, and with duplicate-row skipping mostly the
+    // FIRST tiles of the instances survive -- instance-major order would put all of them on one XCD.
+    const int ninst = (int)(P.rows / P.rows_per_inst);
+    const int inst = blockIdx.x % ninst, tile = blockIdx.x / ninst;
+    if (tile * FM >= P.rows_per_inst) return;
+    // rows beyond valid[instance] are copies of earlier rows (the padding rule, test_region_grow.py:240,:252):
+    // their per-point results are identical and the max-pool ignores duplicates, so whole tiles of them are skipped
+    if (P.valid && tile * FM >= P.valid[inst]) return;
+    const long r0 = (long)inst * P.rows_per_inst + (long)tile * FM;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;

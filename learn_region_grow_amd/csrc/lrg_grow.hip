@@ -423,10 +423,15 @@ __global__ __launch_bounds__(256) void lrg_gather_center_kernel(const LrgSlot *s
                                                                  LrgGrowParams prm, const int32_t *sample_in,
                                                                  const int32_t *sample_nb, const float *center,
                                                                  float *inlier, float *neighbor, int32_t *gt_remove,
-                                                                 int32_t *gt_add) {
+                                                                 int32_t *gt_add, int32_t *rows_in, int32_t *rows_nb) {
     const int s = blockIdx.x, side = blockIdx.y;
     const LrgSlot *S = &slots[s];
-    if (S->status != LRG_ACTIVE || S->room < 0) return;
+    const bool active = S->status == LRG_ACTIVE && S->room >= 0;
+    if (rows_in && blockIdx.z == 0 && threadIdx.x == 0) {
+        if (side == 0) rows_in[s] = active ? min(S->nc, prm.n_inlier) : 0;
+        else rows_nb[s] = active ? min(S->ne, prm.n_neighbor) : 0;
+    }
+    if (!active) return;
     const LrgRoom *R = &rooms[S->room];
     const int F = prm.feature_size;
     const int k = side == 0 ? prm.n_inlier : prm.n_neighbor;
@@ -463,7 +468,8 @@ __global__ __launch_bounds__(512) void lrg_mask_update_kernel(LrgSlot *slots, co
                                                                const float *center, const float *add_logits,
                                                                const float *rmv_logits, const int32_t *gt_remove,
                                                                const int32_t *gt_add, const uint8_t *add_mask,
-                                                               const uint8_t *rmv_mask, int64_t *stats) {
+                                                               const uint8_t *rmv_mask, const int32_t *sample_in,
+                                                               const int32_t *sample_nb, int64_t *stats) {
     __shared__ int sh_upd;
     const int s = blockIdx.x;
     LrgSlot *S = &slots[s];
@@ -483,7 +489,9 @@ __global__ __launch_bounds__(512) void lrg_mask_update_kernel(LrgSlot *slots, co
         if (prm.policy == 2) take = gt_add[o] != 0;
         else if (add_mask) take = add_mask[o] != 0;
         else {
-            float conf = lrg_conf(add_logits + 2 * o);
+            // logits exist only for the distinct leading rows when the set was padded: read the source row's
+            const long lo = (sample_nb && S->ne < prm.n_neighbor) ? (long)s * prm.n_neighbor + sample_nb[o] : o;
+            float conf = lrg_conf(add_logits + 2 * lo);
             if (prm.policy == 1) take = conf > 0.5f;
             else take = lrg_uniform01(lrg_rng_word((uint32_t)j, LRG_PURPOSE_ADD, (uint32_t)S->seed, (uint32_t)S->restart,
                                                    (uint32_t)S->step, k0, k1)) < conf;
@@ -505,7 +513,8 @@ __global__ __launch_bounds__(512) void lrg_mask_update_kernel(LrgSlot *slots, co
         if (prm.policy == 2) take = gt_remove[o] != 0;
         else if (rmv_mask) take = rmv_mask[o] != 0;
         else {
-            float conf = lrg_conf(rmv_logits + 2 * o);
+            const long lo = (sample_in && S->nc < prm.n_inlier) ? (long)s * prm.n_inlier + sample_in[o] : o;
+            float conf = lrg_conf(rmv_logits + 2 * lo);
             if (prm.policy == 1) take = conf > 0.5f;
             else take = lrg_uniform01(lrg_rng_word((uint32_t)j, LRG_PURPOSE_RMV, (uint32_t)S->seed, (uint32_t)S->restart,
                                                    (uint32_t)S->step, k0, k1)) < conf;
@@ -669,13 +678,15 @@ int lrg_sample(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const Lr
 
 int lrg_gather_center(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params,
                       const int32_t *sample_in, const int32_t *sample_nb, const float *center, float *inlier,
-                      float *neighbor, int32_t *gt_remove, int32_t *gt_add, void *stream) {
+                      float *neighbor, int32_t *gt_remove, int32_t *gt_add, int32_t *rows_in, int32_t *rows_nb,
+                      void *stream) {
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || !sample_in || !sample_nb || !center || !inlier || !neighbor || n_slots <= 0)
         return LRG_EINVAL - 1;
+    if ((rows_in == nullptr) != (rows_nb == nullptr)) return LRG_EINVAL - 2;
     hipLaunchKernelGGL(lrg_gather_center_kernel, dim3(n_slots, 2, 4), dim3(256), 0, (hipStream_t)stream, slots, rooms,
-                       *params, sample_in, sample_nb, center, inlier, neighbor, gt_remove, gt_add);
+                       *params, sample_in, sample_nb, center, inlier, neighbor, gt_remove, gt_add, rows_in, rows_nb);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -683,7 +694,7 @@ int lrg_gather_center(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, c
 int lrg_mask_update(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, const float *inlier,
                     const float *neighbor, const float *center, const float *add_logits, const float *rmv_logits,
                     const int32_t *gt_remove, const int32_t *gt_add, const uint8_t *add_mask, const uint8_t *rmv_mask,
-                    int64_t *stats, void *stream) {
+                    const int32_t *sample_in, const int32_t *sample_nb, int64_t *stats, void *stream) {
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || !inlier || !neighbor || !center || n_slots <= 0) return LRG_EINVAL - 1;
@@ -691,7 +702,8 @@ int lrg_mask_update(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const Lrg
     if (params->policy != 2 && ((add_mask == nullptr) != (rmv_mask == nullptr))) return LRG_EINVAL - 3;
     if (params->policy != 2 && !add_mask && (!add_logits || !rmv_logits)) return LRG_EINVAL - 4;
     hipLaunchKernelGGL(lrg_mask_update_kernel, dim3(n_slots), dim3(512), 0, (hipStream_t)stream, slots, rooms, *params,
-                       inlier, neighbor, center, add_logits, rmv_logits, gt_remove, gt_add, add_mask, rmv_mask, stats);
+                       inlier, neighbor, center, add_logits, rmv_logits, gt_remove, gt_add, add_mask, rmv_mask, sample_in,
+                       sample_nb, stats);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -709,12 +721,16 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowPara
     }
     if ((rc = lrg_median(slots, rooms, n_slots, params, b->center, stream))) return rc;
     if ((rc = lrg_sample(slots, rooms, n_slots, params, b->sample_in, b->sample_nb, stream))) return rc;
+    const bool rows = b->rows_in && b->rows_nb && (forward_flags & LRG_FWD_FUSED);
     if ((rc = lrg_gather_center(slots, rooms, n_slots, params, b->sample_in, b->sample_nb, b->center, b->inlier,
-                                b->neighbor, b->gt_remove, b->gt_add, stream))) return rc;
-    if ((rc = lrg_forward(weights, b->inlier, b->neighbor, n_slots, params->n_inlier, params->n_neighbor, b->add_logits,
-                          b->rmv_logits, b->workspace, b->workspace_bytes, forward_flags, stream))) return rc;
+                                b->neighbor, b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr,
+                                rows ? b->rows_nb : nullptr, stream))) return rc;
+    if ((rc = lrg_forward_rows(weights, b->inlier, b->neighbor, n_slots, params->n_inlier, params->n_neighbor,
+                               rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, b->add_logits, b->rmv_logits,
+                               b->workspace, b->workspace_bytes, forward_flags, stream))) return rc;
     return lrg_mask_update(slots, rooms, n_slots, params, b->inlier, b->neighbor, b->center, b->add_logits,
-                           b->rmv_logits, b->gt_remove, b->gt_add, nullptr, nullptr, b->stats, stream);
+                           b->rmv_logits, b->gt_remove, b->gt_add, nullptr, nullptr, rows ? b->sample_in : nullptr,
+                           rows ? b->sample_nb : nullptr, b->stats, stream);
 }
 
 int lrg_nn1_fill(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *stream) {

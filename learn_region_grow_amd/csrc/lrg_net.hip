@@ -363,8 +363,8 @@ static int fwd_layout(const LrgWeights *w, int B, int ni, int nn, LrgFwdLayout *
 
 // Fused evaluation: 3 launches (both branches | pooled-feature GEMV | both heads).
 static int forward_fused(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
-                         int n_neighbor, float *add_logits, float *rmv_logits, float *ws, const LrgFwdLayout &L,
-                         bool keep_acts, hipStream_t st) {
+                         int n_neighbor, const int32_t *rows_in, const int32_t *rows_nb, float *add_logits,
+                         float *rmv_logits, float *ws, const LrgFwdLayout &L, bool keep_acts, hipStream_t st) {
     const long rows[2] = {(long)B * n_inlier, (long)B * n_neighbor};
     const int rpi[2] = {n_inlier, n_neighbor};
     const int nc = w->n_conv, nh = w->n_head;
@@ -378,6 +378,7 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
             P.ldx = w->feature_size; P.Kin = w->feature_size;
             P.rows = rows[br]; P.rows_per_inst = rpi[br];
             P.pool = ws + L.pooled + (br == 0 ? 0 : Clast); P.pool_stride = L.P;
+            P.valid = br == 0 ? rows_in : rows_nb;
             P.nlayers = nc;
             for (int i = 0; i < nc; ++i) {
                 LrgFusedLayer &F = P.L[i];
@@ -414,6 +415,7 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
             P.x = ws + L.conv[br][1];
             P.ldx = w->conv_ch[1]; P.Kin = w->conv_ch[1];
             P.rows = rows[br]; P.rows_per_inst = rpi[br];
+            P.valid = br == 0 ? rows_in : rows_nb;
             P.nlayers = nh - 1;
             for (int i = 0; i < nh - 1; ++i) {
                 LrgFusedLayer &F = P.L[i];
@@ -536,6 +538,13 @@ int lrg_head_final(const float *h, const float *w, const float *bias, float *log
 int lrg_forward(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
                 int n_neighbor, float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes,
                 unsigned flags, void *stream) {
+    return lrg_forward_rows(w, inlier, neighbor, B, n_inlier, n_neighbor, nullptr, nullptr, add_logits, rmv_logits,
+                            workspace, workspace_bytes, flags, stream);
+}
+
+int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
+                     int n_neighbor, const int32_t *rows_in, const int32_t *rows_nb, float *add_logits,
+                     float *rmv_logits, void *workspace, size_t workspace_bytes, unsigned flags, void *stream) {
     LrgFwdLayout L;
     int rc = fwd_layout(w, B, n_inlier, n_neighbor, &L);
     if (rc) return rc;
@@ -556,8 +565,10 @@ int lrg_forward(const LrgWeights *w, const float *inlier, const float *neighbor,
     for (int i = 0; fused && i < nh - 1; ++i)
         if (w->head_ch[i] % 64 != 0 || w->head_ch[i] > ((i & 1) ? 128 : 256) ||
             ((i & 1) && w->head_ch[i] > 64 && i != nh - 2)) fused = false;
-    if (fused) return forward_fused(w, inlier, neighbor, B, n_inlier, n_neighbor, add_logits, rmv_logits, ws, L,
-                                    (flags & LRG_FWD_KEEP_ACTS) != 0, st);
+    if ((rows_in == nullptr) != (rows_nb == nullptr)) return LRG_EINVAL - 11;
+    if (rows_in && !fused) return LRG_EINVAL - 12;      // row counts are honoured by the fused kernels only
+    if (fused) return forward_fused(w, inlier, neighbor, B, n_inlier, n_neighbor, rows_in, rows_nb, add_logits, rmv_logits,
+                                    ws, L, (flags & LRG_FWD_KEEP_ACTS) != 0, st);
     if (fuse_pool) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
 
     // ---- branches (:106-119): both branches in one launch per layer ----

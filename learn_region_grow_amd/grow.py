@@ -48,7 +48,8 @@ class RoomResult:
 
 class RegionGrower:
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
-                 resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=2, pipeline_depth=4):
+                 resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=2, pipeline_depth=4,
+                 skip_duplicate_rows=True):
         self.lib = _lib.load()
         self.net = net
         self.dev = net.device
@@ -77,6 +78,8 @@ class RegionGrower:
         p.policy = POLICIES[policy]
         self.params = p
         self.policy = policy
+        # evaluate LrgNet only on the distinct leading rows of each stacked set (the rest are copies, :240,:252)
+        self.skip_duplicate_rows = bool(skip_duplicate_rows) and rng == 'counter' and net.mode == 'fused'
         self.debug_hook = None      # tests: called once per active slot per legacy iteration with the step's data
         self._rooms_loaded = False
 
@@ -169,6 +172,8 @@ class RegionGrower:
         self.b_amask = torch.zeros((S, Nn), dtype=torch.uint8, device=dev)
         self.b_rmask = torch.zeros((S, Ni), dtype=torch.uint8, device=dev)
         self.d_stats = torch.zeros(LRG_STATS_WORDS, dtype=torch.int64, device=dev)
+        self.b_rows_in = torch.zeros(S, dtype=torch.int32, device=dev)
+        self.b_rows_nb = torch.zeros(S, dtype=torch.int32, device=dev)
         ws = self.net._workspace(S)
         sb = LrgStepBuffers()
         sb.center, sb.sample_in, sb.sample_nb = self.b_center.data_ptr(), self.b_sin.data_ptr(), self.b_snb.data_ptr()
@@ -177,6 +182,8 @@ class RegionGrower:
         sb.add_logits, sb.rmv_logits = self.b_add.data_ptr(), self.b_rmv.data_ptr()
         sb.workspace, sb.workspace_bytes = ws.data_ptr(), ws.numel()
         sb.stats = self.d_stats.data_ptr()
+        if self.skip_duplicate_rows:
+            sb.rows_in, sb.rows_nb = self.b_rows_in.data_ptr(), self.b_rows_nb.data_ptr()
         self.step_buffers = sb
         self.h_stats = [torch.zeros(LRG_STATS_WORDS, dtype=torch.int64).pin_memory() for _ in range(self.depth)]
         self.ev = [torch.cuda.Event() for _ in range(self.depth)]
@@ -282,7 +289,7 @@ class RegionGrower:
             _lib.check(lib.lrg_median(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.b_center), st), 'lrg_median')
             _lib.check(lib.lrg_gather_center(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.b_sin),
                                              _ptr(self.b_snb), _ptr(self.b_center), _ptr(self.b_inl), _ptr(self.b_nbr),
-                                             _ptr(self.b_gtr), _ptr(self.b_gta), st), 'lrg_gather_center')
+                                             _ptr(self.b_gtr), _ptr(self.b_gta), None, None, st), 'lrg_gather_center')
             self.net.forward(self.b_inl, self.b_nbr, self.b_add, self.b_rmv)
             amask = rmask = None
             need_logits = self.policy != 'gt'
@@ -324,7 +331,7 @@ class RegionGrower:
                 prm.policy = 0      # the masks were thresholded on the host
             _lib.check(lib.lrg_mask_update(_ptr(self.d_slots), _ptr(self.d_rooms), S, ctypes.byref(prm), _ptr(self.b_inl),
                                            _ptr(self.b_nbr), _ptr(self.b_center), _ptr(self.b_add), _ptr(self.b_rmv),
-                                           _ptr(self.b_gtr), _ptr(self.b_gta), _ptr(amask), _ptr(rmask),
+                                           _ptr(self.b_gtr), _ptr(self.b_gta), _ptr(amask), _ptr(rmask), None, None,
                                            _ptr(self.d_stats), st), 'lrg_mask_update')
         self.iterations += 1
         return slots

@@ -120,8 +120,10 @@ class LrgNetHIP:
             self._ws_batch = B
         return self._ws
 
-    def forward(self, inlier, neighbor, add_out=None, rmv_out=None):
-        """inlier [B,Ni,F], neighbor [B,Nn,F] float32 CUDA tensors -> (add [B,Nn,2], rmv [B,Ni,2])."""
+    def forward(self, inlier, neighbor, add_out=None, rmv_out=None, rows_in=None, rows_nb=None):
+        """inlier [B,Ni,F], neighbor [B,Nn,F] float32 CUDA tensors -> (add [B,Nn,2], rmv [B,Ni,2]).
+        rows_in / rows_nb ([B] int32 CUDA, optional): evaluate only the leading rows of each instance, the rest
+        being copies of them (lrg_forward_rows); logits of the other rows are left unwritten."""
         if self._w is None:
             raise _lib.LrgHipError('load_weights() first')
         assert inlier.is_cuda and neighbor.is_cuda and inlier.dtype == torch.float32 and neighbor.dtype == torch.float32
@@ -135,10 +137,10 @@ class LrgNetHIP:
         if rmv_out is None:
             rmv_out = torch.empty((B, self.num_inlier_points, 2), dtype=torch.float32, device=self.device)
         flags = self.forward_flags
-        rc = self.lib.lrg_forward(ctypes.byref(self._w), _ptr(inlier), _ptr(neighbor), B, self.num_inlier_points,
-                                  self.num_neighbor_points, _ptr(add_out), _ptr(rmv_out), _ptr(ws), ws.numel(), flags,
-                                  _stream_ptr())
-        _lib.check(rc, 'lrg_forward')
+        rc = self.lib.lrg_forward_rows(ctypes.byref(self._w), _ptr(inlier), _ptr(neighbor), B, self.num_inlier_points,
+                                       self.num_neighbor_points, _ptr(rows_in), _ptr(rows_nb), _ptr(add_out),
+                                       _ptr(rmv_out), _ptr(ws), ws.numel(), flags, _stream_ptr())
+        _lib.check(rc, 'lrg_forward_rows')
         self.add_output, self.remove_output = add_out, rmv_out
         return add_out, rmv_out
 

@@ -138,3 +138,38 @@ def test_fused_and_streamed_paths_agree(cuda_device):
     close(outs['fused'][0], outs['streamed'][0], 'add')
     close(outs['fused'][1], outs['streamed'][1], 'rmv')
     close(outs['fused'][2], outs['streamed'][2], 'pooled')
+
+
+def test_forward_rows_skips_duplicate_rows_exactly(cuda_device):
+    """Sets padded by duplication (test_region_grow.py:240,:252): evaluating only the distinct leading rows gives
+    bit-identical logits for them and the same pooled feature as evaluating all 512 rows."""
+    import torch
+    rs = np.random.RandomState(8)
+    B = 7
+    n_in = np.array([1, 57, 64, 65, 300, 512, 0])
+    n_nb = np.array([5, 512, 128, 63, 449, 200, 17])
+    xi = (rs.randn(B, 512, 13) * 0.5).astype(np.float32)
+    xn = (rs.randn(B, 512, 13) * 0.5).astype(np.float32)
+    for b in range(B):
+        for x, n in ((xi, n_in[b]), (xn, n_nb[b])):
+            if 0 < n < 512:
+                x[b, n:] = x[b, rs.randint(0, n, 512 - n)]
+    net, _ = make_net(cuda_device, 0, 13, 512, 512, 'fused')
+    dxi, dxn = torch.from_numpy(xi).to(cuda_device), torch.from_numpy(xn).to(cuda_device)
+    add_full, rmv_full = [t.cpu().numpy().copy() for t in net.forward(dxi, dxn)]
+    pooled_full = net.intermediate('pooled', 0, B).cpu().numpy().copy().reshape(B, -1)
+    add = torch.full((B, 512, 2), float('nan'), device=cuda_device)
+    rmv = torch.full((B, 512, 2), float('nan'), device=cuda_device)
+    rin = torch.from_numpy(n_in.astype(np.int32)).to(cuda_device)
+    rnb = torch.from_numpy(n_nb.astype(np.int32)).to(cuda_device)
+    net.forward(dxi, dxn, add, rmv, rows_in=rin, rows_nb=rnb)
+    add, rmv = add.cpu().numpy(), rmv.cpu().numpy()
+    pooled = net.intermediate('pooled', 0, B).cpu().numpy().reshape(B, -1)
+    for b in range(B):
+        if n_in[b] == 0 or n_nb[b] == 0:
+            continue                      # a zero count skips the instance: outputs undefined
+        np.testing.assert_array_equal(rmv[b, :n_in[b]], rmv_full[b, :n_in[b]])
+        np.testing.assert_array_equal(add[b, :n_nb[b]], add_full[b, :n_nb[b]])
+        np.testing.assert_array_equal(pooled[b], pooled_full[b])
+        tiles = -(-n_in[b] // 64) * 64
+        assert np.isnan(rmv[b, tiles:]).all()          # whole tiles of duplicates were never touched
