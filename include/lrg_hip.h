@@ -169,7 +169,14 @@ typedef struct LrgSlot {
     int32_t seq_mn[3], seq_mx[3]; /* seqMinDims / seqMaxDims (:201-202)                                      */
     int32_t target;          /* obj_id[seed] (:190)                                                          */
     int32_t pad;             /* 1 while cur_idx / cand_idx describe the current mask and bbox (set by lrg_box_query)  */
+    int32_t *chunk_cnt;      /* [2 * ceil(cap / LRG_SCAN_CHUNK)] per-chunk (current, candidate) counts of lrg_box_query */
+    int32_t scan_cnt;        /* lrg_bbox_stop scratch: members / min / max voxel of the updated mask, consumed (and    */
+    int32_t scan_mn[3];      /*   reset) by lrg_advance                                                               */
+    int32_t scan_mx[3];
+    int32_t query;           /* lrg_box_query scratch: 1 if this call re-derives the slot's lists                     */
 } LrgSlot;
+
+#define LRG_SCAN_CHUNK 4096  /* points per workgroup of the chunked mask scans */
 
 typedef struct LrgGrowParams {
     float resolution;        /* 0.1 (test_region_grow.py:27)                                                 */
@@ -193,9 +200,11 @@ int lrg_voxelize(const float *points, int n, int F, float resolution, int32_t *v
 int lrg_voxel_hash_build(const int32_t *voxels, int n, uint64_t *keys, int32_t *vals, int hash_mask,
                          int32_t *dup_flag, void *stream);
 
-/* Stop / bounding-box bookkeeping of the step just taken (:291-306), for every ACTIVE slot that has taken a
- * mask update (slot.updated >= 0). */
-int lrg_bbox_stop(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, void *stream);
+/* Scan of the updated mask (:292-293): member count and min / max voxel of every ACTIVE slot that has taken a mask
+ * update (slot.updated >= 0), reduced into slot.scan_*.  The stop / stuck decision of :291-306 is taken from those
+ * values at the start of the following lrg_advance.  max_points = capacity of the per-slot masks (grid sizing). */
+int lrg_bbox_stop(LrgSlot *slots, const LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                  void *stream);
 
 /* Commit finished seeds (:210-217 / restart :169-197), pick the next unvisited seed (:186-188) and reset
  * the group's slots (:197-204).  stats (device, LRG_STATS_WORDS x int64, nullable): see LrgStepBuffers. */
@@ -204,7 +213,8 @@ int lrg_advance(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams
 
 /* Dilated voxel-box neighbour query + ordered compaction (:221-235): fills cur_idx/nc, cand_idx/ne; a slot
  * with ne == 0 stops with LRG_STOP_NONEIGHBOR. */
-int lrg_box_query(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, void *stream);
+int lrg_box_query(LrgSlot *slots, const LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                  void *stream);
 
 /* center[s, c] = median over the slot's current points of channel c for c in {0,1} U [6,F), 0 elsewhere
  * (numpy.median, :241; only those channels are used, :243-247).  center is [n_slots,16]. */
@@ -266,8 +276,9 @@ typedef struct LrgStepBuffers {
  *   lrg_bbox_stop; advance_rounds x (lrg_advance; lrg_box_query); lrg_median; lrg_sample;
  *   lrg_gather_center; lrg_forward; lrg_mask_update.
  * `weights` and `buffers` are HOST structs of device pointers. */
-int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams *params, const LrgWeights *weights,
-                  const LrgStepBuffers *buffers, int advance_rounds, unsigned forward_flags, void *stream);
+int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                  const LrgWeights *weights, const LrgStepBuffers *buffers, int advance_rounds, unsigned forward_flags,
+                  void *stream);
 
 /* 1-NN fill-in of unlabeled points in all F feature dims, first-min ties (:308-316). */
 int lrg_nn1_fill(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *stream);

@@ -53,7 +53,11 @@ class LrgSlot(ctypes.Structure):
                 ('best_restart', ctypes.c_int32), ('last_reason', ctypes.c_int32),
                 ('mn', ctypes.c_int32 * 3), ('mx', ctypes.c_int32 * 3),
                 ('seq_mn', ctypes.c_int32 * 3), ('seq_mx', ctypes.c_int32 * 3),
-                ('target', ctypes.c_int32), ('pad', ctypes.c_int32)]
+                ('target', ctypes.c_int32), ('pad', ctypes.c_int32), ('chunk_cnt', _fp), ('scan_cnt', ctypes.c_int32),
+                ('scan_mn', ctypes.c_int32 * 3), ('scan_mx', ctypes.c_int32 * 3), ('query', ctypes.c_int32)]
+
+
+LRG_SCAN_CHUNK = 4096
 
 
 class LrgGrowParams(ctypes.Structure):
@@ -113,16 +117,16 @@ _SIGS = {
     'lrg_head_final': (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_long, ctypes.c_int, _fp]),
     'lrg_voxelize': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _fp, _fp]),
     'lrg_voxel_hash_build': (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, _fp]),
-    'lrg_bbox_stop': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp]),
+    'lrg_bbox_stop': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp]),
     'lrg_advance': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp]),
-    'lrg_box_query': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp]),
+    'lrg_box_query': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp]),
     'lrg_median': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp]),
     'lrg_sample': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp]),
     'lrg_gather_center': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp,
                                          _fp, _fp, _fp, _fp, _fp]),
     'lrg_mask_update': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp,
                                        _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
-    'lrg_grow_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgWeights),
+    'lrg_grow_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgWeights),
                                      ctypes.POINTER(LrgStepBuffers), ctypes.c_int, ctypes.c_uint, _fp]),
     'lrg_nn1_fill': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
     'lrg_query_ball_point': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _fp,

@@ -75,20 +75,22 @@ __device__ __forceinline__ int lrg_block_sum(int v, int *red) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// stop / bbox bookkeeping of the step just taken   (test_region_grow.py:291-306)
+// scan of the updated mask (test_region_grow.py:292-293): one workgroup per (slot, 4096-point chunk)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_bbox_stop_kernel(LrgSlot *slots, const LrgRoom *rooms,
-                                                                          LrgGrowParams prm) {
+__global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_bbox_scan_kernel(LrgSlot *slots, const LrgRoom *rooms) {
     __shared__ int red[16];
     LrgSlot *S = &slots[blockIdx.x];
     if (S->status != LRG_ACTIVE || S->updated < 0 || S->room < 0) return;
     const LrgRoom *R = &rooms[S->room];
     const int n = R->n;
+    const int i0 = blockIdx.y * LRG_SCAN_CHUNK;
+    if (i0 >= n) return;
     const uint8_t *cur = S->cur;
     const int32_t *vox = R->voxels;
     int cnt = 0;
     int mn0 = INT_MAX, mn1 = INT_MAX, mn2 = INT_MAX, mx0 = INT_MIN, mx1 = INT_MIN, mx2 = INT_MIN;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int iend = min(n, i0 + LRG_SCAN_CHUNK);
+    for (int i = i0 + threadIdx.x; i < iend; i += blockDim.x) {
         if (cur[i]) {
             ++cnt;
             int a = vox[3 * i], b = vox[3 * i + 1], c = vox[3 * i + 2];
@@ -97,10 +99,24 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_bbox_stop_kernel(LrgSlot
         }
     }
     cnt = lrg_block_sum(cnt, red);
+    if (cnt == 0) return;
     mn0 = lrg_block_min(mn0, red); mn1 = lrg_block_min(mn1, red); mn2 = lrg_block_min(mn2, red);
     mx0 = lrg_block_max(mx0, red); mx1 = lrg_block_max(mx1, red); mx2 = lrg_block_max(mx2, red);
     if (threadIdx.x != 0) return;
+    atomicAdd(&S->scan_cnt, cnt);
+    atomicMin(&S->scan_mn[0], mn0); atomicMin(&S->scan_mn[1], mn1); atomicMin(&S->scan_mn[2], mn2);
+    atomicMax(&S->scan_mx[0], mx0); atomicMax(&S->scan_mx[1], mx1); atomicMax(&S->scan_mx[2], mx2);
+}
+
+// stop / bbox decision of the step just taken (:291-306), from the scan results; run by one thread of lrg_advance
+__device__ void lrg_stop_logic(LrgSlot *S) {
     const int updated = S->updated;
+    const int cnt = S->scan_cnt;
+    const int mn0 = S->scan_mn[0], mn1 = S->scan_mn[1], mn2 = S->scan_mn[2];
+    const int mx0 = S->scan_mx[0], mx1 = S->scan_mx[1], mx2 = S->scan_mx[2];
+    S->scan_cnt = 0;
+    S->scan_mn[0] = S->scan_mn[1] = S->scan_mn[2] = INT_MAX;
+    S->scan_mx[0] = S->scan_mx[1] = S->scan_mx[2] = INT_MIN;
     S->updated = -1;
     S->count = cnt;
     if (!updated) { S->status = LRG_STOP_NOEXPAND; S->last_reason = LRG_STOP_NOEXPAND; return; }   // :304-306
@@ -139,12 +155,15 @@ __device__ void lrg_reset_slot(LrgSlot *S, const LrgRoom *R, int seed, int resta
         }
         S->target = R->obj_id ? R->obj_id[seed] : 0;
         S->pad = 0;
+        S->scan_cnt = 0;
+        S->scan_mn[0] = S->scan_mn[1] = S->scan_mn[2] = INT_MAX;
+        S->scan_mx[0] = S->scan_mx[1] = S->scan_mx[2] = INT_MIN;
         S->status = LRG_ACTIVE;
     }
 }
 
-__global__ __launch_bounds__(256) void lrg_advance_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
-                                                           LrgGrowParams prm, int64_t *stats) {
+__global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
+                                                                        LrgGrowParams prm, int64_t *stats) {
     __shared__ int sh_next;
     __shared__ int sh_flag;
     const int G = prm.group_size, RST = prm.restarts;
@@ -155,6 +174,20 @@ __global__ __launch_bounds__(256) void lrg_advance_kernel(LrgSlot *slots, LrgRoo
     LrgRoom *R = &rooms[S0->room];
     const int n = R->n;
     if (S0->status == LRG_DONE || S0->status == LRG_IDLE) return;
+
+    // ---- phase 0: stop / stuck decision of the step just taken, from lrg_bbox_stop's scan ----
+    if (threadIdx.x == 0) {
+        int work = 0;
+        for (int s = 0; s < G && g0 + s < n_slots; ++s) {
+            LrgSlot *S = &slots[g0 + s];
+            if (S->status == LRG_ACTIVE && S->updated >= 0) lrg_stop_logic(S);
+            if (S->status != LRG_ACTIVE) work = 1;
+        }
+        sh_flag = work;
+    }
+    __syncthreads();
+    if (!sh_flag) return;      // every slot of the group keeps growing: nothing to bank, commit or reseed
+    __syncthreads();
 
     // ---- phase 1: bank finished grows, start the slot's next restart (restart :173-175,:187-197) ----
     for (int s = 0; s < G && g0 + s < n_slots; ++s) {
@@ -270,56 +303,92 @@ __global__ __launch_bounds__(256) void lrg_advance_kernel(LrgSlot *slots, LrgRoo
 
 // ------------------------------------------------------------------------------------------------
 // dilated voxel-box query + ordered compaction   (test_region_grow.py:221-235)
+// two passes over (slot, 4096-point chunk) workgroups: count, then compact at the chunk's global offset
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_query_kernel(LrgSlot *slots, const LrgRoom *rooms,
-                                                                          LrgGrowParams prm) {
-    __shared__ int wtot_c[16], wtot_e[16];
-    LrgSlot *S = &slots[blockIdx.x];
-    if (S->status != LRG_ACTIVE || S->room < 0) return;
-    if (S->pad == 1) return;      // lists still valid: nothing changed since the last query of this iteration
-    const LrgRoom *R = &rooms[S->room];
-    const int n = R->n;
-    const uint8_t *cur = S->cur;
-    const uint8_t *visited = R->visited;
-    const int32_t *vox = R->voxels;
+struct LrgBoxFlags { int c, e; };   // bit k: point 4*tid+k of the chunk is current / is an expand candidate
+
+__device__ __forceinline__ LrgBoxFlags lrg_box_flags(const LrgSlot *S, const LrgRoom *R, int i0, int n) {
     const int lo0 = S->mn[0] - 1, lo1 = S->mn[1] - 1, lo2 = S->mn[2] - 1;     // :222-225
     const int hi0 = S->mx[0] + 1, hi1 = S->mx[1] + 1, hi2 = S->mx[2] + 1;
-    const int lane = lrg_lane(), wave = threadIdx.x >> 6;
-    const unsigned long long lt = (1ULL << lane) - 1ULL;
-    int base_c = 0, base_e = 0;
-    for (int i0 = 0; i0 < n; i0 += LRG_SCAN_THREADS) {
-        int i = i0 + threadIdx.x;
-        bool c = false, e = false;
+    LrgBoxFlags f = {0, 0};
+    const int ib = i0 + 4 * threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = ib + k;
         if (i < n) {
-            c = cur[i] != 0;
-            if (!c && !visited[i]) {                                           // :227-228
-                int a = vox[3 * i], b = vox[3 * i + 1], d = vox[3 * i + 2];
-                e = a >= lo0 && a <= hi0 && b >= lo1 && b <= hi1 && d >= lo2 && d <= hi2;   // :226
+            const bool c = S->cur[i] != 0;
+            if (c) f.c |= 1 << k;
+            else if (!R->visited[i]) {                                          // :227-228
+                const int a = R->voxels[3 * i], b = R->voxels[3 * i + 1], d = R->voxels[3 * i + 2];
+                if (a >= lo0 && a <= hi0 && b >= lo1 && b <= hi1 && d >= lo2 && d <= hi2) f.e |= 1 << k;   // :226
             }
         }
-        unsigned long long mc = __ballot(c), me = __ballot(e);
-        if (lane == 0) { wtot_c[wave] = __popcll(mc); wtot_e[wave] = __popcll(me); }
-        __syncthreads();
-        int off_c = 0, off_e = 0, tot_c = 0, tot_e = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            int tc = wtot_c[w], te = wtot_e[w];
-            if (w < wave) { off_c += tc; off_e += te; }
-            tot_c += tc; tot_e += te;
-        }
-        if (c) S->cur_idx[base_c + off_c + __popcll(mc & lt)] = i;
-        if (e) S->cand_idx[base_e + off_e + __popcll(me & lt)] = i;
-        base_c += tot_c; base_e += tot_e;
-        __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    return f;
+}
+
+__global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_count_kernel(LrgSlot *slots, const LrgRoom *rooms) {
+    __shared__ int red[16];
+    LrgSlot *S = &slots[blockIdx.x];
+    const bool go = S->status == LRG_ACTIVE && S->room >= 0 && S->pad != 1;
+    if (blockIdx.y == 0 && threadIdx.x == 0) S->query = go ? 1 : 0;           // read by the compaction pass
+    if (!go) return;
+    const LrgRoom *R = &rooms[S->room];
+    const int n = R->n;
+    const int i0 = blockIdx.y * LRG_SCAN_CHUNK;
+    if (i0 >= n) return;
+    LrgBoxFlags f = lrg_box_flags(S, R, i0, n);
+    int packed = __popc(f.c) | (__popc(f.e) << 16);
+    packed = lrg_block_sum(packed, red);
+    if (threadIdx.x == 0) { S->chunk_cnt[2 * blockIdx.y] = packed & 0xFFFF; S->chunk_cnt[2 * blockIdx.y + 1] = packed >> 16; }
+}
+
+__global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_compact_kernel(LrgSlot *slots, const LrgRoom *rooms,
+                                                                            LrgGrowParams prm) {
+    __shared__ int wtot[16];
+    LrgSlot *S = &slots[blockIdx.x];
+    if (S->room < 0 || S->query != 1) return;
+    const LrgRoom *R = &rooms[S->room];
+    const int n = R->n;
+    const int i0 = blockIdx.y * LRG_SCAN_CHUNK;
+    if (i0 >= n) return;
+    const int nchunk = (n + LRG_SCAN_CHUNK - 1) / LRG_SCAN_CHUNK;
+    int base_c = 0, base_e = 0, tot_c = 0, tot_e = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        const int cc = S->chunk_cnt[2 * c], ce = S->chunk_cnt[2 * c + 1];
+        if (c < (int)blockIdx.y) { base_c += cc; base_e += ce; }
+        tot_c += cc; tot_e += ce;
+    }
+    LrgBoxFlags f = lrg_box_flags(S, R, i0, n);
+    // exclusive scan of the packed per-thread counts over the 1024 threads
+    const int lane = lrg_lane(), wave = threadIdx.x >> 6;
+    const int mine = __popc(f.c) | (__popc(f.e) << 16);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wtot[w];
+    const int excl = woff + incl - mine;
+    int pc = base_c + (excl & 0xFFFF), pe = base_e + (excl >> 16);
+    const int ib = i0 + 4 * threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (f.c >> k & 1) S->cur_idx[pc++] = ib + k;
+        if (f.e >> k & 1) S->cand_idx[pe++] = ib + k;
+    }
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
         S->pad = 1;
-        S->nc = base_c;
-        S->ne = base_e;
-        if (base_e == 0) {                                                      // :233-235
-            S->status = LRG_STOP_NONEIGHBOR; S->last_reason = LRG_STOP_NONEIGHBOR; S->count = base_c;
+        S->nc = tot_c;
+        S->ne = tot_e;
+        if (tot_e == 0) {                                                       // :233-235
+            S->status = LRG_STOP_NONEIGHBOR; S->last_reason = LRG_STOP_NONEIGHBOR; S->count = tot_c;
         } else if (prm.max_region_steps > 0 && S->step >= prm.max_region_steps) {
-            S->status = LRG_STOP_MAXSTEPS; S->last_reason = LRG_STOP_MAXSTEPS; S->count = base_c;
+            S->status = LRG_STOP_MAXSTEPS; S->last_reason = LRG_STOP_MAXSTEPS; S->count = tot_c;
         }
     }
 }
@@ -328,7 +397,8 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_query_kernel(LrgSlot
 // per-channel median of the current points   (numpy.median, test_region_grow.py:241)
 // one workgroup per (slot, channel); radix select on order-preserving keys
 // ------------------------------------------------------------------------------------------------
-#define LRG_MED_CAP 16384
+#define LRG_MED_SMALL 4096      // keys cached in 16 KB of LDS: many workgroups per CU
+#define LRG_MED_LARGE 36864     // 144 KB: one workgroup per CU, only launched work for the few big regions
 __device__ __forceinline__ uint32_t lrg_f2key(float f) {
     uint32_t b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -369,21 +439,24 @@ __device__ void lrg_select2(const uint32_t *cache, bool cached, const float *pts
     *ra_out = ra; *rb_out = rb;
 }
 
+template <int CAP, bool LARGE>
 __global__ __launch_bounds__(256) void lrg_median_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                           float *center) {
-    __shared__ uint32_t cache[LRG_MED_CAP];
-    __shared__ int sh[8];
+    extern __shared__ __attribute__((aligned(16))) uint32_t cache[];      // [CAP] keys, then 8 ints of scratch
+    int *sh = reinterpret_cast<int *>(cache + CAP);
     const int s = blockIdx.x, ch = blockIdx.y;
     const LrgSlot *S = &slots[s];
     const int F = prm.feature_size;
     const bool centred = (ch < 2 || ch >= 6) && ch < F;                         // :243-247
-    if (!centred || S->status != LRG_ACTIVE || S->room < 0) {
-        if (threadIdx.x == 0) center[s * 16 + ch] = 0.f;
+    const bool active = S->status == LRG_ACTIVE && S->room >= 0;
+    if (!centred || !active) {
+        if (!LARGE && threadIdx.x == 0) center[s * 16 + ch] = 0.f;
         return;
     }
-    const LrgRoom *R = &rooms[S->room];
     const int nc = S->nc;
-    const bool cached = nc <= LRG_MED_CAP;
+    if (LARGE ? nc <= LRG_MED_SMALL : nc > LRG_MED_SMALL) return;              // the other launch owns this slot
+    const LrgRoom *R = &rooms[S->room];
+    const bool cached = nc <= CAP;
     if (cached) {
         for (int j = threadIdx.x; j < nc; j += blockDim.x) cache[j] = lrg_f2key(R->points[(long)S->cur_idx[j] * F + ch]);
         __syncthreads();
@@ -624,12 +697,14 @@ static int check_params(const LrgGrowParams *p) {
     return 0;
 }
 
-int lrg_bbox_stop(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, void *stream) {
+int lrg_bbox_stop(LrgSlot *slots, const LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                  void *stream) {
     int rc = check_params(params);
     if (rc) return rc;
-    if (!slots || !rooms || n_slots <= 0) return LRG_EINVAL - 1;
-    hipLaunchKernelGGL(lrg_bbox_stop_kernel, dim3(n_slots), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream, slots, rooms,
-                       *params);
+    if (!slots || !rooms || n_slots <= 0 || max_points <= 0) return LRG_EINVAL - 1;
+    const int nchunk = (max_points + LRG_SCAN_CHUNK - 1) / LRG_SCAN_CHUNK;
+    hipLaunchKernelGGL(lrg_bbox_scan_kernel, dim3(n_slots, nchunk), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream, slots,
+                       rooms);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -638,18 +713,23 @@ int lrg_advance(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || n_slots <= 0 || n_slots % params->group_size != 0) return LRG_EINVAL - 1;
-    hipLaunchKernelGGL(lrg_advance_kernel, dim3(n_slots / params->group_size), dim3(256), 0, (hipStream_t)stream, slots,
+    hipLaunchKernelGGL(lrg_advance_kernel, dim3(n_slots / params->group_size), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream, slots,
                        rooms, n_slots, *params, stats);
     LRG_LAUNCH_CHECK();
     return 0;
 }
 
-int lrg_box_query(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, void *stream) {
+int lrg_box_query(LrgSlot *slots, const LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                  void *stream) {
     int rc = check_params(params);
     if (rc) return rc;
-    if (!slots || !rooms || n_slots <= 0) return LRG_EINVAL - 1;
-    hipLaunchKernelGGL(lrg_box_query_kernel, dim3(n_slots), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream, slots, rooms,
-                       *params);
+    if (!slots || !rooms || n_slots <= 0 || max_points <= 0) return LRG_EINVAL - 1;
+    const int nchunk = (max_points + LRG_SCAN_CHUNK - 1) / LRG_SCAN_CHUNK;
+    hipLaunchKernelGGL(lrg_box_count_kernel, dim3(n_slots, nchunk), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream, slots,
+                       rooms);
+    LRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lrg_box_compact_kernel, dim3(n_slots, nchunk), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream,
+                       slots, rooms, *params);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -659,8 +739,19 @@ int lrg_median(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const Lr
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || !center || n_slots <= 0) return LRG_EINVAL - 1;
-    hipLaunchKernelGGL(lrg_median_kernel, dim3(n_slots, 16), dim3(256), 0, (hipStream_t)stream, slots, rooms, *params,
-                       center);
+    const size_t lds_small = LRG_MED_SMALL * 4 + 32, lds_large = LRG_MED_LARGE * 4 + 32;
+    auto large = lrg_median_kernel<LRG_MED_LARGE, true>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(large), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds_large));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((lrg_median_kernel<LRG_MED_SMALL, false>), dim3(n_slots, 16), dim3(256), lds_small,
+                       (hipStream_t)stream, slots, rooms, *params, center);
+    LRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(large, dim3(n_slots, params->feature_size), dim3(256), lds_large, (hipStream_t)stream, slots, rooms,
+                       *params, center);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -708,16 +799,17 @@ int lrg_mask_update(LrgSlot *slots, const LrgRoom *rooms, int n_slots, const Lrg
     return 0;
 }
 
-int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams *params, const LrgWeights *weights,
-                  const LrgStepBuffers *b, int advance_rounds, unsigned forward_flags, void *stream) {
+int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                  const LrgWeights *weights, const LrgStepBuffers *b, int advance_rounds, unsigned forward_flags,
+                  void *stream) {
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || !weights || !b || n_slots <= 0 || advance_rounds < 1) return LRG_EINVAL - 1;
     if (weights->feature_size != params->feature_size) return LRG_EINVAL - 2;
-    if ((rc = lrg_bbox_stop(slots, rooms, n_slots, params, stream))) return rc;
+    if ((rc = lrg_bbox_stop(slots, rooms, n_slots, max_points, params, stream))) return rc;
     for (int r = 0; r < advance_rounds; ++r) {
         if ((rc = lrg_advance(slots, rooms, n_slots, params, b->stats, stream))) return rc;
-        if ((rc = lrg_box_query(slots, rooms, n_slots, params, stream))) return rc;
+        if ((rc = lrg_box_query(slots, rooms, n_slots, max_points, params, stream))) return rc;
     }
     if ((rc = lrg_median(slots, rooms, n_slots, params, b->center, stream))) return rc;
     if ((rc = lrg_sample(slots, rooms, n_slots, params, b->sample_in, b->sample_nb, stream))) return rc;

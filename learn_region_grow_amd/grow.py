@@ -147,6 +147,8 @@ class RegionGrower:
         self.d_best = torch.zeros((S, cap), dtype=torch.uint8, device=dev)
         self.d_curidx = torch.zeros((S, cap), dtype=torch.int32, device=dev)
         self.d_candidx = torch.zeros((S, cap), dtype=torch.int32, device=dev)
+        nchunk = (cap + _lib.LRG_SCAN_CHUNK - 1) // _lib.LRG_SCAN_CHUNK
+        self.d_chunkcnt = torch.zeros((S, 2 * nchunk), dtype=torch.int32, device=dev)
         self.h_slots = (LrgSlot * S)()
         for s in range(S):
             sl = self.h_slots[s]
@@ -154,6 +156,7 @@ class RegionGrower:
             sl.best = self.d_best.data_ptr() + s * cap
             sl.cur_idx = self.d_curidx.data_ptr() + s * cap * 4
             sl.cand_idx = self.d_candidx.data_ptr() + s * cap * 4
+            sl.chunk_cnt = self.d_chunkcnt.data_ptr() + s * 2 * nchunk * 4
             sl.room = -1
             sl.status = LRG_IDLE
             sl.seed = -1
@@ -219,6 +222,10 @@ class RegionGrower:
             sl.count = -1
             sl.best_count = -1
             sl.pad = 0
+            sl.scan_cnt = 0
+            sl.query = 0
+            for d in range(3):
+                sl.scan_mn[d], sl.scan_mx[d] = 2147483647, -2147483648
         a, b = group * self.G, (group + 1) * self.G
         buf = np.frombuffer(bytes(self.h_slots), dtype=np.uint8)[a * sz:b * sz].copy()
         self.d_slots[a * sz:b * sz].copy_(torch.from_numpy(buf))
@@ -235,7 +242,7 @@ class RegionGrower:
     def enqueue_iteration(self):
         """One lock-step iteration, device-side randomness (no host sync)."""
         flags = self.net.forward_flags
-        rc = self.lib.lrg_grow_step(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, ctypes.byref(self.params),
+        rc = self.lib.lrg_grow_step(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, self.cap, ctypes.byref(self.params),
                                     ctypes.byref(self.net._w), ctypes.byref(self.step_buffers), self.advance_rounds,
                                     flags, _stream_ptr())
         _lib.check(rc, 'lrg_grow_step')
@@ -267,10 +274,10 @@ class RegionGrower:
     def _legacy_iteration(self, streams):
         lib, st, P = self.lib, _stream_ptr(), ctypes.byref(self.params)
         S, Ni, Nn = self.S, self.net.num_inlier_points, self.net.num_neighbor_points
-        _lib.check(lib.lrg_bbox_stop(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, st), 'lrg_bbox_stop')
+        _lib.check(lib.lrg_bbox_stop(_ptr(self.d_slots), _ptr(self.d_rooms), S, self.cap, P, st), 'lrg_bbox_stop')
         for _ in range(self.advance_rounds):
             _lib.check(lib.lrg_advance(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.d_stats), st), 'lrg_advance')
-            _lib.check(lib.lrg_box_query(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, st), 'lrg_box_query')
+            _lib.check(lib.lrg_box_query(_ptr(self.d_slots), _ptr(self.d_rooms), S, self.cap, P, st), 'lrg_box_query')
         slots = self._read_slots()
         active = [s for s in range(S) if slots[s].status == LRG_ACTIVE]
         if active:
