@@ -235,6 +235,12 @@ int lrg_gather_center(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, c
                       float *neighbor, int32_t *gt_remove, int32_t *gt_add, int32_t *rows_in, int32_t *rows_nb,
                       void *stream);
 
+/* lrg_median + lrg_sample + lrg_gather_center in one pass per slot (counter stream): the preparation of a step,
+ * test_region_grow.py:237-254.  Same outputs as the three calls. */
+int lrg_prepare(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
+                int32_t *sample_in, int32_t *sample_nb, float *inlier, float *neighbor, int32_t *gt_remove, int32_t *gt_add,
+                int32_t *rows_in, int32_t *rows_nb, void *stream);
+
 /* Confidence + Bernoulli masks + voxel-set mask update (:262-288).
  * add_mask / rmv_mask (nullable, uint8 [n_slots,n]) : host-decided masks (reference-order RNG);
  * when NULL the masks are drawn on the device from the counter stream against
@@ -273,8 +279,8 @@ typedef struct LrgStepBuffers {
 
 /* One whole lock-step iteration with device-side (counter-stream) randomness -- the body of the
  * `while True` loop at test_region_grow.py:208-306 for every slot at once:
- *   lrg_bbox_stop; advance_rounds x (lrg_advance; lrg_box_query); lrg_median; lrg_sample;
- *   lrg_gather_center; lrg_forward; lrg_mask_update.
+ *   lrg_bbox_stop; advance_rounds x (lrg_advance; lrg_box_query); lrg_prepare (= lrg_median + lrg_sample +
+ *   lrg_gather_center); lrg_forward_rows; lrg_mask_update.
  * `weights` and `buffers` are HOST structs of device pointers. */
 int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                   const LrgWeights *weights, const LrgStepBuffers *buffers, int advance_rounds, unsigned forward_flags,

@@ -124,6 +124,8 @@ _SIGS = {
     'lrg_sample': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp]),
     'lrg_gather_center': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp,
                                          _fp, _fp, _fp, _fp, _fp]),
+    'lrg_prepare': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp, _fp, _fp,
+                                   _fp, _fp, _fp]),
     'lrg_mask_update': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp,
                                        _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     'lrg_grow_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgWeights),

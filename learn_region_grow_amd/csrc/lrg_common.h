@@ -57,3 +57,21 @@ __device__ __forceinline__ int lrg_hash_lookup(const uint64_t *keys, const int32
 
 // rint(x / res) exactly as numpy.round(float32 / float32) (test_region_grow.py:175): IEEE divide, half-to-even.
 __device__ __forceinline__ int lrg_voxel_of(float x, float res) { return (int)rintf(__fdiv_rn(x, res)); }
+
+// Wavefront reductions on the DPP cross-lane network (VALU speed; __shfl_* go through the LDS crossbar at ~100 cycles a hop
+// and ballot+popcount pays a VALU->SALU round trip per call).  The result is returned to every lane.
+#define LRG_DPP_REDUCE(OP)                                                                                   \
+    v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0xB1, 0xF, 0xF, false));  /* quad_perm [1,0,3,2] */        \
+    v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x4E, 0xF, 0xF, false));  /* quad_perm [2,3,0,1] */        \
+    v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x141, 0xF, 0xF, false)); /* row_half_mirror    */        \
+    v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x140, 0xF, 0xF, false)); /* row_mirror         */        \
+    v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xA, 0xF, false)); /* row_bcast15 -> rows 1,3 */    \
+    v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xC, 0xF, false)); /* row_bcast31 -> rows 2,3 */    \
+    return __builtin_amdgcn_readlane(v, 63);
+
+__device__ __forceinline__ int lrg_op_add(int a, int b) { return a + b; }
+__device__ __forceinline__ int lrg_op_umin(int a, int b) { return (int)min((unsigned)a, (unsigned)b); }
+__device__ __forceinline__ int lrg_op_umax(int a, int b) { return (int)max((unsigned)a, (unsigned)b); }
+__device__ __forceinline__ int lrg_wave_sum_i32(int v) { const int ident = 0; LRG_DPP_REDUCE(lrg_op_add) }
+__device__ __forceinline__ unsigned lrg_wave_min_u32(unsigned x) { int v = (int)x; const int ident = -1; LRG_DPP_REDUCE(lrg_op_umin) }
+__device__ __forceinline__ unsigned lrg_wave_max_u32(unsigned x) { int v = (int)x; const int ident = 0; LRG_DPP_REDUCE(lrg_op_umax) }

@@ -141,8 +141,10 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
     const int nlayers = P.nlayers;
     int prevN = Kp;
     int lastN = 0, lastflags = 0;
+    LrgFusedLayer Lnext = P.L[0];
     for (int l = 0; l < nlayers; ++l) {
-        const LrgFusedLayer L = P.L[l];            // one batch of scalar loads per layer
+        const LrgFusedLayer L = Lnext;             // descriptors are fetched one layer ahead (scalar loads off the critical path)
+        if (l + 1 < nlayers) Lnext = P.L[l + 1];
         const bool inplace = (L.flags & LRG_FL_INPLACE) != 0;
         const float *act_in = (l & 1) ? buf0 : buf1;
         float *act_out = ((l & 1) != 0) == !inplace ? buf1 : buf0;
@@ -159,6 +161,9 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+            float bv = 0.f;                          // issued before the MFMAs so that its latency hides behind them
+            if (wave_on && L.bias)
+                bv = (L.flags & LRG_FL_INST_BIAS) ? L.bias[(r0 / P.rows_per_inst) * L.N + col0 + li] : L.bias[col0 + li];
             if (wave_on) {
                 const float *wrow = L.w + col0;
                 if (L.K == 128) tile_mfma<16, RT>(acc, ap, ld_in, wrow, loff, L.ldw);
@@ -170,8 +175,6 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
             if (wave_on) {
                 // ---- epilogue: bias, ReLU, keep in LDS / copy to HBM / column max ----
                 const int col = col0 + li;
-                float bv = 0.f;
-                if (L.bias) bv = (L.flags & LRG_FL_INST_BIAS) ? L.bias[(r0 / P.rows_per_inst) * L.N + col] : L.bias[col];
                 float cmax = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16 * RT; ++r) {

@@ -8,6 +8,17 @@
 
 #define LRG_SCAN_THREADS 1024
 
+#ifndef LRG_TRACE
+#define LRG_TRACE 0
+#endif
+#if LRG_TRACE
+__device__ long long *g_lrg_trace2 = nullptr;
+extern "C" void lrg_set_trace2(long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lrg_trace2), &p, sizeof(p)); }
+#define TRACE2(slot, i) do { if (threadIdx.x == 0 && g_lrg_trace2) g_lrg_trace2[(long)(slot) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE2(slot, i)
+#endif
+
 __device__ __forceinline__ bool lrg_is_stop(int st) { return st >= LRG_STOP_NONEIGHBOR && st <= LRG_STOP_MAXSTEPS; }
 
 // ------------------------------------------------------------------------------------------------
@@ -89,13 +100,21 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_bbox_scan_kernel(LrgSlot
     const int32_t *vox = R->voxels;
     int cnt = 0;
     int mn0 = INT_MAX, mn1 = INT_MAX, mn2 = INT_MAX, mx0 = INT_MIN, mx1 = INT_MIN, mx2 = INT_MIN;
-    const int iend = min(n, i0 + LRG_SCAN_CHUNK);
-    for (int i = i0 + threadIdx.x; i < iend; i += blockDim.x) {
-        if (cur[i]) {
-            ++cnt;
-            int a = vox[3 * i], b = vox[3 * i + 1], c = vox[3 * i + 2];
-            mn0 = min(mn0, a); mn1 = min(mn1, b); mn2 = min(mn2, c);
-            mx0 = max(mx0, a); mx1 = max(mx1, b); mx2 = max(mx2, c);
+    {
+        const int ib = i0 + 4 * threadIdx.x;
+        int m[4], a[4], b[4], c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                 // unconditional loads (clamped): no dependent round trips
+            const int i = min(ib + k, n - 1);
+            m[k] = cur[i]; a[k] = vox[3 * i]; b[k] = vox[3 * i + 1]; c[k] = vox[3 * i + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (ib + k < n && m[k]) {
+                ++cnt;
+                mn0 = min(mn0, a[k]); mn1 = min(mn1, b[k]); mn2 = min(mn2, c[k]);
+                mx0 = max(mx0, a[k]); mx1 = max(mx1, b[k]); mx2 = max(mx2, c[k]);
+            }
         }
     }
     cnt = lrg_block_sum(cnt, red);
@@ -310,18 +329,24 @@ struct LrgBoxFlags { int c, e; };   // bit k: point 4*tid+k of the chunk is curr
 __device__ __forceinline__ LrgBoxFlags lrg_box_flags(const LrgSlot *S, const LrgRoom *R, int i0, int n) {
     const int lo0 = S->mn[0] - 1, lo1 = S->mn[1] - 1, lo2 = S->mn[2] - 1;     // :222-225
     const int hi0 = S->mx[0] + 1, hi1 = S->mx[1] + 1, hi2 = S->mx[2] + 1;
+    const uint8_t *cur = S->cur, *visited = R->visited;
+    const int32_t *vox = R->voxels;
     LrgBoxFlags f = {0, 0};
     const int ib = i0 + 4 * threadIdx.x;
+    // all loads unconditional (clamped index): dependent predicated loads would serialise into 12 round trips
+    int c[4], vis[4], a[4], b[4], d[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int i = ib + k;
-        if (i < n) {
-            const bool c = S->cur[i] != 0;
-            if (c) f.c |= 1 << k;
-            else if (!R->visited[i]) {                                          // :227-228
-                const int a = R->voxels[3 * i], b = R->voxels[3 * i + 1], d = R->voxels[3 * i + 2];
-                if (a >= lo0 && a <= hi0 && b >= lo1 && b <= hi1 && d >= lo2 && d <= hi2) f.e |= 1 << k;   // :226
-            }
+        const int i = min(ib + k, n - 1);
+        c[k] = cur[i]; vis[k] = visited[i];
+        a[k] = vox[3 * i]; b[k] = vox[3 * i + 1]; d[k] = vox[3 * i + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (ib + k < n) {
+            if (c[k]) f.c |= 1 << k;
+            else if (!vis[k] && a[k] >= lo0 && a[k] <= hi0 && b[k] >= lo1 && b[k] <= hi1 && d[k] >= lo2 && d[k] <= hi2)
+                f.e |= 1 << k;                                                  // :226-228
         }
     }
     return f;
@@ -397,7 +422,7 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_compact_kernel(LrgSl
 // per-channel median of the current points   (numpy.median, test_region_grow.py:241)
 // one workgroup per (slot, channel); radix select on order-preserving keys
 // ------------------------------------------------------------------------------------------------
-#define LRG_MED_SMALL 4096      // keys cached in 16 KB of LDS: many workgroups per CU
+#define LRG_MED_SMALL 1024      // up to 16 keys per lane: one wavefront per (slot, channel), registers only, no barriers
 #define LRG_MED_LARGE 36864     // 144 KB: one workgroup per CU, only launched work for the few big regions
 __device__ __forceinline__ uint32_t lrg_f2key(float f) {
     uint32_t b = __float_as_uint(f);
@@ -412,22 +437,41 @@ __device__ __forceinline__ float lrg_key2f(uint32_t k) {
 // with #(key < r) <= k.  32 counting passes, no atomics, no sorting (regions of 1..10^4 points, test_region_grow.py:241).
 __device__ void lrg_select2(const uint32_t *cache, bool cached, const float *pts, const int32_t *idx, int F, int ch,
                             int nc, int ka, int kb, int *sh, uint32_t *ra_out, uint32_t *rb_out) {
-    uint32_t ra = 0, rb = 0;
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int nround = (nc + blockDim.x - 1) / blockDim.x;
-    for (int bit = 31; bit >= 0; --bit) {
+    // The keys of one channel of one region are clustered (coordinates within a room, near-constant normals): their
+    // common high bits cannot discriminate, so find them first (one min/max pass) and bisect only the bits below.
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (int it = 0; it < nround; ++it) {
+        int j = it * blockDim.x + threadIdx.x;
+        if (j < nc) {
+            uint32_t key = cached ? cache[j] : lrg_f2key(pts[(long)idx[j] * F + ch]);
+            kmin = min(kmin, key); kmax = max(kmax, key);
+        }
+    }
+    kmin = lrg_wave_min_u32(kmin);
+    kmax = lrg_wave_max_u32(kmax);
+    if (lrg_lane() == 0) { sh[2 * wave] = (int)kmin; sh[2 * wave + 1] = (int)kmax; }
+    __syncthreads();
+    for (int w = 0; w < nw; ++w) { kmin = min(kmin, (uint32_t)sh[2 * w]); kmax = max(kmax, (uint32_t)sh[2 * w + 1]); }
+    __syncthreads();
+    const uint32_t diff = kmin ^ kmax;
+    const int hb = diff ? 32 - __clz((int)diff) : 0;              // bits [hb,32) are common to every key
+    const uint32_t common = hb >= 32 ? 0u : (kmin >> hb) << hb;
+    uint32_t ra = common, rb = common;
+    for (int bit = hb - 1; bit >= 0; --bit) {
         const uint32_t ca = ra | (1u << bit), cb = rb | (1u << bit);
         int cnt_a = 0, cnt_b = 0;
         for (int it = 0; it < nround; ++it) {
             int j = it * blockDim.x + threadIdx.x;
-            bool la = false, lb = false;
             if (j < nc) {
                 uint32_t key = cached ? cache[j] : lrg_f2key(pts[(long)idx[j] * F + ch]);
-                la = key < ca; lb = key < cb;
+                cnt_a += key < ca ? 1 : 0;
+                cnt_b += key < cb ? 1 : 0;
             }
-            cnt_a += (int)__popcll(__ballot(la));
-            cnt_b += (int)__popcll(__ballot(lb));
         }
+        cnt_a = lrg_wave_sum_i32(cnt_a);
+        cnt_b = lrg_wave_sum_i32(cnt_b);
         if (lrg_lane() == 0) { sh[2 * wave] = cnt_a; sh[2 * wave + 1] = cnt_b; }
         __syncthreads();
         int ta = 0, tb = 0;
@@ -439,26 +483,185 @@ __device__ void lrg_select2(const uint32_t *cache, bool cached, const float *pts
     *ra_out = ra; *rb_out = rb;
 }
 
-template <int CAP, bool LARGE>
-__global__ __launch_bounds__(256) void lrg_median_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
-                                                          float *center) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cache[];      // [CAP] keys, then 8 ints of scratch
-    int *sh = reinterpret_cast<int *>(cache + CAP);
-    const int s = blockIdx.x, ch = blockIdx.y;
+// Median of channel ch over nc <= 1024 current points by ONE wavefront: up to 16 keys per lane in registers; per-lane
+// VALU counters and one DPP wave reduction per bisection step -- no LDS, no barriers, no scalar popcounts
+// (the common case: the median Area-5 region has 57 points).
+__device__ float lrg_median_wave(const float *points, const int32_t *idx, int F, int ch, int nc) {
+    const int lane = lrg_lane();
+    const float *pts = points + ch;
+    const int nr = (nc + 63) >> 6;
+    uint32_t key[16];
+    int id[16];
+    // unconditional loads at clamped positions: predicated loads would each sit in their own branch with a full
+    // s_waitcnt behind it (16 dependent round trips instead of 2)
+    if (nr <= 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) id[r] = idx[min(r * 64 + lane, nc - 1)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) key[r] = (r * 64 + lane < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 4; r < 16; ++r) key[r] = 0xFFFFFFFFu;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) id[r] = idx[min(r * 64 + lane, nc - 1)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) key[r] = (r * 64 + lane < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
+    }
+    // common high bits of the (clustered) keys cannot discriminate: bisect only below them
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (r * 64 + lane < nc) { kmin = min(kmin, key[r]); kmax = max(kmax, key[r]); }
+    kmin = lrg_wave_min_u32(kmin);
+    kmax = lrg_wave_max_u32(kmax);
+    const uint32_t diff = kmin ^ kmax;
+    const int hb = diff ? 32 - __clz((int)diff) : 0;
+    const uint32_t common = hb >= 32 ? 0u : (kmin >> hb) << hb;
+    const int k2 = nc >> 1;
+    const int k1 = (nc & 1) ? k2 : k2 - 1;
+    uint32_t ra = common, rb = common;
+    for (int bit = hb - 1; bit >= 0; --bit) {
+        const uint32_t ca = ra | (1u << bit), cb = rb | (1u << bit);
+        int cnt = 0;                                   // low half: #(key < ca), high half: #(key < cb); nc <= 1024 fits
+        if (nr <= 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cnt += (key[r] < ca ? 1 : 0) + (key[r] < cb ? 0x10000 : 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cnt += (key[r] < ca ? 1 : 0) + (key[r] < cb ? 0x10000 : 0);   // padding keys never count
+        }
+        const int tot = lrg_wave_sum_i32(cnt);
+        if ((tot & 0xFFFF) <= k1) ra = ca;
+        if ((tot >> 16) <= k2) rb = cb;
+    }
+    float lo = lrg_key2f(ra), hi = lrg_key2f(rb);
+    return (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);   // numpy.mean of the two middle float32 values
+}
+
+__global__ __launch_bounds__(256) void lrg_median_wave_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
+                                                               float *center, int n_slots) {
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int s = pair >> 4, ch = pair & 15;
+    if (s >= n_slots) return;
     const LrgSlot *S = &slots[s];
     const int F = prm.feature_size;
     const bool centred = (ch < 2 || ch >= 6) && ch < F;                         // :243-247
     const bool active = S->status == LRG_ACTIVE && S->room >= 0;
     if (!centred || !active) {
-        if (!LARGE && threadIdx.x == 0) center[s * 16 + ch] = 0.f;
+        if (lrg_lane() == 0) center[s * 16 + ch] = 0.f;
         return;
     }
     const int nc = S->nc;
-    if (LARGE ? nc <= LRG_MED_SMALL : nc > LRG_MED_SMALL) return;              // the other launch owns this slot
+    if (nc > LRG_MED_SMALL) return;                                             // the block-level launch owns this slot
+    float med = lrg_median_wave(rooms[S->room].points, S->cur_idx, F, ch, nc);
+    if (lrg_lane() == 0) center[s * 16 + ch] = med;
+}
+
+// Fused per-slot preparation of a step for the counter stream: medians of small regions (large ones come from
+// lrg_median_block_kernel, launched just before), subset sampling, gather + centre   (test_region_grow.py:237-254).
+// 9 wavefronts: one per centred channel for the medians; then element-wise (coalesced) gather of the sampled rows.
+#define LRG_PREP_THREADS 576
+__global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const LrgSlot *slots, const LrgRoom *rooms,
+                                                                       LrgGrowParams prm, float *center, int32_t *sample_in,
+                                                                       int32_t *sample_nb, float *inlier, float *neighbor,
+                                                                       int32_t *gt_remove, int32_t *gt_add, int32_t *rows_in,
+                                                                       int32_t *rows_nb) {
+    __shared__ float sh_c[16];
+    __shared__ int sh_src[2][1024];
+    const int s = blockIdx.x;
+    TRACE2(s, 0);
+    const LrgSlot *S = &slots[s];
+    const bool active = S->status == LRG_ACTIVE && S->room >= 0;
+    if (rows_in && threadIdx.x == 0) {
+        rows_in[s] = active ? min(S->nc, prm.n_inlier) : 0;
+        rows_nb[s] = active ? min(S->ne, prm.n_neighbor) : 0;
+    }
+    if (!active) return;
     const LrgRoom *R = &rooms[S->room];
-    const bool cached = nc <= CAP;
+    const int F = prm.feature_size, nc = S->nc, ne = S->ne;
+    const int wave = threadIdx.x >> 6, lane = lrg_lane();
+    const int kin = min(prm.n_inlier, 1024), knb = min(prm.n_neighbor, 1024);
+    const float *points = R->points;
+    const int32_t *obj = R->obj_id;
+    // ---- subset sampling (:237-240, :249-252): positions -> source indices (independent of the centre) ----
+    const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
+    for (int u = threadIdx.x; u < kin + knb; u += blockDim.x) {
+        const int side = u >= kin, j = side ? u - kin : u;
+        const int pos = (int)lrg_sample_position((uint32_t)j, (uint32_t)(side ? ne : nc), (uint32_t)(side ? knb : kin),
+                                                 side ? LRG_PURPOSE_NEIGHBOR : LRG_PURPOSE_INLIER, (uint32_t)S->seed,
+                                                 (uint32_t)S->restart, (uint32_t)S->step, k0, k1);
+        const int src = (side ? S->cand_idx : S->cur_idx)[pos];
+        sh_src[side][j] = src;
+        if (side) {
+            sample_nb[(long)s * prm.n_neighbor + j] = pos;
+            if (gt_add) gt_add[(long)s * prm.n_neighbor + j] = obj ? (obj[src] == S->target) : 0;          // :230,:254
+        } else {
+            sample_in[(long)s * prm.n_inlier + j] = pos;
+            if (gt_remove) gt_remove[(long)s * prm.n_inlier + j] = obj ? (obj[src] != S->target) : 0;      // :231,:248
+        }
+    }
+    // ---- centre (:241) ----
+    if (threadIdx.x < 16) sh_c[threadIdx.x] = 0.f;
+    __syncthreads();
+    TRACE2(s, 1);
+    if (nc <= LRG_MED_SMALL) {
+        int k = 0;                                        // k-th centred channel goes to wave k (9 channels, 9 waves)
+        for (int ch = 0; ch < F; ++ch) {
+            if (!(ch < 2 || ch >= 6)) continue;           // :243-247
+            if ((k++ % (LRG_PREP_THREADS / 64)) != wave) continue;
+            float med = lrg_median_wave(points, S->cur_idx, F, ch, nc);
+            if (lane == 0) { sh_c[ch] = med; center[s * 16 + ch] = med; }
+        }
+        if (threadIdx.x < 16 && !((threadIdx.x < 2 || threadIdx.x >= 6) && threadIdx.x < F)) center[s * 16 + threadIdx.x] = 0.f;
+    } else if (threadIdx.x < 16) {
+        sh_c[threadIdx.x] = ((threadIdx.x < 2 || threadIdx.x >= 6) && threadIdx.x < F) ? center[s * 16 + threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+    TRACE2(s, 2);
+#if LRG_TRACE
+    if (threadIdx.x == 0 && g_lrg_trace2) g_lrg_trace2[(long)s * 16 + 8] = nc;
+#endif
+    // ---- gather + centre (:242-254), element-wise so that loads and stores of a row are contiguous across lanes ----
+    for (int side = 0; side < 2; ++side) {
+        const int k = side ? knb : kin;
+        float *out = side ? neighbor + (long)s * prm.n_neighbor * F : inlier + (long)s * prm.n_inlier * F;
+        for (int e = threadIdx.x; e < k * F; e += blockDim.x) {
+            const int j = e / F, f = e - j * F;
+            out[e] = __fsub_rn(points[(long)sh_src[side][j] * F + f], sh_c[f]);
+        }
+    }
+    TRACE2(s, 3);
+}
+
+// Larger regions: one 1024-thread workgroup per (slot, channel), keys cached in LDS (up to 36864), block-wide counts.
+__global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
+                                                                 float *center) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cache[];      // [LRG_MED_LARGE] keys, then 32 ints of scratch
+    int *sh = reinterpret_cast<int *>(cache + LRG_MED_LARGE);
+    const int s = blockIdx.x, ch = blockIdx.y;
+    const LrgSlot *S = &slots[s];
+    const int F = prm.feature_size;
+    const bool centred = (ch < 2 || ch >= 6) && ch < F;
+    if (!centred || S->status != LRG_ACTIVE || S->room < 0) return;
+    const int nc = S->nc;
+    if (nc <= LRG_MED_SMALL) return;                                           // done by the wave-level launch
+    const LrgRoom *R = &rooms[S->room];
+    const bool cached = nc <= LRG_MED_LARGE;
     if (cached) {
-        for (int j = threadIdx.x; j < nc; j += blockDim.x) cache[j] = lrg_f2key(R->points[(long)S->cur_idx[j] * F + ch]);
+        // gather 8 values per thread per round: the index load and the dependent feature load of the 8 are independent,
+        // so their two global latencies are paid once per round instead of once per element
+        const int32_t *idx = S->cur_idx;
+        const float *pts = R->points + ch;
+        for (int j0 = threadIdx.x; j0 < nc; j0 += 8 * blockDim.x) {
+            int id[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { int jj = j0 + u * blockDim.x; id[u] = jj < nc ? idx[jj] : 0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pts[(long)id[u] * F];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { int jj = j0 + u * blockDim.x; if (jj < nc) cache[jj] = lrg_f2key(v[u]); }
+        }
         __syncthreads();
     }
     const int k2 = nc >> 1;
@@ -466,7 +669,7 @@ __global__ __launch_bounds__(256) void lrg_median_kernel(const LrgSlot *slots, c
     uint32_t ka, kb;
     lrg_select2(cache, cached, R->points, S->cur_idx, F, ch, nc, k1, k2, sh, &ka, &kb);
     float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
-    float med = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);   // numpy.mean of the two middle float32 values
+    float med = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
     if (threadIdx.x == 0) center[s * 16 + ch] = med;
 }
 
@@ -739,19 +942,42 @@ int lrg_median(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const Lr
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || !center || n_slots <= 0) return LRG_EINVAL - 1;
-    const size_t lds_small = LRG_MED_SMALL * 4 + 32, lds_large = LRG_MED_LARGE * 4 + 32;
-    auto large = lrg_median_kernel<LRG_MED_LARGE, true>;
+    const size_t lds_large = LRG_MED_LARGE * 4 + 128;
     static bool attr_done = false;
     if (!attr_done) {
-        LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(large), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds_large));
+        LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_median_block_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_large));
         attr_done = true;
     }
-    hipLaunchKernelGGL((lrg_median_kernel<LRG_MED_SMALL, false>), dim3(n_slots, 16), dim3(256), lds_small,
+    hipLaunchKernelGGL(lrg_median_wave_kernel, dim3((n_slots * 16 + 3) / 4), dim3(256), 0, (hipStream_t)stream, slots, rooms,
+                       *params, center, n_slots);
+    LRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lrg_median_block_kernel, dim3(n_slots, params->feature_size), dim3(1024), lds_large,
                        (hipStream_t)stream, slots, rooms, *params, center);
     LRG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(large, dim3(n_slots, params->feature_size), dim3(256), lds_large, (hipStream_t)stream, slots, rooms,
-                       *params, center);
+    return 0;
+}
+
+int lrg_prepare(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
+                int32_t *sample_in, int32_t *sample_nb, float *inlier, float *neighbor, int32_t *gt_remove, int32_t *gt_add,
+                int32_t *rows_in, int32_t *rows_nb, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || !center || !sample_in || !sample_nb || !inlier || !neighbor || n_slots <= 0) return LRG_EINVAL - 1;
+    if ((rows_in == nullptr) != (rows_nb == nullptr)) return LRG_EINVAL - 2;
+    if (params->n_inlier > 1024 || params->n_neighbor > 1024) return LRG_EINVAL - 3;
+    const size_t lds_large = LRG_MED_LARGE * 4 + 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_median_block_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_large));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(lrg_median_block_kernel, dim3(n_slots, params->feature_size), dim3(1024), lds_large,
+                       (hipStream_t)stream, slots, rooms, *params, center);
+    LRG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lrg_prepare_kernel, dim3(n_slots), dim3(LRG_PREP_THREADS), 0, (hipStream_t)stream, slots, rooms, *params, center,
+                       sample_in, sample_nb, inlier, neighbor, gt_remove, gt_add, rows_in, rows_nb);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -811,12 +1037,10 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
         if ((rc = lrg_advance(slots, rooms, n_slots, params, b->stats, stream))) return rc;
         if ((rc = lrg_box_query(slots, rooms, n_slots, max_points, params, stream))) return rc;
     }
-    if ((rc = lrg_median(slots, rooms, n_slots, params, b->center, stream))) return rc;
-    if ((rc = lrg_sample(slots, rooms, n_slots, params, b->sample_in, b->sample_nb, stream))) return rc;
     const bool rows = b->rows_in && b->rows_nb && (forward_flags & LRG_FWD_FUSED);
-    if ((rc = lrg_gather_center(slots, rooms, n_slots, params, b->sample_in, b->sample_nb, b->center, b->inlier,
-                                b->neighbor, b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr,
-                                rows ? b->rows_nb : nullptr, stream))) return rc;
+    if ((rc = lrg_prepare(slots, rooms, n_slots, params, b->center, b->sample_in, b->sample_nb, b->inlier, b->neighbor,
+                          b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, stream)))
+        return rc;
     if ((rc = lrg_forward_rows(weights, b->inlier, b->neighbor, n_slots, params->n_inlier, params->n_neighbor,
                                rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, b->add_logits, b->rmv_logits,
                                b->workspace, b->workspace_bytes, forward_flags, stream))) return rc;
