@@ -159,6 +159,13 @@ def main():
         torch.cuda.synchronize()
         fwd_rows_ms = ev0.elapsed_time(ev1) / reps
 
+    # HBM traffic of one dense evaluation from rocprofv3 FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py,
+    # gfx950 corrections applied there); collected offline at S=68 and committed under profiles/
+    traffic = None
+    tpath = os.path.join(REPO, 'profiles', 'r01_traffic_%s.json' % args.net_mode)
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath))['hbm_bytes_per_forward'] * S / 68.0
+
     # ---- final label gather over RCCL (the only collective of the path) ----
     if world > 1:
         labs = [gr.d_label[int(gr.room_off[r]):int(gr.room_off[r]) + gr.room_n[r]].cpu().numpy() for r in range(2)]
@@ -184,7 +191,8 @@ def main():
                        'active_fraction': inst_steps / (args.steps * S * world)},
             'roofline': {'bound': 'hbm', 'kernel': 'lrg_forward (all launches of one LrgNet evaluation batch)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'ms_per_launch': fwd_ms, 'instances_per_launch': S,
+                         'traffic': traffic, 'traffic_source': 'profiles/r01_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, S=68)' % args.net_mode,
+                         'algorithmic_bytes': S * BYTES_PER_INSTANCE_STEP, 'ms_per_launch': fwd_ms, 'instances_per_launch': S,
                          'bytes_per_instance': BYTES_PER_INSTANCE_STEP,
                          'fp32_matrix_tflops': tflops, 'fp32_matrix_frac': tflops / FP32_MATRIX_PEAK_TFLOPS,
                          'note': 'dense launch: all 512+512 rows of every instance evaluated',
