@@ -38,6 +38,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--rooms', type=int, default=68, help='rooms in flight per GPU (the Area-5 set has 68)')
     ap.add_argument('--restarts', type=int, default=1)
+    ap.add_argument('--workload', default='area5', choices=['area5', 'kitti'],
+                    help='area5: 68 Area-5-shaped rooms (configs[1]); kitti: 100 k-point scenes at 0.3 m (configs[4])')
     ap.add_argument('--policy', default='gt', choices=['net', 'gt', 'threshold'],
                     help="mask policy: 'net' = the reference's Bernoulli draws against the network's confidence "
                          "(test_region_grow.py:266-267); 'gt' = its commented-out ground-truth masks (:268-269). "
@@ -101,10 +103,15 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     weights = synthetic.make_synthetic_weights(seed=0)
-    rooms = workloads.area5_rooms(args.rooms, seed_base=1000 + 100 * rank, cache_dir=args.cache)
+    resolution = 0.1
+    if args.workload == 'kitti':
+        resolution = 0.3
+        rooms = workloads.kitti_scenes(min(args.rooms, 8), seed_base=5000 + 100 * rank, cache_dir=args.cache)
+    else:
+        rooms = workloads.area5_rooms(args.rooms, seed_base=1000 + 100 * rank, cache_dir=args.cache)
     net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, fuse_pool=bool(args.fuse_pool), mode=args.net_mode).load_weights(weights)
     gr = RegionGrower(net, rooms_in_flight=len(rooms), restarts=args.restarts, rng='counter', seed=rank,
-                      policy=args.policy, advance_rounds=args.advance_rounds)
+                      policy=args.policy, advance_rounds=args.advance_rounds, resolution=resolution)
     gr.load_rooms(rooms)
     for g in range(gr.n_groups):
         gr.bind(g, g)
@@ -182,9 +189,11 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'S3DIS Area-5-shaped synthetic rooms (68-room set per GPU, all in flight, cycled), '
-                                   'greedy test_region_grow.py loop' if args.restarts == 1 else
-                                   'Area-5-shaped rooms, random restarts x%d' % args.restarts,
+            'config': {'workload': ('Semantic-KITTI-shaped synthetic scenes (~100 k points at 0.3 m), %d in flight' % len(rooms)
+                                    if args.workload == 'kitti' else
+                                    'S3DIS Area-5-shaped synthetic rooms (68-room set per GPU, all in flight, cycled)') +
+                                   (', greedy test_region_grow.py loop' if args.restarts == 1 else
+                                    ', test_random_restart.py loop with %d restarts per seed batched per launch' % args.restarts),
                        'rooms_in_flight_per_gpu': len(rooms), 'slots_per_gpu': S, 'policy': args.policy,
                        'restarts': args.restarts, 'points': '512 inlier + 512 neighbour x 13 features',
                        'rng': 'counter (Philox) stream', 'weights': 'synthetic, seed 0', 'net_mode': args.net_mode,

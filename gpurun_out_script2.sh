@@ -1,12 +1,3 @@
-mkdir -p gpurun_out
-R=$(pwd)
-python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
-cd /tmp && export TMPDIR=/tmp
-for mode in fused streamed; do
-  O=$R/gpurun_out/traffic_$mode; rm -rf $O; mkdir -p $O
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python $R/tools/fwd_only.py 68 $mode 4 > $O/fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- python $R/tools/fwd_only.py 68 $mode 4 > $O/write.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib_fetch -o p --output-format csv -- python $R/tools/pmc_calib.py > $O/cf.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/calib_write -o p --output-format csv -- python $R/tools/pmc_calib.py > $O/cw.log 2>&1
-  python $R/tools/pmc_traffic.py $O 5 $R/gpurun_out/traffic_$mode.json
-done
+cd learn_region_grow_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -w -DLRG_TRACE=1 -o ../liblrg_hip.so lrg_net.hip lrg_fused.hip lrg_grow.hip lrg_grouping.hip; echo rc=$?
+cd ../..; python tools/trace_prepare.py 2>&1 | grep -v amdgpu | tail -10

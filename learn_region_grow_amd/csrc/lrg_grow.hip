@@ -422,7 +422,8 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_compact_kernel(LrgSl
 // per-channel median of the current points   (numpy.median, test_region_grow.py:241)
 // one workgroup per (slot, channel); radix select on order-preserving keys
 // ------------------------------------------------------------------------------------------------
-#define LRG_MED_SMALL 1024      // up to 16 keys per lane: one wavefront per (slot, channel), registers only, no barriers
+#define LRG_MED_SMALL 1024      // lrg_median (stand-alone): up to 16 keys per lane, one wavefront per (slot, channel)
+#define LRG_MED_PREP 1024       // lrg_prepare: up to 16 keys per lane, rows staged once through LDS for all channels
 #define LRG_MED_LARGE 36864     // 144 KB: one workgroup per CU, only launched work for the few big regions
 __device__ __forceinline__ uint32_t lrg_f2key(float f) {
     uint32_t b = __float_as_uint(f);
@@ -483,59 +484,67 @@ __device__ void lrg_select2(const uint32_t *cache, bool cached, const float *pts
     *ra_out = ra; *rb_out = rb;
 }
 
-// Median of channel ch over nc <= 1024 current points by ONE wavefront: up to 16 keys per lane in registers; per-lane
-// VALU counters and one DPP wave reduction per bisection step -- no LDS, no barriers, no scalar popcounts
-// (the common case: the median Area-5 region has 57 points).
-__device__ float lrg_median_wave(const float *points, const int32_t *idx, int F, int ch, int nc) {
+// Bisection select of the two middle ranks over R register keys per lane (padding keys = 0xFFFFFFFF never count):
+// per-lane VALU counters and one DPP wave reduction per step -- no LDS, no barriers, no scalar popcounts.
+template <int R>
+__device__ __forceinline__ float lrg_select_regs(const uint32_t (&key)[R], int nc) {
     const int lane = lrg_lane();
-    const float *pts = points + ch;
-    const int nr = (nc + 63) >> 6;
-    uint32_t key[16];
-    int id[16];
-    // unconditional loads at clamped positions: predicated loads would each sit in their own branch with a full
-    // s_waitcnt behind it (16 dependent round trips instead of 2)
-    if (nr <= 4) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) id[r] = idx[min(r * 64 + lane, nc - 1)];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) key[r] = (r * 64 + lane < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
-#pragma unroll
-        for (int r = 4; r < 16; ++r) key[r] = 0xFFFFFFFFu;
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) id[r] = idx[min(r * 64 + lane, nc - 1)];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) key[r] = (r * 64 + lane < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
-    }
     // common high bits of the (clustered) keys cannot discriminate: bisect only below them
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int r = 0; r < R; ++r)
         if (r * 64 + lane < nc) { kmin = min(kmin, key[r]); kmax = max(kmax, key[r]); }
     kmin = lrg_wave_min_u32(kmin);
     kmax = lrg_wave_max_u32(kmax);
     const uint32_t diff = kmin ^ kmax;
     const int hb = diff ? 32 - __clz((int)diff) : 0;
     const uint32_t common = hb >= 32 ? 0u : (kmin >> hb) << hb;
+    // upper median = element of rank k2 = the largest r with #(key < r) <= k2; one compare per key per step
     const int k2 = nc >> 1;
-    const int k1 = (nc & 1) ? k2 : k2 - 1;
-    uint32_t ra = common, rb = common;
+    uint32_t rb = common;
     for (int bit = hb - 1; bit >= 0; --bit) {
-        const uint32_t ca = ra | (1u << bit), cb = rb | (1u << bit);
-        int cnt = 0;                                   // low half: #(key < ca), high half: #(key < cb); nc <= 1024 fits
-        if (nr <= 4) {
+        const uint32_t cb = rb | (1u << bit);
+        int cnt = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cnt += (key[r] < ca ? 1 : 0) + (key[r] < cb ? 0x10000 : 0);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cnt += (key[r] < ca ? 1 : 0) + (key[r] < cb ? 0x10000 : 0);   // padding keys never count
-        }
-        const int tot = lrg_wave_sum_i32(cnt);
-        if ((tot & 0xFFFF) <= k1) ra = ca;
-        if ((tot >> 16) <= k2) rb = cb;
+        for (int r = 0; r < R; ++r) cnt += key[r] < cb ? 1 : 0;        // padding keys (0xFFFFFFFF) never count
+        if (lrg_wave_sum_i32(cnt) <= k2) rb = cb;
     }
-    float lo = lrg_key2f(ra), hi = lrg_key2f(rb);
-    return (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);   // numpy.mean of the two middle float32 values
+    float hi = lrg_key2f(rb);
+    if (nc & 1) return hi;
+    // even count: the element of rank k2-1 is rb itself when fewer than k2 keys lie below rb (duplicates of rb span
+    // both ranks), otherwise it is the largest key below rb
+    int below = 0;
+    uint32_t mx = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (key[r] < rb) { ++below; mx = max(mx, key[r]); }
+    below = lrg_wave_sum_i32(below);
+    mx = lrg_wave_max_u32(mx);
+    float lo = below >= k2 ? lrg_key2f(mx) : hi;
+    return __fmul_rn(__fadd_rn(lo, hi), 0.5f);                          // numpy.mean of the two middle float32 values
+}
+
+// Median of one channel over nc <= 64*R current points by ONE wavefront, keys gathered straight from HBM.
+// All loads are unconditional at clamped positions: predicated loads would each sit in their own branch with a full
+// s_waitcnt behind it (R dependent round trips instead of 2).
+template <int R>
+__device__ __forceinline__ float lrg_median_wave_r(const float *pts, const int32_t *idx, int F, int nc) {
+    const int lane = lrg_lane();
+    uint32_t key[R];
+    {
+        int id[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) id[r] = idx[min(r * 64 + lane, nc - 1)];
+#pragma unroll
+        for (int r = 0; r < R; ++r) key[r] = (r * 64 + lane < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
+    }
+    return lrg_select_regs<R>(key, nc);
+}
+
+__device__ float lrg_median_wave(const float *points, const int32_t *idx, int F, int ch, int nc) {
+    const float *pts = points + ch;
+    if (nc <= 256) return lrg_median_wave_r<4>(pts, idx, F, nc);       // the common case: the median Area-5 region has 57 points
+    return lrg_median_wave_r<16>(pts, idx, F, nc);
 }
 
 __global__ __launch_bounds__(256) void lrg_median_wave_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
@@ -568,6 +577,8 @@ __global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const Lrg
                                                                        int32_t *rows_nb) {
     __shared__ float sh_c[16];
     __shared__ int sh_src[2][1024];
+    __shared__ float sh_rows[1024 * 16];       // one 1024-row chunk of the current points (median staging)
+    __shared__ int sh_idx[1024];
     const int s = blockIdx.x;
     TRACE2(s, 0);
     const LrgSlot *S = &slots[s];
@@ -604,13 +615,50 @@ __global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const Lrg
     if (threadIdx.x < 16) sh_c[threadIdx.x] = 0.f;
     __syncthreads();
     TRACE2(s, 1);
-    if (nc <= LRG_MED_SMALL) {
-        int k = 0;                                        // k-th centred channel goes to wave k (9 channels, 9 waves)
-        for (int ch = 0; ch < F; ++ch) {
-            if (!(ch < 2 || ch >= 6)) continue;           // :243-247
-            if ((k++ % (LRG_PREP_THREADS / 64)) != wave) continue;
-            float med = lrg_median_wave(points, S->cur_idx, F, ch, nc);
-            if (lane == 0) { sh_c[ch] = med; center[s * 16 + ch] = med; }
+    if (nc <= LRG_MED_PREP) {
+        // rows of the current points are fetched ONCE, element-wise (13 contiguous floats per row), into an LDS tile of
+        // 1024 rows; wave k then keeps the keys of the k-th centred channel in registers (stride-13 LDS reads are
+        // conflict-free) and bisects them without further memory traffic
+        int mych = -1;
+        {
+            int k = 0;
+            for (int ch = 0; ch < F; ++ch) {
+                if (!(ch < 2 || ch >= 6)) continue;       // :243-247
+                if (k++ == wave) mych = ch;
+            }
+        }
+        uint32_t key[16];
+        {
+            // indices first (coalesced), then the rows with 8 loads in flight per thread: a plain dependent
+            // idx -> row loop would pay two global round trips per iteration
+            for (int j = threadIdx.x; j < nc; j += blockDim.x) sh_idx[j] = S->cur_idx[j];
+            __syncthreads();
+            const int ne8 = nc * F;
+            for (int e0 = threadIdx.x; e0 < ne8; e0 += 8 * blockDim.x) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u * (int)blockDim.x, ne8 - 1);
+                    const int j = e / F, f = e - j * F;
+                    v[u] = points[(long)sh_idx[j] * F + f];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * (int)blockDim.x;
+                    if (e < ne8) sh_rows[e] = v[u];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jl = r * 64 + lane;
+                key[r] = (mych >= 0 && jl < nc) ? lrg_f2key(sh_rows[jl * F + mych]) : 0xFFFFFFFFu;
+            }
+        }
+        if (mych >= 0) {
+            float med = nc <= 256 ? lrg_select_regs<4>(reinterpret_cast<const uint32_t (&)[4]>(key), nc)
+                                  : lrg_select_regs<16>(key, nc);
+            if (lane == 0) { sh_c[mych] = med; center[s * 16 + mych] = med; }
         }
         if (threadIdx.x < 16 && !((threadIdx.x < 2 || threadIdx.x >= 6) && threadIdx.x < F)) center[s * 16 + threadIdx.x] = 0.f;
     } else if (threadIdx.x < 16) {
@@ -625,18 +673,81 @@ __global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const Lrg
     for (int side = 0; side < 2; ++side) {
         const int k = side ? knb : kin;
         float *out = side ? neighbor + (long)s * prm.n_neighbor * F : inlier + (long)s * prm.n_inlier * F;
-        for (int e = threadIdx.x; e < k * F; e += blockDim.x) {
-            const int j = e / F, f = e - j * F;
-            out[e] = __fsub_rn(points[(long)sh_src[side][j] * F + f], sh_c[f]);
+        const int nel = k * F;
+        for (int e0 = threadIdx.x; e0 < nel; e0 += 8 * blockDim.x) {       // 8 independent row loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + u * (int)blockDim.x, nel - 1);
+                const int j = e / F, f = e - j * F;
+                v[u] = __fsub_rn(points[(long)sh_src[side][j] * F + f], sh_c[f]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                if (e < nel) out[e] = v[u];
+            }
         }
     }
     TRACE2(s, 3);
 }
 
-// Larger regions: one 1024-thread workgroup per (slot, channel), keys cached in LDS (up to 36864), block-wide counts.
+// Larger regions: one 1024-thread workgroup per (slot, channel), KT keys per thread in REGISTERS (two global round
+// trips in all), bisection with per-thread counters, a DPP wave sum and one LDS atomic + one barrier per step.
+template <int KT>
+__device__ __forceinline__ float lrg_median_block_regs(const float *pts, const int32_t *idx, int F, int nc, int *sh) {
+    const int tid = threadIdx.x, lane = lrg_lane();
+    uint32_t key[KT];
+    {
+        int id[KT];
+#pragma unroll
+        for (int r = 0; r < KT; ++r) id[r] = idx[min(r * 1024 + tid, nc - 1)];
+#pragma unroll
+        for (int r = 0; r < KT; ++r) key[r] = (r * 1024 + tid < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
+    }
+    // sh[0] = min, sh[1] = max, sh[2..35] = one counter per bisection step (+ below-count), sh[36] = max below
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int r = 0; r < KT; ++r)
+        if (r * 1024 + tid < nc) { kmin = min(kmin, key[r]); kmax = max(kmax, key[r]); }
+    kmin = lrg_wave_min_u32(kmin);
+    kmax = lrg_wave_max_u32(kmax);
+    if (lane == 0) { atomicMin(reinterpret_cast<unsigned *>(&sh[0]), kmin); atomicMax(reinterpret_cast<unsigned *>(&sh[1]), kmax); }
+    __syncthreads();
+    kmin = (uint32_t)sh[0]; kmax = (uint32_t)sh[1];
+    const uint32_t diff = kmin ^ kmax;
+    const int hb = diff ? 32 - __clz((int)diff) : 0;
+    const uint32_t common = hb >= 32 ? 0u : (kmin >> hb) << hb;
+    const int k2 = nc >> 1;
+    uint32_t rb = common;
+    for (int bit = hb - 1; bit >= 0; --bit) {
+        const uint32_t cb = rb | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < KT; ++r) cnt += key[r] < cb ? 1 : 0;
+        cnt = lrg_wave_sum_i32(cnt);
+        if (lane == 0 && cnt) atomicAdd(&sh[2 + bit], cnt);
+        __syncthreads();
+        if (sh[2 + bit] <= k2) rb = cb;
+    }
+    float hi = lrg_key2f(rb);
+    if (nc & 1) return hi;
+    int below = 0;
+    uint32_t mx = 0u;
+#pragma unroll
+    for (int r = 0; r < KT; ++r)
+        if (key[r] < rb) { ++below; mx = max(mx, key[r]); }
+    below = lrg_wave_sum_i32(below);
+    mx = lrg_wave_max_u32(mx);
+    if (lane == 0) { if (below) atomicAdd(&sh[34], below); atomicMax(reinterpret_cast<unsigned *>(&sh[35]), mx); }
+    __syncthreads();
+    float lo = sh[34] >= k2 ? lrg_key2f((uint32_t)sh[35]) : hi;
+    return __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+}
+
 __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
-                                                                 float *center) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cache[];      // [LRG_MED_LARGE] keys, then 32 ints of scratch
+                                                                 float *center, int min_points) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cache[];      // [LRG_MED_LARGE] keys, then 64 ints of scratch
     int *sh = reinterpret_cast<int *>(cache + LRG_MED_LARGE);
     const int s = blockIdx.x, ch = blockIdx.y;
     const LrgSlot *S = &slots[s];
@@ -644,8 +755,17 @@ __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *s
     const bool centred = (ch < 2 || ch >= 6) && ch < F;
     if (!centred || S->status != LRG_ACTIVE || S->room < 0) return;
     const int nc = S->nc;
-    if (nc <= LRG_MED_SMALL) return;                                           // done by the wave-level launch
+    if (nc <= min_points) return;                                              // done by the wave-level code
     const LrgRoom *R = &rooms[S->room];
+    if (threadIdx.x < 40) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;         // sh[0] = 0xFFFFFFFF (min identity)
+    __syncthreads();
+    if (nc <= 16 * 1024) {
+        const float *pts = R->points + ch;
+        float med = nc <= 4096 ? lrg_median_block_regs<4>(pts, S->cur_idx, F, nc, sh)
+                               : lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh);
+        if (threadIdx.x == 0) center[s * 16 + ch] = med;
+        return;
+    }
     const bool cached = nc <= LRG_MED_LARGE;
     if (cached) {
         // gather 8 values per thread per round: the index load and the dependent feature load of the 8 are independent,
@@ -942,7 +1062,7 @@ int lrg_median(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const Lr
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || !center || n_slots <= 0) return LRG_EINVAL - 1;
-    const size_t lds_large = LRG_MED_LARGE * 4 + 128;
+    const size_t lds_large = LRG_MED_LARGE * 4 + 256;
     static bool attr_done = false;
     if (!attr_done) {
         LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_median_block_kernel),
@@ -953,7 +1073,7 @@ int lrg_median(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const Lr
                        *params, center, n_slots);
     LRG_LAUNCH_CHECK();
     hipLaunchKernelGGL(lrg_median_block_kernel, dim3(n_slots, params->feature_size), dim3(1024), lds_large,
-                       (hipStream_t)stream, slots, rooms, *params, center);
+                       (hipStream_t)stream, slots, rooms, *params, center, LRG_MED_SMALL);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -966,7 +1086,7 @@ int lrg_prepare(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const L
     if (!slots || !rooms || !center || !sample_in || !sample_nb || !inlier || !neighbor || n_slots <= 0) return LRG_EINVAL - 1;
     if ((rows_in == nullptr) != (rows_nb == nullptr)) return LRG_EINVAL - 2;
     if (params->n_inlier > 1024 || params->n_neighbor > 1024) return LRG_EINVAL - 3;
-    const size_t lds_large = LRG_MED_LARGE * 4 + 128;
+    const size_t lds_large = LRG_MED_LARGE * 4 + 256;
     static bool attr_done = false;
     if (!attr_done) {
         LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_median_block_kernel),
@@ -974,7 +1094,7 @@ int lrg_prepare(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const L
         attr_done = true;
     }
     hipLaunchKernelGGL(lrg_median_block_kernel, dim3(n_slots, params->feature_size), dim3(1024), lds_large,
-                       (hipStream_t)stream, slots, rooms, *params, center);
+                       (hipStream_t)stream, slots, rooms, *params, center, LRG_MED_PREP);
     LRG_LAUNCH_CHECK();
     hipLaunchKernelGGL(lrg_prepare_kernel, dim3(n_slots), dim3(LRG_PREP_THREADS), 0, (hipStream_t)stream, slots, rooms, *params, center,
                        sample_in, sample_nb, inlier, neighbor, gt_remove, gt_add, rows_in, rows_nb);

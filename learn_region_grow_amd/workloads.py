@@ -17,23 +17,29 @@ def make_room(target_points, seed, room_id, resolution=0.1):
     return dict(points=p['points'], obj_id=p['obj_id'], order=p['order'].astype(np.int32), room_id=room_id)
 
 
-def area5_rooms(n_rooms=68, seed_base=1000, cache_dir=None, targets=None, scale=1.0):
+def area5_rooms(n_rooms=68, seed_base=1000, cache_dir=None, targets=None, scale=1.0, resolution=0.1):
     targets = list(targets if targets is not None else synthetic.AREA5_POINTS)
     rooms = []
     cache = None
     if cache_dir:
         os.makedirs(cache_dir, exist_ok=True)
-        cache = os.path.join(cache_dir, 'lrg_area5_%d_%d_%g.npz' % (n_rooms, seed_base, scale))
+        cache = os.path.join(cache_dir, 'lrg_area5_%d_%d_%g_%g_%d.npz' % (n_rooms, seed_base, scale, resolution,
+                                                                            targets[0] if targets else 0))
         if os.path.exists(cache):
             z = np.load(cache)
             return [dict(points=z['p%d' % i], obj_id=z['o%d' % i], order=z['s%d' % i], room_id=int(z['ids'][i]))
                     for i in range(n_rooms)]
     for i in range(n_rooms):
         t = max(300, int(targets[i % len(targets)] * scale))
-        rooms.append(make_room(t, seed_base + i, seed_base + i))
+        rooms.append(make_room(t, seed_base + i, seed_base + i, resolution=resolution))
     if cache:
         d = {'ids': np.array([r['room_id'] for r in rooms])}
         for i, r in enumerate(rooms):
             d['p%d' % i], d['o%d' % i], d['s%d' % i] = r['points'], r['obj_id'], r['order']
         np.savez(cache, **d)
     return rooms
+
+
+def kitti_scenes(n_scenes=8, seed_base=5000, cache_dir=None, points=100000, resolution=0.3):
+    """BASELINE.json configs[4] shape: ~100 k points per scene at 0.3 m resolution (README.md:156 of the reference)."""
+    return area5_rooms(n_scenes, seed_base=seed_base, cache_dir=cache_dir, targets=[points], resolution=resolution)

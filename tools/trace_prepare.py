@@ -33,3 +33,7 @@ for i, nm in enumerate(['load', 'median', 'sample+gather']):
     print('  %-14s %8d %8d %8d' % (nm, np.median(a[:, i]), np.percentile(a[:, i], 90), a[:, i].max()))
 big = a[a[:, 3] > 1024]
 print('nc: median %d max %d; slots with nc>1024: %d' % (np.median(a[:, 3]), a[:, 3].max(), len(big)))
+for lo, hi in ((0, 256), (256, 1024), (1024, 4096), (4096, 10**9)):
+    m = (a[:, 3] > lo) & (a[:, 3] <= hi)
+    if m.any():
+        print('  nc in (%d,%d]: n=%d  median-phase cycles p50 %d max %d | gather p50 %d | load p50 %d' % (lo, hi, m.sum(), np.median(a[m, 1]), a[m, 1].max(), np.median(a[m, 2]), np.median(a[m, 0])))
