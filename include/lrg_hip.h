@@ -59,6 +59,13 @@ typedef struct LrgWeights {
 #define LRG_FWD_FUSED 2u     /* whole branch / whole head per 64-row tile in one kernel each: activations stay in LDS,
                                 only conv[1], the pooled maxima and the logits reach HBM (3 launches per call)         */
 #define LRG_FWD_KEEP_ACTS 4u /* with LRG_FWD_FUSED: also copy every intermediate into the workspace (parity tests)     */
+#define LRG_FWD_SPLIT_SPARSE 16u /* lrg_forward_rows + LRG_FWD_FUSED: while the live-tile counter in the workspace scratch
+                                  (view kind 5, element 0, int32; maintained by lrg_prepare) is small, split the widest
+                                  branch layer over 4 workgroups per tile to shorten the critical path                    */
+#define LRG_FWD_POOL_ZEROED 8u /* with LRG_FWD_FUSED: the workspace was zero-filled once by the caller and is only ever used
+                                by calls carrying this flag -- the pooled-feature block is then zero on entry and is
+                                left zero on return (cleared by the head kernel), which saves the per-call memset.
+                                Precondition on rows: rows_nb[b] > 0 whenever rows_in[b] > 0.                            */
 
 /* Bytes of scratch lrg_forward needs for a batch of B instances (host-side arithmetic only). */
 size_t lrg_forward_workspace_bytes(const LrgWeights *w, int B, int n_inlier, int n_neighbor);
@@ -81,7 +88,8 @@ int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neig
 
 /* Workspace introspection for layer-by-layer parity tests: float offset / element count of a named
  * intermediate inside `workspace`.  kind: 0 conv[i] (inlier), 1 neighbor_conv[i], 2 pooled [B,2*C_last],
- * 3 add head hidden[i], 4 remove head hidden[i].  Returns 0, or LRG_EINVAL. */
+ * 3 add head hidden[i], 4 remove head hidden[i], 5 scratch (64 floats; element 0 = live-tile counter).
+ * Returns 0, or LRG_EINVAL. */
 int lrg_forward_workspace_view(const LrgWeights *w, int B, int n_inlier, int n_neighbor, int kind, int index,
                                size_t *offset_floats, size_t *count_floats);
 
@@ -239,7 +247,8 @@ int lrg_gather_center(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, c
  * test_region_grow.py:237-254.  Same outputs as the three calls. */
 int lrg_prepare(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
                 int32_t *sample_in, int32_t *sample_nb, float *inlier, float *neighbor, int32_t *gt_remove, int32_t *gt_add,
-                int32_t *rows_in, int32_t *rows_nb, void *stream);
+                int32_t *rows_in, int32_t *rows_nb, int32_t *tile_total, void *stream);
+/* tile_total (nullable, device int32): receives the number of 64-row tiles lrg_forward_rows will evaluate. */
 
 /* Confidence + Bernoulli masks + voxel-set mask update (:262-288).
  * add_mask / rmv_mask (nullable, uint8 [n_slots,n]) : host-decided masks (reference-order RNG);

@@ -17,6 +17,8 @@ LRG_MAX_HEAD = 3
 LRG_FWD_FUSE_POOL = 1
 LRG_FWD_FUSED = 2
 LRG_FWD_KEEP_ACTS = 4
+LRG_FWD_POOL_ZEROED = 8
+LRG_FWD_SPLIT_SPARSE = 16
 
 (LRG_IDLE, LRG_ACTIVE, LRG_STOP_NONEIGHBOR, LRG_STOP_NOEXPAND, LRG_STOP_STUCK, LRG_STOP_EMPTY, LRG_STOP_MAXSTEPS,
  LRG_DONE, LRG_WAIT) = range(9)
@@ -125,7 +127,7 @@ _SIGS = {
     'lrg_gather_center': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp,
                                          _fp, _fp, _fp, _fp, _fp]),
     'lrg_prepare': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp, _fp, _fp,
-                                   _fp, _fp, _fp]),
+                                   _fp, _fp, _fp, _fp]),
     'lrg_mask_update': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp, _fp, _fp, _fp,
                                        _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     'lrg_grow_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgWeights),

@@ -111,6 +111,15 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
     // their per-point results are identical and the max-pool ignores duplicates, so whole tiles of them are skipped
     if (P.valid && tile * FM >= P.valid[inst]) return;
     const long r0 = (long)inst * P.rows_per_inst + (long)tile * FM;
+    // Column split of the pooled (last, widest) layer over gridDim.z workgroups: each recomputes the narrow layers and
+    // takes every gridDim.z-th 128-column block of the last one.  It shortens the critical path of a tile ~2.5x when
+    // few tiles are live (duplicate-row skipping) at the price of ~1.5x the MFMA work, so it is dropped -- z > 0
+    // workgroups exit, z = 0 does everything -- once the live-tile count says the chip would be full anyway.
+    int zsplit = gridDim.z;
+    if (zsplit > 1 && P.tile_total && *P.tile_total * zsplit > P.split_limit) zsplit = 1;
+    const int zme = blockIdx.z;
+    if (zme >= zsplit) return;
+    if (zsplit > 1 && zme >= (P.L[P.nlayers - 1].N + FBN - 1) / FBN) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -152,8 +161,9 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
         const float *ap = act_in + li * ld_in + 4 * lh;
         const int loff = 4 * lh * L.ldw + li;
         const int ncb = (L.N + FBN - 1) / FBN;
+        const bool split_here = zsplit > 1 && l == nlayers - 1;
         TRACE(2 + 2 * l);
-        for (int cb = 0; cb < ncb; ++cb) {
+        for (int cb = split_here ? zme : 0; cb < ncb; cb += split_here ? zsplit : 1) {
             const int col0 = cb * FBN + wn * 32;
             const bool wave_on = col0 < L.N;         // 64-wide layers keep only two of the four waves busy
             f32x16 acc[RT];
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
                     float v = acc[r >> 4][rr] + bv;
                     if (L.flags & LRG_FL_RELU) v = fmaxf(v, 0.f);
                     if (L.flags & LRG_FL_KEEP) act_out[rl * ld_out + col] = v;
-                    if (L.gout) L.gout[(r0 + rl) * L.N + col] = v;
+                    if (L.gout && (zme == 0 || split_here)) L.gout[(r0 + rl) * L.N + col] = v;
                     cmax = fmaxf(cmax, v);
                 }
                 if (L.flags & LRG_FL_POOL) {
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
         for (int c = tid; c < lastN; c += FTHREADS) atomicMax(reinterpret_cast<int *>(&dst[c]), __float_as_int(poolbuf[c]));
     }
     // ---- final 2-wide layer of a head, no ReLU (:145-149, :158-162) ----
-    if (P.fw) {
+    if (P.fw && zme == 0) {
         const int C = lastN;
         const bool odd = ((nlayers - 1) & 1) != 0;
         const float *act = (odd == !(lastflags & LRG_FL_INPLACE)) ? buf1 : buf0;
@@ -228,11 +238,14 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
             P.fout[(r0 + row) * 2 + 1] = s1 + P.fb[1];
         }
     }
+    // ---- leave the pooled feature of this instance zero for the next evaluation (it was consumed by the GEMV) ----
+    if (P.zero_pool && tile == 0 && zme == 0)
+        for (int c = tid; c < P.zero_count; c += FTHREADS) P.zero_pool[(long)inst * P.zero_count + c] = 0.f;
     TRACE(20);
 }
 
 template <int CAP0, int CAP1, int RT>
-static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
+static int launch_stack(const LrgFusedArgs &a, int nprob, int split, hipStream_t st) {
     constexpr int FM = 32 * RT;
     long maxrows = 0;
     for (int i = 0; i < nprob; ++i) {
@@ -264,15 +277,15 @@ static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM), nprob, 1), dim3(FTHREADS), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM), nprob, split < 1 ? 1 : split), dim3(FTHREADS), lds, st, a);
     LRG_LAUNCH_CHECK();
     return 0;
 }
 
-int lrg_fused_branches(const LrgFusedArgs &a, int nprob, hipStream_t st) {
-    return launch_stack<64 * 68, 64 * 132, 2>(a, nprob, st);       // lite 0/1/2: hidden widths 64 / 128
+int lrg_fused_branches(const LrgFusedArgs &a, int nprob, int split, hipStream_t st) {
+    return launch_stack<64 * 68, 64 * 132, 2>(a, nprob, split, st);       // lite 0/1/2: hidden widths 64 / 128
 }
 
 int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st) {
-    return launch_stack<32 * 260, 32 * 68, 1>(a, nprob, st);      // 64 -> 256 -> 128 (-> 2); the last hidden layer is written in place
+    return launch_stack<32 * 260, 32 * 68, 1>(a, nprob, 1, st);      // 64 -> 256 -> 128 (-> 2); the last hidden layer is written in place
 }

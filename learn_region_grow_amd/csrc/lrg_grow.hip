@@ -574,7 +574,7 @@ __global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const Lrg
                                                                        LrgGrowParams prm, float *center, int32_t *sample_in,
                                                                        int32_t *sample_nb, float *inlier, float *neighbor,
                                                                        int32_t *gt_remove, int32_t *gt_add, int32_t *rows_in,
-                                                                       int32_t *rows_nb) {
+                                                                       int32_t *rows_nb, int32_t *tile_total) {
     __shared__ float sh_c[16];
     __shared__ int sh_src[2][1024];
     __shared__ float sh_rows[1024 * 16];       // one 1024-row chunk of the current points (median staging)
@@ -584,8 +584,10 @@ __global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const Lrg
     const LrgSlot *S = &slots[s];
     const bool active = S->status == LRG_ACTIVE && S->room >= 0;
     if (rows_in && threadIdx.x == 0) {
-        rows_in[s] = active ? min(S->nc, prm.n_inlier) : 0;
-        rows_nb[s] = active ? min(S->ne, prm.n_neighbor) : 0;
+        const int ri = active ? min(S->nc, prm.n_inlier) : 0, rn = active ? min(S->ne, prm.n_neighbor) : 0;
+        rows_in[s] = ri;
+        rows_nb[s] = rn;
+        if (tile_total && active) atomicAdd(tile_total, (ri + 63) / 64 + (rn + 63) / 64);
     }
     if (!active) return;
     const LrgRoom *R = &rooms[S->room];
@@ -746,7 +748,8 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
 }
 
 __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
-                                                                 float *center, int min_points) {
+                                                                 float *center, int min_points, int32_t *tile_total) {
+    if (tile_total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *tile_total = 0;   // lrg_prepare (next launch) accumulates
     extern __shared__ __attribute__((aligned(16))) uint32_t cache[];      // [LRG_MED_LARGE] keys, then 64 ints of scratch
     int *sh = reinterpret_cast<int *>(cache + LRG_MED_LARGE);
     const int s = blockIdx.x, ch = blockIdx.y;
@@ -1073,14 +1076,14 @@ int lrg_median(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const Lr
                        *params, center, n_slots);
     LRG_LAUNCH_CHECK();
     hipLaunchKernelGGL(lrg_median_block_kernel, dim3(n_slots, params->feature_size), dim3(1024), lds_large,
-                       (hipStream_t)stream, slots, rooms, *params, center, LRG_MED_SMALL);
+                       (hipStream_t)stream, slots, rooms, *params, center, LRG_MED_SMALL, (int32_t *)nullptr);
     LRG_LAUNCH_CHECK();
     return 0;
 }
 
 int lrg_prepare(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
                 int32_t *sample_in, int32_t *sample_nb, float *inlier, float *neighbor, int32_t *gt_remove, int32_t *gt_add,
-                int32_t *rows_in, int32_t *rows_nb, void *stream) {
+                int32_t *rows_in, int32_t *rows_nb, int32_t *tile_total, void *stream) {
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || !center || !sample_in || !sample_nb || !inlier || !neighbor || n_slots <= 0) return LRG_EINVAL - 1;
@@ -1094,10 +1097,10 @@ int lrg_prepare(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const L
         attr_done = true;
     }
     hipLaunchKernelGGL(lrg_median_block_kernel, dim3(n_slots, params->feature_size), dim3(1024), lds_large,
-                       (hipStream_t)stream, slots, rooms, *params, center, LRG_MED_PREP);
+                       (hipStream_t)stream, slots, rooms, *params, center, LRG_MED_PREP, tile_total);
     LRG_LAUNCH_CHECK();
     hipLaunchKernelGGL(lrg_prepare_kernel, dim3(n_slots), dim3(LRG_PREP_THREADS), 0, (hipStream_t)stream, slots, rooms, *params, center,
-                       sample_in, sample_nb, inlier, neighbor, gt_remove, gt_add, rows_in, rows_nb);
+                       sample_in, sample_nb, inlier, neighbor, gt_remove, gt_add, rows_in, rows_nb, tile_total);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -1158,8 +1161,15 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
         if ((rc = lrg_box_query(slots, rooms, n_slots, max_points, params, stream))) return rc;
     }
     const bool rows = b->rows_in && b->rows_nb && (forward_flags & LRG_FWD_FUSED);
+    int32_t *tile_total = nullptr;
+    if (rows && (forward_flags & LRG_FWD_SPLIT_SPARSE)) {
+        size_t off = 0, cnt = 0;
+        if ((rc = lrg_forward_workspace_view(weights, n_slots, params->n_inlier, params->n_neighbor, 5, 0, &off, &cnt))) return rc;
+        tile_total = reinterpret_cast<int32_t *>(static_cast<float *>(b->workspace) + off);
+    }
     if ((rc = lrg_prepare(slots, rooms, n_slots, params, b->center, b->sample_in, b->sample_nb, b->inlier, b->neighbor,
-                          b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, stream)))
+                          b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, tile_total,
+                          stream)))
         return rc;
     if ((rc = lrg_forward_rows(weights, b->inlier, b->neighbor, n_slots, params->n_inlier, params->n_neighbor,
                                rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, b->add_logits, b->rmv_logits,

@@ -235,16 +235,17 @@ struct LrgGemvArgs {
     int ldw, B, P, C;
 };
 
-// 64 output columns x TB instances per 256-thread block; the 4 waves split K and their partial sums are
+// 64 output columns x TB instances per 512-thread block; the 8 waves split K and their partial sums are
 // combined through LDS in a fixed order (deterministic, no atomics).
-__global__ __launch_bounds__(256) void lrg_head_gemv_kernel(LrgGemvArgs a) {
+#define LRG_GEMV_WAVES 8
+__global__ __launch_bounds__(64 * LRG_GEMV_WAVES) void lrg_head_gemv_kernel(LrgGemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float pl[];   // [TB][P] pooled rows, then [4][TB][64] partials
     const int z = blockIdx.z;
     const int b0 = blockIdx.y * LRG_GEMV_TB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int nb = min(LRG_GEMV_TB, a.B - b0);
-    for (int i = threadIdx.x; i < LRG_GEMV_TB * a.P; i += 256) {
+    for (int i = threadIdx.x; i < LRG_GEMV_TB * a.P; i += 64 * LRG_GEMV_WAVES) {
         int bi = i / a.P;
         pl[i] = bi < nb ? a.pooled[(long)(b0 + bi) * a.P + (i - bi * a.P)] : 0.f;
     }
@@ -252,11 +253,11 @@ __global__ __launch_bounds__(256) void lrg_head_gemv_kernel(LrgGemvArgs a) {
     float acc[LRG_GEMV_TB];
 #pragma unroll
     for (int i = 0; i < LRG_GEMV_TB; ++i) acc[i] = 0.f;
-    const int kq = (a.P + 3) / 4;
+    const int kq = (a.P + LRG_GEMV_WAVES - 1) / LRG_GEMV_WAVES;
     const int k0 = wave * kq, k1 = min(a.P, k0 + kq);
     if (c < a.C) {
         const float *w = a.w[z] + c;
-#pragma unroll 8
+#pragma unroll 16
         for (int k = k0; k < k1; ++k) {
             float wv = w[(long)k * a.ldw];
 #pragma unroll
@@ -271,9 +272,8 @@ __global__ __launch_bounds__(256) void lrg_head_gemv_kernel(LrgGemvArgs a) {
         float bv = a.bias[z] ? a.bias[z][c] : 0.f;
         for (int i = 0; i < nb; ++i) {
             float s = part[(0 * LRG_GEMV_TB + i) * 64 + lane];
-            s += part[(1 * LRG_GEMV_TB + i) * 64 + lane];
-            s += part[(2 * LRG_GEMV_TB + i) * 64 + lane];
-            s += part[(3 * LRG_GEMV_TB + i) * 64 + lane];
+#pragma unroll
+            for (int wv = 1; wv < LRG_GEMV_WAVES; ++wv) s += part[(wv * LRG_GEMV_TB + i) * 64 + lane];
             a.hb[z][(long)(b0 + i) * a.C + c] = s + bv;
         }
     }
@@ -329,6 +329,7 @@ struct LrgFwdLayout {
     size_t pooled;
     size_t hb[2];                   // 0 add, 1 remove
     size_t hid[2][LRG_MAX_HEAD];
+    size_t scratch;                 // 64 floats: [0] = live-tile counter of lrg_forward_rows (written by lrg_prepare)
     size_t total;
     int P;                          // 2*C_last
 };
@@ -357,6 +358,8 @@ static int fwd_layout(const LrgWeights *w, int B, int ni, int nn, LrgFwdLayout *
             L->hid[hd][i] = off;
             off = lrg_align_up(off + (size_t)rows[hd == 0 ? 1 : 0] * w->head_ch[i], 64);
         }
+    L->scratch = off;
+    off = lrg_align_up(off + 64, 64);
     L->total = off;
     return 0;
 }
@@ -364,12 +367,13 @@ static int fwd_layout(const LrgWeights *w, int B, int ni, int nn, LrgFwdLayout *
 // Fused evaluation: 3 launches (both branches | pooled-feature GEMV | both heads).
 static int forward_fused(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
                          int n_neighbor, const int32_t *rows_in, const int32_t *rows_nb, float *add_logits,
-                         float *rmv_logits, float *ws, const LrgFwdLayout &L, bool keep_acts, hipStream_t st) {
+                         float *rmv_logits, float *ws, const LrgFwdLayout &L, bool keep_acts, bool pool_zeroed,
+                         bool split, hipStream_t st) {
     const long rows[2] = {(long)B * n_inlier, (long)B * n_neighbor};
     const int rpi[2] = {n_inlier, n_neighbor};
     const int nc = w->n_conv, nh = w->n_head;
     const int Clast = w->conv_ch[nc - 1];
-    LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
+    if (!pool_zeroed) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
     {
         LrgFusedArgs a = {};
         for (int br = 0; br < 2; ++br) {
@@ -379,6 +383,7 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
             P.rows = rows[br]; P.rows_per_inst = rpi[br];
             P.pool = ws + L.pooled + (br == 0 ? 0 : Clast); P.pool_stride = L.P;
             P.valid = br == 0 ? rows_in : rows_nb;
+            if (split) { P.tile_total = reinterpret_cast<const int *>(ws + L.scratch); P.split_limit = 1024; }
             P.nlayers = nc;
             for (int i = 0; i < nc; ++i) {
                 LrgFusedLayer &F = P.L[i];
@@ -390,7 +395,7 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
                 F.gout = (i == 1 || keep_acts) ? ws + L.conv[br][i] : nullptr;      // conv[1] feeds the heads (:130,:134)
             }
         }
-        int rc = lrg_fused_branches(a, 2, st);
+        int rc = lrg_fused_branches(a, 2, split ? 4 : 1, st);
         if (rc) return rc;
     }
     const int C0 = w->head_ch[0];
@@ -401,9 +406,9 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
         g.bias[0] = w->add_b[0]; g.bias[1] = w->rmv_b[0];
         g.hb[0] = ws + L.hb[0]; g.hb[1] = ws + L.hb[1];
         g.ldw = C0; g.B = B; g.P = L.P; g.C = C0;
-        size_t sh = ((size_t)LRG_GEMV_TB * L.P + 4 * LRG_GEMV_TB * 64) * sizeof(float);
+        size_t sh = ((size_t)LRG_GEMV_TB * L.P + LRG_GEMV_WAVES * LRG_GEMV_TB * 64) * sizeof(float);
         hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C0 + 63) / 64, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 2),
-                           dim3(256), sh, st, g);
+                           dim3(64 * LRG_GEMV_WAVES), sh, st, g);
         LRG_LAUNCH_CHECK();
     }
     {
@@ -440,6 +445,7 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
             P.fw = hd == 0 ? w->add_w[nh - 1] : w->rmv_w[nh - 1];
             P.fb = hd == 0 ? w->add_b[nh - 1] : w->rmv_b[nh - 1];
             P.fout = hd == 0 ? add_logits : rmv_logits;
+            if (pool_zeroed && hd == 0) { P.zero_pool = ws + L.pooled; P.zero_count = L.P; }
         }
         return lrg_fused_heads(a, 2, st);
     }
@@ -479,6 +485,8 @@ int lrg_forward_workspace_view(const LrgWeights *w, int B, int n_inlier, int n_n
         return 0;
     case 2:
         *offset_floats = L.pooled; *count_floats = (size_t)B * L.P; return 0;
+    case 5:
+        *offset_floats = L.scratch; *count_floats = 64; return 0;
     case 3: case 4:
         if (index < 0 || index >= w->n_head - 1) return LRG_EINVAL - 5;
         *offset_floats = L.hid[kind - 3][index];
@@ -517,8 +525,8 @@ int lrg_head_pool_gemv(const float *pooled, const float *w, int ldw, const float
     if (!pooled || !w || !hb || B <= 0 || P <= 0 || C <= 0 || ldw < C) return LRG_EINVAL - 1;
     LrgGemvArgs a = {};
     a.pooled = pooled; a.w[0] = w; a.bias[0] = bias; a.hb[0] = hb; a.ldw = ldw; a.B = B; a.P = P; a.C = C;
-    size_t sh = ((size_t)LRG_GEMV_TB * P + 4 * LRG_GEMV_TB * 64) * sizeof(float);
-    hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C + 63) / 64, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 1), dim3(256),
+    size_t sh = ((size_t)LRG_GEMV_TB * P + LRG_GEMV_WAVES * LRG_GEMV_TB * 64) * sizeof(float);
+    hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C + 63) / 64, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 1), dim3(64 * LRG_GEMV_WAVES),
                        sh, (hipStream_t)stream, a);
     LRG_LAUNCH_CHECK();
     return 0;
@@ -568,7 +576,8 @@ int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neig
     if ((rows_in == nullptr) != (rows_nb == nullptr)) return LRG_EINVAL - 11;
     if (rows_in && !fused) return LRG_EINVAL - 12;      // row counts are honoured by the fused kernels only
     if (fused) return forward_fused(w, inlier, neighbor, B, n_inlier, n_neighbor, rows_in, rows_nb, add_logits, rmv_logits,
-                                    ws, L, (flags & LRG_FWD_KEEP_ACTS) != 0, st);
+                                    ws, L, (flags & LRG_FWD_KEEP_ACTS) != 0, (flags & LRG_FWD_POOL_ZEROED) != 0,
+                                    (flags & LRG_FWD_SPLIT_SPARSE) != 0 && rows_in != nullptr, st);
     if (fuse_pool) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
 
     // ---- branches (:106-119): both branches in one launch per layer ----
@@ -613,9 +622,9 @@ int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neig
         g.bias[0] = w->add_b[0]; g.bias[1] = w->rmv_b[0];
         g.hb[0] = ws + L.hb[0]; g.hb[1] = ws + L.hb[1];
         g.ldw = C0; g.B = B; g.P = L.P; g.C = C0;
-        size_t sh = ((size_t)LRG_GEMV_TB * L.P + 4 * LRG_GEMV_TB * 64) * sizeof(float);
+        size_t sh = ((size_t)LRG_GEMV_TB * L.P + LRG_GEMV_WAVES * LRG_GEMV_TB * 64) * sizeof(float);
         hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C0 + 63) / 64, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 2),
-                           dim3(256), sh, st, g);
+                           dim3(64 * LRG_GEMV_WAVES), sh, st, g);
         LRG_LAUNCH_CHECK();
     }
     const int hbr[2] = {1, 0};   // branch feeding each head

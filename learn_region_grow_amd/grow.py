@@ -49,7 +49,7 @@ class RoomResult:
 class RegionGrower:
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=2, pipeline_depth=4,
-                 skip_duplicate_rows=True):
+                 skip_duplicate_rows=True, poll_every=4):
         self.lib = _lib.load()
         self.net = net
         self.dev = net.device
@@ -64,6 +64,7 @@ class RegionGrower:
         self.S = self.n_groups * self.G
         self.advance_rounds = int(advance_rounds)
         self.depth = int(pipeline_depth)
+        self.poll_every = max(1, int(poll_every))      # iterations between two read-backs of the device stats block
         self.seed = seed
         p = LrgGrowParams()
         p.resolution = resolution
@@ -177,7 +178,9 @@ class RegionGrower:
         self.d_stats = torch.zeros(LRG_STATS_WORDS, dtype=torch.int64, device=dev)
         self.b_rows_in = torch.zeros(S, dtype=torch.int32, device=dev)
         self.b_rows_nb = torch.zeros(S, dtype=torch.int32, device=dev)
-        ws = self.net._workspace(S)
+        # a workspace of its own, zero-filled once and only ever used through lrg_grow_step (LRG_FWD_POOL_ZEROED)
+        nbytes = self.lib.lrg_forward_workspace_bytes(ctypes.byref(self.net._w), S, Ni, Nn)
+        ws = self.d_ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         sb = LrgStepBuffers()
         sb.center, sb.sample_in, sb.sample_nb = self.b_center.data_ptr(), self.b_sin.data_ptr(), self.b_snb.data_ptr()
         sb.inlier, sb.neighbor = self.b_inl.data_ptr(), self.b_nbr.data_ptr()
@@ -193,6 +196,8 @@ class RegionGrower:
         self.group_room = [-1] * self.n_groups
         self.iterations = 0
         self._seen_done = 0
+        self._polls = 0
+        self._polls_seen = -1
         self._rooms_loaded = True
         return self
 
@@ -241,23 +246,30 @@ class RegionGrower:
     # ------------------------------------------------------------------------------------------
     def enqueue_iteration(self):
         """One lock-step iteration, device-side randomness (no host sync)."""
-        flags = self.net.forward_flags
+        # LRG_FWD_SPLIT_SPARSE measured no gain at 68 rooms in flight (profiles/r01 notes): not enabled
+        flags = self.net.forward_flags | (_lib.LRG_FWD_POOL_ZEROED if self.net.mode == 'fused' else 0)
         rc = self.lib.lrg_grow_step(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, self.cap, ctypes.byref(self.params),
                                     ctypes.byref(self.net._w), ctypes.byref(self.step_buffers), self.advance_rounds,
                                     flags, _stream_ptr())
         _lib.check(rc, 'lrg_grow_step')
-        k = self.iterations % self.depth
-        self.h_stats[k].copy_(self.d_stats, non_blocking=True)
-        self.ev[k].record()
         self.iterations += 1
+        if self.iterations % self.poll_every == 0:
+            k = self._polls % self.depth
+            self.h_stats[k].copy_(self.d_stats, non_blocking=True)
+            self.ev[k].record()
+            self._polls += 1
 
     def poll_done(self, wait=False):
-        """Groups whose room finished, as seen `depth-1` iterations ago (or now, if wait)."""
-        if self.iterations == 0:
+        """Groups whose room finished, as seen `depth-1` read-backs ago (or at the latest one, if wait)."""
+        if self._polls == 0:
             return []
-        k = (self.iterations - 1) % self.depth if wait else self.iterations % self.depth
-        if not wait and self.iterations < self.depth:
-            return []
+        if wait:
+            k = (self._polls - 1) % self.depth
+        else:
+            if self._polls < self.depth or self._polls == self._polls_seen:
+                return []
+            k = self._polls % self.depth
+        self._polls_seen = self._polls
         self.ev[k].synchronize()
         st = self.h_stats[k]
         done_total = int(st[1])
