@@ -1,0 +1,96 @@
+"""GPU: BASELINE.json's full sizes.  Exact parity where the oracle finishes in seconds (the ground-truth mask policy
+does not depend on the logits, so the oracle can skip the network), size-independent properties elsewhere."""
+import numpy as np
+import pytest
+
+from learn_region_grow_amd import synthetic, workloads
+from oracle import grow_ref, rng_ref
+
+pytestmark = pytest.mark.gpu
+WEIGHT_KW = dict(seed=0, gain=2.0, bias_std=0.2, add_bias_shift=0.0, rmv_bias_shift=-3.0)
+
+
+@pytest.fixture(scope='module')
+def net(cuda_device):
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    return LrgNetHIP(1, 1, 512, 512, 13, 0, device=cuda_device).load_weights(synthetic.make_synthetic_weights(**WEIGHT_KW))
+
+
+def zero_net(xi, xn):
+    return np.zeros((1, 512, 2), np.float32), np.zeros((1, 512, 2), np.float32)
+
+
+def check_invariants(room, res, cluster_threshold=10):
+    n = len(room['points'])
+    lab, filled = res.cluster_label, res.filled_label
+    assert filled.shape == (n,) and (filled > 0).all()                      # the fill-in leaves no point unlabeled (:308-316)
+    assert (filled[lab > 0] == lab[lab > 0]).all()                          # ... and never touches a labeled one
+    ids, counts = np.unique(lab[lab > 0], return_counts=True)
+    assert (counts > cluster_threshold).all()                               # :213
+    assert ids.tolist() == list(range(1, len(ids) + 1))                     # cluster ids are consecutive (:214-215)
+    labeled = [r for r in res.regions if r['labeled']]
+    assert len(labeled) == len(ids)
+    assert sorted(r['points'] for r in labeled) == sorted(counts.tolist())  # the log agrees with the labels
+    assert sum(r['points'] for r in res.regions) == n                       # regions partition the room (visited, :212)
+    assert len({r['seed'] for r in res.regions}) == len(res.regions)
+
+
+def test_area5_median_room_matches_oracle_exactly(net):
+    """A 9.4 k-point Area-5-shaped room (the median Area-5 size), ground-truth masks, device-side RNG."""
+    from learn_region_grow_amd.grow import RegionGrower
+    room = workloads.make_room(9304, 1007, 1007)
+    res = RegionGrower(net, rooms_in_flight=1, rng='counter', seed=3, policy='gt').run([room])[0]
+    want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.CounterStream(3, 1007),
+                              net_fn=zero_net, policy='gt')
+    assert [(r['seed'], r['steps'], r['points'], r['reason']) for r in res.regions] == \
+           [(r['seed'], r['steps'], r['points'], r['reason']) for r in want.regions]
+    np.testing.assert_array_equal(res.cluster_label, want.cluster_label)
+    np.testing.assert_array_equal(res.filled_label, want.filled_label)
+    check_invariants(room, res)
+
+
+def test_area5_largest_room_and_restarts(net):
+    """The largest Area-5 room (45 k points) next to small ones, greedy and 4 batched restarts: invariants,
+    run-to-run determinism, independence from what else is in flight."""
+    from learn_region_grow_amd.grow import RegionGrower
+    big = workloads.make_room(45063, 1057, 57)
+    small = [workloads.make_room(2164, 1021, 21), workloads.make_room(5090, 1001, 1)]
+    a = RegionGrower(net, rooms_in_flight=3, rng='counter', seed=11, policy='gt').run([big] + small)
+    b = RegionGrower(net, rooms_in_flight=1, rng='counter', seed=11, policy='gt').run([big])
+    for room, res in zip([big] + small, a):
+        check_invariants(room, res)
+    np.testing.assert_array_equal(a[0].filled_label, b[0].filled_label)
+    want = grow_ref.grow_room(big['points'], big['obj_id'], big['order'], None, rng_ref.CounterStream(11, 57),
+                              net_fn=zero_net, policy='gt')
+    np.testing.assert_array_equal(a[0].filled_label, want.filled_label)
+    r = RegionGrower(net, rooms_in_flight=2, rng='counter', seed=11, policy='gt', restarts=4).run(small)
+    for room, res in zip(small, r):
+        check_invariants(room, res)
+        assert all(0 <= x['restart'] < 4 for x in res.regions)
+
+
+def test_kitti_scale_scene(net):
+    """~100 k points at 0.3 m (configs[4]): the 1-NN fill-in and the mask scans at scale."""
+    from learn_region_grow_amd.grow import RegionGrower
+    scene = workloads.make_room(100000, 5000, 5000, resolution=0.3)
+    res = RegionGrower(net, rooms_in_flight=1, rng='counter', seed=2, policy='gt', resolution=0.3).run([scene])[0]
+    check_invariants(scene, res)
+    want = grow_ref.grow_room(scene['points'], scene['obj_id'], scene['order'], None, rng_ref.CounterStream(2, 5000),
+                              net_fn=zero_net, policy='gt', resolution=0.3, fill=False)
+    np.testing.assert_array_equal(res.cluster_label, want.cluster_label)
+    # the fill-in against the C oracle (NumPy-order float32 distances, first-min ties)
+    from oracle import grouping_ref
+    np.testing.assert_array_equal(res.filled_label, grouping_ref.nn1_fill(scene['points'], res.cluster_label))
+
+
+def test_net_policy_full_size_is_deterministic_and_batch_independent(net):
+    """The reference's Bernoulli policy at full size: no oracle in reach (hundreds of LrgNet evaluations per room
+    on the CPU), so: determinism and independence from batching, plus the invariants."""
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = [workloads.make_room(t, 1000 + i, i) for i, t in enumerate([13220, 5090, 8866])]
+    a = RegionGrower(net, rooms_in_flight=3, rng='counter', seed=5).run(rooms)
+    b = RegionGrower(net, rooms_in_flight=2, rng='counter', seed=5).run(rooms[::-1])[::-1]
+    for room, x, y in zip(rooms, a, b):
+        check_invariants(room, x)
+        np.testing.assert_array_equal(x.filled_label, y.filled_label)
+        assert x.total_steps == y.total_steps
