@@ -39,8 +39,9 @@ class GrowResult:
         self.regions = []              # dicts: seed, target, steps, points, gt, iou, add_acc, rmv_acc, reason, labeled
         self.total_steps = 0           # LrgNet evaluations
         self.min_margin = np.inf       # min |u - conf| over all Bernoulli draws
-        self.min_safety = np.inf       # min |u - conf| / (1e-4*conf*(1-conf) + 1e-9): < 1 means a draw sits within
-                                       # fp32 noise of its confidence, so another fp32 network may flip it
+        self.min_rel_margin = np.inf   # min |u - conf| / (conf*(1-conf) + 1e-6): how large a RELATIVE error in a logit
+                                       # difference it takes to flip the closest Bernoulli draw.  Same logits, other
+                                       # exp/divide: errors ~1e-7; another fp32 evaluation of the network: ~1e-5..1e-4
         self.lines = []                # reference-format log lines (:217)
 
 
@@ -134,7 +135,7 @@ def grow_room(points, obj_id, order, weights, stream, *, cls_id=None, classes=No
                     for u_, c_ in ((u_add, add_conf), (u_rmv, rmv_conf)):
                         d_ = np.abs(np.asarray(u_, np.float64) - c_)
                         res.min_margin = min(res.min_margin, float(d_.min()))
-                        res.min_safety = min(res.min_safety, float((d_ / (1e-4 * c_ * (1.0 - c_) + 1e-9)).min()))
+                        res.min_rel_margin = min(res.min_rel_margin, float((d_ / (c_ * (1.0 - c_) + 1e-6)).min()))
                 elif policy == 'threshold':                                      # :264-265 (commented out upstream)
                     add_mask = add_conf > 0.5
                     rmv_mask = rmv_conf > 0.5
