@@ -96,11 +96,20 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    # LRG_BENCH_ONE_DEVICE=1 (testing on a 1-GPU box): every rank uses cuda:0 and the collectives go over gloo
+    one_dev = os.environ.get('LRG_BENCH_ONE_DEVICE') == '1'
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    coll_dev = dev
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if one_dev:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            coll_dev = torch.device('cpu')
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     weights = synthetic.make_synthetic_weights(seed=0)
     resolution = 0.1
@@ -137,9 +146,9 @@ def main():
     barrier()
     t1 = time.perf_counter()
     s1 = gr.d_stats[:3].cpu().numpy().copy()
-    elapsed = lrg_dist.allreduce_max(t1 - t0, device=dev)
+    elapsed = lrg_dist.allreduce_max(t1 - t0, device=coll_dev)
     inst_steps, rooms_done, seeds = lrg_dist.allreduce_sum([float(s1[2] - s0[2]), float(s1[1] - s0[1]), float(s1[0] - s0[0])],
-                                                           device=dev)
+                                                           device=coll_dev)
 
     # ---- roofline of the LrgNet evaluation (the dominant kernels), HIP events on the launch stream ----
     S = gr.S
@@ -176,7 +185,7 @@ def main():
     # ---- final label gather over RCCL (the only collective of the path) ----
     if world > 1:
         labs = [gr.d_label[int(gr.room_off[r]):int(gr.room_off[r]) + gr.room_n[r]].cpu().numpy() for r in range(2)]
-        lrg_dist.gather_room_labels([rank * 2, rank * 2 + 1], labs, 2 * world, device=dev)
+        lrg_dist.gather_room_labels([rank * 2, rank * 2 + 1], labs, 2 * world, device=coll_dev)
 
     if rank == 0:
         out = {

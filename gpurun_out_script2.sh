@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -rs 2>&1 | tail -15
+LRG_BENCH_ONE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 300 --warmup 50 --cpu-seconds 0 2>&1 | tail -3 | cut -c1-500
