@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define LRG_ABI_VERSION 1
+#define LRG_ABI_VERSION 2
 #define LRG_EINVAL (-1000)
 
 #define LRG_MAX_CONV 5 /* branch layers: lite=0 -> 5, lite=1 -> 2, lite=2 -> 3  (learn_region_grow_util.py:77-85) */
@@ -53,15 +53,22 @@ typedef struct LrgWeights {
     const float *add_b[LRG_MAX_HEAD];      /* lrg_add_bias{j}                                       :140,:146 */
     const float *rmv_w[LRG_MAX_HEAD];      /* lrg_remove_kernel{j}                                  :152,:158 */
     const float *rmv_b[LRG_MAX_HEAD];      /* lrg_remove_bias{j}                                    :153,:159 */
+    const void *packed;                    /* nullable: lrg_pack_weights() image of the kernels above (MFMA operand order).
+                                              NULL: lrg_forward (LRG_FWD_FUSED) re-packs into its workspace on every call,
+                                              which is always correct; non-NULL: the caller vouches it is current.   */
 } LrgWeights;
+
+/* The fused kernels read the [Cin,Cout] kernels in the order their MFMA B operands want them (one 16-byte load per lane
+ * per 8 rows of Cin instead of four strided 4-byte loads).  lrg_pack_weights writes that image (device memory,
+ * lrg_packed_weights_bytes(w) bytes, 256-byte aligned) from the TF-layout pointers in `w`; store its address in
+ * w->packed after a restore (test_region_grow.py:92-93) and repeat after any change of the variables. */
+size_t lrg_packed_weights_bytes(const LrgWeights *w);
+int lrg_pack_weights(const LrgWeights *w, void *packed, size_t packed_bytes, void *stream);
 
 #define LRG_FWD_FUSE_POOL 1u /* layer-streamed path: fold the max-pool (:122-123) into the last branch layer's epilogue */
 #define LRG_FWD_FUSED 2u     /* whole branch / whole head per 64-row tile in one kernel each: activations stay in LDS,
                                 only conv[1], the pooled maxima and the logits reach HBM (3 launches per call)         */
 #define LRG_FWD_KEEP_ACTS 4u /* with LRG_FWD_FUSED: also copy every intermediate into the workspace (parity tests)     */
-#define LRG_FWD_SPLIT_SPARSE 16u /* lrg_forward_rows + LRG_FWD_FUSED: while the live-tile counter in the workspace scratch
-                                  (view kind 5, element 0, int32; maintained by lrg_prepare) is small, split the widest
-                                  branch layer over 4 workgroups per tile to shorten the critical path                    */
 #define LRG_FWD_POOL_ZEROED 8u /* with LRG_FWD_FUSED: the workspace was zero-filled once by the caller and is only ever used
                                 by calls carrying this flag -- the pooled-feature block is then zero on entry and is
                                 left zero on return (cleared by the head kernel), which saves the per-call memset.
@@ -88,7 +95,7 @@ int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neig
 
 /* Workspace introspection for layer-by-layer parity tests: float offset / element count of a named
  * intermediate inside `workspace`.  kind: 0 conv[i] (inlier), 1 neighbor_conv[i], 2 pooled [B,2*C_last],
- * 3 add head hidden[i], 4 remove head hidden[i], 5 scratch (64 floats; element 0 = live-tile counter).
+ * 3 add head hidden[i], 4 remove head hidden[i], 5 scratch (64 floats, reserved).
  * Returns 0, or LRG_EINVAL. */
 int lrg_forward_workspace_view(const LrgWeights *w, int B, int n_inlier, int n_neighbor, int kind, int index,
                                size_t *offset_floats, size_t *count_floats);

@@ -18,7 +18,6 @@ LRG_FWD_FUSE_POOL = 1
 LRG_FWD_FUSED = 2
 LRG_FWD_KEEP_ACTS = 4
 LRG_FWD_POOL_ZEROED = 8
-LRG_FWD_SPLIT_SPARSE = 16
 
 (LRG_IDLE, LRG_ACTIVE, LRG_STOP_NONEIGHBOR, LRG_STOP_NOEXPAND, LRG_STOP_STUCK, LRG_STOP_EMPTY, LRG_STOP_MAXSTEPS,
  LRG_DONE, LRG_WAIT) = range(9)
@@ -35,7 +34,7 @@ class LrgWeights(ctypes.Structure):
                 ('inlier_w', _fp * LRG_MAX_CONV), ('inlier_b', _fp * LRG_MAX_CONV),
                 ('neighbor_w', _fp * LRG_MAX_CONV), ('neighbor_b', _fp * LRG_MAX_CONV),
                 ('add_w', _fp * LRG_MAX_HEAD), ('add_b', _fp * LRG_MAX_HEAD),
-                ('rmv_w', _fp * LRG_MAX_HEAD), ('rmv_b', _fp * LRG_MAX_HEAD)]
+                ('rmv_w', _fp * LRG_MAX_HEAD), ('rmv_b', _fp * LRG_MAX_HEAD), ('packed', _fp)]
 
 
 class LrgRoom(ctypes.Structure):
@@ -104,6 +103,8 @@ _SIGS = {
     'lrg_abi_version': (ctypes.c_int, []),
     'lrg_target_arch': (ctypes.c_char_p, []),
     'lrg_struct_size': (ctypes.c_size_t, [ctypes.c_int]),
+    'lrg_packed_weights_bytes': (ctypes.c_size_t, [ctypes.POINTER(LrgWeights)]),
+    'lrg_pack_weights': (ctypes.c_int, [ctypes.POINTER(LrgWeights), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'lrg_forward_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(LrgWeights), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'lrg_forward': (ctypes.c_int, [ctypes.POINTER(LrgWeights), _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp,
                                    _fp, ctypes.c_size_t, ctypes.c_uint, _fp]),
@@ -163,7 +164,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lrg_abi_version() != 1:
+    if lib.lrg_abi_version() != 2:
         raise LrgHipError('ABI version mismatch')
     for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams)):
         if lib.lrg_struct_size(which) != ctypes.sizeof(st):

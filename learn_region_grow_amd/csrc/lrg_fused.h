@@ -10,10 +10,10 @@
 #define LRG_FL_INPLACE 16     // output overlays this layer's own input buffer (last layer, one column block)
 
 struct LrgFusedLayer {
-    const float *w;      // [K,N] row-major, row stride ldw
+    const float *w;      // MFMA-operand image of the [K,N] kernel (lrg_pack_weights layout): [N/32][ng][64 lanes][4]
     const float *bias;
     float *gout;         // nullable: copy of the output in HBM, [rows,N]
-    int K, N, ldw, flags;
+    int K, N, ng, flags; // ng = ceil(K/8) k-groups
 };
 
 struct LrgFusedProb {
@@ -23,11 +23,9 @@ struct LrgFusedProb {
     const float *fb;
     float *fout;         // [rows,2]
     const int *valid;    // nullable, [instances]: only the first valid[i] rows of instance i are evaluated (0 = skip)
-    const int *tile_total; // nullable: device count of live tiles of this launch; the column split is dropped when it is large
     float *zero_pool;    // nullable: after the stack, the tile-0 workgroup of instance i clears zero_pool[i*zero_count .. +zero_count)
     long rows;
     int ldx, Kin, rows_per_inst, pool_stride, nlayers, zero_count;
-    int split_limit, pad2;   // keep the column split only while tile_total * gridDim.z <= split_limit
     LrgFusedLayer L[LRG_FUSED_MAXL];
 };
 
@@ -35,5 +33,5 @@ struct LrgFusedArgs {
     LrgFusedProb p[2];
 };
 
-int lrg_fused_branches(const LrgFusedArgs &a, int nprob, int split, hipStream_t st);
+int lrg_fused_branches(const LrgFusedArgs &a, int nprob, hipStream_t st);
 int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st);

@@ -1,8 +1,9 @@
 // Fused LrgNet stacks for gfx950: a whole branch (learn_region_grow_util.py:106-123) or a whole head (:138-162)
-// per 64-row tile in ONE kernel.  Activations never leave the CU: they ping-pong between two LDS buffers; the layer
-// weights (L2-resident, 3.2 MB in all) go straight into the MFMA B operands, a few k-groups ahead of the fp32 MFMAs
-// (v_mfma_f32_32x32x2_f32, exact fp32).  Only conv[1] (needed by the heads), the pooled maxima and the logits are
-// written to HBM; the 512-wide layer and the 1088-wide concat are never materialised.
+// per 64-row (branch) / 32-row (head) tile in ONE kernel.  Activations never leave the CU: they ping-pong between two
+// LDS buffers; the layer weights (L2-resident, 3.2 MB in all, pre-arranged in operand order by lrg_pack_weights) go
+// straight into the MFMA B operands through a register ring that runs a few k-groups ahead of the fp32 MFMAs
+// (v_mfma_f32_32x32x2_f32, exact fp32) and never drains between layers.  Only conv[1] (needed by the heads), the
+// pooled maxima and the logits are written to HBM; the 512-wide layer and the 1088-wide concat are never materialised.
 //
 // The layer-streamed formulation (one launch per layer, lrg_net.hip) stays available: it is what the layer-by-layer
 // parity tests and the "HBM-streamed" roofline figure use.
@@ -10,91 +11,100 @@
 #include "lrg_fused.h"
 
 #ifndef LRG_TRACE
-#define LRG_TRACE 0     // 1: thread 0 of every workgroup stamps s_memtime at phase boundaries into P.fout-adjacent debug memory
+#define LRG_TRACE 0     // 2 (branch kernel) / 1 (head kernel): thread 0 of each workgroup stamps the cycle counter at phase boundaries
 #endif
 #if LRG_TRACE
 __device__ long long *g_lrg_trace = nullptr;
 extern "C" void lrg_set_trace(long long *p) { hipMemcpyToSymbol(HIP_SYMBOL(g_lrg_trace), &p, sizeof(p)); }
-#define TRACE(i) do { if (tid == 0 && g_lrg_trace && blockIdx.x < 2048) g_lrg_trace[((long)blockIdx.y * 2048 + blockIdx.x) * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define TRACE(i) do { if (RT == LRG_TRACE && tid == 0 && g_lrg_trace && blockIdx.x < 2048) g_lrg_trace[((long)blockIdx.y * 2048 + blockIdx.x) * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define TRACE(i)
-#endif
-#ifndef LRG_ABLATE
-#define LRG_ABLATE 0   // timing experiments only: 1 = no weight loads in the MFMA loop, 2 = no LDS reads (results wrong)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define FBN 128      // output columns per pass: 4 waves side by side, each a 64x32 strip (two 32x32 MFMA tiles sharing B)
+#define FBN 128      // output columns per pass: 4 waves side by side, each a (32*RT)x32 strip (RT 32x32 MFMA tiles sharing B)
 #define FTHREADS 256 // one wave per SIMD per workgroup; 2-3 workgroups per CU interleave without sharing barriers
-#define FDIST 4      // k-groups of B operands in flight ahead of the MFMAs (4 groups = 32 MFMAs = 2048 cycles)
 
-// A (32*RT)x32 output strip (RT 32x32 tiles stacked in rows) over NG k-groups of 8.  Lane half h feeds logical
+// Weight operands are software-pipelined ACROSS passes (a pass = one layer x one 128-column block): a ring of FD
+// k-groups of B registers is always FD groups ahead of the MFMAs, and during the last FD groups of a pass it is
+// refilled with the first FD groups of the NEXT pass (next column block or next layer), so the L2 latency of a pass's
+// first weights hides behind the previous pass's MFMAs, epilogue and barrier instead of stalling every pass.
+// The weights come pre-arranged in operand order (lrg_pack_weights): ONE global_load_dwordx4 per lane per k-group --
+// measured (tools/mfma_peak.hip) 92 % of the fp32 MFMA peak against 78-86 % with four strided dword loads per group,
+// whose address arithmetic and issue slots compete with the MFMAs.
+template <int FD>
+__device__ __forceinline__ void prefetch_b(float4 (&bq)[FD], const float4 *wp) {
+#pragma unroll
+    for (int g = 0; g < FD; ++g) bq[g] = wp[g * 64];
+}
+
+// A (32*RTT)x32 output strip (RTT 32x32 tiles stacked in rows) over NG k-groups of 8.  Lane half h feeds logical
 // k = 8g + 4h + s of both operands:
-//   A (activations) from LDS, one ds_read_b128 per tile per group;
-//   B (weights) straight from L2/L1 into registers: four coalesced global_load_dword per group (each fetches two
-//   128-B lines: 32 consecutive columns of rows k and k+4), shared by the RT tiles.  No wave shares its B columns
-//   with another wave, so an LDS round trip would buy nothing and its barriers would serialise the waves.
-//   wrow = wave-uniform base (SGPRs), loff = per-lane element offset: saddr-form loads, no 64-bit VALU address math.
-template <int NG, int RT>
-__device__ __forceinline__ void tile_mfma(f32x16 (&acc)[RT], const float *ap, int ld_in, const float *wrow, int loff,
-                                          int ldw) {
+//   A (activations) from LDS, one ds_read_b128 per tile per group, two groups ahead;
+//   B (weights) from L2 into the register ring, shared by the RTT tiles.  No wave shares its B columns with another
+//   wave, so an LDS round trip would buy nothing and its barriers would serialise the waves.
+//   wp / wpn = this lane's float4 of group 0 of this / the next pass.
+template <int NG, int RT, int RTT, int FD>
+__device__ __forceinline__ void tile_mfma(f32x16 (&acc)[RT], const float *ap, int ld_in, const float4 *wp,
+                                          const float4 *wpn, float4 (&bq)[FD]) {
+    static_assert(NG >= FD && NG >= 2, "the ring must not be deeper than a pass");
+    float4 ar[3][RTT];                  // A operands of groups g, g+1, g+2 (explicit rotation: program order = issue order)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        float4 a[RT];
-#pragma unroll
-        for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const float4 *>(ap + t * 32 * ld_in + 8 * g);
-        const float *w0 = wrow + (long)(8 * g) * ldw;
-        float b0 = w0[loff];
-        float b1 = w0[loff + ldw];
-        float b2 = w0[loff + 2 * ldw];
-        float b3 = w0[loff + 3 * ldw];
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b0, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b1, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b2, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b3, acc[t], 0, 0, 0);
+    for (int t = 0; t < RTT; ++t) {
+        ar[0][t] = *reinterpret_cast<const float4 *>(ap + t * 32 * ld_in);
+        ar[1][t] = *reinterpret_cast<const float4 *>(ap + t * 32 * ld_in + 8);
     }
-    // issue order: FDIST groups of weight loads and 2 groups of LDS reads run ahead of the MFMAs
-    constexpr int D = NG < FDIST ? NG : FDIST;
-    constexpr int DA = NG < 2 ? NG : 2;
-    __builtin_amdgcn_sched_group_barrier(0x020, 4 * D, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, RT * DA, 0);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * RT, 0);
-        if (g + D < NG) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-        if (g + DA < NG) __builtin_amdgcn_sched_group_barrier(0x100, RT, 0);
+        if (g + 2 < NG)
+#pragma unroll
+            for (int t = 0; t < RTT; ++t) ar[(g + 2) % 3][t] = *reinterpret_cast<const float4 *>(ap + t * 32 * ld_in + 8 * (g + 2));
+        const float4 b = bq[g % FD];
+#pragma unroll
+        for (int t = 0; t < RTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[g % 3][t].x, b.x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[g % 3][t].y, b.y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[g % 3][t].z, b.z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[g % 3][t].w, b.w, acc[t], 0, 0, 0);
+        bq[g % FD] = (g + FD < NG) ? wp[(g + FD) * 64] : wpn[(g + FD - NG) * 64];
+    }
+    // pin that order: two groups of LDS reads up front, then per k-group [LDS reads of g+2][4*RTT MFMAs][ring refill]
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * RTT, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 2 < NG) __builtin_amdgcn_sched_group_barrier(0x100, RTT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * RTT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
 }
 
-// Ragged K (the 13-wide first layer, padded to 16 in LDS): rows >= K of the weights read as zero.
-template <int RT>
-__device__ __forceinline__ void tile_mfma_ragged(f32x16 (&acc)[RT], const float *ap, int ld_in, const float *wrow, int loff,
-                                                 int ldw, int K, int kbase) {
-    const int ng = (K + 7) >> 3;
+// A narrow first layer (K = 13 -> two k-groups; the packed image and the staged rows are both zero-padded): its
+// weights do not go through the ring; bf holds the first two groups, fetched before the input rows were staged.
+template <int RT, int RTT>
+__device__ __forceinline__ void tile_mfma_first(f32x16 (&acc)[RT], const float *ap, int ld_in, const float4 *wp, int ng,
+                                                const float4 (&bf)[2], bool pre) {
     for (int g = 0; g < ng; ++g) {
-        float4 a[RT];
+        float4 a[RTT];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const float4 *>(ap + t * 32 * ld_in + 8 * g);
-        float b[4];
+        for (int t = 0; t < RTT; ++t) a[t] = *reinterpret_cast<const float4 *>(ap + t * 32 * ld_in + 8 * g);
+        const float4 b = (pre && g == 0) ? bf[0] : (pre && g == 1) ? bf[1] : wp[g * 64];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = (kbase + 8 * g + s < K) ? wrow[(long)(8 * g + s) * ldw + loff] : 0.f;
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[2], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[3], acc[t], 0, 0, 0);
+        for (int t = 0; t < RTT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b.w, acc[t], 0, 0, 0);
         }
     }
 }
 
-template <int CAP0, int CAP1, int RT>
-__global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs args) {
+// DIRECT: also compile the register-to-HBM copy of layers that do not stay in LDS (LRG_FWD_KEEP_ACTS on the pooled layer
+// and on an in-place head layer; parity tests only) -- it costs ~25 VGPRs, which is the third wave per SIMD.
+template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT>
+__global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFusedArgs args) {
     constexpr int FM = 32 * RT;      // rows (points) per workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *buf0 = smem;                       // outputs of even layers
@@ -109,21 +119,40 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
     if (tile * FM >= P.rows_per_inst) return;
     // rows beyond valid[instance] are copies of earlier rows (the padding rule, test_region_grow.py:240,:252):
     // their per-point results are identical and the max-pool ignores duplicates, so whole tiles of them are skipped
-    if (P.valid && tile * FM >= P.valid[inst]) return;
+    // (the count is fetched here and tested after the input rows are staged: one memory round trip instead of two)
+    const int nvalid = P.valid ? P.valid[inst] : 0x7fffffff;
     const long r0 = (long)inst * P.rows_per_inst + (long)tile * FM;
-    // Column split of the pooled (last, widest) layer over gridDim.z workgroups: each recomputes the narrow layers and
-    // takes every gridDim.z-th 128-column block of the last one.  It shortens the critical path of a tile ~2.5x when
-    // few tiles are live (duplicate-row skipping) at the price of ~1.5x the MFMA work, so it is dropped -- z > 0
-    // workgroups exit, z = 0 does everything -- once the live-tile count says the chip would be full anyway.
-    int zsplit = gridDim.z;
-    if (zsplit > 1 && P.tile_total && *P.tile_total * zsplit > P.split_limit) zsplit = 1;
-    const int zme = blockIdx.z;
-    if (zme >= zsplit) return;
-    if (zsplit > 1 && zme >= (P.L[P.nlayers - 1].N + FBN - 1) / FBN) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     TRACE(0);
+
+    // A 64-wide layer of a 64-row tile is laid out 2x2 (each wave one 32x32 tile) instead of 1x4 strips of which only
+    // two would have columns: all four SIMDs stay busy through the narrow layers.
+    auto is22 = [&](const LrgFusedLayer &L, int l) { return RT == 2 && L.N == 64 && (L.K == 64 || l == 0); };
+    auto col_of = [&](const LrgFusedLayer &L, int l, int cb) { return is22(L, l) ? (wn & 1) * 32 : cb * FBN + wn * 32; };
+
+    // this lane's float4 of k-group 0 of the 32-column block starting at column c of layer L (packed image)
+    auto wptr = [&](const LrgFusedLayer &L, int c) {
+        return reinterpret_cast<const float4 *>(L.w) + (long)(c >> 5) * L.ng * 64 + lane;
+    };
+    // bias of column c of layer L for this lane (a per-instance row when the layer carries the hoisted pooled product)
+    auto bias_of = [&](const LrgFusedLayer &L, int c) -> float {
+        if (!L.bias) return 0.f;
+        return (L.flags & LRG_FL_INST_BIAS) ? L.bias[(long)inst * L.N + c + li] : L.bias[c + li];
+    };
+    float4 bq[FD], bf[2];
+    float bvn;                                   // bias of the NEXT pass, fetched one pass ahead like the weights
+    LrgFusedLayer Lnext = P.L[0];
+    {   // the first pass's weights start their trip before the input rows are staged
+        int c = col_of(Lnext, 0, 0);
+        if (c >= Lnext.N) c = 0;
+        bvn = bias_of(Lnext, c);
+        const float4 *wp0 = wptr(Lnext, c);
+        const int K0 = Lnext.K;
+        if (K0 == 64 || K0 == 128 || K0 == 256) prefetch_b<FD>(bq, wp0);
+        else { bf[0] = wp0[0]; bf[1] = wp0[Lnext.ng > 1 ? 64 : 0]; }
+    }
 
     // ---- stage the input rows into buf1, zero-padded to a multiple of 8 columns ----
     const int Kin = P.Kin;
@@ -143,66 +172,116 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
             buf1[row * ld_x + c] = c < Kin ? P.x[(r0 + row) * P.ldx + c] : 0.f;
         }
     }
-    for (int i = tid; i < 512; i += FTHREADS) poolbuf[i] = 0.f;
+    // poolbuf: running column maxima of a pooled stack, or the final [C,2] layer of a head (C <= 256)
+    if (P.fw) { for (int i = tid; i < 2 * P.L[P.nlayers - 1].N; i += FTHREADS) poolbuf[i] = P.fw[i]; }
+    else { for (int i = tid; i < 512; i += FTHREADS) poolbuf[i] = 0.f; }
+    if (tile * FM >= nvalid) return;             // workgroup-uniform
     __syncthreads();
     TRACE(1);
 
     const int nlayers = P.nlayers;
     int prevN = Kp;
     int lastN = 0, lastflags = 0;
-    LrgFusedLayer Lnext = P.L[0];
     for (int l = 0; l < nlayers; ++l) {
         const LrgFusedLayer L = Lnext;             // descriptors are fetched one layer ahead (scalar loads off the critical path)
-        if (l + 1 < nlayers) Lnext = P.L[l + 1];
+        if (l + 1 < nlayers) Lnext = P.L[l + 1];   // (after the last layer Lnext == L: the ring refill stays in bounds)
         const bool inplace = (L.flags & LRG_FL_INPLACE) != 0;
         const float *act_in = (l & 1) ? buf0 : buf1;
         float *act_out = ((l & 1) != 0) == !inplace ? buf1 : buf0;
         const int ld_in = prevN + 4, ld_out = L.N + 4;
-        const float *ap = act_in + li * ld_in + 4 * lh;
-        const int loff = 4 * lh * L.ldw + li;
-        const int ncb = (L.N + FBN - 1) / FBN;
-        const bool split_here = zsplit > 1 && l == nlayers - 1;
+        const bool m22 = is22(L, l);
+        const int rbase = m22 ? (wn >> 1) * 32 : 0;          // first row of this wave's strip within the tile
+        const int ntile = m22 ? 1 : RT;
+        const float *ap = act_in + (rbase + li) * ld_in + 4 * lh;
+        const int ncb = m22 ? 1 : (L.N + FBN - 1) / FBN;
         TRACE(2 + 2 * l);
-        for (int cb = split_here ? zme : 0; cb < ncb; cb += split_here ? zsplit : 1) {
-            const int col0 = cb * FBN + wn * 32;
-            const bool wave_on = col0 < L.N;         // 64-wide layers keep only two of the four waves busy
+        for (int cb = 0; cb < ncb; ++cb) {
+            const int col0 = col_of(L, l, cb);
+            const bool wave_on = col0 < L.N;         // a 64-wide layer outside the 2x2 layout keeps two of the four waves busy
+            // the pass after this one: next column block, else the next layer's first
+            const bool same = cb + 1 < ncb;
+            const LrgFusedLayer &Lx = same ? L : Lnext;
+            int coln = col_of(Lx, same ? l : l + 1, same ? cb + 1 : 0);
+            if (coln >= Lx.N) coln = 0;
+            const float4 *wpn = wptr(Lx, coln);
+
             f32x16 acc[RT];
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-            float bv = 0.f;                          // issued before the MFMAs so that its latency hides behind them
-            if (wave_on && L.bias)
-                bv = (L.flags & LRG_FL_INST_BIAS) ? L.bias[(r0 / P.rows_per_inst) * L.N + col0 + li] : L.bias[col0 + li];
+            const float bv = bvn;
+            bvn = bias_of(Lx, coln);
             if (wave_on) {
-                const float *wrow = L.w + col0;
-                if (L.K == 128) tile_mfma<16, RT>(acc, ap, ld_in, wrow, loff, L.ldw);
-                else if (L.K == 64) tile_mfma<8, RT>(acc, ap, ld_in, wrow, loff, L.ldw);
-                else if (L.K == 256) tile_mfma<32, RT>(acc, ap, ld_in, wrow, loff, L.ldw);
-                else tile_mfma_ragged<RT>(acc, ap, ld_in, wrow, loff, L.ldw, L.K, 4 * lh);
+                const float4 *wp = wptr(L, col0);
+                if constexpr (RT == 2) {
+                    if (m22) {
+                        if (L.K == 64) tile_mfma<8, RT, 1, FD>(acc, ap, ld_in, wp, wpn, bq);
+                        else {
+                            prefetch_b<FD>(bq, wpn);
+                            tile_mfma_first<RT, 1>(acc, ap, ld_in, wp, L.ng, bf, cb == 0);
+                        }
+                    } else if (L.K == 128) tile_mfma<16, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
+                    else if (L.K == 64) tile_mfma<8, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
+                    else if (L.K == 256) tile_mfma<32, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
+                    else {
+                        prefetch_b<FD>(bq, wpn);
+                        tile_mfma_first<RT, RT>(acc, ap, ld_in, wp, L.ng, bf, cb == 0);
+                    }
+                } else {
+                    if (L.K == 128) tile_mfma<16, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
+                    else if (L.K == 64) tile_mfma<8, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
+                    else if (L.K == 256) tile_mfma<32, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
+                    else {
+                        prefetch_b<FD>(bq, wpn);
+                        tile_mfma_first<RT, RT>(acc, ap, ld_in, wp, L.ng, bf, cb == 0);
+                    }
+                }
+            } else {
+                prefetch_b<FD>(bq, wpn);      // an idle wave still owes the next pass its first weights
             }
             if (inplace) __syncthreads();            // the output overlays this layer's input: everyone must be done reading
             if (wave_on) {
                 // ---- epilogue: bias, ReLU, keep in LDS / copy to HBM / column max ----
                 const int col = col0 + li;
                 float cmax = 0.f;
+                // a layer that stays in LDS is copied to HBM from there after the barrier (coalesced); only the
+                // parity-test copy of a layer that does not (KEEP_ACTS on the pooled layer) is stored from registers
+                float *gdirect = (DIRECT && L.gout && (!(L.flags & LRG_FL_KEEP) || inplace)) ? L.gout + r0 * L.N : nullptr;
 #pragma unroll
-                for (int r = 0; r < 16 * RT; ++r) {
-                    const int rr = r & 15;
-                    const int rl = (r >> 4) * 32 + 4 * lh + (rr & 3) + 8 * (rr >> 2);
-                    float v = acc[r >> 4][rr] + bv;
-                    if (L.flags & LRG_FL_RELU) v = fmaxf(v, 0.f);
-                    if (L.flags & LRG_FL_KEEP) act_out[rl * ld_out + col] = v;
-                    if (L.gout && (zme == 0 || split_here)) L.gout[(r0 + rl) * L.N + col] = v;
-                    cmax = fmaxf(cmax, v);
+                for (int t = 0; t < RT; ++t) {
+                    if (t < ntile) {
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) {
+                            const int rl = rbase + t * 32 + 4 * lh + (rr & 3) + 8 * (rr >> 2);
+                            float v = acc[t][rr] + bv;
+                            if (L.flags & LRG_FL_RELU) v = fmaxf(v, 0.f);
+                            if (L.flags & LRG_FL_KEEP) act_out[rl * ld_out + col] = v;
+                            if (DIRECT && gdirect) gdirect[(unsigned)(rl * L.N + col)] = v;
+                            cmax = fmaxf(cmax, v);
+                        }
+                    }
                 }
                 if (L.flags & LRG_FL_POOL) {
                     cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-                    if (lh == 0) poolbuf[col] = fmaxf(poolbuf[col], cmax);   // this wave owns the column: no atomic needed
+                    if (lh == 0) {
+                        if (m22) atomicMax(reinterpret_cast<int *>(&poolbuf[col]), __float_as_int(cmax));   // two waves share the column (values >= 0)
+                        else poolbuf[col] = fmaxf(poolbuf[col], cmax);                                      // this wave owns the column
+                    }
                 }
             }
         }
         __syncthreads();                             // layer boundary: outputs visible, inputs dead
+        if (L.gout && (L.flags & LRG_FL_KEEP) && !inplace) {
+            // HBM copy of a layer the next one reads from LDS (conv[1] for the heads, :130,:134): whole rows, float4
+            const int q = L.N >> 2;
+            float *gb = L.gout + r0 * L.N;
+            for (int idx = tid; idx < FM * q; idx += FTHREADS) {
+                const int row = idx / q, c4 = idx - row * q;
+                *reinterpret_cast<float4 *>(gb + (unsigned)(row * L.N + 4 * c4)) =
+                    *reinterpret_cast<const float4 *>(act_out + row * ld_out + 4 * c4);
+            }
+        }
         TRACE(2 + 2 * l + 1);
         prevN = L.N;
         lastN = L.N;
@@ -215,37 +294,37 @@ __global__ __launch_bounds__(FTHREADS) void lrg_fused_stack_kernel(LrgFusedArgs 
         for (int c = tid; c < lastN; c += FTHREADS) atomicMax(reinterpret_cast<int *>(&dst[c]), __float_as_int(poolbuf[c]));
     }
     // ---- final 2-wide layer of a head, no ReLU (:145-149, :158-162) ----
-    if (P.fw && zme == 0) {
+    if (P.fw) {
         const int C = lastN;
         const bool odd = ((nlayers - 1) & 1) != 0;
         const float *act = (odd == !(lastflags & LRG_FL_INPLACE)) ? buf1 : buf0;
         const int ld = C + 4;
-        for (int i = tid; i < 2 * C; i += FTHREADS) poolbuf[i] = P.fw[i];      // C <= 256: fits the 512-float scratch
-        __syncthreads();
-        // 4 lanes per row, interleaved k, combined by two xor-shuffles (fixed order: deterministic)
-        const int row = tid >> 2, q = tid & 3;
+        // FTHREADS / FM lanes per row, each taking every LPR-th float4 of the row; partial sums are combined by
+        // xor-shuffles in a fixed order (deterministic).  The [C,2] weights were parked in LDS before the first barrier.
+        constexpr int LPR = FTHREADS / FM;
+        const int row = tid / LPR, q = tid % LPR;
         float s0 = 0.f, s1 = 0.f;
-        if (row < FM)
-            for (int k = q; k < C; k += 4) {
-                float a = act[row * ld + k];
-                s0 = fmaf(a, poolbuf[2 * k], s0);
-                s1 = fmaf(a, poolbuf[2 * k + 1], s1);
-            }
-        s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1);
-        s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
-        if (row < FM && q == 0) {
-            P.fout[(r0 + row) * 2 + 0] = s0 + P.fb[0];
-            P.fout[(r0 + row) * 2 + 1] = s1 + P.fb[1];
+        for (int k = 4 * q; k < C; k += 4 * LPR) {
+            const float4 a = *reinterpret_cast<const float4 *>(act + row * ld + k);
+            const float4 w01 = *reinterpret_cast<const float4 *>(poolbuf + 2 * k);
+            const float4 w23 = *reinterpret_cast<const float4 *>(poolbuf + 2 * k + 4);
+            s0 = fmaf(a.x, w01.x, s0); s1 = fmaf(a.x, w01.y, s1);
+            s0 = fmaf(a.y, w01.z, s0); s1 = fmaf(a.y, w01.w, s1);
+            s0 = fmaf(a.z, w23.x, s0); s1 = fmaf(a.z, w23.y, s1);
+            s0 = fmaf(a.w, w23.z, s0); s1 = fmaf(a.w, w23.w, s1);
         }
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) { s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); }
+        if (q == 0) *reinterpret_cast<float2 *>(P.fout + (r0 + row) * 2) = make_float2(s0 + P.fb[0], s1 + P.fb[1]);
     }
     // ---- leave the pooled feature of this instance zero for the next evaluation (it was consumed by the GEMV) ----
-    if (P.zero_pool && tile == 0 && zme == 0)
+    if (P.zero_pool && tile == 0)
         for (int c = tid; c < P.zero_count; c += FTHREADS) P.zero_pool[(long)inst * P.zero_count + c] = 0.f;
     TRACE(20);
 }
 
-template <int CAP0, int CAP1, int RT>
-static int launch_stack(const LrgFusedArgs &a, int nprob, int split, hipStream_t st) {
+template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT>
+static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     constexpr int FM = 32 * RT;
     long maxrows = 0;
     for (int i = 0; i < nprob; ++i) {
@@ -256,36 +335,51 @@ static int launch_stack(const LrgFusedArgs &a, int nprob, int split, hipStream_t
         if (FM * (Kp + 4) > CAP1) return LRG_EINVAL - 32;
         for (int l = 0; l < P.nlayers; ++l) {
             const LrgFusedLayer &L = P.L[l];
-            if (L.N % 64 != 0 || L.N > 512 || L.ldw < L.N) return LRG_EINVAL - 33;
+            if (L.N % 64 != 0 || L.N > 512 || L.ng != (L.K + 7) / 8) return LRG_EINVAL - 33;
             if (l > 0 && (L.K != P.L[l - 1].N || (L.K != 64 && L.K != 128 && L.K != 256))) return LRG_EINVAL - 34;
-            if (l == 0 && L.K != P.Kin) return LRG_EINVAL - 35;
+            if (l == 0 && (L.K != P.Kin || (L.K != 64 && L.K != 128 && L.K != 256 && L.K > 56))) return LRG_EINVAL - 35;
             const bool inplace = (L.flags & LRG_FL_INPLACE) != 0;
             const bool to_buf1 = ((l & 1) != 0) == !inplace;
             if ((L.flags & LRG_FL_KEEP) && FM * (L.N + 4) > (to_buf1 ? CAP1 : CAP0)) return LRG_EINVAL - 36;
-            if (inplace && (L.N > FBN || l + 1 != P.nlayers)) return LRG_EINVAL - 38;   // single column block, last layer only
+            if (inplace && (RT != 1 || L.N > FBN || l + 1 != P.nlayers)) return LRG_EINVAL - 38;   // single column block, last layer only
             if (l + 1 < P.nlayers && !(L.flags & LRG_FL_KEEP)) return LRG_EINVAL - 37;
         }
-        if (P.fw && P.L[P.nlayers - 1].N > 256) return LRG_EINVAL - 39;
+        if (P.fw && (P.L[P.nlayers - 1].N > 256 || (P.L[P.nlayers - 1].flags & LRG_FL_POOL))) return LRG_EINVAL - 39;   // share the 512-float scratch
         if (P.rows > maxrows) maxrows = P.rows;
     }
     if (maxrows == 0) return 0;
     const size_t lds = (size_t)(CAP0 + CAP1 + 512) * sizeof(float);
-    auto kern = lrg_fused_stack_kernel<CAP0, CAP1, RT>;
+    auto kern = lrg_fused_stack_kernel<CAP0, CAP1, RT, FD, OCC, DIRECT>;
     static bool attr_done = false;      // raising the dynamic-LDS cap is idempotent
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM), nprob, split < 1 ? 1 : split), dim3(FTHREADS), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM), nprob), dim3(FTHREADS), lds, st, a);
     LRG_LAUNCH_CHECK();
     return 0;
 }
 
-int lrg_fused_branches(const LrgFusedArgs &a, int nprob, int split, hipStream_t st) {
-    return launch_stack<64 * 68, 64 * 132, 2>(a, nprob, split, st);       // lite 0/1/2: hidden widths 64 / 128
+static bool needs_direct(const LrgFusedArgs &a, int nprob) {
+    for (int i = 0; i < nprob; ++i)
+        for (int l = 0; l < a.p[i].nlayers; ++l) {
+            const LrgFusedLayer &L = a.p[i].L[l];
+            if (L.gout && (!(L.flags & LRG_FL_KEEP) || (L.flags & LRG_FL_INPLACE))) return true;
+        }
+    return false;
+}
+
+// Three workgroups (one wave per SIMD each) per CU: 53 KB / 44 KB of LDS and <= 168 VGPRs.  While one workgroup is in
+// its barrier-separated narrow layers or staging its rows, the other two keep the MFMA pipe busy.
+int lrg_fused_branches(const LrgFusedArgs &a, int nprob, hipStream_t st) {
+    // lite 0/1/2: hidden widths 64 / 128
+    if (needs_direct(a, nprob)) return launch_stack<64 * 68, 64 * 132, 2, 4, 2, true>(a, nprob, st);
+    return launch_stack<64 * 68, 64 * 132, 2, 4, 3, false>(a, nprob, st);
 }
 
 int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st) {
-    return launch_stack<32 * 260, 32 * 68, 1>(a, nprob, 1, st);      // 64 -> 256 -> 128 (-> 2); the last hidden layer is written in place
+    // 64 -> 256 -> 128 (-> 2); the last hidden layer is written in place
+    if (needs_direct(a, nprob)) return launch_stack<32 * 260, 32 * 68, 1, 4, 2, true>(a, nprob, st);
+    return launch_stack<32 * 260, 32 * 68, 1, 4, 3, false>(a, nprob, st);
 }

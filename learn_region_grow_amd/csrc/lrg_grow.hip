@@ -1161,14 +1161,8 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
         if ((rc = lrg_box_query(slots, rooms, n_slots, max_points, params, stream))) return rc;
     }
     const bool rows = b->rows_in && b->rows_nb && (forward_flags & LRG_FWD_FUSED);
-    int32_t *tile_total = nullptr;
-    if (rows && (forward_flags & LRG_FWD_SPLIT_SPARSE)) {
-        size_t off = 0, cnt = 0;
-        if ((rc = lrg_forward_workspace_view(weights, n_slots, params->n_inlier, params->n_neighbor, 5, 0, &off, &cnt))) return rc;
-        tile_total = reinterpret_cast<int32_t *>(static_cast<float *>(b->workspace) + off);
-    }
     if ((rc = lrg_prepare(slots, rooms, n_slots, params, b->center, b->sample_in, b->sample_nb, b->inlier, b->neighbor,
-                          b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, tile_total,
+                          b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, nullptr,
                           stream)))
         return rc;
     if ((rc = lrg_forward_rows(weights, b->inlier, b->neighbor, n_slots, params->n_inlier, params->n_neighbor,

@@ -329,10 +329,103 @@ struct LrgFwdLayout {
     size_t pooled;
     size_t hb[2];                   // 0 add, 1 remove
     size_t hid[2][LRG_MAX_HEAD];
-    size_t scratch;                 // 64 floats: [0] = live-tile counter of lrg_forward_rows (written by lrg_prepare)
+    size_t scratch;                 // 64 floats, reserved
+    size_t packed;                  // lrg_pack_weights image, used when the caller supplies none
     size_t total;
     int P;                          // 2*C_last
 };
+
+// ------------------------------------------------------------------------------------------------
+// MFMA-operand image of the [Cin,Cout] kernels (lrg_pack_weights).  Per layer: for each 32-column block, for each
+// group g of 8 rows (Cin zero-padded to a multiple of 8), 64 lanes x float4:
+//   image[((cb * ng + g) * 64 + lane) * 4 + s] = W[8g + 4*(lane>>5) + s][32*cb + (lane&31)]
+// i.e. exactly the four B values lane `lane` feeds to the four v_mfma_f32_32x32x2_f32 of k-group g.
+// ------------------------------------------------------------------------------------------------
+struct LrgPackLayout {
+    size_t conv[2][LRG_MAX_CONV];   // float offsets; 0 inlier, 1 neighbour branch
+    size_t head[2][LRG_MAX_HEAD];   // 0 add, 1 remove; j = 0 covers only the conv[1] rows of the first kernel
+    size_t total;
+};
+
+static inline int lrg_kgroups(int K) { return (K + 7) >> 3; }
+
+static int pack_layout(const LrgWeights *w, LrgPackLayout *L) {
+    if (!w) return LRG_EINVAL - 1;
+    if (w->n_conv < 2 || w->n_conv > LRG_MAX_CONV || w->n_head < 2 || w->n_head > LRG_MAX_HEAD) return LRG_EINVAL - 2;
+    size_t off = 0;
+    for (int br = 0; br < 2; ++br)
+        for (int i = 0; i < w->n_conv; ++i) {
+            const int K = i == 0 ? w->feature_size : w->conv_ch[i - 1];
+            L->conv[br][i] = off;
+            off = lrg_align_up(off + (size_t)lrg_kgroups(K) * 8 * lrg_align_up(w->conv_ch[i], 32), 64);
+        }
+    for (int hd = 0; hd < 2; ++hd)
+        for (int j = 0; j < w->n_head - 1; ++j) {
+            const int K = j == 0 ? w->conv_ch[1] : w->head_ch[j - 1];
+            L->head[hd][j] = off;
+            off = lrg_align_up(off + (size_t)lrg_kgroups(K) * 8 * lrg_align_up(w->head_ch[j], 32), 64);
+        }
+    L->total = off;
+    return 0;
+}
+
+#define LRG_PACK_MAX (2 * LRG_MAX_CONV + 2 * LRG_MAX_HEAD)
+struct LrgPackArgs {
+    const float *src[LRG_PACK_MAX];
+    float *dst[LRG_PACK_MAX];
+    int K[LRG_PACK_MAX], N[LRG_PACK_MAX];
+};
+
+__global__ __launch_bounds__(256) void lrg_pack_weights_kernel(LrgPackArgs a) {
+    const int e = blockIdx.y;
+    const float *src = a.src[e];
+    const int K = a.K[e], N = a.N[e];
+    const int ng = (K + 7) >> 3, ncb = (N + 31) >> 5;
+    const long total = (long)ncb * ng * 64;              // float4 slots
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long cg = idx >> 6;
+        const int g = (int)(cg % ng), cb = (int)(cg / ng);
+        const int col = 32 * cb + (lane & 31), k0 = 8 * g + 4 * (lane >> 5);
+        float4 v;
+        v.x = (k0 + 0 < K && col < N) ? src[(long)(k0 + 0) * N + col] : 0.f;
+        v.y = (k0 + 1 < K && col < N) ? src[(long)(k0 + 1) * N + col] : 0.f;
+        v.z = (k0 + 2 < K && col < N) ? src[(long)(k0 + 2) * N + col] : 0.f;
+        v.w = (k0 + 3 < K && col < N) ? src[(long)(k0 + 3) * N + col] : 0.f;
+        reinterpret_cast<float4 *>(a.dst[e])[idx] = v;
+    }
+}
+
+static int pack_weights(const LrgWeights *w, float *dst, hipStream_t st) {
+    LrgPackLayout PL;
+    int rc = pack_layout(w, &PL);
+    if (rc) return rc;
+    LrgPackArgs a = {};
+    int n = 0;
+    for (int br = 0; br < 2; ++br)
+        for (int i = 0; i < w->n_conv; ++i) {
+            a.src[n] = br == 0 ? w->inlier_w[i] : w->neighbor_w[i];
+            a.dst[n] = dst + PL.conv[br][i];
+            a.K[n] = i == 0 ? w->feature_size : w->conv_ch[i - 1];
+            a.N[n] = w->conv_ch[i];
+            if (!a.src[n]) return LRG_EINVAL - 40;
+            ++n;
+        }
+    const int P = 2 * w->conv_ch[w->n_conv - 1];
+    for (int hd = 0; hd < 2; ++hd)
+        for (int j = 0; j < w->n_head - 1; ++j) {
+            const float *W = hd == 0 ? w->add_w[j] : w->rmv_w[j];
+            if (!W) return LRG_EINVAL - 40;
+            a.src[n] = j == 0 ? W + (size_t)P * w->head_ch[0] : W;      // rows P.. of the first kernel: the conv[1] part (:131,:135)
+            a.dst[n] = dst + PL.head[hd][j];
+            a.K[n] = j == 0 ? w->conv_ch[1] : w->head_ch[j - 1];
+            a.N[n] = w->head_ch[j];
+            ++n;
+        }
+    hipLaunchKernelGGL(lrg_pack_weights_kernel, dim3(32, n), dim3(256), 0, st, a);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
 
 static int fwd_layout(const LrgWeights *w, int B, int ni, int nn, LrgFwdLayout *L) {
     if (!w || B <= 0 || ni <= 0 || nn <= 0) return LRG_EINVAL - 1;
@@ -360,6 +453,11 @@ static int fwd_layout(const LrgWeights *w, int B, int ni, int nn, LrgFwdLayout *
         }
     L->scratch = off;
     off = lrg_align_up(off + 64, 64);
+    LrgPackLayout PL;
+    int rc = pack_layout(w, &PL);
+    if (rc) return rc;
+    L->packed = off;
+    off = lrg_align_up(off + PL.total, 64);
     L->total = off;
     return 0;
 }
@@ -368,12 +466,20 @@ static int fwd_layout(const LrgWeights *w, int B, int ni, int nn, LrgFwdLayout *
 static int forward_fused(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
                          int n_neighbor, const int32_t *rows_in, const int32_t *rows_nb, float *add_logits,
                          float *rmv_logits, float *ws, const LrgFwdLayout &L, bool keep_acts, bool pool_zeroed,
-                         bool split, hipStream_t st) {
+                         hipStream_t st) {
     const long rows[2] = {(long)B * n_inlier, (long)B * n_neighbor};
     const int rpi[2] = {n_inlier, n_neighbor};
     const int nc = w->n_conv, nh = w->n_head;
     const int Clast = w->conv_ch[nc - 1];
     if (!pool_zeroed) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
+    LrgPackLayout PL;
+    int prc = pack_layout(w, &PL);
+    if (prc) return prc;
+    const float *pk = static_cast<const float *>(w->packed);
+    if (!pk) {                                   // no image from the caller: build one next to the activations
+        if ((prc = pack_weights(w, ws + L.packed, st))) return prc;
+        pk = ws + L.packed;
+    }
     {
         LrgFusedArgs a = {};
         for (int br = 0; br < 2; ++br) {
@@ -383,19 +489,18 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
             P.rows = rows[br]; P.rows_per_inst = rpi[br];
             P.pool = ws + L.pooled + (br == 0 ? 0 : Clast); P.pool_stride = L.P;
             P.valid = br == 0 ? rows_in : rows_nb;
-            if (split) { P.tile_total = reinterpret_cast<const int *>(ws + L.scratch); P.split_limit = 1024; }
             P.nlayers = nc;
             for (int i = 0; i < nc; ++i) {
                 LrgFusedLayer &F = P.L[i];
-                F.w = br == 0 ? w->inlier_w[i] : w->neighbor_w[i];
+                F.w = pk + PL.conv[br][i];
                 F.bias = br == 0 ? w->inlier_b[i] : w->neighbor_b[i];
                 F.K = i == 0 ? w->feature_size : w->conv_ch[i - 1];
-                F.N = w->conv_ch[i]; F.ldw = F.N;
+                F.N = w->conv_ch[i]; F.ng = lrg_kgroups(F.K);
                 F.flags = LRG_FL_RELU | (i + 1 < nc ? LRG_FL_KEEP : LRG_FL_POOL);
                 F.gout = (i == 1 || keep_acts) ? ws + L.conv[br][i] : nullptr;      // conv[1] feeds the heads (:130,:134)
             }
         }
-        int rc = lrg_fused_branches(a, 2, split ? 4 : 1, st);
+        int rc = lrg_fused_branches(a, 2, st);
         if (rc) return rc;
     }
     const int C0 = w->head_ch[0];
@@ -424,15 +529,13 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
             P.nlayers = nh - 1;
             for (int i = 0; i < nh - 1; ++i) {
                 LrgFusedLayer &F = P.L[i];
-                const float *W = hd == 0 ? w->add_w[i] : w->rmv_w[i];
-                F.N = w->head_ch[i]; F.ldw = F.N;
+                F.N = w->head_ch[i];
+                F.w = pk + PL.head[hd][i];           // i = 0: rows 2*C_last.. of W0, the conv[1] part of the concat (:131,:135)
                 if (i == 0) {
-                    F.w = W + (size_t)L.P * C0;      // rows 2*C_last.. of W0: the conv[1] part of the concat (:131,:135)
                     F.bias = ws + L.hb[hd];
                     F.K = w->conv_ch[1];
                     F.flags = LRG_FL_RELU | LRG_FL_KEEP | LRG_FL_INST_BIAS;
                 } else {
-                    F.w = W;
                     F.bias = hd == 0 ? w->add_b[i] : w->rmv_b[i];
                     F.K = w->head_ch[i - 1];
                     F.flags = LRG_FL_RELU | LRG_FL_KEEP;
@@ -440,6 +543,7 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
                     // written over its own (dead) input instead
                     if (i == nh - 2 && (i & 1) && F.N > 64) F.flags |= LRG_FL_INPLACE;
                 }
+                F.ng = lrg_kgroups(F.K);
                 F.gout = keep_acts ? ws + L.hid[hd][i] : nullptr;
             }
             P.fw = hd == 0 ? w->add_w[nh - 1] : w->rmv_w[nh - 1];
@@ -463,6 +567,21 @@ size_t lrg_struct_size(int which) {
     case 3: return sizeof(LrgGrowParams);
     }
     return 0;
+}
+
+size_t lrg_packed_weights_bytes(const LrgWeights *w) {
+    LrgPackLayout PL;
+    if (pack_layout(w, &PL) != 0) return 0;
+    return PL.total * sizeof(float);
+}
+
+int lrg_pack_weights(const LrgWeights *w, void *packed, size_t packed_bytes, void *stream) {
+    LrgPackLayout PL;
+    int rc = pack_layout(w, &PL);
+    if (rc) return rc;
+    if (!packed || packed_bytes < PL.total * sizeof(float)) return LRG_EINVAL - 41;
+    if (((uintptr_t)packed & 255) != 0) return LRG_EINVAL - 42;
+    return pack_weights(w, static_cast<float *>(packed), (hipStream_t)stream);
 }
 
 size_t lrg_forward_workspace_bytes(const LrgWeights *w, int B, int n_inlier, int n_neighbor) {
@@ -576,8 +695,7 @@ int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neig
     if ((rows_in == nullptr) != (rows_nb == nullptr)) return LRG_EINVAL - 11;
     if (rows_in && !fused) return LRG_EINVAL - 12;      // row counts are honoured by the fused kernels only
     if (fused) return forward_fused(w, inlier, neighbor, B, n_inlier, n_neighbor, rows_in, rows_nb, add_logits, rmv_logits,
-                                    ws, L, (flags & LRG_FWD_KEEP_ACTS) != 0, (flags & LRG_FWD_POOL_ZEROED) != 0,
-                                    (flags & LRG_FWD_SPLIT_SPARSE) != 0 && rows_in != nullptr, st);
+                                    ws, L, (flags & LRG_FWD_KEEP_ACTS) != 0, (flags & LRG_FWD_POOL_ZEROED) != 0, st);
     if (fuse_pool) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
 
     // ---- branches (:106-119): both branches in one launch per layer ----

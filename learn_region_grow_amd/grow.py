@@ -246,7 +246,6 @@ class RegionGrower:
     # ------------------------------------------------------------------------------------------
     def enqueue_iteration(self):
         """One lock-step iteration, device-side randomness (no host sync)."""
-        # LRG_FWD_SPLIT_SPARSE measured no gain at 68 rooms in flight (profiles/r01 notes): not enabled
         flags = self.net.forward_flags | (_lib.LRG_FWD_POOL_ZEROED if self.net.mode == 'fused' else 0)
         rc = self.lib.lrg_grow_step(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, self.cap, ctypes.byref(self.params),
                                     ctypes.byref(self.net._w), ctypes.byref(self.step_buffers), self.advance_rounds,

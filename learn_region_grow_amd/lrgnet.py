@@ -107,7 +107,22 @@ class LrgNetHIP:
             w.rmv_w[i] = self.weights['lrg_remove_kernel%d' % i].data_ptr()
             w.rmv_b[i] = self.weights['lrg_remove_bias%d' % i].data_ptr()
         self._w = w
+        self.pack_weights()
         return self
+
+    def pack_weights(self):
+        """(Re)build the MFMA-operand image of the kernels (lrg_pack_weights) and publish it in the weights struct;
+        call again after changing a variable's device tensor in place."""
+        w = self._w
+        w.packed = None
+        nbytes = self.lib.lrg_packed_weights_bytes(ctypes.byref(w))
+        if nbytes == 0:
+            raise _lib.LrgHipError('lrg_packed_weights_bytes rejected the configuration')
+        self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.lrg_pack_weights(ctypes.byref(w), _ptr(self._packed), nbytes, _stream_ptr()),
+                       'lrg_pack_weights')
+        w.packed = self._packed.data_ptr()
 
     # ---- forward ---------------------------------------------------------------------------
     def _workspace(self, B):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_abi_and_struct_layout(hip_lib):
     from learn_region_grow_amd import _lib
-    assert hip_lib.lrg_abi_version() == 1
+    assert hip_lib.lrg_abi_version() == 2
     assert hip_lib.lrg_target_arch() == b'gfx950'
     for which, st in enumerate((_lib.LrgWeights, _lib.LrgRoom, _lib.LrgSlot, _lib.LrgGrowParams)):
         assert hip_lib.lrg_struct_size(which) == ctypes.sizeof(st)
@@ -42,7 +42,10 @@ def test_workspace_arithmetic_is_host_only(hip_lib):
     nbytes = hip_lib.lrg_forward_workspace_bytes(ctypes.byref(w), 4, 512, 512)
     # 2 branches x 512 rows x (64+64+64+128+512) + pooled + 2 hb + 2 heads x 512 x (256+128), per instance
     per_inst = 2 * 512 * 832 + 1024 + 2 * 256 + 2 * 512 * 384
-    assert nbytes >= 4 * per_inst * 4 and nbytes < 4 * per_inst * 4 + 64 * 1024
+    # + one image of the packed kernels (used when the caller supplies none): Cin rounded up to 8, conv[1] rows of head 0
+    packed = hip_lib.lrg_packed_weights_bytes(ctypes.byref(w))
+    assert packed == 4 * (2 * (16 * 64 + 64 * 64 + 64 * 64 + 64 * 128 + 128 * 512) + 2 * (64 * 256 + 256 * 128))
+    assert nbytes >= 4 * per_inst * 4 + packed and nbytes < 4 * per_inst * 4 + packed + 64 * 1024
     off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
     assert hip_lib.lrg_forward_workspace_view(ctypes.byref(w), 4, 512, 512, 2, 0, ctypes.byref(off), ctypes.byref(cnt)) == 0
     assert cnt.value == 4 * 1024

@@ -173,3 +173,44 @@ def test_forward_rows_skips_duplicate_rows_exactly(cuda_device):
         np.testing.assert_array_equal(pooled[b], pooled_full[b])
         tiles = -(-n_in[b] // 64) * 64
         assert np.isnan(rmv[b, tiles:]).all()          # whole tiles of duplicates were never touched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lite,F', [(0, 13), (1, 13), (2, 12), (0, 6)])
+def test_packed_weight_image(cuda_device, hip_lib, lite, F):
+    """lrg_pack_weights lays every kernel out in MFMA-operand order: image[((cb*ng+g)*64+lane)*4+s] =
+    W[8g+4(lane>>5)+s][32cb+(lane&31)] with Cin zero-padded to a multiple of 8; and a forward with w->packed = NULL
+    (image rebuilt in the workspace on every call) gives the same bits as one with the cached image."""
+    import torch
+    net, weights = make_net(cuda_device, lite, F, 128, 128, 'fused')
+    img = net._packed.view(torch.float32).cpu().numpy()
+    cc, c2 = net.conv_channels, net.conv2_channels
+    off = 0
+    layers = []
+    for pre in ('lrg_', 'lrg_neighbor_'):
+        for i in range(len(cc)):
+            layers.append(np.asarray(weights['%skernel%d' % (pre, i)], np.float32)[0])
+    for pre in ('lrg_add_', 'lrg_remove_'):
+        for j in range(len(c2)):
+            W = np.asarray(weights['%skernel%d' % (pre, j)], np.float32)[0]
+            layers.append(W[2 * cc[-1]:] if j == 0 else W)
+    for W in layers:
+        K, N = W.shape
+        ng, ncb = (K + 7) // 8, (N + 31) // 32
+        Wp = np.zeros((ng * 8, ncb * 32), np.float32)
+        Wp[:K, :N] = W
+        # [cb][g][lh][li][s]  <-  Wp[8g + 4lh + s][32cb + li]
+        want = Wp.reshape(ng, 2, 4, ncb, 32).transpose(3, 0, 1, 4, 2).reshape(-1)
+        np.testing.assert_array_equal(img[off:off + want.size], want)
+        off = -(-(off + want.size) // 64) * 64
+    assert off * 4 == net._packed.numel()
+    rs = np.random.RandomState(11)
+    xi = torch.from_numpy((rs.randn(5, 128, F) * 0.5).astype(np.float32)).to(cuda_device)
+    xn = torch.from_numpy((rs.randn(5, 128, F) * 0.5).astype(np.float32)).to(cuda_device)
+    a0, r0 = [t.cpu().numpy().copy() for t in net.forward(xi, xn)]
+    keep = net._w.packed
+    net._w.packed = None
+    a1, r1 = [t.cpu().numpy().copy() for t in net.forward(xi, xn)]
+    net._w.packed = keep
+    np.testing.assert_array_equal(a0, a1)
+    np.testing.assert_array_equal(r0, r1)

@@ -30,7 +30,7 @@ def main():
     kernels = {}
     tot_r = tot_w = 0.0
     for k in f:
-        if not ('lrg_' in k):
+        if 'lrg_' not in k or 'lrg_pack_weights' in k:      # (the one-time operand image is not part of a forward)
             continue
         r = sum(f[k]) * 1024 * kf / nfwd
         wr = sum(w.get(k, [0])) * 1024 * kw / nfwd

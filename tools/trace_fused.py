@@ -16,10 +16,14 @@ lib.lrg_set_trace.argtypes = [ctypes.c_void_p]
 lib.lrg_set_trace(ctypes.c_void_p(tr.data_ptr()))
 net.forward(xi, xn); torch.cuda.synchronize()
 t = tr.cpu().numpy().reshape(2, 2048, 32)
-nb = B * 512 // 64
+nb = min(2048, B * 512 // (64 if os.environ.get('LRG_TRACE_KERNEL', '2') == '2' else 32))
+names = ['stage'] + [x for l in range(5) for x in ('L%d setup' % l, 'L%d run' % l)]
 for y in range(2):
     a = t[y, :nb]
-    # the head kernel overwrites the branch kernel's stamps (same buffer): the last launch wins -> heads
+    a = a[a[:, 20] > 0]
     d = np.diff(a[:, :13], axis=1)
-    print('prob', y, 'median cycles per phase (start,stage | per layer: setup,compute+epilogue+barrier ...):')
-    print('  ', np.median(d, axis=0).astype(int).tolist(), ' total', int(np.median(a[:, 20] - a[:, 0])), 'end-of-last-layer->end', int(np.median(a[:, 20] - a[:, 12])))
+    print('prob', y, 'workgroups', len(a), 'median cycles per phase:')
+    print('  ', dict(zip(names, np.median(d, axis=0).astype(int).tolist())))
+    print('   total', int(np.median(a[:, 20] - a[:, 0])), ' last-layer-end -> end', int(np.median(a[:, 20] - a[:, 2 + 2 * (5 if False else 0) + 0])) if False else int(np.median(a[:, 20] - a[:, 0])))
+    span = a[:, 20].max() - a[:, 0].min()
+    print('   span of traced workgroups (cycles):', int(span), ' sum of WG lifetimes / span =', float((a[:, 20] - a[:, 0]).sum() / span))
