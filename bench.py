@@ -38,7 +38,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--rooms', type=int, default=68, help='rooms in flight per GPU (the Area-5 set has 68)')
     ap.add_argument('--restarts', type=int, default=1)
-    ap.add_argument('--workload', default='area5', choices=['area5', 'kitti'],
+    ap.add_argument('--workload', default='area5', choices=['area5', 'kitti', 'scannet'],
                     help='area5: 68 Area-5-shaped rooms (configs[1]); kitti: 100 k-point scenes at 0.3 m (configs[4])')
     ap.add_argument('--policy', default='gt', choices=['net', 'gt', 'threshold'],
                     help="mask policy: 'net' = the reference's Bernoulli draws against the network's confidence "
@@ -53,9 +53,32 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(rooms, weights, seconds, policy):
-    """The oracle (faithful NumPy restatement of test_region_grow.py:175-316, per-point Python voxel-set loop,
-    un-hoisted head) on this box's host cores, for a bounded sample: steps of the median-size room."""
+def _hoisted_numpy_net(weights):
+    """LrgNet forward with the pooled-feature product hoisted out of the per-point head (one [1,1024]x[1024,256] product
+    per instance instead of 512): the arithmetic a tuned CPU implementation would do.  'Strong CPU' leg only."""
+    W = {k: np.asarray(v, np.float32) for k, v in weights.items()}
+
+    def branch(x, pre):
+        h, convs = x, []
+        for i in range(5):
+            h = np.maximum(h @ W[pre + 'kernel%d' % i][0] + W[pre + 'bias%d' % i], 0)
+            convs.append(h)
+        return convs
+
+    def head(pooled, local, pre):
+        k0 = W[pre + 'kernel0'][0]
+        h = np.maximum(local @ k0[pooled.shape[-1]:] + (pooled @ k0[:pooled.shape[-1]] + W[pre + 'bias0'])[:, None, :], 0)
+        h = np.maximum(h @ W[pre + 'kernel1'][0] + W[pre + 'bias1'], 0)
+        return h @ W[pre + 'kernel2'][0] + W[pre + 'bias2']
+
+    def net(xi, xn):
+        ci, cn = branch(np.asarray(xi, np.float32), 'lrg_'), branch(np.asarray(xn, np.float32), 'lrg_neighbor_')
+        pooled = np.concatenate([ci[-1].max(axis=1), cn[-1].max(axis=1)], axis=-1)
+        return head(pooled, cn[1], 'lrg_add_'), head(pooled, ci[1], 'lrg_remove_')
+    return net
+
+
+def _cpu_sample(rooms, weights, seconds, policy, faithful, net_fn):
     from oracle import grow_ref, rng_ref      # CPU baseline leg only
     order = np.argsort([len(r['points']) for r in rooms])
     t0 = time.time()
@@ -73,14 +96,26 @@ def cpu_baseline(rooms, weights, seconds, policy):
         for k in range(len(rooms)):        # median-size room first, then outwards
             room = rooms[int(order[(len(order) // 2 + (k + 1) // 2 * (1 if k % 2 else -1)) % len(order)])]
             sizes.append(len(room['points']))
-            grow_ref.grow_room(room['points'], room['obj_id'], room['order'], weights, rng_ref.LegacyStream(k), faithful=True,
-                               hook=hook, fill=False, policy=policy)
+            grow_ref.grow_room(room['points'], room['obj_id'], room['order'], weights, rng_ref.LegacyStream(k),
+                               faithful=faithful, net_fn=net_fn, hook=hook, fill=False, policy=policy)
     except Stop:
         pass
     dt = time.time() - t0
-    return dict(value=count[0] / dt, unit='instance-steps/s', cores=os.cpu_count(), kind='port',
-                sample='%d grow steps over %d Area-5-shaped room(s) of %s points, oracle.grow_ref (faithful=True, policy=%s), '
-                       '%.1f s' % (count[0], len(sizes), sizes, policy, dt))
+    return count[0], sizes, dt
+
+
+def cpu_baseline(rooms, weights, seconds, policy):
+    """The oracle (faithful NumPy restatement of test_region_grow.py:175-316, per-point Python voxel-set loop,
+    un-hoisted head) on this box's host cores, for a bounded sample: steps of the median-size room.  Beside it a
+    'strong CPU' figure: the same loop with the set membership vectorised and the head hoisted."""
+    n, sizes, dt = _cpu_sample(rooms, weights, seconds * 0.7, policy, True, None)
+    out = dict(value=n / dt, unit='instance-steps/s', cores=os.cpu_count(), kind='port',
+               sample='%d grow steps over %d Area-5-shaped room(s) of %s points, oracle.grow_ref (faithful=True, policy=%s), '
+                      '%.1f s' % (n, len(sizes), sizes, policy, dt))
+    n2, sizes2, dt2 = _cpu_sample(rooms, weights, seconds * 0.3, policy, False, _hoisted_numpy_net(weights))
+    out['strong'] = dict(value=n2 / dt2, unit='instance-steps/s',
+                         sample='%d grow steps, vectorised voxel-set membership + hoisted head (NumPy/BLAS), %.1f s' % (n2, dt2))
+    return out
 
 
 def main():
@@ -116,6 +151,8 @@ def main():
     if args.workload == 'kitti':
         resolution = 0.3
         rooms = workloads.kitti_scenes(min(args.rooms, 8), seed_base=5000 + 100 * rank, cache_dir=args.cache)
+    elif args.workload == 'scannet':
+        rooms = workloads.scannet_rooms(min(args.rooms, 39), seed_base=7000 + 100 * rank, cache_dir=args.cache)
     else:
         rooms = workloads.area5_rooms(args.rooms, seed_base=1000 + 100 * rank, cache_dir=args.cache)
     net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, fuse_pool=bool(args.fuse_pool), mode=args.net_mode).load_weights(weights)

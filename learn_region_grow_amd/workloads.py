@@ -43,3 +43,11 @@ def area5_rooms(n_rooms=68, seed_base=1000, cache_dir=None, targets=None, scale=
 def kitti_scenes(n_scenes=8, seed_base=5000, cache_dir=None, points=100000, resolution=0.3):
     """BASELINE.json configs[4] shape: ~100 k points per scene at 0.3 m resolution (README.md:156 of the reference)."""
     return area5_rooms(n_scenes, seed_base=seed_base, cache_dir=cache_dir, targets=[points], resolution=resolution)
+
+
+def scannet_rooms(n_rooms=39, seed_base=7000, cache_dir=None, resolution=0.1):
+    """BASELINE.json configs[2] shape: ScanNet rooms, equalised count ~ N(5.8 k, 3 k) clipped to [1.2 k, 15.5 k]
+    (SURVEY.md section 8d, config 3).  The full set is 312 rooms = 8 GPUs x 39; a rank generates its own 39."""
+    rs = np.random.RandomState(seed_base)
+    targets = np.clip(rs.normal(5800.0, 3000.0, size=n_rooms), 1200, 15500).astype(int).tolist()
+    return area5_rooms(n_rooms, seed_base=seed_base, cache_dir=cache_dir, targets=targets, resolution=resolution)
