@@ -139,6 +139,10 @@ def grow_room(points, obj_id, order, weights, stream, *, cls_id=None, classes=No
                 elif policy == 'threshold':                                      # :264-265 (commented out upstream)
                     add_mask = add_conf > 0.5
                     rmv_mask = rmv_conf > 0.5
+                    for c_ in (add_conf, rmv_conf):                              # distance of a confidence from the cut
+                        d_ = np.abs(np.asarray(c_, np.float64) - 0.5)
+                        res.min_margin = min(res.min_margin, float(d_.min()))
+                        res.min_rel_margin = min(res.min_rel_margin, float((d_ / 0.25).min()))
                 elif policy == 'gt':                                             # :268-269 (commented out upstream)
                     add_mask = input_add.astype(bool)
                     rmv_mask = input_remove.astype(bool)

@@ -1,0 +1,187 @@
+"""On-disk formats either side of the path: TensorFlow checkpoint bundles, HDF5 room files,
+PLY / PCD export.  Pinned by data files of the reference itself (the index of its LrgNet checkpoint, bytes of its MCPNet
+checkpoint), by files written with h5py (tests/golden/make_h5_fixture.py) and by the output of the reference's own
+savePLY / savePCD (tests/golden/make_format_golden.py)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from learn_region_grow_amd import checkpoint as ck
+from learn_region_grow_amd import h5lite, synthetic
+from learn_region_grow_amd import io as lio
+
+
+# ---- CRC-32C / table / bundle -----------------------------------------------------------------------------------------
+def test_crc32c_known_answers():
+    assert ck.crc32c(b'123456789') == 0xe3069283            # the standard check value of CRC-32C (Castagnoli)
+    assert ck.crc32c(b'\x00' * 32) == 0x8a9136aa             # RFC 3720 B.4
+    assert ck.crc32c(b'\xff' * 32) == 0x62a8ab43
+    assert ck.crc32c(bytes(range(32))) == 0x46dd794e
+    assert ck.crc32c(bytes(range(31, -1, -1))) == 0x113fdb5c
+    assert ck.crc32c(b'456789', ck.crc32c(b'123')) == 0xe3069283       # incremental
+    assert ck.crc32c(b'') == 0
+    for v in (0, 1, 0x12345678, 0xffffffff):
+        assert ck.unmask_crc(ck.mask_crc(v)) == v
+
+
+def test_real_lrgnet_checkpoint_index(tmp_path):
+    """The index of the reference's trained LrgNet checkpoint: 99 variables, the 32 trainables exactly the shapes
+    LrgNet(.., feature_size=13, lite=0) declares (learn_region_grow_util.py:107-159), 791 044 parameters."""
+    shutil.copy(os.path.join(GOLDEN, 'lrgnet_model5.ckpt.index'), tmp_path / 'm.ckpt.index')
+    header, entries = ck.read_bundle_index(str(tmp_path / 'm.ckpt'))       # block checksums verified
+    assert header == dict(num_shards=1, endianness=0)
+    assert len(entries) == 99
+    shapes = ck.lrgnet_variable_shapes(13, 0)
+    assert len(shapes) == 32
+    for name, shp in shapes.items():
+        e = entries[name]
+        assert tuple(e.shape) == shp and e.dtype == 1 and e.size == 4 * int(np.prod(shp))
+        assert name + '/Adam' in entries and name + '/Adam_1' in entries
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 791044
+    assert entries['lrg_kernel0'].offset == 3753252 and entries['lrg_add_kernel0'].offset == 4644
+    assert max(e.offset + e.size for e in entries.values()) == 9492540
+    # the data blob is not distributed: loading must fail loudly, not return garbage
+    with pytest.raises(FileNotFoundError):
+        ck.load_lrgnet_weights(str(tmp_path / 'm.ckpt'))
+    # lite / feature-size mismatches are caught against the index alone
+    with pytest.raises((KeyError, ck.BundleError)):
+        ck.load_lrgnet_weights(str(tmp_path / 'm.ckpt'), lite=2)
+    with pytest.raises(ck.BundleError):
+        ck.load_lrgnet_weights(str(tmp_path / 'm.ckpt'), feature_size=12)
+
+
+def test_real_checkpoint_bytes_pass_their_crc(tmp_path):
+    """Bytes TensorFlow wrote (MCPNet checkpoint of the reference, variables <= 4 KiB): masked CRC-32C of the raw
+    tensor bytes equals the index entry; entries re-encode to the very bytes TensorFlow serialized."""
+    z = np.load(os.path.join(GOLDEN, 'mcpnet_bundle_small.npz'))
+    (tmp_path / 'mcp.ckpt.index').write_bytes(z['index'].tobytes())
+    _, entries = ck.read_bundle_index(str(tmp_path / 'mcp.ckpt'))
+    table = ck.read_table(str(tmp_path / 'mcp.ckpt.index'))
+    assert len(entries) == 27
+    for i, name in enumerate(z['names']):
+        e = entries[str(name)]
+        raw = z['raw_%d' % i].tobytes()
+        assert len(raw) == e.size
+        assert ck.mask_crc(ck.crc32c(raw)) == e.crc32c, name
+        assert ck._encode_entry(e.dtype, e.shape, e.offset, e.size, e.crc32c) == table[str(name).encode()], name
+    assert entries['mcp_kernel1'].shape == (1, 6, 200)
+    assert ck.DTYPES[entries['Variable'].dtype] == np.dtype('<i4') and entries['Variable'].shape == ()
+
+
+def test_bundle_roundtrip_and_corruption(tmp_path):
+    w = synthetic.make_synthetic_weights(seed=0)
+    extra = dict(w)
+    extra['Variable'] = np.int32(1234)
+    extra['beta1_power'] = np.float32(0.5)
+    extra['lrg_kernel0/Adam'] = np.zeros((1, 13, 64), np.float32)
+    prefix = str(tmp_path / 'sub' / 'synthetic.ckpt')
+    ck.write_bundle(prefix, extra)
+    got = ck.load_lrgnet_weights(prefix)
+    assert sorted(got) == sorted(w)
+    for k in w:
+        assert got[k].dtype == np.float32 and np.array_equal(got[k], np.asarray(w[k], np.float32))
+    allv = ck.load_bundle(prefix)
+    assert allv['Variable'] == 1234 and allv['Variable'].shape == ()
+    # a flipped bit in the data file is detected through the per-tensor CRC
+    path = prefix + '.data-00000-of-00001'
+    blob = bytearray(open(path, 'rb').read())
+    _, entries = ck.read_bundle_index(prefix)
+    blob[entries['lrg_bias3'].offset + 5] ^= 0x10
+    open(path, 'wb').write(bytes(blob))
+    with pytest.raises(ck.BundleError, match='lrg_bias3'):
+        ck.load_lrgnet_weights(prefix)
+    assert np.array_equal(ck.load_bundle(prefix, ['lrg_bias2'])['lrg_bias2'], w['lrg_bias2'])
+    # ... and one in the index through the block checksum
+    idx = bytearray(open(prefix + '.index', 'rb').read())
+    idx[40] ^= 0x01
+    open(prefix + '.index', 'wb').write(bytes(idx))
+    with pytest.raises(ck.BundleError):
+        ck.read_bundle_index(prefix)
+    with pytest.raises(ck.BundleError):
+        ck.read_table(os.path.join(GOLDEN, 'rooms_gzip.h5'))
+
+
+def test_table_prefix_compression_and_many_keys(tmp_path):
+    items = [(('var_%04d/part' % i).encode(), bytes([i % 251]) * (i % 7)) for i in range(300)]
+    ck.write_table(str(tmp_path / 't.index'), items)
+    assert list(ck.read_table(str(tmp_path / 't.index')).items()) == items
+    with pytest.raises(ck.BundleError):
+        ck.write_table(str(tmp_path / 'bad.index'), [(b'b', b''), (b'a', b'')])
+
+
+# ---- HDF5 ---------------------------------------------------------------------------------------------------------------
+def test_h5_reader_on_h5py_files():
+    z = np.load(os.path.join(GOLDEN, 'rooms_expected.npz'))
+    f = h5lite.File(os.path.join(GOLDEN, 'rooms_gzip.h5'))          # what the reference's generator writes
+    assert f.keys() == ['count_room', 'points']
+    assert f['points'].shape == (162, 8) and f['points'].dtype == np.float32
+    assert np.array_equal(f['points'].read(), z['points'])
+    assert f['count_room'].dtype == np.int32 and np.array_equal(f['count_room'].read(), z['count_room'])
+    g = h5lite.File(os.path.join(GOLDEN, 'rooms_variants.h5'))
+    for k in ('contiguous', 'shuffled', 'checksummed'):
+        assert np.array_equal(g[k].read(), z['points']), k
+    assert np.array_equal(g['multichunk'].read(), z['big'])          # 11 x 3 chunks of 64 x 3, ragged edges
+    assert np.array_equal(g['i64'].read(), np.arange(-5, 20))
+    assert np.array_equal(g['f64'].read(), z['big'][:9, :2].astype(np.float64))
+    assert np.array_equal(g['u8'].read(), (z['big'][:50, 0] * 40).astype(np.uint8))
+    assert g['scalar'].shape == () and g['scalar'].read() == np.float32(2.5)
+    with pytest.raises(KeyError):
+        g['nope']
+    with pytest.raises(h5lite.H5Error):
+        h5lite.File(os.path.join(GOLDEN, 'ref_savePLY.ply'))
+
+
+def test_loadFromH5_matches_reference_semantics(tmp_path):
+    """learn_region_grow_util.py:11-31: rooms split by count_room, last two columns are object / class ids."""
+    z = np.load(os.path.join(GOLDEN, 'rooms_expected.npz'))
+    rooms, labels, classes = lio.loadFromH5(os.path.join(GOLDEN, 'rooms_gzip.h5'))
+    assert [len(r) for r in rooms] == z['count_room'].tolist()
+    start = 0
+    for r, l, c, n in zip(rooms, labels, classes, z['count_room']):
+        blk = z['points'][start:start + n]
+        assert r.shape == (n, 6) and np.array_equal(r, blk[:, :6])
+        assert l.dtype.kind == 'i' and np.array_equal(l, blk[:, 6].astype(int)) and np.array_equal(c, blk[:, 7].astype(int))
+        start += n
+    raw = lio.loadFromH5(os.path.join(GOLDEN, 'rooms_gzip.h5'), load_labels=False)
+    assert np.array_equal(np.vstack(raw), z['points'])
+    # write -> read back
+    lio.saveToH5(str(tmp_path / 'w.h5'), raw)
+    back = lio.loadFromH5(str(tmp_path / 'w.h5'), load_labels=False)
+    assert all(np.array_equal(a, b) for a, b in zip(raw, back)) and len(raw) == len(back)
+
+
+@pytest.mark.skipif(not os.path.exists('/opt/conda/bin/python3.9'), reason='h5py lives in the conda interpreter of the build container only')
+def test_h5_writer_is_readable_by_h5py(tmp_path):
+    z = np.load(os.path.join(GOLDEN, 'rooms_expected.npz'))
+    path = str(tmp_path / 'w.h5')
+    h5lite.write_file(path, {'points': z['points'], 'count_room': z['count_room'], 'f64': np.arange(7.0),
+                             'i8': np.arange(5, dtype=np.int8), 'empty': np.zeros((0, 8), np.float32)})
+    code = ("import h5py, numpy as np, sys\n"
+            "f = h5py.File(sys.argv[1], 'r'); z = np.load(sys.argv[2])\n"
+            "assert sorted(f.keys()) == ['count_room', 'empty', 'f64', 'i8', 'points'], list(f.keys())\n"
+            "assert f['points'].dtype == np.float32 and np.array_equal(f['points'][:], z['points'])\n"
+            "assert f['count_room'].dtype == np.int32 and np.array_equal(f['count_room'][:], z['count_room'])\n"
+            "assert np.array_equal(f['f64'][:], np.arange(7.0)) and np.array_equal(f['i8'][:], np.arange(5))\n"
+            "assert f['empty'].shape == (0, 8)\n")
+    r = subprocess.run(['/opt/conda/bin/python3.9', '-c', code, path, os.path.join(GOLDEN, 'rooms_expected.npz')],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+# ---- PLY / PCD ------------------------------------------------------------------------------------------------------------
+def test_ply_and_pcd_text_equal_the_reference_output(tmp_path, capsys):
+    pts = np.load(os.path.join(GOLDEN, 'ref_save_points.npy'))
+    lio.savePLY(str(tmp_path / 'a.ply'), pts)
+    lio.savePCD(str(tmp_path / 'a.pcd'), pts)
+    assert open(tmp_path / 'a.ply').read() == open(os.path.join(GOLDEN, 'ref_savePLY.ply')).read()
+    assert open(tmp_path / 'a.pcd').read() == open(os.path.join(GOLDEN, 'ref_savePCD.pcd')).read()
+    out = capsys.readouterr().out
+    assert 'Saved to' in out and '(40 points)' in out and 'Saved 40 points to' in out
+    lio.savePCD(str(tmp_path / 'none.pcd'), pts[:0])                  # the reference returns without writing
+    assert not os.path.exists(tmp_path / 'none.pcd')
+    c = lio.label_colors(5)
+    assert c[0].tolist() == [100, 100, 100] and np.array_equal(c[1:], np.random.RandomState(0).randint(0, 255, (5, 3))[1:])
