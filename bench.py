@@ -50,6 +50,7 @@ def parse():
     ap.add_argument('--advance-rounds', type=int, default=2)
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
+    ap.add_argument('--p0-rooms', type=int, default=4, help='rooms of the preprocessing (P0) side measurement (0 = skip)')
     return ap.parse_args()
 
 
@@ -115,6 +116,31 @@ def cpu_baseline(rooms, weights, seconds, policy):
     n2, sizes2, dt2 = _cpu_sample(rooms, weights, seconds * 0.3, policy, False, _hoisted_numpy_net(weights))
     out['strong'] = dict(value=n2 / dt2, unit='instance-steps/s',
                          sample='%d grow steps, vectorised voxel-set membership + hoisted head (NumPy/BLAS), %.1f s' % (n2, dt2))
+    return out
+
+
+def p0_rates(n_rooms, dev):
+    """Preprocessing P0 (test_region_grow.py:119-173) is upstream of the timed loop and reported separately (SURVEY.md
+    8d): rooms/s from raw points in host memory to the 13-feature room, GPU (all on device / LAPACK finish) and host."""
+    import torch
+    from learn_region_grow_amd import preprocess, preprocess_gpu, synthetic
+    targets = [synthetic.AREA5_POINTS[(7 * i) % len(synthetic.AREA5_POINTS)] for i in range(n_rooms)]
+    raws = []
+    for i, t in enumerate(targets):
+        r = synthetic.area5_shaped_room(t, 9000 + i).astype(np.float32)
+        raws.append((r[:, :6], r[:, 6].astype(int), r[:, 7].astype(int)))
+    preprocess_gpu.preprocess_room(*raws[0], device=dev)
+    out = {}
+    for name, fn in (('gpu', lambda raw: preprocess_gpu.preprocess_room(*raw, device=dev)),
+                     ('gpu_lapack_finish', lambda raw: preprocess_gpu.preprocess_room(*raw, eig='lapack', device=dev)),
+                     ('host_numpy', lambda raw: preprocess.preprocess_room(*raw))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for raw in raws:
+            fn(raw)
+        torch.cuda.synchronize()
+        out[name + '_rooms_per_sec'] = n_rooms / (time.perf_counter() - t0)
+    out['sample'] = '%d Area-5-shaped rooms, %s raw points, host memory in / host memory out' % (n_rooms, [len(r[0]) for r in raws])
     return out
 
 
@@ -256,6 +282,8 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             out['cpu_baseline'] = cpu_baseline(rooms, weights, args.cpu_seconds, args.policy)
+        if world == 1 and args.p0_rooms > 0:
+            out['preprocessing_p0'] = p0_rates(args.p0_rooms, dev)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -324,6 +324,26 @@ int lrg_group_point_grad(int b, int n, int c, int m, int nsample, const float *g
 /* dist[b,m,n] = sum_c (xyz1[b,n,c]-xyz2[b,m,c])^2 -- the matrix knn_point builds at tf_grouping.py:62-65 */
 int lrg_pairwise_sqdist(int b, int n, int m, int c, const float *xyz1, const float *xyz2, float *dist, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Room preprocessing P0 (replaces the per-room block test_region_grow.py:119-173: equalisation, per-point PCA normals and
+ * curvature, feature stack).  SURVEY.md section 8f, row f1.
+ *
+ * raw [n_raw, raw_stride >= 6] float32 rows (x y z r g b ...), obj_id / cls_id [n_raw] (nullable).  Outputs (device,
+ * capacity n_raw rows): equalized_idx [N] = raw index of the first point of every resolution-sized voxel, in file order
+ * (:127-129,:134); unequalized_idx [n_raw] = equalised row of each raw point (:130); *n_equalized (device int32) = N.
+ * eig_mode 0: cov [N,9] float64 = the covariance of :157, bit-identical to the NumPy loop (same neighbour and summation
+ *             order); the host finishes with numpy.linalg.svd exactly as the reference does.  points may be NULL.
+ * eig_mode 1: also points [N,feature_size] float32 (:165-172), obj_out / cls_out [N], curvatures [N] float64 (:163), with the
+ *             3x3 decompositions done here by Jacobi iteration in float64 (agrees with LAPACK to ~1e-16 |cov|).
+ * workspace: lrg_preprocess_workspace_bytes(n_raw) bytes, 256-byte aligned.  Points whose voxel falls outside a 21-bit
+ * window per axis are reported by lrg_preprocess_status (1) and left out. */
+size_t lrg_preprocess_workspace_bytes(int n_raw);
+int lrg_preprocess(const float *raw, int raw_stride, const int32_t *obj_id, const int32_t *cls_id, int n_raw, float resolution,
+                   int feature_size, int eig_mode, void *workspace, size_t workspace_bytes, float *points, int32_t *obj_out,
+                   int32_t *cls_out, double *curvatures, int32_t *equalized_idx, int32_t *unequalized_idx, double *cov,
+                   int32_t *n_equalized, void *stream);
+int lrg_preprocess_status(const void *workspace, int n_raw, int32_t *host_status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

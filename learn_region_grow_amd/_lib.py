@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(HERE, 'liblrg_hip.so')
-SOURCES = ['lrg_net.hip', 'lrg_fused.hip', 'lrg_grow.hip', 'lrg_grouping.hip']
+SOURCES = ['lrg_net.hip', 'lrg_fused.hip', 'lrg_grow.hip', 'lrg_grouping.hip', 'lrg_preprocess.hip']
 
 LRG_MAX_CONV = 5
 LRG_MAX_HEAD = 3
@@ -142,6 +142,10 @@ _SIGS = {
     'lrg_group_point_grad': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
                                             _fp, _fp, _fp]),
     'lrg_pairwise_sqdist': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
+    'lrg_preprocess_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
+    'lrg_preprocess': (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp,
+                                      ctypes.c_size_t, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    'lrg_preprocess_status': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), _fp]),
 }
 
 EXPORTS = sorted(_SIGS)

@@ -21,7 +21,7 @@ def voxel_keys(xyz, resolution):
     return v, ((v[:, 0] + VOX_OFF) << 42) | ((v[:, 1] + VOX_OFF) << 21) | (v[:, 2] + VOX_OFF)
 
 
-def preprocess_room(unequalized_points, obj_id, cls_id, resolution=0.1, feature_size=13, chunk=4096):
+def preprocess_room(unequalized_points, obj_id, cls_id, resolution=0.1, feature_size=13, chunk=4096, return_cov=False):
     raw = np.asarray(unequalized_points)
     vox, keys = voxel_keys(raw[:, :3], resolution)
     uniq, first_idx, inverse = np.unique(keys, return_index=True, return_inverse=True)
@@ -52,6 +52,7 @@ def preprocess_room(unequalized_points, obj_id, cls_id, resolution=0.1, feature_
     vq = vox[equalized_idx]
     normals = np.zeros((N, 3))
     curv = np.zeros(N)
+    covs = np.zeros((N, 3, 3)) if return_cov else None
     for c0 in range(0, N, chunk):
         c1 = min(N, c0 + chunk)
         nb = vq[c0:c1, None, :] + _OFFSETS[None, :, :]                      # [C,27,3] (:147-148)
@@ -69,10 +70,22 @@ def preprocess_room(unequalized_points, obj_id, cls_id, resolution=0.1, feature_
         within = np.arange(flat_cnt.sum()) - np.repeat(np.cumsum(flat_cnt) - flat_cnt, flat_cnt)
         nbr = order[seg_start + within]
         bounds = np.concatenate([[0], np.cumsum(tot)[:-1]])
-        accA = np.add.reduceat(prod[nbr], bounds, axis=0).reshape(-1, 3, 3)   # sequential row adds (:155)
-        accB = np.add.reduceat(p64[nbr], bounds, axis=0)                      # (:156)
+        # strictly sequential adds per point, vectorised across the chunk (:155-156).  (numpy.add.reduceat is NOT
+        # sequential: on a [n,9] operand its ninth column goes through an unrolled pairwise loop and rounds differently
+        # once a neighbourhood has more than a few rows.)
+        accA = np.zeros((c1 - c0, 9))
+        accB = np.zeros((c1 - c0, 3))
+        live = np.arange(c1 - c0)
+        for t in range(int(tot.max()) if len(tot) else 0):
+            live = live[tot[live] > t]
+            idx = nbr[bounds[live] + t]
+            accA[live] += prod[idx]
+            accB[live] += p64[idx]
+        accA = accA.reshape(-1, 3, 3)
         n = tot.astype(np.float64)
         cov = accA / n[:, None, None] - (accB[:, :, None] * accB[:, None, :]) / (n ** 2)[:, None, None]   # :157
+        if return_cov:
+            covs[c0:c1] = cov
         U, S, V = np.linalg.svd(cov)                                          # :158
         normals[c0:c1] = np.fabs(V[:, 2, :])                                  # :159
         curv[c0:c1] = np.fabs(S[:, 2] / (S[:, 0] + S[:, 1] + S[:, 2]))        # :160-161
@@ -85,6 +98,9 @@ def preprocess_room(unequalized_points, obj_id, cls_id, resolution=0.1, feature_
         feats = np.hstack((xyz, room_coordinates, rgb, normals)).astype(np.float32)
     else:
         feats = np.hstack((xyz, room_coordinates, rgb, normals, curv.reshape(-1, 1))).astype(np.float32)
-    return dict(points=feats, obj_id=obj_eq.astype(np.int32), cls_id=cls_eq.astype(np.int32), curvatures=curv,
-                order=np.argsort(curv),   # :183 -- same call as the reference (default sort kind; tie order is NumPy's)
-                equalized_idx=equalized_idx, unequalized_idx=unequalized_idx)
+    out = dict(points=feats, obj_id=obj_eq.astype(np.int32), cls_id=cls_eq.astype(np.int32), curvatures=curv,
+               order=np.argsort(curv),   # :183 -- same call as the reference (default sort kind; tie order is NumPy's)
+               equalized_idx=equalized_idx, unequalized_idx=unequalized_idx)
+    if return_cov:
+        out['cov'] = covs
+    return out

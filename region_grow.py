@@ -43,6 +43,10 @@ def parse():
     ap.add_argument('--rooms-in-flight', type=int, default=68)
     ap.add_argument('--max-rooms', type=int, default=0)
     ap.add_argument('--device', default='cuda:0')
+    ap.add_argument('--preprocess', default='gpu-lapack', choices=['gpu-lapack', 'gpu', 'host'],
+                    help="equalisation / normals / curvature (test_region_grow.py:119-173): 'gpu-lapack' = GPU gathering and "
+                         "covariances + the reference's numpy.linalg.svd on the host (bit-identical features); 'gpu' = all on the "
+                         "GPU (Jacobi eigen-solve, features equal to float32 rounding); 'host' = vectorised NumPy")
     return ap.parse_args()
 
 
@@ -71,7 +75,7 @@ def data_path(args, area):
 def main():
     args = parse()
     import torch
-    from learn_region_grow_amd import checkpoint, metrics, preprocess, synthetic
+    from learn_region_grow_amd import checkpoint, metrics, preprocess, preprocess_gpu, synthetic
     from learn_region_grow_amd import io as lio
     from learn_region_grow_amd.grow import RegionGrower
     from learn_region_grow_amd.lrgnet import LrgNetHIP
@@ -93,8 +97,14 @@ def main():
         all_points, all_obj_id, all_cls_id = lio.loadFromH5(data_path(args, area))
         n_rooms = len(all_points) if not args.max_rooms else min(args.max_rooms, len(all_points))
         t0 = time.time()
-        pre = [preprocess.preprocess_room(all_points[r], all_obj_id[r], all_cls_id[r], resolution=args.resolution,
-                                          feature_size=args.feature_size) for r in range(n_rooms)]
+        if args.preprocess == 'host':
+            pre = [preprocess.preprocess_room(all_points[r], all_obj_id[r], all_cls_id[r], resolution=args.resolution,
+                                              feature_size=args.feature_size) for r in range(n_rooms)]
+        else:
+            pre = [preprocess_gpu.preprocess_room(all_points[r], all_obj_id[r], all_cls_id[r], resolution=args.resolution,
+                                                  feature_size=args.feature_size, device=args.device,
+                                                  eig='lapack' if args.preprocess == 'gpu-lapack' else 'jacobi')
+                   for r in range(n_rooms)]
         t_feature = time.time() - t0
         rooms = [dict(points=p['points'], obj_id=p['obj_id'], order=p['order'].astype(np.int32), room_id=r)
                  for r, p in enumerate(pre)]
@@ -116,8 +126,8 @@ def main():
                 name = ('scannet%d.ply' if area == 'scannet' else '%d.ply') % save_id
                 lio.savePLY(os.path.join(args.save, name), cloud)
                 save_id += 1
-        print('%d rooms: preprocessing %.2f s (host), region growing %.2f s (%d regions, %d grow steps, %.0f steps/s)' % (
-            n_rooms, t_feature, t_grow, sum(len(res.regions) for res in results), steps, steps / max(t_grow, 1e-9)))
+        print('%d rooms: preprocessing %.2f s (%s), region growing %.2f s (%d regions, %d grow steps, %.0f steps/s)' % (
+            n_rooms, t_feature, args.preprocess, t_grow, sum(len(res.regions) for res in results), steps, steps / max(t_grow, 1e-9)))
     print(metrics.aggregate_line(all_metrics))
     return 0
 

@@ -122,3 +122,18 @@ def test_voxelize_is_float32_half_even():
     x = np.array([[0.25, 0.35, 0.05], [-0.25, 1.15, 2.5], [0.15, 0.45, -0.05]], dtype=np.float32)
     want = np.round(x / 0.1).astype(int)          # the reference expression (test_region_grow.py:175)
     np.testing.assert_array_equal(grow_ref.voxelize(x, 0.1), want)
+
+
+def test_host_preprocessing_equals_oracle_loop_on_dense_neighbourhoods():
+    """The vectorised host P0 (learn_region_grow_amd.preprocess) against the oracle loop where a point's 27-voxel
+    neighbourhood holds ~100-200 raw points: float64 accumulation order matters there (numpy.add.reduceat would not do)."""
+    from learn_region_grow_amd import preprocess, synthetic
+    from oracle import preprocess_ref
+    r = synthetic.area5_shaped_room(1500, 77).astype(np.float32)
+    raw = (r[:, :6], r[:, 6].astype(int), r[:, 7].astype(int))
+    want = preprocess_ref.preprocess_room(*raw)
+    got = preprocess.preprocess_room(*raw, chunk=500)
+    assert len(raw[0]) / len(want['points']) > 3            # several raw points per voxel
+    for k in ('equalized_idx', 'unequalized_idx', 'obj_id', 'cls_id', 'points', 'curvatures'):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    np.testing.assert_array_equal(got['order'], np.argsort(want['curvatures']))
