@@ -252,7 +252,8 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'region-grow steps/sec (rooms/sec alongside), S3DIS Area-5 shape',
+            'metric': 'region-grow steps/sec (rooms/sec alongside), %s shape' % {'area5': 'S3DIS Area-5', 'scannet': 'ScanNet',
+                                                                                 'kitti': 'KITTI'}[args.workload],
             'value': inst_steps / elapsed,
             'unit': 'instance-steps/s',
             'rooms_per_sec': rooms_done / elapsed,
