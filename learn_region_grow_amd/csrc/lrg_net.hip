@@ -4,7 +4,8 @@
 // 512 rows of each, [pooled | conv[1]] concat, two 3-layer heads).  Restated here as
 //   lrg_pointwise_mfma_kernel  y = relu(x @ W + b)  -- v_mfma_f32_32x32x2_f32 (exact fp32, == fmaf chain)
 //   lrg_segmax_kernel          column max over an instance's rows
-//   lrg_head_gemv_kernel       pooled @ W0[:2*C_last] + b0  once per instance (the tiled concat is never built)
+//   lrg_head_gemv_kernel /     pooled @ W0[:2*C_last] + b0  once per instance (the tiled concat is never built)
+//   lrg_head_gemm_kernel       (the same on the matrix cores for batches of 8+ instances)
 //   lrg_head_final_kernel      [C] -> 2 logits
 #include "lrg_common.h"
 #include "lrg_fused.h"
@@ -279,6 +280,71 @@ __global__ __launch_bounds__(64 * LRG_GEMV_WAVES) void lrg_head_gemv_kernel(LrgG
     }
 }
 
+// The same product as a GEMM on the matrix cores, for batches: a 32-instance x 32-column tile per workgroup, the 8 waves
+// split K (each P/8 deep) and their partial tiles are summed through LDS in a fixed order.  The weights are then read once
+// per 32 instances instead of once per LRG_GEMV_TB (70 MB -> 6 MB of L2 traffic at 68 instances).
+typedef float gemm_f32x16 __attribute__((ext_vector_type(16)));
+#define LRG_GEMM_WAVES 8
+template <int NG>      // k-groups of 8 per wave: P = 64 * NG; fully unrolled so that every operand load is in flight at once
+__global__ __launch_bounds__(64 * LRG_GEMM_WAVES) void lrg_head_gemm_kernel(LrgGemvArgs a) {
+    __shared__ float part[LRG_GEMM_WAVES][32][33];
+    const int z = blockIdx.z, c0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int k0 = wave * 8 * NG;
+    const int row = min(b0 + li, a.B - 1);                                   // rows past the batch repeat the last one
+    const float *ap = a.pooled + (long)row * a.P + k0 + 4 * lh;
+    const float *wp = a.w[z] + (long)(k0 + 4 * lh) * a.ldw + c0 + li;
+    gemm_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // every operand of this wave's K range is requested before the first MFMA (one memory round trip, not NG)
+    float4 av[NG];
+    float wv[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {                                           // lane half h feeds k = 8g + 4h + s
+        av[g] = *reinterpret_cast<const float4 *>(ap + 8 * g);
+        const float *w0 = wp + (long)(8 * g) * a.ldw;
+        wv[g][0] = w0[0]; wv[g][1] = w0[a.ldw]; wv[g][2] = w0[2 * a.ldw]; wv[g][3] = w0[3 * a.ldw];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].x, wv[g][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].y, wv[g][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].z, wv[g][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].w, wv[g][3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 32 * 32; o += 64 * LRG_GEMM_WAVES) {
+        const int r = o >> 5, c = o & 31;
+        float s = part[0][r][c];
+#pragma unroll
+        for (int w = 1; w < LRG_GEMM_WAVES; ++w) s += part[w][r][c];
+        if (b0 + r < a.B) a.hb[z][(long)(b0 + r) * a.C + c0 + c] = s + (a.bias[z] ? a.bias[z][c0 + c] : 0.f);
+    }
+}
+
+// picks the formulation: the matrix-core GEMM for aligned shapes and more than a handful of instances
+static int launch_head_gemv(const LrgGemvArgs &g, int nheads, hipStream_t st) {
+    const int ng = g.P / (8 * LRG_GEMM_WAVES);
+    const bool aligned = g.P == ng * 8 * LRG_GEMM_WAVES && (ng == 16 || ng == 8 || ng == 2) && g.C % 32 == 0 &&
+                         (((uintptr_t)g.pooled) & 15) == 0;
+    if (aligned && g.B >= 8) {
+        const dim3 grid(g.C / 32, (g.B + 31) / 32, nheads), block(64 * LRG_GEMM_WAVES);
+        if (ng == 16) hipLaunchKernelGGL(lrg_head_gemm_kernel<16>, grid, block, 0, st, g);        // lite 0: P = 1024
+        else if (ng == 8) hipLaunchKernelGGL(lrg_head_gemm_kernel<8>, grid, block, 0, st, g);     // lite 2: P = 512
+        else hipLaunchKernelGGL(lrg_head_gemm_kernel<2>, grid, block, 0, st, g);                  // lite 1: P = 128
+    } else {
+        size_t sh = ((size_t)LRG_GEMV_TB * g.P + LRG_GEMV_WAVES * LRG_GEMV_TB * 64) * sizeof(float);
+        hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((g.C + 63) / 64, (g.B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, nheads),
+                           dim3(64 * LRG_GEMV_WAVES), sh, st, g);
+    }
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // final head layer: [rows,C] @ [C,2] + b, no ReLU.  16 lanes per row, float4 loads.
 // ------------------------------------------------------------------------------------------------
@@ -511,10 +577,8 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
         g.bias[0] = w->add_b[0]; g.bias[1] = w->rmv_b[0];
         g.hb[0] = ws + L.hb[0]; g.hb[1] = ws + L.hb[1];
         g.ldw = C0; g.B = B; g.P = L.P; g.C = C0;
-        size_t sh = ((size_t)LRG_GEMV_TB * L.P + LRG_GEMV_WAVES * LRG_GEMV_TB * 64) * sizeof(float);
-        hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C0 + 63) / 64, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 2),
-                           dim3(64 * LRG_GEMV_WAVES), sh, st, g);
-        LRG_LAUNCH_CHECK();
+        int grc = launch_head_gemv(g, 2, st);
+        if (grc) return grc;
     }
     {
         const int hbr[2] = {1, 0};      // head 0 = add on the neighbour rows, head 1 = remove on the inlier rows
@@ -644,11 +708,7 @@ int lrg_head_pool_gemv(const float *pooled, const float *w, int ldw, const float
     if (!pooled || !w || !hb || B <= 0 || P <= 0 || C <= 0 || ldw < C) return LRG_EINVAL - 1;
     LrgGemvArgs a = {};
     a.pooled = pooled; a.w[0] = w; a.bias[0] = bias; a.hb[0] = hb; a.ldw = ldw; a.B = B; a.P = P; a.C = C;
-    size_t sh = ((size_t)LRG_GEMV_TB * P + LRG_GEMV_WAVES * LRG_GEMV_TB * 64) * sizeof(float);
-    hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C + 63) / 64, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 1), dim3(64 * LRG_GEMV_WAVES),
-                       sh, (hipStream_t)stream, a);
-    LRG_LAUNCH_CHECK();
-    return 0;
+    return launch_head_gemv(a, 1, (hipStream_t)stream);
 }
 
 int lrg_head_final(const float *h, const float *w, const float *bias, float *logits, long rows, int C, void *stream) {
@@ -740,10 +800,8 @@ int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neig
         g.bias[0] = w->add_b[0]; g.bias[1] = w->rmv_b[0];
         g.hb[0] = ws + L.hb[0]; g.hb[1] = ws + L.hb[1];
         g.ldw = C0; g.B = B; g.P = L.P; g.C = C0;
-        size_t sh = ((size_t)LRG_GEMV_TB * L.P + LRG_GEMV_WAVES * LRG_GEMV_TB * 64) * sizeof(float);
-        hipLaunchKernelGGL(lrg_head_gemv_kernel, dim3((C0 + 63) / 64, (B + LRG_GEMV_TB - 1) / LRG_GEMV_TB, 2),
-                           dim3(64 * LRG_GEMV_WAVES), sh, st, g);
-        LRG_LAUNCH_CHECK();
+        int grc = launch_head_gemv(g, 2, st);
+        if (grc) return grc;
     }
     const int hbr[2] = {1, 0};   // branch feeding each head
     for (int i = 0; i < nh - 1; ++i) {
