@@ -47,7 +47,7 @@ def parse():
                          "Area-5-like region dynamics (regions per room, steps per region)")
     ap.add_argument('--fuse-pool', type=int, default=0)
     ap.add_argument('--net-mode', default='fused', choices=['fused', 'streamed'])
-    ap.add_argument('--advance-rounds', type=int, default=2)
+    ap.add_argument('--advance-rounds', type=int, default=1)
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
     ap.add_argument('--p0-rooms', type=int, default=4, help='rooms of the preprocessing (P0) side measurement (0 = skip)')

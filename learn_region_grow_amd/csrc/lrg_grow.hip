@@ -181,10 +181,12 @@ __device__ void lrg_reset_slot(LrgSlot *S, const LrgRoom *R, int seed, int resta
     }
 }
 
+#define LRG_SEED_TRIES 64   // isolated seeds committed per call before the search is resumed by the next one
 __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
                                                                         LrgGrowParams prm, int64_t *stats) {
     __shared__ int sh_next;
     __shared__ int sh_flag;
+    __shared__ int sh_list[32];
     const int G = prm.group_size, RST = prm.restarts;
     const int g0 = blockIdx.x * G;
     if (g0 >= n_slots) return;
@@ -278,41 +280,93 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *
     }
 
     // ---- next unvisited seed in curvature order (:186-188) ----
+    // The first box query of a fresh seed (:221-229 with mn = mx = the seed's voxel) is answered here from the room's voxel
+    // hash: an equalised room has one point per voxel, so the candidates are the unvisited points of the 26 surrounding
+    // voxels, in index order.  A seed without any (:233-235, 'noneighbor') is committed on the spot as a one-point region
+    // and the search goes on, so a slot never spends an iteration on it.
     int cursor = R->seed_cursor;
-    int found = -1;
-    while (cursor < n) {
-        int pos = cursor + threadIdx.x;
-        int cand = INT_MAX;
-        if (pos < n && !R->visited[R->order[pos]]) cand = pos;
-        if (threadIdx.x == 0) sh_next = INT_MAX;
-        __syncthreads();
-        if (cand != INT_MAX) atomicMin(&sh_next, cand);
-        __syncthreads();
-        int best = sh_next;
-        __syncthreads();
-        if (best != INT_MAX) { found = best; break; }
-        cursor += blockDim.x;
-    }
-    if (found < 0) {
-        if (threadIdx.x == 0) {
-            R->seed_cursor = n;
-            R->done = 1;
-            for (int s = 0; s < G && g0 + s < n_slots; ++s) slots[g0 + s].status = LRG_DONE;
-            if (stats) {
-                unsigned long long k = atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), 1ULL);
-                stats[4 + (k % LRG_DONE_RING)] = g0;
-            }
+    int seed = -1, n_cand = 0;
+    for (int tries = 0; tries < LRG_SEED_TRIES; ++tries) {
+        int found = -1;
+        while (cursor < n) {
+            int pos = cursor + threadIdx.x;
+            int cand = INT_MAX;
+            if (pos < n && !R->visited[R->order[pos]]) cand = pos;
+            if (threadIdx.x == 0) sh_next = INT_MAX;
+            __syncthreads();
+            if (cand != INT_MAX) atomicMin(&sh_next, cand);
+            __syncthreads();
+            int best = sh_next;
+            __syncthreads();
+            if (best != INT_MAX) { found = best; break; }
+            cursor += blockDim.x;
         }
+        if (found < 0) {
+            if (threadIdx.x == 0) {
+                R->seed_cursor = n;
+                R->done = 1;
+                for (int s = 0; s < G && g0 + s < n_slots; ++s) slots[g0 + s].status = LRG_DONE;
+                if (stats) {
+                    unsigned long long k = atomicAdd(reinterpret_cast<unsigned long long *>(&stats[1]), 1ULL);
+                    stats[4 + (k % LRG_DONE_RING)] = g0;
+                }
+            }
+            return;
+        }
+        const int sd = R->order[found];
+        cursor = found + 1;
+        if (!R->hash_keys) { seed = sd; n_cand = -1; break; }            // no hash: leave the query to lrg_box_query
+        // 26 probes by the first lanes of wave 0, then an ordered (ascending index) list in LDS
+        if (threadIdx.x < 64) {
+            int idx = -1;
+            if (threadIdx.x < 27 && threadIdx.x != 13) {
+                const int dx = threadIdx.x / 9 - 1, dy = (threadIdx.x / 3) % 3 - 1, dz = threadIdx.x % 3 - 1;
+                const int32_t *v = R->voxels + 3 * (long)sd;
+                idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(v[0] + dx, v[1] + dy, v[2] + dz));
+                if (idx >= 0 && (R->visited[idx] || idx == sd)) idx = -1;
+            }
+            int rank = 0, total = 0;
+            for (int l = 0; l < 27; ++l) {
+                const int o = __shfl(idx, l);
+                if (o >= 0) { ++total; if (idx >= 0 && o < idx) ++rank; }
+            }
+            if (idx >= 0) sh_list[rank] = idx;
+            if (threadIdx.x == 0) sh_flag = total;
+        }
+        __syncthreads();
+        const int total = sh_flag;
+        __syncthreads();
+        if (total > 0) { seed = sd; n_cand = total; break; }
+        // no neighbour: the region is the seed alone (:233-235 -> :210-217)
+        if (threadIdx.x == 0) {
+            const int labeled = 1 > prm.cluster_threshold;
+            R->visited[sd] = 1;
+            if (labeled) { R->label[sd] = R->next_cluster_id; R->next_cluster_id += 1; }
+            int32_t *log = R->region_log + 6 * (long)R->n_regions;
+            log[0] = sd; log[1] = 0; log[2] = 1; log[3] = LRG_STOP_NONEIGHBOR; log[4] = labeled; log[5] = 0;
+            R->n_regions += 1;
+            if (stats) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), 1ULL);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) R->seed_cursor = cursor;
+    if (seed < 0) {
+        // try budget spent on isolated points: park the group as a fresh binding, the next call continues the search
+        if (threadIdx.x == 0)
+            for (int s = 0; s < G && g0 + s < n_slots; ++s) { slots[g0 + s].seed = -1; slots[g0 + s].status = LRG_WAIT; slots[g0 + s].count = -1; }
         return;
     }
-    const int seed = R->order[found];
     __syncthreads();
-    if (threadIdx.x == 0) R->seed_cursor = found + 1;
     for (int s = 0; s < G && g0 + s < n_slots; ++s) {
         LrgSlot *S = &slots[g0 + s];
         if (threadIdx.x == 0) { S->steps_total = 0; S->best_count = -1; S->best_restart = INT_MAX; S->last_reason = 0; }
         if (s < RST) {
             lrg_reset_slot(S, R, seed, s);
+            if (n_cand > 0) {                                          // the slot's lists are ready: lrg_box_query skips it
+                if ((int)threadIdx.x < n_cand) S->cand_idx[threadIdx.x] = sh_list[threadIdx.x];
+                __syncthreads();
+                if (threadIdx.x == 0) { S->cur_idx[0] = seed; S->nc = 1; S->ne = n_cand; S->pad = 1; }
+            }
         } else if (threadIdx.x == 0) {
             S->seed = seed; S->status = LRG_WAIT; S->count = -1;
         }

@@ -48,7 +48,7 @@ class RoomResult:
 
 class RegionGrower:
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
-                 resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=2, pipeline_depth=4,
+                 resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
                  skip_duplicate_rows=True, poll_every=4):
         self.lib = _lib.load()
         self.net = net
