@@ -88,7 +88,7 @@ int lrg_forward(const LrgWeights *w, const float *inlier, const float *neighbor,
  * guarantees that every later row is a copy of one of those (the reference pads small sets by duplication,
  * test_region_grow.py:240,:252), so their logits equal the source row's bit for bit and the max-pool (:122-123) is
  * unchanged; logits of rows that are not evaluated are left unwritten.  A count of 0 skips the instance.
- * Needs LRG_FWD_FUSED (whole 64-row tiles are skipped). */
+ * Needs LRG_FWD_FUSED (whole 32-row tiles of copies are skipped). */
 int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
                      int n_neighbor, const int32_t *rows_in, const int32_t *rows_nb, float *add_logits,
                      float *rmv_logits, void *workspace, size_t workspace_bytes, unsigned flags, void *stream);

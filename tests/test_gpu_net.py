@@ -171,7 +171,7 @@ def test_forward_rows_skips_duplicate_rows_exactly(cuda_device):
         np.testing.assert_array_equal(rmv[b, :n_in[b]], rmv_full[b, :n_in[b]])
         np.testing.assert_array_equal(add[b, :n_nb[b]], add_full[b, :n_nb[b]])
         np.testing.assert_array_equal(pooled[b], pooled_full[b])
-        tiles = -(-n_in[b] // 64) * 64
+        tiles = -(-n_in[b] // 32) * 32
         assert np.isnan(rmv[b, tiles:]).all()          # whole tiles of duplicates were never touched
 
 
