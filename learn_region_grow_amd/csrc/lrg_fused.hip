@@ -378,7 +378,7 @@ int lrg_fused_branches(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     // With per-instance row counts (the grow loop: most sets are far below 512 distinct rows) 32-row tiles waste fewer
     // padded rows than 64-row ones (+7 % loop throughput); dense batches keep the 64-row tile, whose two stacked MFMA
     // tiles share every weight operand.
-    if (a.p[0].valid) return launch_stack<32 * 68, 32 * 132, 1, 4, 4, false>(a, nprob, st);
+    if (a.p[0].valid) return launch_stack<32 * 68, 32 * 132, 1, 4, 4, false>(a, nprob, st);    // (5 per CU spills: slower)
     return launch_stack<64 * 68, 64 * 132, 2, 4, 3, false>(a, nprob, st);
 }
 
