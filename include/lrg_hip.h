@@ -69,6 +69,11 @@ int lrg_pack_weights(const LrgWeights *w, void *packed, size_t packed_bytes, voi
 #define LRG_FWD_FUSED 2u     /* whole branch / whole head per 64-row tile in one kernel each: activations stay in LDS,
                                 only conv[1], the pooled maxima and the logits reach HBM (3 launches per call)         */
 #define LRG_FWD_KEEP_ACTS 4u /* with LRG_FWD_FUSED: also copy every intermediate into the workspace (parity tests)     */
+#define LRG_FWD_TILE_LISTS 16u /* lrg_forward_rows + LRG_FWD_FUSED: the workspace's tile-list block (view kind 6) was filled by
+                                  lrg_prepare for exactly these row counts: only the listed 32-row tiles are launched as
+                                  working workgroups, back to back, so they spread evenly over the compute units (skipping
+                                  by row count alone leaves the survivors wherever the dead tiles happened to sit).      */
+#define LRG_ROW_TILE 32        /* rows per tile of those lists */
 #define LRG_FWD_POOL_ZEROED 8u /* with LRG_FWD_FUSED: the workspace was zero-filled once by the caller and is only ever used
                                 by calls carrying this flag -- the pooled-feature block is then zero on entry and is
                                 left zero on return (cleared by the head kernel), which saves the per-call memset.
@@ -95,7 +100,9 @@ int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neig
 
 /* Workspace introspection for layer-by-layer parity tests: float offset / element count of a named
  * intermediate inside `workspace`.  kind: 0 conv[i] (inlier), 1 neighbor_conv[i], 2 pooled [B,2*C_last],
- * 3 add head hidden[i], 4 remove head hidden[i], 5 scratch (64 floats, reserved).
+ * 3 add head hidden[i], 4 remove head hidden[i], 5 scratch (64 floats, reserved), 6 tile lists (int32: [0] inlier tile
+ * count, [1] neighbour tile count, then B*ceil(n_inlier/32) inlier entries and B*ceil(n_neighbor/32) neighbour entries,
+ * entry = instance * 64 + tile).
  * Returns 0, or LRG_EINVAL. */
 int lrg_forward_workspace_view(const LrgWeights *w, int B, int n_inlier, int n_neighbor, int kind, int index,
                                size_t *offset_floats, size_t *count_floats);
@@ -255,7 +262,8 @@ int lrg_gather_center(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, c
 int lrg_prepare(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
                 int32_t *sample_in, int32_t *sample_nb, float *inlier, float *neighbor, int32_t *gt_remove, int32_t *gt_add,
                 int32_t *rows_in, int32_t *rows_nb, int32_t *tile_total, void *stream);
-/* tile_total (nullable, device int32): receives the number of 64-row tiles lrg_forward_rows will evaluate. */
+/* tile_total (nullable, device int32 block = workspace view kind 6 of an n_slots-instance forward): receives the lists of
+ * live 32-row tiles for lrg_forward_rows(LRG_FWD_TILE_LISTS). */
 
 /* Confidence + Bernoulli masks + voxel-set mask update (:262-288).
  * add_mask / rmv_mask (nullable, uint8 [n_slots,n]) : host-decided masks (reference-order RNG);

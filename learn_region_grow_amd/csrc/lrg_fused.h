@@ -23,6 +23,8 @@ struct LrgFusedProb {
     const float *fb;
     float *fout;         // [rows,2]
     const int *valid;    // nullable, [instances]: only the first valid[i] rows of instance i are evaluated (0 = skip)
+    const int *tile_count; // nullable pair: *tile_count live tiles, tile_list[b] = instance * 64 + tile of workgroup b
+    const int *tile_list;
     float *zero_pool;    // nullable: after the stack, the tile-0 workgroup of instance i clears zero_pool[i*zero_count .. +zero_count)
     long rows;
     int ldx, Kin, rows_per_inst, pool_stride, nlayers, zero_count;

@@ -115,12 +115,23 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     // Tile-major block order (instance fastest): block b runs on XCD b % 8, and with duplicate-row skipping mostly the
     // FIRST tiles of the instances survive -- instance-major order would put all of them on one XCD.
     const int ninst = (int)(P.rows / P.rows_per_inst);
-    const int inst = blockIdx.x % ninst, tile = blockIdx.x / ninst;
+    int inst, tile, nvalid = 0x7fffffff;
+    if (P.tile_list) {
+        // a compacted list of the live tiles (lrg_prepare): workgroups 0 .. count-1 work, the rest leave at once -- the
+        // dispatcher deals consecutive workgroups round the XCDs and CUs, so the live ones are spread evenly
+        if ((int)blockIdx.x >= *P.tile_count) return;
+        const int code = P.tile_list[blockIdx.x];
+        inst = code >> 6;
+        tile = code & 63;
+    } else {
+        inst = blockIdx.x % ninst;
+        tile = blockIdx.x / ninst;
+        // rows beyond valid[instance] are copies of earlier rows (the padding rule, test_region_grow.py:240,:252):
+        // their per-point results are identical and the max-pool ignores duplicates, so whole tiles of them are skipped
+        // (the count is fetched here and tested after the input rows are staged: one memory round trip instead of two)
+        if (P.valid) nvalid = P.valid[inst];
+    }
     if (tile * FM >= P.rows_per_inst) return;
-    // rows beyond valid[instance] are copies of earlier rows (the padding rule, test_region_grow.py:240,:252):
-    // their per-point results are identical and the max-pool ignores duplicates, so whole tiles of them are skipped
-    // (the count is fetched here and tested after the input rows are staged: one memory round trip instead of two)
-    const int nvalid = P.valid ? P.valid[inst] : 0x7fffffff;
     const long r0 = (long)inst * P.rows_per_inst + (long)tile * FM;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);

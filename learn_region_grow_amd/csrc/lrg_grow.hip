@@ -641,7 +641,15 @@ __global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const Lrg
         const int ri = active ? min(S->nc, prm.n_inlier) : 0, rn = active ? min(S->ne, prm.n_neighbor) : 0;
         rows_in[s] = ri;
         rows_nb[s] = rn;
-        if (tile_total && active) atomicAdd(tile_total, (ri + 63) / 64 + (rn + 63) / 64);
+        if (tile_total && active) {
+            // reserve this slot's entries in the two live-tile lists (order among slots does not matter)
+            const int ti = (ri + LRG_ROW_TILE - 1) / LRG_ROW_TILE, tn = (rn + LRG_ROW_TILE - 1) / LRG_ROW_TILE;
+            const int cap_in = (int)gridDim.x * ((prm.n_inlier + LRG_ROW_TILE - 1) / LRG_ROW_TILE);
+            int32_t *list_in = tile_total + 2, *list_nb = tile_total + 2 + cap_in;
+            const int bi = atomicAdd(&tile_total[0], ti), bn = atomicAdd(&tile_total[1], tn);
+            for (int t = 0; t < ti; ++t) list_in[bi + t] = s * 64 + t;
+            for (int t = 0; t < tn; ++t) list_nb[bn + t] = s * 64 + t;
+        }
     }
     if (!active) return;
     const LrgRoom *R = &rooms[S->room];
@@ -803,7 +811,7 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
 
 __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                                  float *center, int min_points, int32_t *tile_total) {
-    if (tile_total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *tile_total = 0;   // lrg_prepare (next launch) accumulates
+    if (tile_total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { tile_total[0] = 0; tile_total[1] = 0; }   // lrg_prepare (next launch) fills the lists
     extern __shared__ __attribute__((aligned(16))) uint32_t cache[];      // [LRG_MED_LARGE] keys, then 64 ints of scratch
     int *sh = reinterpret_cast<int *>(cache + LRG_MED_LARGE);
     const int s = blockIdx.x, ch = blockIdx.y;
@@ -1215,8 +1223,15 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
         if ((rc = lrg_box_query(slots, rooms, n_slots, max_points, params, stream))) return rc;
     }
     const bool rows = b->rows_in && b->rows_nb && (forward_flags & LRG_FWD_FUSED);
+    int32_t *tile_lists = nullptr;
+    if (rows && params->n_inlier <= 64 * LRG_ROW_TILE && params->n_neighbor <= 64 * LRG_ROW_TILE) {
+        size_t off = 0, cnt = 0;
+        if ((rc = lrg_forward_workspace_view(weights, n_slots, params->n_inlier, params->n_neighbor, 6, 0, &off, &cnt))) return rc;
+        tile_lists = reinterpret_cast<int32_t *>(static_cast<float *>(b->workspace) + off);
+        forward_flags |= LRG_FWD_TILE_LISTS;
+    }
     if ((rc = lrg_prepare(slots, rooms, n_slots, params, b->center, b->sample_in, b->sample_nb, b->inlier, b->neighbor,
-                          b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, nullptr,
+                          b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, tile_lists,
                           stream)))
         return rc;
     if ((rc = lrg_forward_rows(weights, b->inlier, b->neighbor, n_slots, params->n_inlier, params->n_neighbor,

@@ -397,6 +397,8 @@ struct LrgFwdLayout {
     size_t hid[2][LRG_MAX_HEAD];
     size_t scratch;                 // 64 floats, reserved
     size_t packed;                  // lrg_pack_weights image, used when the caller supplies none
+    size_t tiles;                   // live-tile lists of lrg_forward_rows (int32; see lrg_hip.h, view kind 6)
+    size_t tiles_cap[2];            // entries of the inlier / neighbour list
     size_t total;
     int P;                          // 2*C_last
 };
@@ -524,6 +526,10 @@ static int fwd_layout(const LrgWeights *w, int B, int ni, int nn, LrgFwdLayout *
     if (rc) return rc;
     L->packed = off;
     off = lrg_align_up(off + PL.total, 64);
+    L->tiles = off;
+    L->tiles_cap[0] = (size_t)B * ((ni + LRG_ROW_TILE - 1) / LRG_ROW_TILE);
+    L->tiles_cap[1] = (size_t)B * ((nn + LRG_ROW_TILE - 1) / LRG_ROW_TILE);
+    off = lrg_align_up(off + 2 + L->tiles_cap[0] + L->tiles_cap[1], 64);
     L->total = off;
     return 0;
 }
@@ -532,12 +538,13 @@ static int fwd_layout(const LrgWeights *w, int B, int ni, int nn, LrgFwdLayout *
 static int forward_fused(const LrgWeights *w, const float *inlier, const float *neighbor, int B, int n_inlier,
                          int n_neighbor, const int32_t *rows_in, const int32_t *rows_nb, float *add_logits,
                          float *rmv_logits, float *ws, const LrgFwdLayout &L, bool keep_acts, bool pool_zeroed,
-                         hipStream_t st) {
+                         bool tile_lists, hipStream_t st) {
     const long rows[2] = {(long)B * n_inlier, (long)B * n_neighbor};
     const int rpi[2] = {n_inlier, n_neighbor};
     const int nc = w->n_conv, nh = w->n_head;
     const int Clast = w->conv_ch[nc - 1];
     if (!pool_zeroed) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
+    const int *tl = reinterpret_cast<const int *>(ws + L.tiles);
     LrgPackLayout PL;
     int prc = pack_layout(w, &PL);
     if (prc) return prc;
@@ -555,6 +562,7 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
             P.rows = rows[br]; P.rows_per_inst = rpi[br];
             P.pool = ws + L.pooled + (br == 0 ? 0 : Clast); P.pool_stride = L.P;
             P.valid = br == 0 ? rows_in : rows_nb;
+            if (tile_lists) { P.tile_count = tl + br; P.tile_list = tl + 2 + (br == 0 ? 0 : L.tiles_cap[0]); }
             P.nlayers = nc;
             for (int i = 0; i < nc; ++i) {
                 LrgFusedLayer &F = P.L[i];
@@ -590,6 +598,7 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
             P.ldx = w->conv_ch[1]; P.Kin = w->conv_ch[1];
             P.rows = rows[br]; P.rows_per_inst = rpi[br];
             P.valid = br == 0 ? rows_in : rows_nb;
+            if (tile_lists) { P.tile_count = tl + br; P.tile_list = tl + 2 + (br == 0 ? 0 : L.tiles_cap[0]); }
             P.nlayers = nh - 1;
             for (int i = 0; i < nh - 1; ++i) {
                 LrgFusedLayer &F = P.L[i];
@@ -668,6 +677,8 @@ int lrg_forward_workspace_view(const LrgWeights *w, int B, int n_inlier, int n_n
         return 0;
     case 2:
         *offset_floats = L.pooled; *count_floats = (size_t)B * L.P; return 0;
+    case 6:
+        *offset_floats = L.tiles; *count_floats = 2 + L.tiles_cap[0] + L.tiles_cap[1]; return 0;
     case 5:
         *offset_floats = L.scratch; *count_floats = 64; return 0;
     case 3: case 4:
@@ -755,7 +766,8 @@ int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neig
     if ((rows_in == nullptr) != (rows_nb == nullptr)) return LRG_EINVAL - 11;
     if (rows_in && !fused) return LRG_EINVAL - 12;      // row counts are honoured by the fused kernels only
     if (fused) return forward_fused(w, inlier, neighbor, B, n_inlier, n_neighbor, rows_in, rows_nb, add_logits, rmv_logits,
-                                    ws, L, (flags & LRG_FWD_KEEP_ACTS) != 0, (flags & LRG_FWD_POOL_ZEROED) != 0, st);
+                                    ws, L, (flags & LRG_FWD_KEEP_ACTS) != 0, (flags & LRG_FWD_POOL_ZEROED) != 0,
+                                    (flags & LRG_FWD_TILE_LISTS) != 0 && rows_in != nullptr && !(flags & LRG_FWD_KEEP_ACTS), st);
     if (fuse_pool) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
 
     // ---- branches (:106-119): both branches in one launch per layer ----
