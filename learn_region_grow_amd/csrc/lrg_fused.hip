@@ -11,12 +11,12 @@
 #include "lrg_fused.h"
 
 #ifndef LRG_TRACE
-#define LRG_TRACE 0     // 2 (branch kernel) / 1 (head kernel): thread 0 of each workgroup stamps the cycle counter at phase boundaries
+#define LRG_TRACE 0     // = CAP0 of the instantiation to trace (4352 / 2176 branch, 8320 head): thread 0 of each workgroup stamps the cycle counter at phase boundaries
 #endif
 #if LRG_TRACE
 __device__ long long *g_lrg_trace = nullptr;
 extern "C" void lrg_set_trace(long long *p) { hipMemcpyToSymbol(HIP_SYMBOL(g_lrg_trace), &p, sizeof(p)); }
-#define TRACE(i) do { if (RT == LRG_TRACE && tid == 0 && g_lrg_trace && blockIdx.x < 2048) g_lrg_trace[((long)blockIdx.y * 2048 + blockIdx.x) * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define TRACE(i) do { if (CAP0 == LRG_TRACE && tid == 0 && g_lrg_trace && blockIdx.x < 2048) g_lrg_trace[((long)blockIdx.y * 2048 + blockIdx.x) * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define TRACE(i)
 #endif

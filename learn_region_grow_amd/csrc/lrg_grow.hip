@@ -784,15 +784,26 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
     const uint32_t common = hb >= 32 ? 0u : (kmin >> hb) << hb;
     const int k2 = nc >> 1;
     uint32_t rb = common;
-    for (int bit = hb - 1; bit >= 0; --bit) {
-        const uint32_t cb = rb | (1u << bit);
-        int cnt = 0;
+    // two bits per step on aligned bit pairs (three thresholds; counts packed 16+16 | 32: a block holds at most 48 Ki keys).
+    // A pair that reaches into the common prefix needs no special case: a threshold that would flip a common bit counts
+    // either every key or the same keys as a lower threshold.  The step cost is the barrier, not the compares.
+    int slot = 2;
+    for (int bit = ((hb + 1) & ~1) - 2; bit >= 0; bit -= 2, slot += 2) {
+        const uint32_t t1 = rb | (1u << bit), t2 = rb | (2u << bit), t3 = rb | (3u << bit);
+        int c12 = 0, c3 = 0;
 #pragma unroll
-        for (int r = 0; r < KT; ++r) cnt += key[r] < cb ? 1 : 0;
-        cnt = lrg_wave_sum_i32(cnt);
-        if (lane == 0 && cnt) atomicAdd(&sh[2 + bit], cnt);
+        for (int r = 0; r < KT; ++r) {
+            c12 += (key[r] < t1 ? 1 : 0) + (key[r] < t2 ? 0x10000 : 0);
+            c3 += key[r] < t3 ? 1 : 0;
+        }
+        c12 = lrg_wave_sum_i32(c12);
+        c3 = lrg_wave_sum_i32(c3);
+        if (lane == 0) { if (c12) atomicAdd(&sh[slot], c12); if (c3) atomicAdd(&sh[slot + 1], c3); }
         __syncthreads();
-        if (sh[2 + bit] <= k2) rb = cb;
+        const int s12 = sh[slot], s3 = sh[slot + 1];
+        if (s3 <= k2) rb = t3;
+        else if ((int)((unsigned)s12 >> 16) <= k2) rb = t2;
+        else if ((s12 & 0xFFFF) <= k2) rb = t1;
     }
     float hi = lrg_key2f(rb);
     if (nc & 1) return hi;
@@ -809,28 +820,48 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
     return __fmul_rn(__fadd_rn(lo, hi), 0.5f);
 }
 
+#define LRG_MED_REGS (48 * 1024)   // largest region whose keys fit the registers of one 1024-thread workgroup
+// centred channel of grid row y: 0, 1, 6, 7, ... (:243-247); -1 past the feature count
+__device__ __forceinline__ int lrg_centred_channel(int y, int F) { const int ch = y < 2 ? y : y + 4; return ch < F ? ch : -1; }
+
+// Regions of (min_points, LRG_MED_REGS] points: keys in registers, 160 B of LDS, so the many workgroups that find nothing to
+// do (most slots hold small regions) come and go two per CU instead of queueing for a 147 KB LDS allocation each.
 __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                                  float *center, int min_points, int32_t *tile_total) {
     if (tile_total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { tile_total[0] = 0; tile_total[1] = 0; }   // lrg_prepare (next launch) fills the lists
-    extern __shared__ __attribute__((aligned(16))) uint32_t cache[];      // [LRG_MED_LARGE] keys, then 64 ints of scratch
-    int *sh = reinterpret_cast<int *>(cache + LRG_MED_LARGE);
-    const int s = blockIdx.x, ch = blockIdx.y;
+    __shared__ int sh[40];
+    const int s = blockIdx.x;
     const LrgSlot *S = &slots[s];
     const int F = prm.feature_size;
-    const bool centred = (ch < 2 || ch >= 6) && ch < F;
-    if (!centred || S->status != LRG_ACTIVE || S->room < 0) return;
+    const int ch = lrg_centred_channel(blockIdx.y, F);
+    if (ch < 0 || S->status != LRG_ACTIVE || S->room < 0) return;
     const int nc = S->nc;
-    if (nc <= min_points) return;                                              // done by the wave-level code
+    if (nc <= min_points || nc > LRG_MED_REGS) return;                         // wave-level code / large-region kernel
     const LrgRoom *R = &rooms[S->room];
     if (threadIdx.x < 40) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;         // sh[0] = 0xFFFFFFFF (min identity)
     __syncthreads();
-    if (nc <= 16 * 1024) {
-        const float *pts = R->points + ch;
-        float med = nc <= 4096 ? lrg_median_block_regs<4>(pts, S->cur_idx, F, nc, sh)
-                               : lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh);
-        if (threadIdx.x == 0) center[s * 16 + ch] = med;
-        return;
-    }
+    const float *pts = R->points + ch;
+    const float med = nc <= 4096 ? lrg_median_block_regs<4>(pts, S->cur_idx, F, nc, sh)
+                    : nc <= 16 * 1024 ? lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh)
+                                      : lrg_median_block_regs<48>(pts, S->cur_idx, F, nc, sh);
+    if (threadIdx.x == 0) center[s * 16 + ch] = med;
+}
+
+// Regions above LRG_MED_REGS points (only rooms that large can hold one: launched when max_points says so)
+__global__ __launch_bounds__(1024) void lrg_median_large_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
+                                                                 float *center) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cache[];      // [LRG_MED_LARGE] keys, then 64 ints of scratch
+    int *sh = reinterpret_cast<int *>(cache + LRG_MED_LARGE);
+    const int s = blockIdx.x;
+    const LrgSlot *S = &slots[s];
+    const int F = prm.feature_size;
+    const int ch = lrg_centred_channel(blockIdx.y, F);
+    if (ch < 0 || S->status != LRG_ACTIVE || S->room < 0) return;
+    const int nc = S->nc;
+    if (nc <= LRG_MED_REGS) return;
+    const LrgRoom *R = &rooms[S->room];
+    if (threadIdx.x < 40) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;         // sh[0] = 0xFFFFFFFF (min identity)
+    __syncthreads();
     const bool cached = nc <= LRG_MED_LARGE;
     if (cached) {
         // gather 8 values per thread per round: the index load and the dependent feature load of the 8 are independent,
@@ -1122,23 +1153,50 @@ int lrg_box_query(LrgSlot *slots, const LrgRoom *rooms, int n_slots, int max_poi
     return 0;
 }
 
+// block-level medians: the register kernel always, the LDS-cache kernel only when a room can hold a region that large
+static int launch_block_medians(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
+                                int min_points, int32_t *tile_total, int max_points, hipStream_t st) {
+    const int ncentred = params->feature_size <= 2 ? params->feature_size : params->feature_size <= 6 ? 2 : params->feature_size - 4;
+    hipLaunchKernelGGL(lrg_median_block_kernel, dim3(n_slots, ncentred), dim3(1024), 0, st, slots, rooms, *params, center, min_points,
+                       tile_total);
+    LRG_LAUNCH_CHECK();
+    if (max_points > LRG_MED_REGS) {
+        const size_t lds_large = LRG_MED_LARGE * 4 + 256;
+        static bool attr_done = false;
+        if (!attr_done) {
+            LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_median_large_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_large));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(lrg_median_large_kernel, dim3(n_slots, ncentred), dim3(1024), lds_large, st, slots, rooms, *params, center);
+        LRG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int lrg_median(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
                void *stream) {
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || !center || n_slots <= 0) return LRG_EINVAL - 1;
-    const size_t lds_large = LRG_MED_LARGE * 4 + 256;
-    static bool attr_done = false;
-    if (!attr_done) {
-        LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_median_block_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_large));
-        attr_done = true;
-    }
     hipLaunchKernelGGL(lrg_median_wave_kernel, dim3((n_slots * 16 + 3) / 4), dim3(256), 0, (hipStream_t)stream, slots, rooms,
                        *params, center, n_slots);
     LRG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(lrg_median_block_kernel, dim3(n_slots, params->feature_size), dim3(1024), lds_large,
-                       (hipStream_t)stream, slots, rooms, *params, center, LRG_MED_SMALL, (int32_t *)nullptr);
+    return launch_block_medians(slots, rooms, n_slots, params, center, LRG_MED_SMALL, nullptr, INT_MAX, (hipStream_t)stream);
+}
+
+static int prepare_impl(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
+                        int32_t *sample_in, int32_t *sample_nb, float *inlier, float *neighbor, int32_t *gt_remove, int32_t *gt_add,
+                        int32_t *rows_in, int32_t *rows_nb, int32_t *tile_total, int max_points, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || !center || !sample_in || !sample_nb || !inlier || !neighbor || n_slots <= 0) return LRG_EINVAL - 1;
+    if ((rows_in == nullptr) != (rows_nb == nullptr)) return LRG_EINVAL - 2;
+    if (params->n_inlier > 1024 || params->n_neighbor > 1024) return LRG_EINVAL - 3;
+    if ((rc = launch_block_medians(slots, rooms, n_slots, params, center, LRG_MED_PREP, tile_total, max_points, (hipStream_t)stream)))
+        return rc;
+    hipLaunchKernelGGL(lrg_prepare_kernel, dim3(n_slots), dim3(LRG_PREP_THREADS), 0, (hipStream_t)stream, slots, rooms, *params, center,
+                       sample_in, sample_nb, inlier, neighbor, gt_remove, gt_add, rows_in, rows_nb, tile_total);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -1146,25 +1204,8 @@ int lrg_median(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const Lr
 int lrg_prepare(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, float *center,
                 int32_t *sample_in, int32_t *sample_nb, float *inlier, float *neighbor, int32_t *gt_remove, int32_t *gt_add,
                 int32_t *rows_in, int32_t *rows_nb, int32_t *tile_total, void *stream) {
-    int rc = check_params(params);
-    if (rc) return rc;
-    if (!slots || !rooms || !center || !sample_in || !sample_nb || !inlier || !neighbor || n_slots <= 0) return LRG_EINVAL - 1;
-    if ((rows_in == nullptr) != (rows_nb == nullptr)) return LRG_EINVAL - 2;
-    if (params->n_inlier > 1024 || params->n_neighbor > 1024) return LRG_EINVAL - 3;
-    const size_t lds_large = LRG_MED_LARGE * 4 + 256;
-    static bool attr_done = false;
-    if (!attr_done) {
-        LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_median_block_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_large));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(lrg_median_block_kernel, dim3(n_slots, params->feature_size), dim3(1024), lds_large,
-                       (hipStream_t)stream, slots, rooms, *params, center, LRG_MED_PREP, tile_total);
-    LRG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(lrg_prepare_kernel, dim3(n_slots), dim3(LRG_PREP_THREADS), 0, (hipStream_t)stream, slots, rooms, *params, center,
-                       sample_in, sample_nb, inlier, neighbor, gt_remove, gt_add, rows_in, rows_nb, tile_total);
-    LRG_LAUNCH_CHECK();
-    return 0;
+    return prepare_impl(slots, rooms, n_slots, params, center, sample_in, sample_nb, inlier, neighbor, gt_remove, gt_add, rows_in,
+                        rows_nb, tile_total, INT_MAX, stream);     // room sizes unknown here: both median kernels
 }
 
 int lrg_sample(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams *params, int32_t *sample_in,
@@ -1230,9 +1271,9 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
         tile_lists = reinterpret_cast<int32_t *>(static_cast<float *>(b->workspace) + off);
         forward_flags |= LRG_FWD_TILE_LISTS;
     }
-    if ((rc = lrg_prepare(slots, rooms, n_slots, params, b->center, b->sample_in, b->sample_nb, b->inlier, b->neighbor,
-                          b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, tile_lists,
-                          stream)))
+    if ((rc = prepare_impl(slots, rooms, n_slots, params, b->center, b->sample_in, b->sample_nb, b->inlier, b->neighbor,
+                           b->gt_remove, b->gt_add, rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, tile_lists,
+                           max_points, stream)))
         return rc;
     if ((rc = lrg_forward_rows(weights, b->inlier, b->neighbor, n_slots, params->n_inlier, params->n_neighbor,
                                rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, b->add_logits, b->rmv_logits,
