@@ -477,7 +477,6 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_compact_kernel(LrgSl
 // one workgroup per (slot, channel); radix select on order-preserving keys
 // ------------------------------------------------------------------------------------------------
 #define LRG_MED_SMALL 1024      // lrg_median (stand-alone): up to 16 keys per lane, one wavefront per (slot, channel)
-#define LRG_MED_PREP 1024       // lrg_prepare: up to 16 keys per lane, rows staged once through LDS for all channels
 #define LRG_MED_LARGE 36864     // 144 KB: one workgroup per CU, only launched work for the few big regions
 __device__ __forceinline__ uint32_t lrg_f2key(float f) {
     uint32_t b = __float_as_uint(f);
@@ -631,8 +630,6 @@ __global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const Lrg
                                                                        int32_t *rows_nb, int32_t *tile_total) {
     __shared__ float sh_c[16];
     __shared__ int sh_src[2][1024];
-    __shared__ float sh_rows[1024 * 16];       // one 1024-row chunk of the current points (median staging)
-    __shared__ int sh_idx[1024];
     const int s = blockIdx.x;
     TRACE2(s, 0);
     const LrgSlot *S = &slots[s];
@@ -679,55 +676,11 @@ __global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const Lrg
     if (threadIdx.x < 16) sh_c[threadIdx.x] = 0.f;
     __syncthreads();
     TRACE2(s, 1);
-    if (nc <= LRG_MED_PREP) {
-        // rows of the current points are fetched ONCE, element-wise (13 contiguous floats per row), into an LDS tile of
-        // 1024 rows; wave k then keeps the keys of the k-th centred channel in registers (stride-13 LDS reads are
-        // conflict-free) and bisects them without further memory traffic
-        int mych = -1;
-        {
-            int k = 0;
-            for (int ch = 0; ch < F; ++ch) {
-                if (!(ch < 2 || ch >= 6)) continue;       // :243-247
-                if (k++ == wave) mych = ch;
-            }
-        }
-        uint32_t key[16];
-        {
-            // indices first (coalesced), then the rows with 8 loads in flight per thread: a plain dependent
-            // idx -> row loop would pay two global round trips per iteration
-            for (int j = threadIdx.x; j < nc; j += blockDim.x) sh_idx[j] = S->cur_idx[j];
-            __syncthreads();
-            const int ne8 = nc * F;
-            for (int e0 = threadIdx.x; e0 < ne8; e0 += 8 * blockDim.x) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = min(e0 + u * (int)blockDim.x, ne8 - 1);
-                    const int j = e / F, f = e - j * F;
-                    v[u] = points[(long)sh_idx[j] * F + f];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * (int)blockDim.x;
-                    if (e < ne8) sh_rows[e] = v[u];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jl = r * 64 + lane;
-                key[r] = (mych >= 0 && jl < nc) ? lrg_f2key(sh_rows[jl * F + mych]) : 0xFFFFFFFFu;
-            }
-        }
-        if (mych >= 0) {
-            float med = nc <= 256 ? lrg_select_regs<4>(reinterpret_cast<const uint32_t (&)[4]>(key), nc)
-                                  : lrg_select_regs<16>(key, nc);
-            if (lane == 0) { sh_c[mych] = med; center[s * 16 + mych] = med; }
-        }
-        if (threadIdx.x < 16 && !((threadIdx.x < 2 || threadIdx.x >= 6) && threadIdx.x < F)) center[s * 16 + threadIdx.x] = 0.f;
-    } else if (threadIdx.x < 16) {
+    // the medians of every slot come from lrg_median_block_kernel, launched just before: one (slot, channel) workgroup each,
+    // a single wavefront for regions up to 1024 points -- nine of them in parallel beat nine waves sharing this workgroup's
+    // staging of the rows (26 -> 12 us for this kernel)
+    if (threadIdx.x < 16)
         sh_c[threadIdx.x] = ((threadIdx.x < 2 || threadIdx.x >= 6) && threadIdx.x < F) ? center[s * 16 + threadIdx.x] : 0.f;
-    }
     __syncthreads();
     TRACE2(s, 2);
 #if LRG_TRACE
@@ -838,6 +791,12 @@ __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *s
     const int nc = S->nc;
     if (nc <= min_points || nc > LRG_MED_REGS) return;                         // wave-level code / large-region kernel
     const LrgRoom *R = &rooms[S->room];
+    if (nc <= 1024) {                                                          // one wavefront, keys in registers, no barriers
+        if (threadIdx.x >= 64) return;
+        const float m = lrg_median_wave(R->points, S->cur_idx, F, ch, nc);
+        if (threadIdx.x == 0) center[s * 16 + ch] = m;
+        return;
+    }
     if (threadIdx.x < 40) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;         // sh[0] = 0xFFFFFFFF (min identity)
     __syncthreads();
     const float *pts = R->points + ch;
@@ -1193,8 +1152,7 @@ static int prepare_impl(const LrgSlot *slots, const LrgRoom *rooms, int n_slots,
     if (!slots || !rooms || !center || !sample_in || !sample_nb || !inlier || !neighbor || n_slots <= 0) return LRG_EINVAL - 1;
     if ((rows_in == nullptr) != (rows_nb == nullptr)) return LRG_EINVAL - 2;
     if (params->n_inlier > 1024 || params->n_neighbor > 1024) return LRG_EINVAL - 3;
-    if ((rc = launch_block_medians(slots, rooms, n_slots, params, center, LRG_MED_PREP, tile_total, max_points, (hipStream_t)stream)))
-        return rc;
+    if ((rc = launch_block_medians(slots, rooms, n_slots, params, center, 0, tile_total, max_points, (hipStream_t)stream))) return rc;
     hipLaunchKernelGGL(lrg_prepare_kernel, dim3(n_slots), dim3(LRG_PREP_THREADS), 0, (hipStream_t)stream, slots, rooms, *params, center,
                        sample_in, sample_nb, inlier, neighbor, gt_remove, gt_add, rows_in, rows_nb, tile_total);
     LRG_LAUNCH_CHECK();
