@@ -127,6 +127,42 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_bbox_scan_kernel(LrgSlot
     atomicMax(&S->scan_mx[0], mx0); atomicMax(&S->scan_mx[1], mx1); atomicMax(&S->scan_mx[2], mx2);
 }
 
+// The same scan by ONE workgroup over the whole room (fused into lrg_advance for greedy growing: a room is at most a few
+// tens of thousands of points, and a launch of its own costs more than the 0.6 MB this reads).  Per-thread partials over
+// all chunks, then a single round of block reductions; thread 0 stores the result where lrg_stop_logic expects it.
+__device__ void lrg_scan_mask_block(LrgSlot *S, const LrgRoom *R, int *red) {
+    const int n = R->n;
+    const uint8_t *cur = S->cur;
+    const int32_t *vox = R->voxels;
+    int cnt = 0;
+    int mn0 = INT_MAX, mn1 = INT_MAX, mn2 = INT_MAX, mx0 = INT_MIN, mx1 = INT_MIN, mx2 = INT_MIN;
+    for (int i0 = 0; i0 < n; i0 += 4 * (int)blockDim.x) {
+        const int ib = i0 + 4 * threadIdx.x;
+        int m[4], a[4], b[4], c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                 // unconditional loads (clamped): no dependent round trips
+            const int i = min(ib + k, n - 1);
+            m[k] = cur[i]; a[k] = vox[3 * i]; b[k] = vox[3 * i + 1]; c[k] = vox[3 * i + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (ib + k < n && m[k]) {
+                ++cnt;
+                mn0 = min(mn0, a[k]); mn1 = min(mn1, b[k]); mn2 = min(mn2, c[k]);
+                mx0 = max(mx0, a[k]); mx1 = max(mx1, b[k]); mx2 = max(mx2, c[k]);
+            }
+        }
+    }
+    cnt = lrg_block_sum(cnt, red);
+    mn0 = lrg_block_min(mn0, red); mn1 = lrg_block_min(mn1, red); mn2 = lrg_block_min(mn2, red);
+    mx0 = lrg_block_max(mx0, red); mx1 = lrg_block_max(mx1, red); mx2 = lrg_block_max(mx2, red);
+    if (threadIdx.x == 0) {
+        S->scan_cnt = cnt;
+        S->scan_mn[0] = mn0; S->scan_mn[1] = mn1; S->scan_mn[2] = mn2;
+        S->scan_mx[0] = mx0; S->scan_mx[1] = mx1; S->scan_mx[2] = mx2;
+    }
+}
+
 // stop / bbox decision of the step just taken (:291-306), from the scan results; run by one thread of lrg_advance
 __device__ void lrg_stop_logic(LrgSlot *S) {
     const int updated = S->updated;
@@ -182,6 +218,7 @@ __device__ void lrg_reset_slot(LrgSlot *S, const LrgRoom *R, int seed, int resta
 }
 
 #define LRG_SEED_TRIES 64   // isolated seeds committed per call before the search is resumed by the next one
+template <bool FUSE_SCAN>     // FUSE_SCAN: do lrg_bbox_stop's scan here (one workgroup per slot; lrg_grow_step, greedy growing)
 __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
                                                                         LrgGrowParams prm, int64_t *stats) {
     __shared__ int sh_next;
@@ -197,6 +234,14 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *
     if (S0->status == LRG_DONE || S0->status == LRG_IDLE) return;
 
     // ---- phase 0: stop / stuck decision of the step just taken, from lrg_bbox_stop's scan ----
+    if (FUSE_SCAN) {
+        __shared__ int red[16];
+        for (int s = 0; s < G && g0 + s < n_slots; ++s) {
+            LrgSlot *S = &slots[g0 + s];
+            if (S->status == LRG_ACTIVE && S->updated >= 0) lrg_scan_mask_block(S, R, red);     // (uniform across the block)
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         int work = 0;
         for (int s = 0; s < G && g0 + s < n_slots; ++s) {
@@ -1091,8 +1136,8 @@ int lrg_advance(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || n_slots <= 0 || n_slots % params->group_size != 0) return LRG_EINVAL - 1;
-    hipLaunchKernelGGL(lrg_advance_kernel, dim3(n_slots / params->group_size), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream, slots,
-                       rooms, n_slots, *params, stats);
+    hipLaunchKernelGGL(lrg_advance_kernel<false>, dim3(n_slots / params->group_size), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream,
+                       slots, rooms, n_slots, *params, stats);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -1216,8 +1261,17 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
     if (rc) return rc;
     if (!slots || !rooms || !weights || !b || n_slots <= 0 || advance_rounds < 1) return LRG_EINVAL - 1;
     if (weights->feature_size != params->feature_size) return LRG_EINVAL - 2;
-    if ((rc = lrg_bbox_stop(slots, rooms, n_slots, max_points, params, stream))) return rc;
-    for (int r = 0; r < advance_rounds; ++r) {
+    if (params->group_size == 1) {
+        // greedy growing: the scan of the updated mask rides in the advance kernel (one workgroup per slot either way)
+        if (n_slots % params->group_size != 0) return LRG_EINVAL - 1;
+        hipLaunchKernelGGL(lrg_advance_kernel<true>, dim3(n_slots), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream, slots, rooms,
+                           n_slots, *params, b->stats);
+        LRG_LAUNCH_CHECK();
+        if ((rc = lrg_box_query(slots, rooms, n_slots, max_points, params, stream))) return rc;
+    } else if ((rc = lrg_bbox_stop(slots, rooms, n_slots, max_points, params, stream))) {
+        return rc;
+    }
+    for (int r = params->group_size == 1 ? 1 : 0; r < advance_rounds; ++r) {
         if ((rc = lrg_advance(slots, rooms, n_slots, params, b->stats, stream))) return rc;
         if ((rc = lrg_box_query(slots, rooms, n_slots, max_points, params, stream))) return rc;
     }
