@@ -1261,7 +1261,9 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
     if (rc) return rc;
     if (!slots || !rooms || !weights || !b || n_slots <= 0 || advance_rounds < 1) return LRG_EINVAL - 1;
     if (weights->feature_size != params->feature_size) return LRG_EINVAL - 2;
-    if (params->group_size == 1) {
+    const bool fuse_scan = params->group_size == 1 && max_points <= 65536;     // (one workgroup scanning a 100 k-point scene is slower
+                                                                               //  than the chunked launch)
+    if (fuse_scan) {
         // greedy growing: the scan of the updated mask rides in the advance kernel (one workgroup per slot either way)
         if (n_slots % params->group_size != 0) return LRG_EINVAL - 1;
         hipLaunchKernelGGL(lrg_advance_kernel<true>, dim3(n_slots), dim3(LRG_SCAN_THREADS), 0, (hipStream_t)stream, slots, rooms,
@@ -1271,7 +1273,7 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
     } else if ((rc = lrg_bbox_stop(slots, rooms, n_slots, max_points, params, stream))) {
         return rc;
     }
-    for (int r = params->group_size == 1 ? 1 : 0; r < advance_rounds; ++r) {
+    for (int r = fuse_scan ? 1 : 0; r < advance_rounds; ++r) {
         if ((rc = lrg_advance(slots, rooms, n_slots, params, b->stats, stream))) return rc;
         if ((rc = lrg_box_query(slots, rooms, n_slots, max_points, params, stream))) return rc;
     }
