@@ -51,28 +51,6 @@ __global__ void lrg_hash_build_kernel(const int32_t *vox, int n, uint64_t *keys,
 // ------------------------------------------------------------------------------------------------
 // block helpers (1024 threads = 16 waves)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lrg_block_min(int v, int *red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    __syncthreads();
-    if (lrg_lane() == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    int nw = blockDim.x >> 6;
-    int r = red[0];
-    for (int i = 1; i < nw; ++i) r = min(r, red[i]);
-    return r;
-}
-__device__ __forceinline__ int lrg_block_max(int v, int *red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    __syncthreads();
-    if (lrg_lane() == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    int nw = blockDim.x >> 6;
-    int r = red[0];
-    for (int i = 1; i < nw; ++i) r = max(r, red[i]);
-    return r;
-}
 __device__ __forceinline__ int lrg_block_sum(int v, int *red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -85,11 +63,38 @@ __device__ __forceinline__ int lrg_block_sum(int v, int *red) {
     return r;
 }
 
+// count + signed min / max of three coordinates over the block in ONE barrier: DPP reductions inside each wavefront, the
+// 16 x 7 partials through LDS, combined by thread 0 (the only consumer).  The seven separate lrg_block_* calls this replaces
+// cost ~2 k cycles each (six LDS-crossbar shuffles, two barriers, a serial read of the partials).
+__device__ __forceinline__ void lrg_block_bbox(int &cnt, int &mn0, int &mn1, int &mn2, int &mx0, int &mx1, int &mx2, int *red7) {
+    const unsigned B = 0x80000000u;                     // order-preserving signed -> unsigned
+    cnt = lrg_wave_sum_i32(cnt);
+    mn0 = (int)(lrg_wave_min_u32((unsigned)mn0 ^ B) ^ B); mn1 = (int)(lrg_wave_min_u32((unsigned)mn1 ^ B) ^ B);
+    mn2 = (int)(lrg_wave_min_u32((unsigned)mn2 ^ B) ^ B);
+    mx0 = (int)(lrg_wave_max_u32((unsigned)mx0 ^ B) ^ B); mx1 = (int)(lrg_wave_max_u32((unsigned)mx1 ^ B) ^ B);
+    mx2 = (int)(lrg_wave_max_u32((unsigned)mx2 ^ B) ^ B);
+    const int w = threadIdx.x >> 6;
+    if (lrg_lane() == 0) {
+        int *r = red7 + 8 * w;
+        r[0] = cnt; r[1] = mn0; r[2] = mn1; r[3] = mn2; r[4] = mx0; r[5] = mx1; r[6] = mx2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int i = 1; i < nw; ++i) {
+            const int *r = red7 + 8 * i;
+            cnt += r[0];
+            mn0 = min(mn0, r[1]); mn1 = min(mn1, r[2]); mn2 = min(mn2, r[3]);
+            mx0 = max(mx0, r[4]); mx1 = max(mx1, r[5]); mx2 = max(mx2, r[6]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // scan of the updated mask (test_region_grow.py:292-293): one workgroup per (slot, 4096-point chunk)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_bbox_scan_kernel(LrgSlot *slots, const LrgRoom *rooms) {
-    __shared__ int red[16];
+    __shared__ int red[16 * 8];
     LrgSlot *S = &slots[blockIdx.x];
     if (S->status != LRG_ACTIVE || S->updated < 0 || S->room < 0) return;
     const LrgRoom *R = &rooms[S->room];
@@ -117,11 +122,8 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_bbox_scan_kernel(LrgSlot
             }
         }
     }
-    cnt = lrg_block_sum(cnt, red);
-    if (cnt == 0) return;
-    mn0 = lrg_block_min(mn0, red); mn1 = lrg_block_min(mn1, red); mn2 = lrg_block_min(mn2, red);
-    mx0 = lrg_block_max(mx0, red); mx1 = lrg_block_max(mx1, red); mx2 = lrg_block_max(mx2, red);
-    if (threadIdx.x != 0) return;
+    lrg_block_bbox(cnt, mn0, mn1, mn2, mx0, mx1, mx2, red);
+    if (threadIdx.x != 0 || cnt == 0) return;
     atomicAdd(&S->scan_cnt, cnt);
     atomicMin(&S->scan_mn[0], mn0); atomicMin(&S->scan_mn[1], mn1); atomicMin(&S->scan_mn[2], mn2);
     atomicMax(&S->scan_mx[0], mx0); atomicMax(&S->scan_mx[1], mx1); atomicMax(&S->scan_mx[2], mx2);
@@ -136,26 +138,26 @@ __device__ void lrg_scan_mask_block(LrgSlot *S, const LrgRoom *R, int *red) {
     const int32_t *vox = R->voxels;
     int cnt = 0;
     int mn0 = INT_MAX, mn1 = INT_MAX, mn2 = INT_MAX, mx0 = INT_MIN, mx1 = INT_MIN, mx2 = INT_MIN;
-    for (int i0 = 0; i0 < n; i0 += 4 * (int)blockDim.x) {
-        const int ib = i0 + 4 * threadIdx.x;
-        int m[4], a[4], b[4], c[4];
+    // 16 points per thread per trip, every load of a trip issued before the first use (the trip count is a run-time value:
+    // left to itself the loop pays one memory round trip per 4 points)
+    for (int i0 = 0; i0 < n; i0 += 16 * (int)blockDim.x) {
+        int m[16], a[16], b[16], c[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                 // unconditional loads (clamped): no dependent round trips
-            const int i = min(ib + k, n - 1);
+        for (int k = 0; k < 16; ++k) {                // unconditional loads (clamped): no dependent round trips
+            const int i = min(i0 + (k >> 2) * 4 * (int)blockDim.x + 4 * (int)threadIdx.x + (k & 3), n - 1);
             m[k] = cur[i]; a[k] = vox[3 * i]; b[k] = vox[3 * i + 1]; c[k] = vox[3 * i + 2];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (ib + k < n && m[k]) {
+        for (int k = 0; k < 16; ++k) {
+            const int i = i0 + (k >> 2) * 4 * (int)blockDim.x + 4 * (int)threadIdx.x + (k & 3);
+            if (i < n && m[k]) {
                 ++cnt;
                 mn0 = min(mn0, a[k]); mn1 = min(mn1, b[k]); mn2 = min(mn2, c[k]);
                 mx0 = max(mx0, a[k]); mx1 = max(mx1, b[k]); mx2 = max(mx2, c[k]);
             }
         }
     }
-    cnt = lrg_block_sum(cnt, red);
-    mn0 = lrg_block_min(mn0, red); mn1 = lrg_block_min(mn1, red); mn2 = lrg_block_min(mn2, red);
-    mx0 = lrg_block_max(mx0, red); mx1 = lrg_block_max(mx1, red); mx2 = lrg_block_max(mx2, red);
+    lrg_block_bbox(cnt, mn0, mn1, mn2, mx0, mx1, mx2, red);
     if (threadIdx.x == 0) {
         S->scan_cnt = cnt;
         S->scan_mn[0] = mn0; S->scan_mn[1] = mn1; S->scan_mn[2] = mn2;
@@ -234,14 +236,16 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *
     if (S0->status == LRG_DONE || S0->status == LRG_IDLE) return;
 
     // ---- phase 0: stop / stuck decision of the step just taken, from lrg_bbox_stop's scan ----
+    TRACE2(g0, 9);
     if (FUSE_SCAN) {
-        __shared__ int red[16];
+        __shared__ int red[16 * 8];
         for (int s = 0; s < G && g0 + s < n_slots; ++s) {
             LrgSlot *S = &slots[g0 + s];
             if (S->status == LRG_ACTIVE && S->updated >= 0) lrg_scan_mask_block(S, R, red);     // (uniform across the block)
         }
         __syncthreads();
     }
+    TRACE2(g0, 10);
     if (threadIdx.x == 0) {
         int work = 0;
         for (int s = 0; s < G && g0 + s < n_slots; ++s) {
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *
     if (!sh_flag) return;      // every slot of the group keeps growing: nothing to bank, commit or reseed
     __syncthreads();
 
+    TRACE2(g0, 11);
     // ---- phase 1: bank finished grows, start the slot's next restart (restart :173-175,:187-197) ----
     for (int s = 0; s < G && g0 + s < n_slots; ++s) {
         LrgSlot *S = &slots[g0 + s];
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *
         __syncthreads();
     }
 
+    TRACE2(g0, 12);
     // ---- phase 2: when every slot of the group waits, commit the seed ----
     if (threadIdx.x == 0) {
         int all_wait = 1;
@@ -324,6 +330,7 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *
         __syncthreads();
     }
 
+    TRACE2(g0, 13);
     // ---- next unvisited seed in curvature order (:186-188) ----
     // The first box query of a fresh seed (:221-229 with mn = mx = the seed's voxel) is answered here from the room's voxel
     // hash: an equalised room has one point per voxel, so the candidates are the unvisited points of the 26 surrounding
@@ -394,6 +401,7 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *
         }
         __syncthreads();
     }
+    TRACE2(g0, 14);
     if (threadIdx.x == 0) R->seed_cursor = cursor;
     if (seed < 0) {
         // try budget spent on isolated points: park the group as a fresh binding, the next call continues the search
@@ -417,6 +425,7 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *
         }
         __syncthreads();
     }
+    TRACE2(g0, 15);
 }
 
 // ------------------------------------------------------------------------------------------------
