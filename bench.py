@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--fuse-pool', type=int, default=0)
     ap.add_argument('--net-mode', default='fused', choices=['fused', 'streamed'])
     ap.add_argument('--advance-rounds', type=int, default=1)
+    ap.add_argument('--lanes', type=int, default=2, help='half-batches on their own HIP streams (LanedRegionGrower); 1 = one stream')
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
     ap.add_argument('--p0-rooms', type=int, default=4, help='rooms of the preprocessing (P0) side measurement (0 = skip)')
@@ -182,19 +183,35 @@ def main():
     else:
         rooms = workloads.area5_rooms(args.rooms, seed_base=1000 + 100 * rank, cache_dir=args.cache)
     net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, fuse_pool=bool(args.fuse_pool), mode=args.net_mode).load_weights(weights)
-    gr = RegionGrower(net, rooms_in_flight=len(rooms), restarts=args.restarts, rng='counter', seed=rank,
-                      policy=args.policy, advance_rounds=args.advance_rounds, resolution=resolution)
-    gr.load_rooms(rooms)
-    for g in range(gr.n_groups):
-        gr.bind(g, g)
+    # the rooms in flight dealt over `lanes` growers, each on its own stream (largest rooms first, round the lanes)
+    n_lanes = max(1, min(args.lanes, len(rooms)))
+    by_size = sorted(range(len(rooms)), key=lambda i: -len(rooms[i]['points']))
+    parts = [[rooms[i] for i in by_size[k::n_lanes]] for k in range(n_lanes)]
+    lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)] if n_lanes > 1 else [torch.cuda.current_stream(dev)]
+    growers = []
+    for k in range(n_lanes):
+        with torch.cuda.stream(lane_streams[k]):
+            g_ = RegionGrower(net, rooms_in_flight=len(parts[k]), restarts=args.restarts, rng='counter', seed=rank,
+                              policy=args.policy, advance_rounds=args.advance_rounds, resolution=resolution)
+            g_.load_rooms(parts[k])
+            for g in range(g_.n_groups):
+                g_.bind(g, g)
+            growers.append(g_)
+    gr = growers[0]
+    torch.cuda.synchronize()
 
     def iterate(k):
         for _ in range(k):
-            gr.enqueue_iteration()
-            for g in gr.poll_done():          # finished rooms restart at once: the set is cycled
-                r = gr.group_room[g]
-                gr.reset_room(r)
-                gr.bind(g, r)
+            for lane, g_ in enumerate(growers):
+                with torch.cuda.stream(lane_streams[lane]):
+                    g_.enqueue_iteration()
+                    for g in g_.poll_done():          # finished rooms restart at once: the set is cycled
+                        r = g_.group_room[g]
+                        g_.reset_room(r)
+                        g_.bind(g, r)
+
+    def read_stats():
+        return sum(g_.d_stats[:3].cpu().numpy().astype(np.float64) for g_ in growers)
 
     def barrier():
         if world > 1:
@@ -203,25 +220,29 @@ def main():
 
     iterate(args.warmup)
     barrier()
-    s0 = gr.d_stats[:3].cpu().numpy().copy()
+    s0 = read_stats()
     t0 = time.perf_counter()
     iterate(args.steps)
     barrier()
     t1 = time.perf_counter()
-    s1 = gr.d_stats[:3].cpu().numpy().copy()
+    s1 = read_stats()
     elapsed = lrg_dist.allreduce_max(t1 - t0, device=coll_dev)
     inst_steps, rooms_done, seeds = lrg_dist.allreduce_sum([float(s1[2] - s0[2]), float(s1[1] - s0[1]), float(s1[0] - s0[0])],
                                                            device=coll_dev)
 
     # ---- roofline of the LrgNet evaluation (the dominant kernels), HIP events on the launch stream ----
-    S = gr.S
+    # (one dense batch of all the instances in flight on this GPU, the stacked inputs of the lanes' last iteration)
+    S = sum(g_.S for g_ in growers)
+    b_inl, b_nbr = torch.cat([g_.b_inl for g_ in growers]), torch.cat([g_.b_nbr for g_ in growers])
+    b_add, b_rmv = torch.cat([g_.b_add for g_ in growers]), torch.cat([g_.b_rmv for g_ in growers])
+    b_rows_in, b_rows_nb = torch.cat([g_.b_rows_in for g_ in growers]), torch.cat([g_.b_rows_nb for g_ in growers])
     reps = 20
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    net.forward(gr.b_inl, gr.b_nbr, gr.b_add, gr.b_rmv)
+    net.forward(b_inl, b_nbr, b_add, b_rmv)
     torch.cuda.synchronize()
     ev0.record()
     for _ in range(reps):
-        net.forward(gr.b_inl, gr.b_nbr, gr.b_add, gr.b_rmv)
+        net.forward(b_inl, b_nbr, b_add, b_rmv)
     ev1.record()
     torch.cuda.synchronize()
     fwd_ms = ev0.elapsed_time(ev1) / reps
@@ -230,10 +251,10 @@ def main():
     # the same evaluation as the grow loop issues it: only the distinct leading rows of each padded set
     rows_frac, fwd_rows_ms = 1.0, fwd_ms
     if gr.skip_duplicate_rows:
-        rows_frac = float((gr.b_rows_in.float().mean() + gr.b_rows_nb.float().mean()).item()) / 1024.0
+        rows_frac = float((b_rows_in.float().mean() + b_rows_nb.float().mean()).item()) / 1024.0
         ev0.record()
         for _ in range(reps):
-            net.forward(gr.b_inl, gr.b_nbr, gr.b_add, gr.b_rmv, rows_in=gr.b_rows_in, rows_nb=gr.b_rows_nb)
+            net.forward(b_inl, b_nbr, b_add, b_rmv, rows_in=b_rows_in, rows_nb=b_rows_nb)
         ev1.record()
         torch.cuda.synchronize()
         fwd_rows_ms = ev0.elapsed_time(ev1) / reps
@@ -267,7 +288,7 @@ def main():
                                     'S3DIS Area-5-shaped synthetic rooms (68-room set per GPU, all in flight, cycled)') +
                                    (', greedy test_region_grow.py loop' if args.restarts == 1 else
                                     ', test_random_restart.py loop with %d restarts per seed batched per launch' % args.restarts),
-                       'rooms_in_flight_per_gpu': len(rooms), 'slots_per_gpu': S, 'policy': args.policy,
+                       'rooms_in_flight_per_gpu': len(rooms), 'slots_per_gpu': S, 'lanes': n_lanes, 'policy': args.policy,
                        'restarts': args.restarts, 'points': '512 inlier + 512 neighbour x 13 features',
                        'rng': 'counter (Philox) stream', 'weights': 'synthetic, seed 0', 'net_mode': args.net_mode,
                        'active_fraction': inst_steps / (args.steps * S * world)},

@@ -419,3 +419,85 @@ class RegionGrower:
     @property
     def instance_steps(self):
         return int(self.d_stats[2].item())
+
+
+class LanedRegionGrower:
+    """The rooms in flight dealt over `lanes` RegionGrower instances, each on its own HIP stream.
+
+    Within one lane an iteration is a strict chain: a dozen small, latency-bound loop kernels, then the LrgNet evaluation that
+    fills the chip, then the mask update.  Two lanes half a batch each let one lane's loop kernels run in the shadow of the
+    other's network evaluation (+8 % instance-steps/s at 68 rooms on one MI355X).  Rooms are independent and the counter
+    random stream is keyed by room id, so results do not depend on the lane count (tests/test_gpu_grow.py)."""
+
+    def __init__(self, net, rooms_in_flight=64, lanes=2, **kw):
+        if kw.get('rng', 'counter') != 'counter':
+            raise ValueError("lanes need rng='counter' (the legacy stream is replayed on the host, one iteration at a time)")
+        self.net = net
+        lanes = max(1, min(int(lanes), int(rooms_in_flight)))
+        share = [rooms_in_flight // lanes + (1 if k < rooms_in_flight % lanes else 0) for k in range(lanes)]
+        self.streams = [torch.cuda.Stream(device=net.device) for _ in range(lanes)]
+        self.growers = []
+        for k in range(lanes):
+            with torch.cuda.stream(self.streams[k]):
+                self.growers.append(RegionGrower(net, rooms_in_flight=share[k], **kw))
+        self.where = []          # original room index -> (lane, index within the lane)
+
+    def load_rooms(self, rooms):
+        L = len(self.growers)
+        order = sorted(range(len(rooms)), key=lambda i: -len(rooms[i]['points']))     # largest first, dealt round the lanes
+        parts = [[] for _ in range(L)]
+        self.where = [None] * len(rooms)
+        for j, i in enumerate(order):
+            k = j % L
+            self.where[i] = (k, len(parts[k]))
+            room = dict(rooms[i])
+            room.setdefault('room_id', i)
+            parts[k].append(room)
+        for k, gr in enumerate(self.growers):
+            gr.n_rooms = 0
+            if parts[k]:
+                with torch.cuda.stream(self.streams[k]):
+                    gr.load_rooms(parts[k])
+        torch.cuda.synchronize()
+
+    def run(self, rooms, fill=True):
+        """Grow every room once; RoomResults in input order."""
+        self.load_rooms(rooms)
+        queues, finished = [], 0
+        for k, gr in enumerate(self.growers):
+            with torch.cuda.stream(self.streams[k]):
+                q = list(range(gr.n_rooms))
+                if gr.n_rooms:
+                    for g in range(gr.n_groups):
+                        gr.bind(g, q.pop(0) if q else -1)
+                queues.append(q)
+        total = sum(gr.n_rooms for gr in self.growers)
+        live = [gr.n_rooms > 0 for gr in self.growers]
+        done = [0] * len(self.growers)
+        while finished < total:
+            for k, gr in enumerate(self.growers):
+                if not live[k]:
+                    continue
+                with torch.cuda.stream(self.streams[k]):
+                    gr.enqueue_iteration()
+                    for g in gr.poll_done():
+                        r = gr.group_room[g]
+                        if fill:
+                            gr.fill(r)
+                        finished += 1
+                        done[k] += 1
+                        gr.bind(g, queues[k].pop(0) if queues[k] else -1)
+                    live[k] = done[k] < gr.n_rooms
+        torch.cuda.synchronize()
+        return self.collect(fill)
+
+    def collect(self, fill=True):
+        per_lane = []
+        for k, gr in enumerate(self.growers):
+            with torch.cuda.stream(self.streams[k]):
+                per_lane.append(gr.collect(fill) if gr.n_rooms else [])
+        return [per_lane[k][j] for k, j in self.where]
+
+    @property
+    def instance_steps(self):
+        return sum(gr.instance_steps for gr in self.growers)

@@ -157,6 +157,21 @@ def test_results_do_not_depend_on_batching(net):
         np.testing.assert_array_equal(x.filled_label, y.filled_label)
 
 
+@pytest.mark.parametrize('lanes,in_flight', [(2, 4), (3, 3), (4, 2)])
+def test_lanes_do_not_change_results(net, lanes, in_flight):
+    """Two or more lanes (half-batches on their own HIP streams, LanedRegionGrower) give the labels of one lane; more lanes
+    than rooms in flight, or than rooms, degrade gracefully."""
+    from learn_region_grow_amd.grow import LanedRegionGrower, RegionGrower
+    rooms = [small_room(610 + i, 500 + 120 * i, room_id=40 + i) for i in range(5)]
+    a = RegionGrower(net, rooms_in_flight=2, rng='counter', seed=11, policy='gt').run(rooms)
+    b = LanedRegionGrower(net, rooms_in_flight=in_flight, lanes=lanes, rng='counter', seed=11, policy='gt').run(rooms)
+    assert [x.room_id for x in b] == [x.room_id for x in a]
+    for x, y in zip(a, b):
+        same_regions(y.regions, x.regions)
+        np.testing.assert_array_equal(x.cluster_label, y.cluster_label)
+        np.testing.assert_array_equal(x.filled_label, y.filled_label)
+
+
 def test_unequalised_room_is_rejected(net):
     from learn_region_grow_amd.grow import RegionGrower
     from learn_region_grow_amd._lib import LrgHipError
