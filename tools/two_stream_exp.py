@@ -27,12 +27,20 @@ for k in range(nsplit):
 torch.cuda.synchronize()
 
 
+host = [0.0, 0.0]
+
+
 def iterate(n):
     for _ in range(n):
         for k, gr in enumerate(growers):
             with torch.cuda.stream(streams[k]):
+                h0 = time.perf_counter()
                 gr.enqueue_iteration()
-                for g in gr.poll_done():
+                h1 = time.perf_counter()
+                done = gr.poll_done()
+                host[0] += h1 - h0
+                host[1] += time.perf_counter() - h1
+                for g in done:
                     r = gr.group_room[g]
                     gr.reset_room(r)
                     gr.bind(g, r)
@@ -46,4 +54,4 @@ iterate(1000)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 s1 = sum(int(g.d_stats[2].item()) for g in growers)
-print('%d stream(s): %.0f instance-steps/s, %.3f ms per round of iterations' % (nsplit, (s1 - s0) / dt, dt))
+print('%d stream(s): %.0f instance-steps/s, %.3f ms per round of iterations; host: enqueue %.1f us, poll %.1f us per lane-iteration' % (nsplit, (s1 - s0) / dt, dt, host[0] / (1100 * nsplit) * 1e6, host[1] / (1100 * nsplit) * 1e6))
