@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--fuse-pool', type=int, default=0)
     ap.add_argument('--net-mode', default='fused', choices=['fused', 'streamed'])
     ap.add_argument('--advance-rounds', type=int, default=1)
+    ap.add_argument('--fill', type=int, default=1, help='1: finished rooms get their 1-NN fill-in before they are recycled (rooms/sec as defined)')
     ap.add_argument('--lanes', type=int, default=2, help='half-batches on their own HIP streams (LanedRegionGrower); 1 = one stream')
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
@@ -205,8 +206,10 @@ def main():
             for lane, g_ in enumerate(growers):
                 with torch.cuda.stream(lane_streams[lane]):
                     g_.enqueue_iteration()
-                    for g in g_.poll_done():          # finished rooms restart at once: the set is cycled
+                    for g in g_.poll_done():          # finished rooms get their fill-in (:308-316) and restart at once
                         r = g_.group_room[g]
+                        if args.fill:
+                            g_.fill(r)
                         g_.reset_room(r)
                         g_.bind(g, r)
 

@@ -312,6 +312,11 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
 
 /* 1-NN fill-in of unlabeled points in all F feature dims, first-min ties (:308-316). */
 int lrg_nn1_fill(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *stream);
+/* The same result through a tiled search that reads the candidate rows once per 64 unlabeled points.  workspace: lrg_nn1_fill_workspace_bytes(n) bytes of device memory, 256-byte aligned.  F <= 13.  (A NaN distance
+ * sorts after every number here; numpy.argmin would return the first NaN.) */
+size_t lrg_nn1_fill_workspace_bytes(int n);
+int lrg_nn1_fill_ws(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *workspace,
+                    size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * tf_ops/grouping replacements.  Same argument order as the reference launchers

@@ -134,6 +134,8 @@ _SIGS = {
     'lrg_grow_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgWeights),
                                      ctypes.POINTER(LrgStepBuffers), ctypes.c_int, ctypes.c_uint, _fp]),
     'lrg_nn1_fill': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
+    'lrg_nn1_fill_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
+    'lrg_nn1_fill_ws': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]),
     'lrg_query_ball_point': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _fp,
                                             _fp, _fp, _fp, _fp]),
     'lrg_selection_sort': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),

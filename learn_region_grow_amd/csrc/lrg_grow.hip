@@ -1097,6 +1097,67 @@ __global__ __launch_bounds__(256) void lrg_nn1_fill_kernel(const float *points, 
     }
 }
 
+// The tiled formulation (lrg_nn1_fill_ws): the unlabeled points are compacted into a list; a workgroup takes 64 of them (one
+// per lane, the query row in registers) and a chunk of 256 candidate rows staged in LDS -- every lane of a wavefront reads the
+// same candidate row at the same time (LDS broadcast), the four wavefronts split the chunk -- and publishes its best
+// (distance, index) with one 64-bit atomicMin per query: the distance is a non-negative float, so (bits << 32 | index) orders
+// exactly like "smallest distance, then smallest index" (numpy.argmin's first minimum).  Candidate rows are read once per 64
+// queries instead of once per query.
+#define LRG_NN1_Q 64
+#define LRG_NN1_C 256
+__global__ void lrg_nn1_prep_kernel(const int32_t *label_in, int n, int32_t *list, int32_t *count, unsigned long long *best) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    best[i] = ~0ull;
+    if (label_in[i] == 0) list[atomicAdd(count, 1)] = i;
+}
+
+__global__ __launch_bounds__(256) void lrg_nn1_search_kernel(const float *points, int n, int F, const int32_t *label_in,
+                                                              const int32_t *list, const int32_t *count, unsigned long long *best) {
+    __shared__ float rows[LRG_NN1_C * 13 + 64];
+    __shared__ int lab[LRG_NN1_C];
+    __shared__ unsigned long long part[4][LRG_NN1_Q];
+    const int U = *count;
+    if ((int)blockIdx.x * LRG_NN1_Q >= U) return;                  // (the host does not know U: a fixed, small number of query
+                                                                   //  columns, each looping over its share of the list)
+    const int c0 = blockIdx.y * LRG_NN1_C;
+    const int nc = min(LRG_NN1_C, n - c0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < nc * F; e += blockDim.x) rows[e] = points[(long)c0 * F + e];       // contiguous block of rows
+    for (int r = threadIdx.x; r < nc; r += blockDim.x) lab[r] = label_in[c0 + r];
+    const int per = (nc + 3) / 4;
+    for (int q0 = blockIdx.x * LRG_NN1_Q; q0 < U; q0 += gridDim.x * LRG_NN1_Q) {
+        const int qi = list[min(q0 + lane, U - 1)];
+        float me[16];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) me[l] = l < F ? points[(long)qi * F + l] : 0.f;
+        __syncthreads();                                               // rows staged / part[] of the previous round consumed
+        unsigned long long bk = ~0ull;
+        const int r1 = min(nc, (wave + 1) * per);
+#pragma unroll 4
+        for (int r = wave * per; r < r1; ++r) {                                          // branch-free: four candidates in flight
+            const float d = lrg_np_sqdist(rows + r * F, me, F);
+            const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(c0 + r);
+            bk = min(bk, lab[r] != 0 ? k : ~0ull);
+        }
+        part[wave][lane] = bk;
+        __syncthreads();
+        if (wave == 0 && q0 + lane < U) {
+            bk = min(min(part[0][lane], part[1][lane]), min(part[2][lane], part[3][lane]));
+            if (bk != ~0ull) atomicMin(&best[qi], bk);
+        }
+    }
+}
+
+__global__ void lrg_nn1_write_kernel(const int32_t *label_in, int n, const unsigned long long *best, int32_t *label_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int li = label_in[i];
+    if (li != 0) { label_out[i] = li; return; }
+    const unsigned long long k = best[i];
+    label_out[i] = k == ~0ull ? 0 : label_in[(int)(k & 0xFFFFFFFFull)];
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -1304,6 +1365,26 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
     return lrg_mask_update(slots, rooms, n_slots, params, b->inlier, b->neighbor, b->center, b->add_logits,
                            b->rmv_logits, b->gt_remove, b->gt_add, nullptr, nullptr, rows ? b->sample_in : nullptr,
                            rows ? b->sample_nb : nullptr, b->stats, stream);
+}
+
+size_t lrg_nn1_fill_workspace_bytes(int n) { return n <= 0 ? 0 : lrg_align_up((size_t)n * 4 + 64, 256) + (size_t)n * 8; }
+
+int lrg_nn1_fill_ws(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *workspace,
+                    size_t workspace_bytes, void *stream) {
+    if (!points || !label_in || !label_out || n < 0 || F < 1 || F > 13) return LRG_EINVAL - 1;
+    if (n == 0) return 0;
+    if (!workspace || workspace_bytes < lrg_nn1_fill_workspace_bytes(n) || ((uintptr_t)workspace & 255)) return LRG_EINVAL - 2;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *count = static_cast<int32_t *>(workspace);
+    int32_t *list = count + 16;
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + lrg_align_up((size_t)n * 4 + 64, 256));
+    LRG_HIP_CHECK(hipMemsetAsync(count, 0, 64, st));
+    hipLaunchKernelGGL(lrg_nn1_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, label_in, n, list, count, best);
+    hipLaunchKernelGGL(lrg_nn1_search_kernel, dim3(min(16, (n + LRG_NN1_Q - 1) / LRG_NN1_Q), (n + LRG_NN1_C - 1) / LRG_NN1_C), dim3(256), 0, st,
+                       points, n, F, label_in, list, count, best);
+    hipLaunchKernelGGL(lrg_nn1_write_kernel, dim3((n + 255) / 256), dim3(256), 0, st, label_in, n, best, label_out);
+    LRG_LAUNCH_CHECK();
+    return 0;
 }
 
 int lrg_nn1_fill(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *stream) {

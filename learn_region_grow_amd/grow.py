@@ -94,6 +94,7 @@ class RegionGrower:
         offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
         tot = int(offs[-1])
         self.room_n, self.room_off, self.n_rooms = ns, offs, len(rooms)
+        self._fill_ws = None
         pts = np.concatenate([np.ascontiguousarray(r['points'], dtype=np.float32) for r in rooms], axis=0)
         assert pts.shape[1] == F
         self.d_points = torch.from_numpy(pts).to(dev)
@@ -237,11 +238,15 @@ class RegionGrower:
         self.group_room[group] = r
 
     def fill(self, r):
+        """1-NN fill-in of room r's unlabeled points (test_region_grow.py:308-316) into d_filled."""
         o, n = int(self.room_off[r]), self.room_n[r]
         F = self.net.feature_size
-        _lib.check(self.lib.lrg_nn1_fill(ctypes.c_void_p(self.d_points.data_ptr() + o * F * 4), n, F,
-                                         ctypes.c_void_p(self.d_label.data_ptr() + o * 4),
-                                         ctypes.c_void_p(self.d_filled.data_ptr() + o * 4), _stream_ptr()), 'lrg_nn1_fill')
+        if getattr(self, '_fill_ws', None) is None:
+            self._fill_ws = torch.empty(self.lib.lrg_nn1_fill_workspace_bytes(max(self.room_n)), dtype=torch.uint8, device=self.dev)
+        _lib.check(self.lib.lrg_nn1_fill_ws(ctypes.c_void_p(self.d_points.data_ptr() + o * F * 4), n, F,
+                                            ctypes.c_void_p(self.d_label.data_ptr() + o * 4),
+                                            ctypes.c_void_p(self.d_filled.data_ptr() + o * 4), _ptr(self._fill_ws),
+                                            self._fill_ws.numel(), _stream_ptr()), 'lrg_nn1_fill_ws')
 
     # ------------------------------------------------------------------------------------------
     def enqueue_iteration(self):

@@ -80,3 +80,28 @@ def test_nn1_fill(cuda_device, hip_lib, F):
     dP, dlab = dev(P, cuda_device), dev(lab, cuda_device)      # keep the device buffers alive across the launch
     _lib.check(hip_lib.lrg_nn1_fill(_ptr(dP), 3000, F, _ptr(dlab), _ptr(out), _stream_ptr()), 'nn1')
     np.testing.assert_array_equal(out.cpu().numpy(), grow_ref.fill_unlabeled(P, lab.astype(np.int64)))
+
+
+@pytest.mark.parametrize('F,n,frac', [(13, 3000, 0.3), (6, 5000, 0.9), (12, 1037, 0.02), (9, 64, 0.5), (13, 2500, 0.0), (13, 700, 1.0)])
+def test_nn1_fill_tiled(cuda_device, hip_lib, F, n, frac):
+    """lrg_nn1_fill_ws (tiled, 64-bit atomicMin on (distance bits, index)) equals the oracle and the one-workgroup-per-point
+    kernel: same float32 distances, first minimum on ties; nothing labeled -> all zero; everything labeled -> copy."""
+    import torch
+    from learn_region_grow_amd import _lib
+    from learn_region_grow_amd.lrgnet import _ptr, _stream_ptr
+    rs = np.random.RandomState(n + F)
+    P = (rs.randn(n, F) * 10 ** rs.uniform(-2, 2, (n, F))).astype(np.float32)
+    P[n // 3] = P[n // 2]                                   # an exact tie between two candidates
+    P[5] = P[6]
+    lab = ((rs.rand(n) < frac) * rs.randint(1, 9, n)).astype(np.int32)
+    want = grow_ref.fill_unlabeled(P, lab.astype(np.int64)) if 0 < (lab != 0).sum() else lab.astype(np.int64)
+    dP, dlab = dev(P, cuda_device), dev(lab, cuda_device)
+    out = torch.full((n,), -7, dtype=torch.int32, device=cuda_device)
+    ws = torch.empty(hip_lib.lrg_nn1_fill_workspace_bytes(n), dtype=torch.uint8, device=cuda_device)
+    for _ in range(2):                                      # the workspace is reusable
+        _lib.check(hip_lib.lrg_nn1_fill_ws(_ptr(dP), n, F, _ptr(dlab), _ptr(out), _ptr(ws), ws.numel(), _stream_ptr()), 'nn1 ws')
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+    ref = torch.zeros(n, dtype=torch.int32, device=cuda_device)
+    _lib.check(hip_lib.lrg_nn1_fill(_ptr(dP), n, F, _ptr(dlab), _ptr(ref), _stream_ptr()), 'nn1')
+    np.testing.assert_array_equal(ref.cpu().numpy(), want)
+    assert hip_lib.lrg_nn1_fill_ws(_ptr(dP), n, F, _ptr(dlab), _ptr(out), _ptr(ws), 16, _stream_ptr()) <= -1000

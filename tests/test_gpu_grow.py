@@ -217,3 +217,30 @@ def test_tiny_rooms(net, n):
     same_regions(res.regions, want.regions)
     np.testing.assert_array_equal(res.filled_label, want.filled_label)
     assert sum(r['points'] for r in res.regions) == n
+
+
+@pytest.mark.parametrize('pattern', ['scattered', 'corner', 'none', 'all'])
+def test_room_fill_in(net, pattern):
+    """RegionGrower.fill (tiled 1-NN search) equals the oracle's exhaustive search on every labelling: scattered holes,
+    labels only in one corner, nothing labeled, everything labeled."""
+    import torch
+    from learn_region_grow_amd.grow import RegionGrower
+    room = small_room(77, 2500, furniture=3, room_id=3)
+    n = len(room['points'])
+    rs = np.random.RandomState(1)
+    if pattern == 'scattered':
+        lab = ((rs.rand(n) < 0.7) * rs.randint(1, 30, n)).astype(np.int32)
+    elif pattern == 'corner':
+        lab = ((room['points'][:, 3] < 0.2) & (room['points'][:, 4] < 0.3)).astype(np.int32) * rs.randint(1, 5, n).astype(np.int32)
+    elif pattern == 'none':
+        lab = np.zeros(n, np.int32)
+    else:
+        lab = rs.randint(1, 9, n).astype(np.int32)
+    gr = RegionGrower(net, rooms_in_flight=1, rng='counter')
+    gr.load_rooms([room])
+    gr.d_label[:n].copy_(torch.from_numpy(lab).to(gr.d_label.device))
+    gr.fill(0)
+    torch.cuda.synchronize()
+    got = gr.d_filled[:n].cpu().numpy()
+    want = grow_ref.fill_unlabeled(room['points'], lab.astype(np.int64)) if (lab != 0).any() else lab
+    np.testing.assert_array_equal(got, want)
