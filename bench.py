@@ -49,7 +49,7 @@ def parse():
     ap.add_argument('--net-mode', default='fused', choices=['fused', 'streamed'])
     ap.add_argument('--advance-rounds', type=int, default=1)
     ap.add_argument('--fill', type=int, default=1, help='1: finished rooms get their 1-NN fill-in before they are recycled (rooms/sec as defined)')
-    ap.add_argument('--lanes', type=int, default=2, help='half-batches on their own HIP streams (LanedRegionGrower); 1 = one stream')
+    ap.add_argument('--lanes', type=int, default=0, help='half-batches on their own HIP streams; 0 = auto (2 from 64 rooms in flight, else 1)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
     ap.add_argument('--p0-rooms', type=int, default=4, help='rooms of the preprocessing (P0) side measurement (0 = skip)')
@@ -152,7 +152,7 @@ def main():
     import torch.distributed as dist
     from learn_region_grow_amd import synthetic, workloads, dist as lrg_dist
     from learn_region_grow_amd.lrgnet import LrgNetHIP
-    from learn_region_grow_amd.grow import RegionGrower
+    from learn_region_grow_amd.grow import RegionGrower, auto_lanes
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -185,7 +185,7 @@ def main():
         rooms = workloads.area5_rooms(args.rooms, seed_base=1000 + 100 * rank, cache_dir=args.cache)
     net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, fuse_pool=bool(args.fuse_pool), mode=args.net_mode).load_weights(weights)
     # the rooms in flight dealt over `lanes` growers, each on its own stream (largest rooms first, round the lanes)
-    n_lanes = max(1, min(args.lanes, len(rooms)))
+    n_lanes = max(1, min(args.lanes, len(rooms))) if args.lanes > 0 else auto_lanes(len(rooms) * args.restarts)
     by_size = sorted(range(len(rooms)), key=lambda i: -len(rooms[i]['points']))
     parts = [[rooms[i] for i in by_size[k::n_lanes]] for k in range(n_lanes)]
     lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)] if n_lanes > 1 else [torch.cuda.current_stream(dev)]

@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--rooms-in-flight', type=int, default=68)
     ap.add_argument('--max-rooms', type=int, default=0)
     ap.add_argument('--device', default='cuda:0')
-    ap.add_argument('--lanes', type=int, default=2, help='half-batches on their own HIP streams (counter stream only)')
+    ap.add_argument('--lanes', type=int, default=0, help='half-batches on their own HIP streams (counter stream only); 0 = auto')
     ap.add_argument('--preprocess', default='gpu-lapack', choices=['gpu-lapack', 'gpu', 'host'],
                     help="equalisation / normals / curvature (test_region_grow.py:119-173): 'gpu-lapack' = GPU gathering and "
                          "covariances + the reference's numpy.linalg.svd on the host (bit-identical features); 'gpu' = all on the "
@@ -111,7 +111,7 @@ def main():
                  for r, p in enumerate(pre)]
         kw = dict(rooms_in_flight=min(args.rooms_in_flight, n_rooms), restarts=max(1, args.restarts), rng=args.rng,
                   seed=args.seed, policy=args.policy, resolution=args.resolution)
-        gr = LanedRegionGrower(net, lanes=args.lanes, **kw) if args.rng == 'counter' and args.lanes > 1 else RegionGrower(net, **kw)
+        gr = LanedRegionGrower(net, lanes=args.lanes, **kw) if args.rng == 'counter' and args.lanes != 1 else RegionGrower(net, **kw)
         t0 = time.time()
         results = gr.run(rooms)
         t_grow = time.time() - t0
