@@ -86,7 +86,7 @@ def golden_lrgnet(lite, feature_size, n_in, n_nb, batch, seed):
     print('wrote', name)
 
 
-def run_reference_script(script, argv, raw_room, tag):
+def run_reference_script(script, argv, raw_room, tag, init_globals=None):
     """Execute a reference top-level script unmodified on ONE synthetic room."""
     standin.install()
     for m in ('learn_region_grow_util', 'class_util'):
@@ -104,7 +104,7 @@ def run_reference_script(script, argv, raw_room, tag):
         sys.path.insert(0, REF)
         sys.argv = [script] + argv
         with contextlib.redirect_stdout(buf):
-            g = runpy.run_path(os.path.join(REF, script), run_name='__main__')
+            g = runpy.run_path(os.path.join(REF, script), init_globals=init_globals, run_name='__main__')
     finally:
         sys.argv = old_argv
         os.chdir(old_cwd)
@@ -125,7 +125,7 @@ def run_reference_script(script, argv, raw_room, tag):
 
 
 def main():
-    which = sys.argv[1:] or ['net', 'greedy', 'restart']
+    which = sys.argv[1:] or ['net', 'greedy', 'restart', 'beam']
     if 'net' in which:
         golden_lrgnet(0, 13, 32, 32, 2, seed=11)
         golden_lrgnet(None, 13, 24, 40, 1, seed=12)     # LITE=None as test_region_grow.py passes it; Ni != Nn
@@ -143,6 +143,14 @@ def main():
     if 'restart' in which:
         room = synthetic.generate_room_points(1000, seed=103).astype(np.float32)
         run_reference_script('test_random_restart.py', ['--area', '5', '--scoring', 'np'], room, 'restart_room103')
+    if 'beam' in which:
+        # test_beam_search.py builds its index lists as ``range(n) + list(...)`` (:212, :224): Python-2 list arithmetic
+        # that raises under Python 3.  The script is still executed unmodified -- it is handed a ``range`` that returns a
+        # list, as Python 2's did, through its module globals.
+        import builtins
+        room = synthetic.generate_room_points(800, seed=105).astype(np.float32)
+        run_reference_script('test_beam_search.py', ['--area', '5', '--scoring', 'np'], room, 'beam_room105',
+                             init_globals={'range': lambda *a: list(builtins.range(*a))})
 
 
 if __name__ == '__main__':

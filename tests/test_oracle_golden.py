@@ -77,6 +77,22 @@ def test_grow_loop_reproduces_reference_script(name, restarts):
     np.testing.assert_allclose([m['nmi'], m['ami'], m['ars'], m['prc'], m['rcl'], m['iou']], g['metrics'], rtol=1e-9)
 
 
+def test_beam_search_reproduces_reference_script():
+    """test_beam_search.py (BEAM_WIDTH = SEARCH_WIDTH = 3, --scoring np), executed unmodified with a list-returning
+    ``range`` in its globals (its ``range(n) + list(...)`` is Python 2): log lines, labels and metrics."""
+    from oracle import beam_ref
+    g = np.load(os.path.join(GOLDEN, 'beam_room105.npz'))
+    w = synthetic.make_synthetic_weights(**WEIGHT_KW)
+    assert digest(w) == str(g['weights_digest'])
+    r = beam_ref.beam_room(g['points'], g['obj_id'], g['order'], w, rng_ref.LegacyStream(0), cls_id=g['cls_id'],
+                           classes=CLASSES_S3DIS)
+    assert list(r.lines) == [str(x) for x in g['region_lines']]
+    np.testing.assert_array_equal(r.filled_label, g['filled_label'])
+    m = metrics_ref.room_metrics(g['obj_id'], r.filled_label)
+    np.testing.assert_allclose([m['nmi'], m['ami'], m['ars'], m['prc'], m['rcl'], m['iou']], g['metrics'], rtol=1e-9)
+    assert r.total_steps == sum(x['steps'] for x in r.regions)
+
+
 def test_faithful_and_vectorised_mask_update_agree():
     g = np.load(os.path.join(GOLDEN, 'greedy_room101.npz'))
     w = synthetic.make_synthetic_weights(**WEIGHT_KW)
