@@ -1,0 +1,216 @@
+"""Beam-search region growing (the reference's third local-search driver, test_beam_search.py:143-290) on the same
+kernels as the greedy / random-restart loop.
+
+Per seed a queue of at most ``beam_width`` masks; every queue entry spawns ``search_width`` stochastic grow steps; the
+children whose mask changed are scored by size (``--scoring np``), the best ``beam_width`` form the next queue; the head of
+the queue is committed when its bounding box stalls twice or no child survives.  All children of a level -- of every room in
+flight -- are one batch: child ``qid * search_width + search_id`` of a group of ``beam_width * search_width`` slots, its random
+stream keyed (seed point, child ordinal, level), so the result does not depend on the order or batching (the reference draws
+them one after the other from one stream: that order is the ``rng='legacy'`` definition of the greedy path and is not
+offered here).  The queue logic (sort, stall test, commit) runs on the host between levels from the slots' scan results;
+masks never leave the device.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LRG_ACTIVE, LRG_IDLE
+from .grow import RegionGrower, RoomResult, _ptr, _stream_ptr
+
+
+class BeamSearchGrower(RegionGrower):
+    def __init__(self, net, rooms_in_flight=16, beam_width=3, search_width=3, seed=0, policy='net', resolution=0.1,
+                 cluster_threshold=10):
+        self.beam_width, self.search_width = int(beam_width), int(search_width)
+        super().__init__(net, rooms_in_flight=rooms_in_flight, restarts=1, group_size=self.beam_width * self.search_width,
+                         rng='counter', seed=seed, policy=policy, resolution=resolution, cluster_threshold=cluster_threshold)
+        self.cluster_threshold = cluster_threshold
+
+    # ---- host-side room state -------------------------------------------------------------------------------------------
+    def load_rooms(self, rooms):
+        super().load_rooms(rooms)
+        self.h_vox = self.d_vox.cpu().numpy()
+        self.h_obj = [np.asarray(r['obj_id']).astype(np.int64) for r in rooms]
+        self.h_order = [np.asarray(r['order']).astype(np.int64) for r in rooms]
+        self.d_parent = torch.zeros((self.n_groups, self.beam_width, self.cap), dtype=torch.uint8, device=self.dev)
+        return self
+
+    def _start_room(self, g, r):
+        self.group_room[g] = r
+        self.state[g] = dict(room=r, visited=np.zeros(self.room_n[r], dtype=bool), cursor=0, regions=[], next_id=1, seed=None)
+
+    def _next_seed(self, st):
+        """The next unvisited seed in curvature order (:154-156), or None."""
+        order, vis = self.h_order[st['room']], st['visited']
+        c = st['cursor']
+        while c < len(order) and vis[order[c]]:
+            c += 1
+        st['cursor'] = c + 1
+        if c >= len(order):
+            return None
+        return int(order[c])
+
+    def _begin_seed(self, g, st, seed):
+        o = int(self.room_off[st['room']])
+        v = self.h_vox[o + seed].astype(np.int64)
+        st.update(seed=seed, level=0, stuck=0, steps=0, seq_mn=v.copy(), seq_mx=v.copy(),
+                  Q=[dict(score=0, count=1, mn=v.copy(), mx=v.copy(), parent=-1)])       # parent -1: the seed-only mask (:164-174)
+
+    def _commit(self, g, st):
+        """visited / label from the head of the queue (:289-293)."""
+        r = st['room']
+        o, n = int(self.room_off[r]), self.room_n[r]
+        head = st['Q'][0]
+        if head['parent'] < 0:
+            mask_h = np.zeros(n, dtype=bool)
+            mask_h[st['seed']] = True
+        else:
+            mask_h = self.d_parent[g, head['parent'], :n].cpu().numpy().astype(bool)
+        st['visited'] |= mask_h
+        sel = torch.from_numpy(mask_h).to(self.dev)
+        self.d_visited[o:o + n][sel] = 1                                    # :289
+        count = int(mask_h.sum())
+        labeled = count > self.cluster_threshold
+        if labeled:
+            self.d_label[o:o + n][sel] = st['next_id']
+            st['next_id'] += 1
+        st['regions'].append(dict(seed=st['seed'], steps=st['steps'], points=count, labeled=labeled))
+        st['seed'] = None
+
+    # ---- one level of every room in flight ------------------------------------------------------------------------------
+    def _level(self):
+        G, SW, S = self.G, self.search_width, self.S
+        lib, st_ptr, P = self.lib, _stream_ptr(), ctypes.byref(self.params)
+        active_groups = []
+        for g in range(self.n_groups):
+            st = self.state[g]
+            if st is None:
+                continue
+            while True:                                   # commit stalled heads / start seeds until the room has work or is done
+                if st['seed'] is None:
+                    seed = self._next_seed(st)
+                    if seed is None:
+                        self._finish_room(g, st)
+                        st = self.state[g]
+                        if st is None:
+                            break
+                        continue
+                    self._begin_seed(g, st, seed)
+                head = st['Q'][0]                          # qid == 0 (:188-198)
+                if not np.any(head['mn'] < st['seq_mn']) and not np.any(head['mx'] > st['seq_mx']):
+                    if st['stuck'] >= 1:
+                        self._commit(g, st)
+                        continue
+                    st['stuck'] += 1
+                else:
+                    st['stuck'] = 0
+                st['seq_mn'] = np.minimum(st['seq_mn'], head['mn'])
+                st['seq_mx'] = np.maximum(st['seq_mx'], head['mx'])
+                break
+            if st is not None:
+                active_groups.append(g)
+        if not active_groups:
+            return False
+        # child slots and their masks
+        for g in range(self.n_groups):
+            st = self.state[g]
+            for c in range(G):
+                sl = self.h_slots[g * G + c]
+                qid = c // SW
+                if st is None or st['seed'] is None or qid >= len(st['Q']):
+                    sl.room, sl.status = -1, LRG_IDLE
+                    continue
+                q = st['Q'][qid]
+                r = st['room']
+                o, n = int(self.room_off[r]), self.room_n[r]
+                sl.room, sl.status, sl.seed, sl.restart, sl.step = r, LRG_ACTIVE, st['seed'], c, st['level']
+                sl.steps_total = sl.stuck = 0
+                sl.updated, sl.pad, sl.nc, sl.ne, sl.count, sl.query = -1, 0, 0, 0, q['count'], 0
+                sl.target = int(self.h_obj[r][st['seed']])
+                sl.scan_cnt = 0
+                for d in range(3):
+                    sl.mn[d], sl.mx[d] = int(q['mn'][d]), int(q['mx'][d])
+                    sl.scan_mn[d], sl.scan_mx[d] = 2147483647, -2147483648
+                if q['parent'] < 0:
+                    self.d_cur[g * G + c, :n].zero_()
+                    self.d_cur[g * G + c, st['seed']] = 1
+                else:
+                    self.d_cur[g * G + c, :n].copy_(self.d_parent[g, q['parent'], :n])
+        self.d_slots.copy_(torch.from_numpy(np.frombuffer(bytes(self.h_slots), dtype=np.uint8).copy()))
+        _lib.check(lib.lrg_box_query(_ptr(self.d_slots), _ptr(self.d_rooms), S, self.cap, P, st_ptr), 'lrg_box_query')
+        _lib.check(lib.lrg_median(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.b_center), st_ptr), 'lrg_median')
+        _lib.check(lib.lrg_sample(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.b_sin), _ptr(self.b_snb), st_ptr), 'lrg_sample')
+        _lib.check(lib.lrg_gather_center(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.b_sin), _ptr(self.b_snb),
+                                         _ptr(self.b_center), _ptr(self.b_inl), _ptr(self.b_nbr), _ptr(self.b_gtr), _ptr(self.b_gta),
+                                         _ptr(self.b_rows_in), _ptr(self.b_rows_nb), st_ptr), 'lrg_gather_center')
+        self.net.forward(self.b_inl, self.b_nbr, self.b_add, self.b_rmv, rows_in=self.b_rows_in, rows_nb=self.b_rows_nb)
+        _lib.check(lib.lrg_mask_update(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.b_inl), _ptr(self.b_nbr),
+                                       _ptr(self.b_center), _ptr(self.b_add), _ptr(self.b_rmv), _ptr(self.b_gtr), _ptr(self.b_gta),
+                                       None, None, _ptr(self.b_sin), _ptr(self.b_snb), _ptr(self.d_stats), st_ptr), 'lrg_mask_update')
+        _lib.check(lib.lrg_bbox_stop(_ptr(self.d_slots), _ptr(self.d_rooms), S, self.cap, P, st_ptr), 'lrg_bbox_stop')
+        slots = self._read_slots()
+        for g in active_groups:
+            st = self.state[g]
+            n = self.room_n[st['room']]
+            newQ = []
+            for qid in range(len(st['Q'])):
+                ran = False
+                for sid in range(SW):
+                    sl = slots[g * G + qid * SW + sid]
+                    if sl.updated < 0:                     # no neighbour to expand into (:212): the parent spawns nothing
+                        continue
+                    ran = True
+                    if sl.updated == 1 and sl.scan_cnt > 0:
+                        newQ.append(dict(score=int(sl.scan_cnt), count=int(sl.scan_cnt), mn=np.array(sl.scan_mn[:], dtype=np.int64),
+                                         mx=np.array(sl.scan_mx[:], dtype=np.int64), slot=g * G + qid * SW + sid))
+                if ran:
+                    st['steps'] += SW                     # :274, one per child
+            newQ.sort(key=lambda q: -q['score'])          # stable: ties keep the (qid, search id) order (:286)
+            newQ = newQ[:self.beam_width]
+            if not newQ:
+                self._commit(g, st)                        # the queue ran dry: its last head is the answer (:179, :289)
+                continue
+            # the survivors become the parents of the next level (copied out of the child slots before those are reused)
+            tmp = torch.stack([self.d_cur[q['slot'], :n] for q in newQ])
+            for k, q in enumerate(newQ):
+                self.d_parent[g, k, :n].copy_(tmp[k])
+                q['parent'] = k
+            st['Q'] = newQ
+            st['level'] += 1
+        return True
+
+    def _finish_room(self, g, st):
+        r = st['room']
+        self.results[r] = st['regions']
+        self.fill(r)
+        self._done += 1
+        nxt = self._queue.pop(0) if self._queue else None
+        if nxt is None:
+            self.state[g] = None
+            self.group_room[g] = -1
+        else:
+            self._start_room(g, nxt)
+
+    def run(self, rooms, fill=True):
+        """Grow every room once with beam search; RoomResults in input order."""
+        self.load_rooms(rooms)
+        self.state = [None] * self.n_groups
+        self.results = [None] * self.n_rooms
+        self._queue = list(range(self.n_rooms))
+        self._done = 0
+        for g in range(self.n_groups):
+            if self._queue:
+                self._start_room(g, self._queue.pop(0))
+        while self._level():
+            pass
+        torch.cuda.synchronize()
+        label = self.d_label.cpu().numpy()
+        filled = self.d_filled.cpu().numpy()
+        out = []
+        for r in range(self.n_rooms):
+            o, n = int(self.room_off[r]), self.room_n[r]
+            out.append(RoomResult(self.room_ids[r], label[o:o + n].astype(np.int64), filled[o:o + n].astype(np.int64),
+                                  self.results[r]))
+        return out

@@ -9,7 +9,8 @@ lines, optional PLY export.
     python region_grow.py --h5 rooms.h5 --synthetic-weights --policy gt
 
 Options of the reference that are kept: --area, --save, --resolution, --lite, --cross-domain/--train-area (model path
-only).  ``--restarts R`` (R >= 2) selects the random-restart search of test_random_restart.py with its default
+only).  ``--beam B`` selects the beam search of test_beam_search.py (B = BEAM_WIDTH, ``--search-width`` = SEARCH_WIDTH, scoring np);
+``--restarts R`` (R >= 2) selects the random-restart search of test_random_restart.py with its default
 ``--scoring np`` (its ``ml`` scoring raises at the second restart, test_random_restart.py:194 / :269, and is not offered).
 ``--rng legacy`` reproduces the reference's per-room NumPy random stream (one room at a time on the host side of the loop);
 the default ``counter`` batches every room of the file on the GPU.
@@ -37,6 +38,8 @@ def parse():
     ap.add_argument('--lite', type=int, default=None)
     ap.add_argument('--feature-size', type=int, default=13, choices=[6, 9, 12, 13])
     ap.add_argument('--restarts', type=int, default=1)
+    ap.add_argument('--beam', type=int, default=0, help='beam width: > 0 selects the beam search of test_beam_search.py (--scoring np)')
+    ap.add_argument('--search-width', type=int, default=3, help='children per beam entry (SEARCH_WIDTH)')
     ap.add_argument('--rng', default='counter', choices=['counter', 'legacy'])
     ap.add_argument('--policy', default='net', choices=['net', 'gt', 'threshold'])
     ap.add_argument('--seed', type=int, default=0)
@@ -111,7 +114,14 @@ def main():
                  for r, p in enumerate(pre)]
         kw = dict(rooms_in_flight=min(args.rooms_in_flight, n_rooms), restarts=max(1, args.restarts), rng=args.rng,
                   seed=args.seed, policy=args.policy, resolution=args.resolution)
-        gr = LanedRegionGrower(net, lanes=args.lanes, **kw) if args.rng == 'counter' and args.lanes != 1 else RegionGrower(net, **kw)
+        if args.beam > 0:
+            from learn_region_grow_amd.beam import BeamSearchGrower
+            gr = BeamSearchGrower(net, rooms_in_flight=min(args.rooms_in_flight, n_rooms), beam_width=args.beam,
+                                  search_width=args.search_width, seed=args.seed, policy=args.policy, resolution=args.resolution)
+        elif args.rng == 'counter' and args.lanes != 1:
+            gr = LanedRegionGrower(net, lanes=args.lanes, **kw)
+        else:
+            gr = RegionGrower(net, **kw)
         t0 = time.time()
         results = gr.run(rooms)
         t_grow = time.time() - t0

@@ -1,0 +1,49 @@
+"""GPU: beam-search driver (learn_region_grow_amd.beam.BeamSearchGrower) against the oracle restatement of
+test_beam_search.py (oracle/beam_ref.py, itself pinned to the reference script's output) under the counter stream, with the
+oracle evaluating the same GPU network: queue contents, step counts, committed regions and labels must agree exactly."""
+import numpy as np
+import pytest
+
+from learn_region_grow_amd import preprocess, synthetic
+from oracle import beam_ref, rng_ref
+
+pytestmark = pytest.mark.gpu
+WEIGHT_KW = dict(seed=0, gain=2.0, bias_std=0.2, add_bias_shift=0.0, rmv_bias_shift=-3.0)
+SAME_LOGITS_MARGIN = 5e-7
+
+
+@pytest.fixture(scope='module')
+def net(cuda_device):
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    return LrgNetHIP(1, 1, 512, 512, 13, 0, device=cuda_device).load_weights(synthetic.make_synthetic_weights(**WEIGHT_KW))
+
+
+def gpu_net_fn(net):
+    def fn(xi, xn):
+        _, add, _, rmv, _ = net.run(xi, xn)
+        return add, rmv
+    return fn
+
+
+def small_room(seed, n_raw, furniture=0, room_id=0):
+    raw = (synthetic.area5_shaped_room(n_raw, seed, n_furniture=furniture) if furniture
+           else synthetic.generate_room_points(n_raw, seed)).astype(np.float32)
+    p = preprocess.preprocess_room(raw[:, :6], raw[:, 6].astype(int), raw[:, 7].astype(int))
+    return dict(points=p['points'], obj_id=p['obj_id'], order=p['order'], room_id=room_id)
+
+
+@pytest.mark.parametrize('policy,beam,search,in_flight', [('gt', 3, 3, 2), ('net', 3, 3, 3), ('net', 2, 4, 1)])
+def test_beam_search_matches_oracle(net, policy, beam, search, in_flight):
+    from learn_region_grow_amd.beam import BeamSearchGrower
+    rooms = [small_room(700 + i, 600 + 150 * i, room_id=30 + i) for i in range(2)] + [small_room(710, 1200, furniture=3, room_id=35)]
+    got = BeamSearchGrower(net, rooms_in_flight=in_flight, beam_width=beam, search_width=search, seed=21, policy=policy).run(rooms)
+    for i, room in enumerate(rooms):
+        want = beam_ref.beam_room(room['points'], room['obj_id'], room['order'], None, rng_ref.CounterStream(21, room['room_id']),
+                                  net_fn=gpu_net_fn(net), policy=policy, beam_width=beam, search_width=search)
+        if policy == 'net' and want.min_rel_margin < SAME_LOGITS_MARGIN:
+            pytest.skip('near-tie draw in the oracle run (margin %.1e)' % want.min_margin)
+        g = [(r['seed'], r['steps'], r['points'], r['labeled']) for r in got[i].regions]
+        w = [(r['seed'], r['steps'], r['points'], r['labeled']) for r in want.regions]
+        assert g == w
+        np.testing.assert_array_equal(got[i].cluster_label, want.cluster_label)
+        np.testing.assert_array_equal(got[i].filled_label, want.filled_label)

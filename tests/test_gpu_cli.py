@@ -52,3 +52,25 @@ def test_cli_matches_oracle_pipeline(cuda_device, tmp_path, policy):
     got_lines = [ln for ln in lines if ln.startswith('Area custom room')]
     assert got_lines == want_lines
     assert lines[-1] == metrics.aggregate_line(want_metrics)
+
+
+def test_cli_beam_search(cuda_device, tmp_path):
+    """--beam: the test_beam_search.py driver end to end; per-room lines equal the oracle beam search on the same files."""
+    from oracle import beam_ref
+    raw = [synthetic.generate_room_points(1500, 60 + i, wlh=(1.3, 1.1, 1.0)).astype(np.float32) for i in range(2)]
+    h5 = str(tmp_path / 'rooms.h5')
+    lio.saveToH5(h5, raw)
+    weights = synthetic.make_synthetic_weights(seed=0)
+    prefix = str(tmp_path / 'lrgnet.ckpt')
+    checkpoint.write_bundle(prefix, weights)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'region_grow.py'), '--h5', h5, '--ckpt', prefix, '--policy', 'gt', '--seed', '4',
+                        '--beam', '2', '--search-width', '2'], capture_output=True, text=True, cwd=str(tmp_path), timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rooms, obj, cls = lio.loadFromH5(h5)
+    want = []
+    for i in range(2):
+        p = preprocess_ref.preprocess_room(rooms[i], obj[i], cls[i])
+        res = beam_ref.beam_room(p['points'], p['obj_id'], np.argsort(p['curvatures']), weights, rng_ref.CounterStream(4, i),
+                                 policy='gt', beam_width=2, search_width=2)
+        want.append(metrics.room_line('custom', i, metrics_ref.room_metrics(p['obj_id'], res.filled_label)))
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith('Area custom room')] == want
