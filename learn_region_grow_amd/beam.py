@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import LRG_ACTIVE, LRG_IDLE
+from ._lib import LRG_ACTIVE, LRG_IDLE, LrgSlot
 from .grow import RegionGrower, RoomResult, _ptr, _stream_ptr
 
 
@@ -35,6 +35,8 @@ class BeamSearchGrower(RegionGrower):
         self.h_obj = [np.asarray(r['obj_id']).astype(np.int64) for r in rooms]
         self.h_order = [np.asarray(r['order']).astype(np.int64) for r in rooms]
         self.d_parent = torch.zeros((self.n_groups, self.beam_width, self.cap), dtype=torch.uint8, device=self.dev)
+        self._slot_dtype = np.dtype(LrgSlot)
+        self._slot_view = np.frombuffer(self.h_slots, dtype=self._slot_dtype)          # writable view of the host slot array
         return self
 
     def _start_room(self, g, r):
@@ -113,32 +115,41 @@ class BeamSearchGrower(RegionGrower):
                 active_groups.append(g)
         if not active_groups:
             return False
-        # child slots and their masks
-        for g in range(self.n_groups):
+        # child slots and their masks, vectorised: the ctypes slot array is edited through a NumPy structured view and the
+        # parent masks are scattered into the child slots with three indexed copies
+        A = self._slot_view
+        A['room'][:] = -1
+        A['status'][:] = LRG_IDLE
+        seed_slots, seed_points, par_slots, par_src = [], [], [], []
+        for g in active_groups:
             st = self.state[g]
-            for c in range(G):
-                sl = self.h_slots[g * G + c]
-                qid = c // SW
-                if st is None or st['seed'] is None or qid >= len(st['Q']):
-                    sl.room, sl.status = -1, LRG_IDLE
-                    continue
-                q = st['Q'][qid]
-                r = st['room']
-                o, n = int(self.room_off[r]), self.room_n[r]
-                sl.room, sl.status, sl.seed, sl.restart, sl.step = r, LRG_ACTIVE, st['seed'], c, st['level']
-                sl.steps_total = sl.stuck = 0
-                sl.updated, sl.pad, sl.nc, sl.ne, sl.count, sl.query = -1, 0, 0, 0, q['count'], 0
-                sl.target = int(self.h_obj[r][st['seed']])
-                sl.scan_cnt = 0
-                for d in range(3):
-                    sl.mn[d], sl.mx[d] = int(q['mn'][d]), int(q['mx'][d])
-                    sl.scan_mn[d], sl.scan_mx[d] = 2147483647, -2147483648
+            r, nq = st['room'], len(st['Q'])
+            lo, hi = g * G, g * G + nq * SW
+            V = A[lo:hi]
+            V['room'], V['status'], V['seed'], V['step'] = r, LRG_ACTIVE, st['seed'], st['level']
+            V['restart'] = np.arange(nq * SW)
+            V['steps_total'] = V['stuck'] = V['pad'] = V['nc'] = V['ne'] = V['query'] = V['scan_cnt'] = 0
+            V['updated'] = -1
+            V['target'] = int(self.h_obj[r][st['seed']])
+            V['scan_mn'], V['scan_mx'] = 2147483647, -2147483648
+            for qid, q in enumerate(st['Q']):
+                W = A[lo + qid * SW:lo + (qid + 1) * SW]
+                W['count'], W['mn'], W['mx'] = q['count'], q['mn'], q['mx']
+                ids = range(lo + qid * SW, lo + (qid + 1) * SW)
                 if q['parent'] < 0:
-                    self.d_cur[g * G + c, :n].zero_()
-                    self.d_cur[g * G + c, st['seed']] = 1
+                    seed_slots.extend(ids)
+                    seed_points.extend([st['seed']] * SW)
                 else:
-                    self.d_cur[g * G + c, :n].copy_(self.d_parent[g, q['parent'], :n])
-        self.d_slots.copy_(torch.from_numpy(np.frombuffer(bytes(self.h_slots), dtype=np.uint8).copy()))
+                    par_slots.extend(ids)
+                    par_src.extend([g * self.beam_width + q['parent']] * SW)
+        if seed_slots:
+            ss = torch.tensor(seed_slots, device=self.dev)
+            self.d_cur[ss] = 0
+            self.d_cur[ss, torch.tensor(seed_points, device=self.dev)] = 1
+        if par_slots:
+            self.d_cur[torch.tensor(par_slots, device=self.dev)] = \
+                self.d_parent.view(-1, self.cap)[torch.tensor(par_src, device=self.dev)]
+        self.d_slots.copy_(torch.from_numpy(np.frombuffer(self.h_slots, dtype=np.uint8)))
         _lib.check(lib.lrg_box_query(_ptr(self.d_slots), _ptr(self.d_rooms), S, self.cap, P, st_ptr), 'lrg_box_query')
         _lib.check(lib.lrg_median(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.b_center), st_ptr), 'lrg_median')
         _lib.check(lib.lrg_sample(_ptr(self.d_slots), _ptr(self.d_rooms), S, P, _ptr(self.b_sin), _ptr(self.b_snb), st_ptr), 'lrg_sample')
@@ -150,35 +161,32 @@ class BeamSearchGrower(RegionGrower):
                                        _ptr(self.b_center), _ptr(self.b_add), _ptr(self.b_rmv), _ptr(self.b_gtr), _ptr(self.b_gta),
                                        None, None, _ptr(self.b_sin), _ptr(self.b_snb), _ptr(self.d_stats), st_ptr), 'lrg_mask_update')
         _lib.check(lib.lrg_bbox_stop(_ptr(self.d_slots), _ptr(self.d_rooms), S, self.cap, P, st_ptr), 'lrg_bbox_stop')
-        slots = self._read_slots()
+        R = np.frombuffer(self.d_slots.cpu().numpy().tobytes(), dtype=self._slot_dtype)
+        upd, cnt = R['updated'].reshape(self.n_groups, G), R['scan_cnt'].reshape(self.n_groups, G)
+        src_slots, dst_rows = [], []
         for g in active_groups:
             st = self.state[g]
-            n = self.room_n[st['room']]
-            newQ = []
-            for qid in range(len(st['Q'])):
-                ran = False
-                for sid in range(SW):
-                    sl = slots[g * G + qid * SW + sid]
-                    if sl.updated < 0:                     # no neighbour to expand into (:212): the parent spawns nothing
-                        continue
-                    ran = True
-                    if sl.updated == 1 and sl.scan_cnt > 0:
-                        newQ.append(dict(score=int(sl.scan_cnt), count=int(sl.scan_cnt), mn=np.array(sl.scan_mn[:], dtype=np.int64),
-                                         mx=np.array(sl.scan_mx[:], dtype=np.int64), slot=g * G + qid * SW + sid))
-                if ran:
-                    st['steps'] += SW                     # :274, one per child
-            newQ.sort(key=lambda q: -q['score'])          # stable: ties keep the (qid, search id) order (:286)
-            newQ = newQ[:self.beam_width]
-            if not newQ:
-                self._commit(g, st)                        # the queue ran dry: its last head is the answer (:179, :289)
+            nq = len(st['Q'])
+            u, c = upd[g, :nq * SW], cnt[g, :nq * SW]
+            ran = (u.reshape(nq, SW) >= 0).any(axis=1)             # a parent without neighbours spawns nothing (:212)
+            st['steps'] += SW * int(ran.sum())                     # :274, one per child
+            alive = np.nonzero((u == 1) & (c > 0))[0]
+            if len(alive) == 0:
+                self._commit(g, st)                                 # the queue ran dry: its last head is the answer (:179, :289)
                 continue
-            # the survivors become the parents of the next level (copied out of the child slots before those are reused)
-            tmp = torch.stack([self.d_cur[q['slot'], :n] for q in newQ])
-            for k, q in enumerate(newQ):
-                self.d_parent[g, k, :n].copy_(tmp[k])
-                q['parent'] = k
+            keep = alive[np.argsort(-c[alive], kind='stable')][:self.beam_width]      # ties keep the (qid, search id) order (:286)
+            newQ = []
+            for k, ci in enumerate(keep):
+                sl = R[g * G + int(ci)]
+                newQ.append(dict(score=int(c[ci]), count=int(c[ci]), mn=sl['scan_mn'].astype(np.int64), mx=sl['scan_mx'].astype(np.int64),
+                                 parent=k))
+                src_slots.append(g * G + int(ci))
+                dst_rows.append(g * self.beam_width + k)
             st['Q'] = newQ
             st['level'] += 1
+        if src_slots:
+            # the survivors become the parents of the next level (gathered out of the child slots before those are reused)
+            self.d_parent.view(-1, self.cap)[torch.tensor(dst_rows, device=self.dev)] = self.d_cur[torch.tensor(src_slots, device=self.dev)]
         return True
 
     def _finish_room(self, g, st):
