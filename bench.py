@@ -112,9 +112,14 @@ def cpu_baseline(rooms, weights, seconds, policy):
     un-hoisted head) on this box's host cores, for a bounded sample: steps of the median-size room.  Beside it a
     'strong CPU' figure: the same loop with the set membership vectorised and the head hoisted."""
     n, sizes, dt = _cpu_sample(rooms, weights, seconds * 0.7, policy, True, None)
-    out = dict(value=n / dt, unit='instance-steps/s', cores=os.cpu_count(), kind='port',
+    try:                                       # threads the NumPy BLAS actually runs the matrix products on
+        import threadpoolctl
+        blas_threads = max([i['num_threads'] for i in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count()
+    out = dict(value=n / dt, unit='instance-steps/s', cores=blas_threads, kind='port',
                sample='%d grow steps over %d Area-5-shaped room(s) of %s points, oracle.grow_ref (faithful=True, policy=%s), '
-                      '%.1f s' % (n, len(sizes), sizes, policy, dt))
+                      '%.1f s; BLAS threads = cores, Python loops single-threaded' % (n, len(sizes), sizes, policy, dt))
     n2, sizes2, dt2 = _cpu_sample(rooms, weights, seconds * 0.3, policy, False, _hoisted_numpy_net(weights))
     out['strong'] = dict(value=n2 / dt2, unit='instance-steps/s',
                          sample='%d grow steps, vectorised voxel-set membership + hoisted head (NumPy/BLAS), %.1f s' % (n2, dt2))
