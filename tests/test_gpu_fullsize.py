@@ -94,3 +94,26 @@ def test_net_policy_full_size_is_deterministic_and_batch_independent(net):
         check_invariants(room, x)
         np.testing.assert_array_equal(x.filled_label, y.filled_label)
         assert x.total_steps == y.total_steps
+
+
+def test_area5_room_bernoulli_policy_matches_oracle(net):
+    """The reference's own policy (Bernoulli draws against the network's confidence, test_region_grow.py:266-267) at Area-5
+    scale: a 5 k-point room grown on the GPU equals the oracle loop evaluating the same GPU network step by step.  The logits
+    of the batched, row-skipping evaluation and of the oracle's one-instance dense evaluation are the same bits, so the only
+    admissible difference is a draw within float32 noise of its confidence (reported by the oracle, then skipped)."""
+    from learn_region_grow_amd.grow import RegionGrower
+
+    def net_fn(xi, xn):
+        _, add, _, rmv, _ = net.run(xi, xn)
+        return add, rmv
+    room = workloads.make_room(5090, 1001, 1)
+    res = RegionGrower(net, rooms_in_flight=1, rng='counter', seed=7, policy='net').run([room])[0]
+    want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.CounterStream(7, 1), net_fn=net_fn,
+                              policy='net')
+    if want.min_rel_margin < 5e-7:
+        pytest.skip('near-tie draw in the oracle run (margin %.1e)' % want.min_margin)
+    assert [(r['seed'], r['steps'], r['points'], r['reason']) for r in res.regions] == \
+           [(r['seed'], r['steps'], r['points'], r['reason']) for r in want.regions]
+    np.testing.assert_array_equal(res.cluster_label, want.cluster_label)
+    np.testing.assert_array_equal(res.filled_label, want.filled_label)
+    check_invariants(room, res)
