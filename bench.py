@@ -3,17 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one lock-step iteration of the batched grow loop (lrg_grow_step) over all rooms in flight: every
-in-flight room takes one region-grow step (one LrgNet evaluation on 512+512 points + neighbour query, median,
-sampling, mask update).  The workload is the 68-room Area-5-shaped set (BASELINE.json configs[1]) with all rooms
-in flight; a room that finishes is replaced at once (the set is cycled) so the batch stays full.  Inputs
-(13-D room features, weights) are resident in HBM before the timed region.
-For N > 1 every rank runs its own 68-room set (weak scaling, no collective inside the loop) and the final
-label gather goes over RCCL.
+Two legs, both with inputs (13-D room features, weights) resident in HBM before the clock starts:
+
+  steady leg (``value``, instance-steps/s).  A *step* is a macro-step of ``--iters-per-step`` (512) lock-step iterations of
+      the batched grow loop over the 68-room Area-5-shaped set (BASELINE.json configs[1]) with all rooms in flight: in every
+      iteration each in-flight room takes one region-grow step (box query, median, sampling, one LrgNet evaluation on its
+      512+512-point sets, mask update).  A room that finishes gets its 1-NN fill-in and restarts at once, so the batch
+      stays full.  W warm-up steps roll the rooms into their steady phase, then EXACTLY K steps are timed (20 steps =
+      10 240 iterations, about a second).  For N > 1 every rank runs its own 68-room set (weak scaling; no collective
+      inside the loop) and the device step counters are summed with one all-reduce after the clock stops.
+  fixed-work leg (``rooms_per_sec``).  R = 544 room jobs (the 68 geometries x 8 random-stream keys) are sharded over the N
+      ranks by point count (longest first), pushed through 68 slots per GPU from reset to final labels (grow + fill-in),
+      and the per-room labels are gathered over RCCL -- the only collective of the path.  Same R for every N (strong scaling).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -26,7 +32,10 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 BYTES_PER_INSTANCE_STEP = 10297344      # layer-streamed algorithmic HBM bytes of one LrgNet evaluation
-FLOPS_PER_INSTANCE_STEP = 271712256     # hoisted-head FLOPs of one LrgNet evaluation
+FLOPS_PER_INSTANCE_STEP = 271712256     # hoisted-head FLOPs of one LrgNet evaluation (512 + 512 rows)
+FLOPS_PER_BRANCH_ROW = 165504           # 2 * (13*64 + 64*64 + 64*64 + 64*128 + 128*512)
+FLOPS_PER_HEAD_ROW = 98816              # 2 * (64*256 + 256*128 + 128*2)
+FLOPS_POOLED_GEMM = 1048576             # per instance: two heads x 2 * 1024 * 256
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 FP32_MATRIX_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: fp32-input MFMA peak
 
@@ -34,8 +43,9 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: fp32-input MFMA p
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=1500)
-    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--iters-per-step', type=int, default=512, help='lock-step iterations per (macro-)step')
     ap.add_argument('--rooms', type=int, default=68, help='rooms in flight per GPU (the Area-5 set has 68)')
     ap.add_argument('--restarts', type=int, default=1)
     ap.add_argument('--workload', default='area5', choices=['area5', 'kitti', 'scannet'],
@@ -45,12 +55,13 @@ def parse():
                          "(test_region_grow.py:266-267); 'gt' = its commented-out ground-truth masks (:268-269). "
                          "The network is evaluated every step either way; with synthetic weights only 'gt' gives "
                          "Area-5-like region dynamics (regions per room, steps per region)")
-    ap.add_argument('--fuse-pool', type=int, default=0)
     ap.add_argument('--net-mode', default='fused', choices=['fused', 'streamed'])
-    ap.add_argument('--advance-rounds', type=int, default=1)
-    ap.add_argument('--fill', type=int, default=1, help='1: finished rooms get their 1-NN fill-in before they are recycled (rooms/sec as defined)')
-    ap.add_argument('--lanes', type=int, default=0, help='half-batches on their own HIP streams; 0 = auto (2 from 64 rooms in flight, else 1)')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--packed', type=int, default=1, help='1: lrg_grow_step_packed (front kernel + packed rows); 0: the nine-launch lrg_grow_step')
+    ap.add_argument('--graph', type=int, default=4, help='packed iterations replayed per host call from a HIP graph (0 = plain launches)')
+    ap.add_argument('--fill', type=int, default=1, help='1: finished rooms get their 1-NN fill-in before they are recycled')
+    ap.add_argument('--lanes', type=int, default=0, help='groups of slots on their own HIP streams; 0 = auto')
+    ap.add_argument('--fixed-rooms', type=int, default=544, help='room jobs of the fixed-work leg over ALL ranks (0 = skip)')
+    ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
     ap.add_argument('--p0-rooms', type=int, default=4, help='rooms of the preprocessing (P0) side measurement (0 = skip)')
     return ap.parse_args()
@@ -81,48 +92,59 @@ def _hoisted_numpy_net(weights):
     return net
 
 
-def _cpu_sample(rooms, weights, seconds, policy, faithful, net_fn):
+class _Stop(Exception):
+    pass
+
+
+def _cpu_room(room, weights, seconds, policy, faithful, net_fn, key):
+    """One room on the CPU oracle (grow, then fill-in) under a time budget: (steps taken, grow seconds, fill seconds or None)."""
     from oracle import grow_ref, rng_ref      # CPU baseline leg only
-    order = np.argsort([len(r['points']) for r in rooms])
     t0 = time.time()
     count = [0]
-
-    class Stop(Exception):
-        pass
 
     def hook(d):
         count[0] += 1
         if time.time() - t0 > seconds:
-            raise Stop()
-    sizes = []
+            raise _Stop()
     try:
-        for k in range(len(rooms)):        # median-size room first, then outwards
-            room = rooms[int(order[(len(order) // 2 + (k + 1) // 2 * (1 if k % 2 else -1)) % len(order)])]
-            sizes.append(len(room['points']))
-            grow_ref.grow_room(room['points'], room['obj_id'], room['order'], weights, rng_ref.LegacyStream(k),
-                               faithful=faithful, net_fn=net_fn, hook=hook, fill=False, policy=policy)
-    except Stop:
-        pass
-    dt = time.time() - t0
-    return count[0], sizes, dt
+        res = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], weights, rng_ref.LegacyStream(key),
+                                 faithful=faithful, net_fn=net_fn, hook=hook, fill=False, policy=policy)
+    except _Stop:
+        return count[0], time.time() - t0, None
+    t1 = time.time()
+    grow_ref.fill_unlabeled(room['points'], res.cluster_label)
+    return count[0], t1 - t0, time.time() - t1
 
 
-def cpu_baseline(rooms, weights, seconds, policy):
-    """The oracle (faithful NumPy restatement of test_region_grow.py:175-316, per-point Python voxel-set loop,
-    un-hoisted head) on this box's host cores, for a bounded sample: steps of the median-size room.  Beside it a
-    'strong CPU' figure: the same loop with the set membership vectorised and the head hoisted."""
-    n, sizes, dt = _cpu_sample(rooms, weights, seconds * 0.7, policy, True, None)
+def cpu_baseline(rooms, weights, seconds, policy, gpu_room_steps):
+    """The oracle (faithful NumPy restatement of test_region_grow.py:175-316: per-point Python voxel-set loop, un-hoisted
+    1088-wide head) on this box's host cores: the median-size room of the set, grown to the end and filled in when the
+    budget allows (rooms/s = 1 / that time), else extrapolated from its step rate and the steps the GPU run took for the same
+    room.  Beside it a 'strong CPU' step rate: set membership vectorised, head hoisted."""
+    order = np.argsort([len(r['points']) for r in rooms])
+    mid = int(order[len(order) // 2])
+    room = rooms[mid]
+    n, t_grow, t_fill = _cpu_room(room, weights, seconds * 0.75, policy, True, None, 0)
     try:                                       # threads the NumPy BLAS actually runs the matrix products on
         import threadpoolctl
         blas_threads = max([i['num_threads'] for i in threadpoolctl.threadpool_info()] or [1])
     except Exception:
         blas_threads = os.cpu_count()
-    out = dict(value=n / dt, unit='instance-steps/s', cores=blas_threads, kind='port',
-               sample='%d grow steps over %d Area-5-shaped room(s) of %s points, oracle.grow_ref (faithful=True, policy=%s), '
-                      '%.1f s; BLAS threads = cores, Python loops single-threaded' % (n, len(sizes), sizes, policy, dt))
-    n2, sizes2, dt2 = _cpu_sample(rooms, weights, seconds * 0.3, policy, False, _hoisted_numpy_net(weights))
-    out['strong'] = dict(value=n2 / dt2, unit='instance-steps/s',
-                         sample='%d grow steps, vectorised voxel-set membership + hoisted head (NumPy/BLAS), %.1f s' % (n2, dt2))
+    out = dict(value=n / t_grow, unit='instance-steps/s', cores=blas_threads, kind='port')
+    if t_fill is not None:
+        out['rooms_per_sec'] = 1.0 / (t_grow + t_fill)
+        how = 'grown to the end (%d steps, %.1f s) and filled in (%.1f s): rooms/s = 1 / %.1f s' % (n, t_grow, t_fill, t_grow + t_fill)
+    else:
+        steps_room = gpu_room_steps.get(mid) or 900
+        out['rooms_per_sec'] = (n / t_grow) / steps_room
+        out['rooms_per_sec_extrapolated'] = True
+        how = ('%d steps in %.1f s, stopped by the budget; rooms/s extrapolated as step rate / %d steps (what the GPU run took for '
+               'this room), fill-in not included' % (n, t_grow, steps_room))
+    out['sample'] = ('the median-size room of the set (%d points), oracle.grow_ref (faithful=True, policy=%s), %s; BLAS threads = '
+                     'cores, Python loops single-threaded' % (len(room['points']), policy, how))
+    n2, t2, _ = _cpu_room(room, weights, seconds * 0.25, policy, False, _hoisted_numpy_net(weights), 0)
+    out['strong'] = dict(value=n2 / t2, unit='instance-steps/s',
+                         sample='%d grow steps of the same room, vectorised voxel-set membership + hoisted head (NumPy/BLAS), %.1f s' % (n2, t2))
     return out
 
 
@@ -155,9 +177,9 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from learn_region_grow_amd import synthetic, workloads, dist as lrg_dist
-    from learn_region_grow_amd.lrgnet import LrgNetHIP
-    from learn_region_grow_amd.grow import RegionGrower, auto_lanes
+    from learn_region_grow_amd import _lib, synthetic, workloads, dist as lrg_dist
+    from learn_region_grow_amd.lrgnet import LrgNetHIP, _ptr
+    from learn_region_grow_amd.grow import LanedRegionGrower, RegionGrower, auto_lanes
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -171,6 +193,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     coll_dev = dev
+    backend = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if one_dev:
@@ -178,39 +201,52 @@ def main():
             coll_dev = torch.device('cpu')
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        backend = dist.get_backend()
 
     weights = synthetic.make_synthetic_weights(seed=0)
     resolution = 0.1
     if args.workload == 'kitti':
         resolution = 0.3
         rooms = workloads.kitti_scenes(min(args.rooms, 8), seed_base=5000 + 100 * rank, cache_dir=args.cache)
+        base = workloads.kitti_scenes(min(args.rooms, 8), seed_base=5000, cache_dir=args.cache) if rank else rooms
     elif args.workload == 'scannet':
         rooms = workloads.scannet_rooms(min(args.rooms, 39), seed_base=7000 + 100 * rank, cache_dir=args.cache)
+        base = workloads.scannet_rooms(min(args.rooms, 39), seed_base=7000, cache_dir=args.cache) if rank else rooms
     else:
         rooms = workloads.area5_rooms(args.rooms, seed_base=1000 + 100 * rank, cache_dir=args.cache)
-    net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, fuse_pool=bool(args.fuse_pool), mode=args.net_mode).load_weights(weights)
-    # the rooms in flight dealt over `lanes` growers, each on its own stream (largest rooms first, round the lanes)
+        base = workloads.area5_rooms(args.rooms, seed_base=1000, cache_dir=args.cache) if rank else rooms
+    net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, mode=args.net_mode).load_weights(weights)
+    packed = bool(args.packed) and args.net_mode == 'fused' and max(len(r['points']) for r in rooms) <= _lib.LRG_PACKED_MAX_POINTS
+    graph = args.graph if packed else 0
+    if graph and args.iters_per_step % graph:
+        raise SystemExit('--iters-per-step must be a multiple of --graph')
+    grow_kw = dict(restarts=args.restarts, rng='counter', policy=args.policy, resolution=resolution, packed=packed,
+                   graph_iterations=graph)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # steady leg: the rooms in flight dealt over `lanes` growers, each on its own stream (largest rooms first, round the lanes)
+    # ------------------------------------------------------------------------------------------------------------------
     n_lanes = max(1, min(args.lanes, len(rooms))) if args.lanes > 0 else auto_lanes(len(rooms) * args.restarts)
     by_size = sorted(range(len(rooms)), key=lambda i: -len(rooms[i]['points']))
-    parts = [[rooms[i] for i in by_size[k::n_lanes]] for k in range(n_lanes)]
-    lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)] if n_lanes > 1 else [torch.cuda.current_stream(dev)]
+    parts = [[i for i in by_size[k::n_lanes]] for k in range(n_lanes)]
+    lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
     growers = []
     for k in range(n_lanes):
         with torch.cuda.stream(lane_streams[k]):
-            g_ = RegionGrower(net, rooms_in_flight=len(parts[k]), restarts=args.restarts, rng='counter', seed=rank,
-                              policy=args.policy, advance_rounds=args.advance_rounds, resolution=resolution)
-            g_.load_rooms(parts[k])
+            g_ = RegionGrower(net, rooms_in_flight=len(parts[k]), seed=rank, **grow_kw)
+            g_.load_rooms([rooms[i] for i in parts[k]])
             for g in range(g_.n_groups):
                 g_.bind(g, g)
             growers.append(g_)
-    gr = growers[0]
     torch.cuda.synchronize()
+    room_steps = {}          # room index -> instance-steps of its last completed pass (from the device's region log)
 
-    def iterate(k):
-        for _ in range(k):
+    def iterate(iters):
+        per_call = graph if graph else 1
+        for _ in range(0, iters, per_call):
             for lane, g_ in enumerate(growers):
                 with torch.cuda.stream(lane_streams[lane]):
-                    g_.enqueue_iteration()
+                    g_.enqueue()
                     for g in g_.poll_done():          # finished rooms get their fill-in (:308-316) and restart at once
                         r = g_.group_room[g]
                         if args.fill:
@@ -226,58 +262,125 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    iterate(args.warmup)
+    iterate(args.warmup * args.iters_per_step)
     barrier()
     s0 = read_stats()
     t0 = time.perf_counter()
-    iterate(args.steps)
+    iterate(args.steps * args.iters_per_step)
     barrier()
     t1 = time.perf_counter()
     s1 = read_stats()
     elapsed = lrg_dist.allreduce_max(t1 - t0, device=coll_dev)
-    inst_steps, rooms_done, seeds = lrg_dist.allreduce_sum([float(s1[2] - s0[2]), float(s1[1] - s0[1]), float(s1[0] - s0[0])],
-                                                           device=coll_dev)
+    inst_steps, rooms_cycled, seeds = lrg_dist.allreduce_sum([float(s1[2] - s0[2]), float(s1[1] - s0[1]), float(s1[0] - s0[0])],
+                                                             device=coll_dev)
+    iterations = args.steps * args.iters_per_step
 
-    # ---- roofline of the LrgNet evaluation (the dominant kernels), HIP events on the launch stream ----
-    # (one dense batch of all the instances in flight on this GPU, the stacked inputs of the lanes' last iteration)
+    # ------------------------------------------------------------------------------------------------------------------
+    # roofline of the LrgNet evaluation (the dominant kernels), HIP events on the launch stream
+    # ------------------------------------------------------------------------------------------------------------------
     S = sum(g_.S for g_ in growers)
-    b_inl, b_nbr = torch.cat([g_.b_inl for g_ in growers]), torch.cat([g_.b_nbr for g_ in growers])
-    b_add, b_rmv = torch.cat([g_.b_add for g_ in growers]), torch.cat([g_.b_rmv for g_ in growers])
-    b_rows_in, b_rows_nb = torch.cat([g_.b_rows_in for g_ in growers]), torch.cat([g_.b_rows_nb for g_ in growers])
     reps = 20
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    net.forward(b_inl, b_nbr, b_add, b_rmv)
+    rs = np.random.RandomState(0)
+    d_inl = torch.from_numpy((rs.randn(S, 512, 13) * 0.5).astype(np.float32)).to(dev)
+    d_nbr = torch.from_numpy((rs.randn(S, 512, 13) * 0.5).astype(np.float32)).to(dev)
+    # (a) dense: all 512 + 512 rows of every instance in flight (the formulation SURVEY.md 8d prices)
+    net.forward(d_inl, d_nbr)
     torch.cuda.synchronize()
     ev0.record()
     for _ in range(reps):
-        net.forward(b_inl, b_nbr, b_add, b_rmv)
+        net.forward(d_inl, d_nbr)
     ev1.record()
     torch.cuda.synchronize()
     fwd_ms = ev0.elapsed_time(ev1) / reps
-    achieved = S * BYTES_PER_INSTANCE_STEP / (fwd_ms * 1e-3) / 1e9
-    tflops = S * FLOPS_PER_INSTANCE_STEP / (fwd_ms * 1e-3) / 1e12
-    # the same evaluation as the grow loop issues it: only the distinct leading rows of each padded set
-    rows_frac, fwd_rows_ms = 1.0, fwd_ms
-    if gr.skip_duplicate_rows:
-        rows_frac = float((b_rows_in.float().mean() + b_rows_nb.float().mean()).item()) / 1024.0
-        ev0.record()
-        for _ in range(reps):
-            net.forward(b_inl, b_nbr, b_add, b_rmv, rows_in=b_rows_in, rows_nb=b_rows_nb)
-        ev1.record()
-        torch.cuda.synchronize()
-        fwd_rows_ms = ev0.elapsed_time(ev1) / reps
+    flops = S * FLOPS_PER_INSTANCE_STEP
+    tflops = flops / (fwd_ms * 1e-3) / 1e12
+    hbm_accounting = S * BYTES_PER_INSTANCE_STEP / (fwd_ms * 1e-3) / 1e9
+    # (b) as the loop issues it: the packed distinct rows of the lanes' last iteration
+    in_loop = None
+    if packed:
+        rows = np.zeros(2)
+        act = 0
+        loop_ms = 0.0
+        for g_ in growers:
+            sr = g_.p_slot_rows.cpu().numpy()
+            rows += sr[:, :2].sum(axis=0)
+            act += int((sr[:, 0] > 0).sum())
+            nr = torch.tensor([int(sr[:, 0].sum()), int(sr[:, 1].sum())], dtype=torch.int32, device=dev)
+            pb = g_.packed_buffers
 
-    # HBM traffic of one dense evaluation from rocprofv3 FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py,
-    # gfx950 corrections applied there); collected offline at S=68 and committed under profiles/
+            def fwd():
+                _lib.check(g_.lib.lrg_forward_packed(ctypes.byref(net._w), pb.x_in, pb.x_nb, pb.row_slot_in, pb.row_slot_nb, _ptr(nr), None,
+                                                     g_.S, pb.row_cap, pb.add_logits, pb.rmv_logits, pb.workspace, pb.workspace_bytes, 0,
+                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'lrg_forward_packed')
+            fwd()
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(reps):
+                fwd()
+            ev1.record()
+            torch.cuda.synchronize()
+            loop_ms += ev0.elapsed_time(ev1) / reps
+        loop_flops = rows[0] * (FLOPS_PER_BRANCH_ROW + FLOPS_PER_HEAD_ROW) + rows[1] * (FLOPS_PER_BRANCH_ROW + FLOPS_PER_HEAD_ROW) + \
+            act * FLOPS_POOLED_GEMM
+        in_loop = {'rows_evaluated_fraction': float(rows.sum()) / (S * 1024.0), 'packed_rows': [int(rows[0]), int(rows[1])],
+                   'ms_per_evaluation_all_lanes': loop_ms, 'tflops': loop_flops / (loop_ms * 1e-3) / 1e12,
+                   'frac_of_fp32_matrix_peak': loop_flops / (loop_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+                   'useful_tflops_over_the_steady_leg': inst_steps / world / elapsed * loop_flops / max(act, 1) / 1e12}
     traffic = None
     tpath = os.path.join(REPO, 'profiles', 'r01_traffic_%s.json' % args.net_mode)
     if os.path.exists(tpath):
         traffic = json.load(open(tpath))['hbm_bytes_per_forward'] * S / 68.0
+    sq = None
+    spath = os.path.join(REPO, 'profiles', 'r02_pmc_sq_loop.json')
+    if os.path.exists(spath):
+        sq = json.load(open(spath))
 
-    # ---- final label gather over RCCL (the only collective of the path) ----
-    if world > 1:
-        labs = [gr.d_label[int(gr.room_off[r]):int(gr.room_off[r]) + gr.room_n[r]].cpu().numpy() for r in range(2)]
-        lrg_dist.gather_room_labels([rank * 2, rank * 2 + 1], labs, 2 * world, device=coll_dev)
+    # ------------------------------------------------------------------------------------------------------------------
+    # fixed-work leg: R room jobs over all ranks, reset -> final labels (grow + fill-in) -> RCCL gather
+    # ------------------------------------------------------------------------------------------------------------------
+    fixed = None
+    if args.fixed_rooms > 0 and args.restarts == 1:
+        for g_ in growers:
+            g_._release_graph()
+        del growers
+        torch.cuda.empty_cache()
+        R = args.fixed_rooms
+        jobs = [(j % len(base), j) for j in range(R)]                   # (geometry, random-stream key): 8 keys per geometry at R = 544
+        sizes = [len(base[b]['points']) for b, _ in jobs]
+        mine = lrg_dist.shard_rooms_lpt(sizes, world)[rank]
+        job_rooms = [dict(base[jobs[j][0]], room_id=100000 + jobs[j][1]) for j in mine]
+        slots = min(args.rooms, max(1, len(job_rooms)))
+        lg = LanedRegionGrower(net, rooms_in_flight=slots, lanes=args.lanes if args.lanes > 0 else None, seed=0, **grow_kw)
+        lg.load_rooms(job_rooms)
+        barrier()
+        tf0 = time.perf_counter()
+        lg.grow_loaded(fill=bool(args.fill))
+        tf_grow = time.perf_counter() - tf0
+        # the final gather: every rank ends up with every room's labels (one table + one flat int32 buffer, all_gather)
+        flat = torch.cat([gr.d_filled for gr in lg.growers if gr.n_rooms]) if job_rooms else torch.zeros(0, dtype=torch.int32, device=dev)
+        ids = [mine[i] for gr in lg.growers if gr.n_rooms for i in gr.room_index]
+        lens = [n for gr in lg.growers if gr.n_rooms for n in gr.room_n]
+        tg0 = time.perf_counter()
+        gathered = lrg_dist.gather_flat_labels(ids, lens, flat, R, device=coll_dev)
+        barrier()
+        tf1 = time.perf_counter()
+        fixed_elapsed = lrg_dist.allreduce_max(tf1 - tf0, device=coll_dev)
+        st = sum(gr.d_stats[:3].cpu().numpy().astype(np.float64) for gr in lg.growers if gr.n_rooms)
+        f_steps, f_rooms = lrg_dist.allreduce_sum([float(st[2]), float(len(job_rooms))], device=coll_dev)
+        ok = all(gathered[j] is not None and len(gathered[j]) == sizes[j] and int(gathered[j].min()) > 0 for j in range(R))
+        for res_lane in [gr for gr in lg.growers if gr.n_rooms]:
+            rl = res_lane.d_rlog.cpu().numpy()
+            rr = res_lane._read_rooms()
+            for k in range(res_lane.n_rooms):
+                o = int(res_lane.room_off[k])
+                room_steps.setdefault(jobs[mine[res_lane.room_index[k]]][0], int(rl[o:o + rr[k].n_regions, 1].sum()))
+        fixed = {'rooms': int(f_rooms), 'seconds': fixed_elapsed, 'rooms_per_sec': f_rooms / fixed_elapsed,
+                 'instance_steps': f_steps, 'instance_steps_per_sec': f_steps / fixed_elapsed, 'scaling': 'strong',
+                 'slots_per_gpu': slots, 'lanes': len(lg.growers), 'grow_seconds_rank0': tf_grow, 'gather_seconds_rank0': tf1 - tg0,
+                 'rccl_ranks': world, 'collective_backend': backend, 'all_rooms_labeled_after_gather': bool(ok),
+                 'what': '%d room jobs = the %d geometries x %d random-stream keys, LPT-sharded by point count over %d rank(s), '
+                         'reset -> grow -> 1-NN fill-in -> all_gather of the labels' % (R, len(base), (R + len(base) - 1) // len(base), world)}
 
     if rank == 0:
         out = {
@@ -285,33 +388,48 @@ def main():
                                                                                  'kitti': 'KITTI'}[args.workload],
             'value': inst_steps / elapsed,
             'unit': 'instance-steps/s',
-            'rooms_per_sec': rooms_done / elapsed,
+            'rooms_per_sec': fixed['rooms_per_sec'] if fixed else rooms_cycled / elapsed,
+            'rooms_per_sec_steady_cycling': rooms_cycled / elapsed,
             'regions_per_sec': seeds / elapsed,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
+            'ms_per_iteration': 1e3 * elapsed / iterations,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('Semantic-KITTI-shaped synthetic scenes (~100 k points at 0.3 m), %d in flight' % len(rooms)
                                     if args.workload == 'kitti' else
+                                    'ScanNet-shaped synthetic rooms (%d-room set per GPU, all in flight, cycled)' % len(rooms)
+                                    if args.workload == 'scannet' else
                                     'S3DIS Area-5-shaped synthetic rooms (68-room set per GPU, all in flight, cycled)') +
                                    (', greedy test_region_grow.py loop' if args.restarts == 1 else
                                     ', test_random_restart.py loop with %d restarts per seed batched per launch' % args.restarts),
+                       'step': '%d lock-step iterations (every in-flight room takes one region-grow step per iteration)' % args.iters_per_step,
+                       'iterations_per_step': args.iters_per_step, 'timed_iterations': iterations,
                        'rooms_in_flight_per_gpu': len(rooms), 'slots_per_gpu': S, 'lanes': n_lanes, 'policy': args.policy,
                        'restarts': args.restarts, 'points': '512 inlier + 512 neighbour x 13 features',
                        'rng': 'counter (Philox) stream', 'weights': 'synthetic, seed 0', 'net_mode': args.net_mode,
-                       'active_fraction': inst_steps / (args.steps * S * world)},
-            'roofline': {'bound': 'hbm', 'kernel': 'lrg_forward (all launches of one LrgNet evaluation batch)',
-                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'traffic_source': 'profiles/r01_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, S=68)' % args.net_mode,
-                         'algorithmic_bytes': S * BYTES_PER_INSTANCE_STEP, 'ms_per_launch': fwd_ms, 'instances_per_launch': S,
-                         'bytes_per_instance': BYTES_PER_INSTANCE_STEP,
-                         'fp32_matrix_tflops': tflops, 'fp32_matrix_frac': tflops / FP32_MATRIX_PEAK_TFLOPS,
+                       'iteration': 'lrg_grow_step_packed (front kernel + branch / GEMM / head on packed rows)' if packed else 'lrg_grow_step',
+                       'hip_graph_iterations': graph,
+                       'active_fraction': inst_steps / (iterations * S * world)},
+            'roofline': {'bound': 'mfma', 'kernel': 'lrg_forward: fused branch stacks + pooled GEMM + head stacks of one dense LrgNet evaluation '
+                                                   'batch (v_mfma_f32_32x32x2_f32, exact fp32)',
+                         'achieved': tflops, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / FP32_MATRIX_PEAK_TFLOPS,
+                         'traffic': traffic,
+                         'traffic_source': 'profiles/r01_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, S=68)' % args.net_mode,
+                         'algorithmic_flops': flops, 'flops_per_instance': FLOPS_PER_INSTANCE_STEP,
+                         'ms_per_launch': fwd_ms, 'instances_per_launch': S,
+                         'hbm_accounting': {'note': 'SURVEY.md 8d layer-streamed accounting (what an unfused implementation would stream); the '
+                                                    'fused kernels keep activations in LDS, so this is NOT traffic',
+                                            'algorithmic_bytes': S * BYTES_PER_INSTANCE_STEP, 'bytes_per_instance': BYTES_PER_INSTANCE_STEP,
+                                            'GBps': hbm_accounting, 'frac_of_hbm_peak': hbm_accounting / HBM_PEAK_GBS},
+                         'traffic_ratio': (traffic / (S * BYTES_PER_INSTANCE_STEP)) if traffic else None,
                          'note': 'dense launch: all 512+512 rows of every instance evaluated',
-                         'in_loop': {'rows_evaluated_fraction': rows_frac, 'ms_per_launch': fwd_rows_ms,
-                                     'padded_equivalent_GBps': S * BYTES_PER_INSTANCE_STEP / (fwd_rows_ms * 1e-3) / 1e9}},
+                         'in_loop': in_loop, 'in_loop_sq_counters': sq},
         }
+        if fixed:
+            out['fixed_work'] = fixed
         if world == 1 and args.cpu_seconds > 0:
-            out['cpu_baseline'] = cpu_baseline(rooms, weights, args.cpu_seconds, args.policy)
+            out['cpu_baseline'] = cpu_baseline(base, weights, args.cpu_seconds, args.policy, room_steps)
         if world == 1 and args.p0_rooms > 0:
             out['preprocessing_p0'] = p0_rates(args.p0_rooms, dev)
         print(json.dumps(out))

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define LRG_ABI_VERSION 2
+#define LRG_ABI_VERSION 3
 #define LRG_EINVAL (-1000)
 
 #define LRG_MAX_CONV 5 /* branch layers: lite=0 -> 5, lite=1 -> 2, lite=2 -> 3  (learn_region_grow_util.py:77-85) */
@@ -30,7 +30,7 @@ extern "C" {
 int lrg_abi_version(void);
 /* Name of the code object's target ("gfx950"); a build sanity hook for the loader. */
 const char *lrg_target_arch(void);
-/* sizeof() of the ABI structs as compiled (0 LrgWeights, 1 LrgRoom, 2 LrgSlot, 3 LrgGrowParams), so that a
+/* sizeof() of the ABI structs as compiled (0 LrgWeights, 1 LrgRoom, 2 LrgSlot, 3 LrgGrowParams, 4 LrgStepBuffers, 5 LrgPackedBuffers), so that a
  * foreign-language binding can verify its mirror of the layout at load time. */
 size_t lrg_struct_size(int which);
 
@@ -309,6 +309,69 @@ typedef struct LrgStepBuffers {
 int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                   const LrgWeights *weights, const LrgStepBuffers *buffers, int advance_rounds, unsigned forward_flags,
                   void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Packed-row formulation of the same iteration (the default of the batched loop).
+ *
+ * A stacked set with fewer points than sample slots is padded by re-drawing its own rows (test_region_grow.py:240,:252);
+ * LrgNet is row-wise up to the max-pool, which ignores duplicates.  Here only the DISTINCT rows of every slot are
+ * gathered, back to back for all slots (one packed array per branch), and the network runs on dense 32-row tiles of
+ * those arrays: a tile may hold rows of several slots; the max-pool (:122-123) and the hoisted per-instance bias
+ * (:128-141) are applied per run of rows of one slot.  Logits come back per packed row; sample slot j of a padded set
+ * reads the logits of its source row.  Results are bit-identical to lrg_grow_step.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* LrgNet on packed rows.  x_in / x_nb [row_cap,F] hold nrows[0] / nrows[1] valid rows (device int32 pair);
+ * row_inst_in / row_inst_nb [row_cap] name the instance (0 <= . < n_inst) of each row, rows of one instance being
+ * contiguous; row_cap is a multiple of LRG_ROW_TILE.  add_logits [row_cap,2] (per neighbour row, net.add_output :149),
+ * rmv_logits [row_cap,2] (per inlier row, net.remove_output :162).
+ * nrows_heads (nullable, device int32 pair): when given, the row counts are handed over to it and nrows is zeroed
+ * between the branch and the head kernels, so that the caller's next allocation pass starts from zero.
+ * flags: LRG_FWD_POOL_ZEROED = the pooled block of the workspace (lrg_forward_packed_pooled_view) is zero on entry.
+ * Needs the layer widths the fused kernels are built for (lite 0/1/2). */
+size_t lrg_forward_packed_workspace_bytes(const LrgWeights *w, int n_inst, int row_cap);
+int lrg_forward_packed_pooled_view(const LrgWeights *w, int n_inst, int row_cap, size_t *offset_floats, size_t *count_floats);
+int lrg_forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const int32_t *row_inst_in,
+                       const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
+                       float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes, unsigned flags,
+                       void *stream);
+
+/* Device buffers of one packed iteration over n_slots slots (all caller-owned; counters zero before the first call). */
+typedef struct LrgPackedBuffers {
+    float *center;          /* [n_slots,16]                                                                  */
+    int32_t *sample_in;     /* [n_slots,n_inlier]   sample positions (:237-240)                              */
+    int32_t *sample_nb;     /* [n_slots,n_neighbor] (:249-252)                                               */
+    float *x_in;            /* [row_cap,F] packed distinct inlier rows of all slots (:245-247)               */
+    float *x_nb;            /* [row_cap,F] packed distinct neighbour rows (:243-244,:253)                    */
+    int32_t *row_slot_in;   /* [row_cap] slot of each packed row                                             */
+    int32_t *row_slot_nb;
+    uint8_t *gt_in;         /* [row_cap] input_remove of the row's point (:248)                              */
+    uint8_t *gt_nb;         /* [row_cap] input_add (:254)                                                    */
+    float *rmv_logits;      /* [row_cap,2] per packed inlier row                                             */
+    float *add_logits;      /* [row_cap,2] per packed neighbour row                                          */
+    int32_t *slot_rows;     /* [n_slots,4] rows_in, rows_nb, first packed inlier row, first packed neighbour row */
+    int32_t *counters;      /* [4] packed rows allocated (in, nb) and their hand-over copy for the heads      */
+    void *workspace;        /* lrg_forward_packed_workspace_bytes(w, n_slots, row_cap), 256-byte aligned       */
+    size_t workspace_bytes;
+    int64_t *stats;         /* LRG_STATS_WORDS x int64, as LrgStepBuffers                                      */
+    int32_t row_cap;        /* multiple of LRG_ROW_TILE, >= n_slots * max(n_inlier, n_neighbor)                */
+    int32_t reserved;
+} LrgPackedBuffers;
+
+/* One lock-step iteration, packed rows: lrg_front_kernel (mask update of the previous evaluation :262-288, stop decision
+ * :291-306, commit / next seed :186-217, box query :221-235, medians :241, sampling :237-252, gather :242-254) and
+ * lrg_forward_packed -- four launches (six with restart groups).  Slot masks (LrgSlot.cur) must be 4-byte aligned;
+ * rooms of up to 131072 points, n_inlier / n_neighbor <= 1024; larger: lrg_grow_step. */
+int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                         const LrgWeights *weights, const LrgPackedBuffers *buffers, void *stream);
+
+/* `iterations` calls of lrg_grow_step_packed captured into a HIP graph on `stream` (not the null stream; weights->packed
+ * set).  Nothing runs at creation.  lrg_step_graph_launch replays them with one host call. */
+int lrg_step_graph_create(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                          const LrgWeights *weights, const LrgPackedBuffers *buffers, int iterations, void *stream,
+                          void **graph_out);
+int lrg_step_graph_launch(void *graph, void *stream);
+int lrg_step_graph_destroy(void *graph);
 
 /* 1-NN fill-in of unlabeled points in all F feature dims, first-min ties (:308-316). */
 int lrg_nn1_fill(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *stream);

@@ -74,6 +74,15 @@ class LrgStepBuffers(ctypes.Structure):
                 ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('rows_in', _fp), ('rows_nb', _fp)]
 
 
+class LrgPackedBuffers(ctypes.Structure):
+    _fields_ = [('center', _fp), ('sample_in', _fp), ('sample_nb', _fp), ('x_in', _fp), ('x_nb', _fp),
+                ('row_slot_in', _fp), ('row_slot_nb', _fp), ('gt_in', _fp), ('gt_nb', _fp), ('rmv_logits', _fp),
+                ('add_logits', _fp), ('slot_rows', _fp), ('counters', _fp), ('workspace', _fp),
+                ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('row_cap', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+LRG_ROW_TILE = 32
+LRG_PACKED_MAX_POINTS = 32 * 4096      # lrg_grow_step_packed: rooms up to 131072 points
 LRG_DONE_RING = 1020
 LRG_STATS_WORDS = 4 + LRG_DONE_RING
 
@@ -85,7 +94,7 @@ class LrgHipError(RuntimeError):
 def build(verbose=False):
     """hipcc --offload-arch=gfx950 -> learn_region_grow_amd/liblrg_hip.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ('lrg_common.h', 'lrg_rng.h', 'lrg_fused.h')] + \
+    deps = srcs + [os.path.join(CSRC, h) for h in ('lrg_common.h', 'lrg_rng.h', 'lrg_fused.h', 'lrg_front.inl')] + \
         [os.path.join(os.path.dirname(HERE), 'include', 'lrg_hip.h')]
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
@@ -133,6 +142,18 @@ _SIGS = {
                                        _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     'lrg_grow_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgWeights),
                                      ctypes.POINTER(LrgStepBuffers), ctypes.c_int, ctypes.c_uint, _fp]),
+    'lrg_forward_packed_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(LrgWeights), ctypes.c_int, ctypes.c_int]),
+    'lrg_forward_packed_pooled_view': (ctypes.c_int, [ctypes.POINTER(LrgWeights), ctypes.c_int, ctypes.c_int,
+                                                      ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    'lrg_forward_packed': (ctypes.c_int, [ctypes.POINTER(LrgWeights), _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
+                                          _fp, _fp, _fp, ctypes.c_size_t, ctypes.c_uint, _fp]),
+    'lrg_grow_step_packed': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
+                                            ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgPackedBuffers), _fp]),
+    'lrg_step_graph_create': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
+                                             ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgPackedBuffers), ctypes.c_int, _fp,
+                                             ctypes.POINTER(ctypes.c_void_p)]),
+    'lrg_step_graph_launch': (ctypes.c_int, [_fp, _fp]),
+    'lrg_step_graph_destroy': (ctypes.c_int, [_fp]),
     'lrg_nn1_fill': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
     'lrg_nn1_fill_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
     'lrg_nn1_fill_ws': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]),
@@ -170,9 +191,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lrg_abi_version() != 2:
+    if lib.lrg_abi_version() != 3:
         raise LrgHipError('ABI version mismatch')
-    for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams)):
+    for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers)):
         if lib.lrg_struct_size(which) != ctypes.sizeof(st):
             raise LrgHipError('struct layout mismatch for %s: C %d vs ctypes %d' %
                               (st.__name__, lib.lrg_struct_size(which), ctypes.sizeof(st)))

@@ -25,7 +25,8 @@ class BeamSearchGrower(RegionGrower):
                  cluster_threshold=10):
         self.beam_width, self.search_width = int(beam_width), int(search_width)
         super().__init__(net, rooms_in_flight=rooms_in_flight, restarts=1, group_size=self.beam_width * self.search_width,
-                         rng='counter', seed=seed, policy=policy, resolution=resolution, cluster_threshold=cluster_threshold)
+                         rng='counter', seed=seed, policy=policy, resolution=resolution, cluster_threshold=cluster_threshold,
+                         packed=False)     # the levels are driven through the separate entry points
         self.cluster_threshold = cluster_threshold
 
     # ---- host-side room state -------------------------------------------------------------------------------------------

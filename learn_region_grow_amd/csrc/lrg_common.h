@@ -20,6 +20,15 @@
 
 static inline size_t lrg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Function attributes (dynamic-LDS cap) are per device: remember per device ordinal which kernels were raised.  A race
+// between host threads only repeats an idempotent call.
+#define LRG_MAX_DEVICES 64
+static inline int lrg_current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= LRG_MAX_DEVICES) d = 0;
+    return d;
+}
+
 __device__ __forceinline__ int lrg_lane() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ float lrg_wave_max(float v) {
@@ -75,3 +84,16 @@ __device__ __forceinline__ int lrg_op_umax(int a, int b) { return (int)max((unsi
 __device__ __forceinline__ int lrg_wave_sum_i32(int v) { const int ident = 0; LRG_DPP_REDUCE(lrg_op_add) }
 __device__ __forceinline__ unsigned lrg_wave_min_u32(unsigned x) { int v = (int)x; const int ident = -1; LRG_DPP_REDUCE(lrg_op_umin) }
 __device__ __forceinline__ unsigned lrg_wave_max_u32(unsigned x) { int v = (int)x; const int ident = 0; LRG_DPP_REDUCE(lrg_op_umax) }
+
+// Inclusive prefix sum over the 64 lanes of a wavefront on the DPP network: Hillis-Steele inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8; lanes without a source add 0), then the row totals ripple through row_bcast15 / row_bcast31.
+// Needs every lane active.
+__device__ __forceinline__ int lrg_wave_incl_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  /* row_shr:1 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  /* row_shr:2 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  /* row_shr:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  /* row_shr:8 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  /* row_bcast15 -> rows 1, 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  /* row_bcast31 -> rows 2, 3 */
+    return v;
+}

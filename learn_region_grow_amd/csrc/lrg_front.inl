@@ -1,0 +1,395 @@
+// Packed-row formulation of one lock-step iteration (lrg_grow_step_packed); included by lrg_grow.hip.
+//
+// lrg_grow_step is a chain of nine launches whose durations are latency, not work (profiles/r02_diag_gaps.txt: advance
+// 24 us, box count 7, box compact 8, medians 15, prepare 15, branch stack 54, pooled GEMM 10, head stack 26, mask update
+// 7), and its network kernels spend ~45 % of their 32-row tiles on padding: every slot's stacked set is tiled on its own,
+// and the median region has 57 points.  Here
+//   * everything between two network evaluations is ONE kernel with one 1024-thread workgroup per slot
+//     (lrg_front_kernel): the mask update of the evaluation just finished (test_region_grow.py:262-288), count and
+//     bounding box of the new mask (:292-293) from the slot's index lists instead of a scan of the room, the stop / stuck
+//     decision (:291-306), commit + next seed (:186-217), the dilated box query with ordered compaction (:221-235) as
+//     one coalesced pass over the room with all flags parked in LDS, the per-channel medians (:241), subset sampling
+//     (:237-252) and the gather (:242-254);
+//   * the gather writes only the DISTINCT rows of each stacked set (the rest are copies, :240,:252), and writes them
+//     back to back for all slots: the network runs on dense 32-row tiles of that packed array (lrg_forward_packed), with
+//     the max-pool (:122-123) and the hoisted per-instance bias (:128-141) applied per run of rows of one slot.
+// Four launches per iteration (front | branch stacks | pooled GEMM | head stacks); results are bit-identical to
+// lrg_grow_step (same arithmetic on the same rows; the max-pool and the atomics are order-independent).
+
+#define LRG_FRONT_THREADS 1024
+#define LRG_FRONT_MAXCHUNK 32                         // 32 x 4096 points: rooms up to 131072 points (KITTI scenes: ~100 k)
+#define LRG_FRONT_MAXSAMPLE 1024                      // n_inlier, n_neighbor <= 1024
+
+struct LrgFrontArgs {
+    float *center;
+    int32_t *sample_in, *sample_nb;
+    float *x_in, *x_nb;
+    int32_t *row_slot_in, *row_slot_nb;
+    uint8_t *gt_in, *gt_nb;
+    const float *rmv_logits, *add_logits;
+    int32_t *slot_rows;      // [n_slots,4]: rows_in, rows_nb, first packed inlier row, first packed neighbour row
+    int32_t *counters;       // [0] packed inlier rows, [1] packed neighbour rows allocated so far in this iteration
+    float *pooled;           // [n_slots, pooled_stride] pooled features of the network workspace (zeroed here per slot)
+    int pooled_stride;
+    int64_t *stats;
+};
+
+// ---- (1) mask update of the evaluation just finished + count / bounding box of the new mask + stop decision ----
+// The new mask is (old members that survive the removes) + (newly added points that survive them): both sets are at
+// hand as index lists -- cur_idx (written by the box query that preceded the evaluation) and the list of points this
+// update switched on -- so :292-293 cost O(region), not O(room).
+__device__ void lrg_front_update(LrgSlot *S, const LrgRoom *R, int s, const LrgGrowParams &prm, const LrgFrontArgs &a,
+                                 int *sh_added, int *red) {
+    __shared__ int sh_upd, sh_nadd;
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int F = prm.feature_size, Ni = prm.n_inlier, Nn = prm.n_neighbor;
+    const int nc = S->nc, ne = S->ne;
+    const int offi = a.slot_rows[4 * s + 2], offn = a.slot_rows[4 * s + 3];
+    const float res = prm.resolution;
+    const float c0 = a.center[s * 16 + 0], c1 = a.center[s * 16 + 1];
+    const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
+    const uint32_t seed = (uint32_t)S->seed, restart = (uint32_t)S->restart, step = (uint32_t)S->step;
+    uint8_t *cur = S->cur;
+    if (tid == 0) { sh_upd = 0; sh_nadd = 0; }
+    __syncthreads();
+    // ---- add pass (:266,:270-273,:283-285): sample slot j draws for itself, its logits / coordinates are its source row's ----
+    for (int j = tid; j < Nn; j += bd) {
+        const long row = offn + (ne < Nn ? a.sample_nb[(long)s * Nn + j] : j);
+        bool take;
+        if (prm.policy == 2) take = a.gt_nb[row] != 0;
+        else {
+            const float conf = lrg_conf(a.add_logits + 2 * row);
+            if (prm.policy == 1) take = conf > 0.5f;
+            else take = lrg_uniform01(lrg_rng_word((uint32_t)j, LRG_PURPOSE_ADD, seed, restart, step, k0, k1)) < conf;
+        }
+        if (take) {
+            const float *p = a.x_nb + row * F;
+            const int vx = lrg_voxel_of(__fadd_rn(p[0], c0), res);      // :271-272: un-centre x,y then rint(/res)
+            const int vy = lrg_voxel_of(__fadd_rn(p[1], c1), res);
+            const int vz = lrg_voxel_of(p[2], res);
+            const int idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(vx, vy, vz));
+            if (idx >= 0) {
+                // several sample slots may name the same point: the word-wide atomic elects the one that switches it on
+                unsigned *w = reinterpret_cast<unsigned *>(cur + (idx & ~3));
+                const unsigned bit = 1u << (8 * (idx & 3));
+                if (!(atomicOr(w, bit) & bit)) { sh_upd = 1; sh_added[atomicAdd(&sh_nadd, 1)] = idx; }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- remove pass (:267,:274-277,:286-287) ----
+    for (int j = tid; j < Ni; j += bd) {
+        const long row = offi + (nc < Ni ? a.sample_in[(long)s * Ni + j] : j);
+        bool take;
+        if (prm.policy == 2) take = a.gt_in[row] != 0;
+        else {
+            const float conf = lrg_conf(a.rmv_logits + 2 * row);
+            if (prm.policy == 1) take = conf > 0.5f;
+            else take = lrg_uniform01(lrg_rng_word((uint32_t)j, LRG_PURPOSE_RMV, seed, restart, step, k0, k1)) < conf;
+        }
+        if (take) {
+            const float *p = a.x_in + row * F;
+            const int vx = lrg_voxel_of(__fadd_rn(p[0], c0), res);
+            const int vy = lrg_voxel_of(__fadd_rn(p[1], c1), res);
+            const int vz = lrg_voxel_of(p[2], res);
+            const int idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(vx, vy, vz));
+            if (idx >= 0) cur[idx] = 0;
+        }
+    }
+    __syncthreads();
+    // ---- members and bounding box of the new mask (:292-293) from the two lists ----
+    const int32_t *vox = R->voxels;
+    const int32_t *lst = S->cur_idx;
+    const int nadd = sh_nadd;
+    int cnt = 0;
+    int mn0 = INT_MAX, mn1 = INT_MAX, mn2 = INT_MAX, mx0 = INT_MIN, mx1 = INT_MIN, mx2 = INT_MIN;
+    for (int i0 = 0; i0 < nc; i0 += 4 * bd) {
+        int id[4], al[4], va[4], vb[4], vc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) id[k] = lst[min(i0 + k * bd + tid, nc - 1)];       // unconditional, clamped: all in flight
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { al[k] = cur[id[k]]; va[k] = vox[3 * id[k]]; vb[k] = vox[3 * id[k] + 1]; vc[k] = vox[3 * id[k] + 2]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k * bd + tid < nc && al[k]) {
+                ++cnt;
+                mn0 = min(mn0, va[k]); mn1 = min(mn1, vb[k]); mn2 = min(mn2, vc[k]);
+                mx0 = max(mx0, va[k]); mx1 = max(mx1, vb[k]); mx2 = max(mx2, vc[k]);
+            }
+    }
+    for (int k = tid; k < nadd; k += bd) {
+        const int idx = sh_added[k];
+        if (cur[idx]) {                                               // (a point added and removed in the same step stays out)
+            const int va = vox[3 * idx], vb = vox[3 * idx + 1], vc = vox[3 * idx + 2];
+            ++cnt;
+            mn0 = min(mn0, va); mn1 = min(mn1, vb); mn2 = min(mn2, vc);
+            mx0 = max(mx0, va); mx1 = max(mx1, vb); mx2 = max(mx2, vc);
+        }
+    }
+    lrg_block_bbox(cnt, mn0, mn1, mn2, mx0, mx1, mx2, red);
+    if (tid == 0) {
+        S->scan_cnt = cnt;
+        S->scan_mn[0] = mn0; S->scan_mn[1] = mn1; S->scan_mn[2] = mn2;
+        S->scan_mx[0] = mx0; S->scan_mx[1] = mx1; S->scan_mx[2] = mx2;
+        S->updated = sh_upd;
+        S->pad = 0;
+        S->step += 1;
+        S->steps_total += 1;                                                    // :288
+        if (a.stats) atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[2]), 1ULL);
+        lrg_stop_logic(S);                                                      // :291-306
+    }
+    __syncthreads();
+}
+
+// ---- (2) dilated voxel-box query with ordered compaction (:221-235) by ONE workgroup ----
+// Pass 1 reads the room once, coalesced, 8 points per thread in flight: a byte of flags per (4096-point chunk, thread)
+// goes to LDS, a packed (current | candidate << 16) count per (chunk, wavefront) to a table.  One exclusive scan of that
+// table (<= 512 entries) gives every (chunk, wavefront) its base; pass 2 takes the flags back from LDS, ranks the lanes of
+// a wavefront with a DPP prefix sum and writes the two index lists in index order.
+__device__ void lrg_front_query(LrgSlot *S, const LrgRoom *R, const LrgGrowParams &prm, uint8_t *sh_flags, int *sh_tab,
+                                int *sh_tabc, int *sh_tabe) {
+    __shared__ int wt_c[8], wt_e[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = R->n;
+    const int nchunk = (n + LRG_SCAN_CHUNK - 1) / LRG_SCAN_CHUNK;
+    const int lo0 = S->mn[0] - 1, lo1 = S->mn[1] - 1, lo2 = S->mn[2] - 1;     // :222-225
+    const int hi0 = S->mx[0] + 1, hi1 = S->mx[1] + 1, hi2 = S->mx[2] + 1;
+    const uint8_t *cur = S->cur, *visited = R->visited;
+    const int32_t *vox = R->voxels;
+    for (int c0 = 0; c0 < nchunk; c0 += 2) {            // 8 points per thread per trip (40 registers of loads in flight)
+        int cu[8], vi[8], va[8], vb[8], vc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                   // unconditional loads at clamped indices: no dependent round trips
+            const int i = min((c0 + (k >> 2)) * LRG_SCAN_CHUNK + 4 * tid + (k & 3), n - 1);
+            cu[k] = cur[i]; vi[k] = visited[i];
+            va[k] = vox[3 * i]; vb[k] = vox[3 * i + 1]; vc[k] = vox[3 * i + 2];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = c0 + q;
+            if (c < nchunk) {                           // workgroup-uniform
+                int fc = 0, fe = 0;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 4 * q + kk;
+                    if (c * LRG_SCAN_CHUNK + 4 * tid + kk < n) {
+                        if (cu[k]) fc |= 1 << kk;
+                        else if (!vi[k] && va[k] >= lo0 && va[k] <= hi0 && vb[k] >= lo1 && vb[k] <= hi1 && vc[k] >= lo2 && vc[k] <= hi2)
+                            fe |= 1 << kk;                                      // :226-228
+                    }
+                }
+                sh_flags[c * LRG_FRONT_THREADS + tid] = (uint8_t)(fc | (fe << 4));
+                const int packed = lrg_wave_sum_i32(__popc(fc) | (__popc(fe) << 16));      // <= 256 per half
+                if (lane == 0) sh_tab[c * 16 + wave] = packed;
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the table in (chunk, wavefront) order by the first 512 threads
+    const int nent = nchunk * 16;
+    int vcn = 0, ven = 0;
+    if (tid < 512 && tid < nent) { const int p = sh_tab[tid]; vcn = p & 0xFFFF; ven = (int)((unsigned)p >> 16); }
+    const int ic = lrg_wave_incl_scan_i32(vcn), ie = lrg_wave_incl_scan_i32(ven);
+    if (tid < 512 && lane == 63) { wt_c[wave] = ic; wt_e[wave] = ie; }
+    __syncthreads();
+    int totc = 0, tote = 0;
+    {
+        int oc = 0, oe = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            if (w < wave) { oc += wt_c[w]; oe += wt_e[w]; }
+            totc += wt_c[w]; tote += wt_e[w];
+        }
+        if (tid < 512) { sh_tabc[tid] = oc + ic - vcn; sh_tabe[tid] = oe + ie - ven; }
+    }
+    __syncthreads();
+    int32_t *cur_idx = S->cur_idx, *cand_idx = S->cand_idx;
+    for (int c = 0; c < nchunk; ++c) {
+        const int f = sh_flags[c * LRG_FRONT_THREADS + tid];
+        const int fc = f & 15, fe = f >> 4;
+        const int mine = __popc(fc) | (__popc(fe) << 16);
+        const int excl = lrg_wave_incl_scan_i32(mine) - mine;
+        int pc = sh_tabc[c * 16 + wave] + (excl & 0xFFFF), pe = sh_tabe[c * 16 + wave] + (int)((unsigned)excl >> 16);
+        const int ib = c * LRG_SCAN_CHUNK + 4 * tid;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (fc >> k & 1) cur_idx[pc++] = ib + k;
+            if (fe >> k & 1) cand_idx[pe++] = ib + k;
+        }
+    }
+    if (tid == 0) {
+        S->pad = 1;
+        S->nc = totc;
+        S->ne = tote;
+        if (tote == 0) {                                                        // :233-235
+            S->status = LRG_STOP_NONEIGHBOR; S->last_reason = LRG_STOP_NONEIGHBOR; S->count = totc;
+        } else if (prm.max_region_steps > 0 && S->step >= prm.max_region_steps) {
+            S->status = LRG_STOP_MAXSTEPS; S->last_reason = LRG_STOP_MAXSTEPS; S->count = totc;
+        }
+    }
+    __syncthreads();
+}
+
+// Median of one channel over nc <= 4096 points by one wavefront, 64 keys per lane; the gather goes in two batches of 32
+// so that index and key registers of a batch are not all live at once (1024-thread workgroups have 128 VGPRs per lane).
+__device__ __forceinline__ float lrg_median_wave_r64(const float *pts, const int32_t *idx, int F, int nc) {
+    const int lane = lrg_lane();
+    uint32_t key[64];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int id[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) id[r] = idx[min((h * 32 + r) * 64 + lane, nc - 1)];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) key[h * 32 + r] = ((h * 32 + r) * 64 + lane < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
+    }
+    return lrg_select_regs<64>(key, nc);
+}
+
+// ---- (3) medians, subset sampling, gather of the distinct rows into the packed arrays ----
+__device__ void lrg_front_prepare(const LrgSlot *S, const LrgRoom *R, int s, const LrgGrowParams &prm, const LrgFrontArgs &a,
+                                  int (*sh_src)[LRG_FRONT_MAXSAMPLE], float *sh_c, int *sh_med) {
+    __shared__ int sh_off[2];
+    const int tid = threadIdx.x, bd = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int F = prm.feature_size, Ni = prm.n_inlier, Nn = prm.n_neighbor;
+    const int nc = S->nc, ne = S->ne;
+    const int rin = min(nc, Ni), rnb = min(ne, Nn);
+    const float *points = R->points;
+    const int32_t *obj = R->obj_id;
+    if (tid == 0) {
+        const int oi = atomicAdd(&a.counters[0], rin), on = atomicAdd(&a.counters[1], rnb);
+        sh_off[0] = oi; sh_off[1] = on;
+        a.slot_rows[4 * s + 0] = rin; a.slot_rows[4 * s + 1] = rnb; a.slot_rows[4 * s + 2] = oi; a.slot_rows[4 * s + 3] = on;
+    }
+    // ---- subset sampling (:237-240, :249-252): positions -> source indices (independent of the centre) ----
+    const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
+    for (int u = tid; u < Ni + Nn; u += bd) {
+        const int side = u >= Ni, j = side ? u - Ni : u;
+        const int n = side ? ne : nc, k = side ? Nn : Ni;
+        const int pos = (int)lrg_sample_position((uint32_t)j, (uint32_t)n, (uint32_t)k, side ? LRG_PURPOSE_NEIGHBOR : LRG_PURPOSE_INLIER,
+                                                 (uint32_t)S->seed, (uint32_t)S->restart, (uint32_t)S->step, k0, k1);
+        (side ? a.sample_nb : a.sample_in)[(long)s * k + j] = pos;
+        if (j < min(n, k)) sh_src[side][j] = (side ? S->cand_idx : S->cur_idx)[pos];     // rows past min(n, k) are copies of these
+    }
+    if (tid < 16) sh_c[tid] = 0.f;
+    __syncthreads();
+    TRACE2(s, 4);
+    // ---- centre (:241): per-channel median of ALL current points, channels 0,1,6.. (:243-247) ----
+    if (nc <= 4096) {
+        // one wavefront per centred channel, keys in registers, no barrier
+        if (wave < 9) {
+            const int ch = lrg_centred_channel(wave, F);
+            if (ch >= 0) {
+                const float *pts = points + ch;
+                const float m = nc <= 256 ? lrg_median_wave_r<4>(pts, S->cur_idx, F, nc)
+                              : nc <= 1024 ? lrg_median_wave_r<16>(pts, S->cur_idx, F, nc)
+                                           : lrg_median_wave_r64(pts, S->cur_idx, F, nc);
+                if (lane == 0) sh_c[ch] = m;
+            }
+        }
+    } else {
+        for (int y = 0; y < 9; ++y) {
+            const int ch = lrg_centred_channel(y, F);
+            if (ch < 0) continue;
+            __syncthreads();
+            if (tid < 64) sh_med[tid] = tid == 0 ? -1 : 0;
+            __syncthreads();
+            const float *pts = points + ch;
+            float m;
+            if (nc <= 16 * 1024) m = lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh_med);
+            else if (nc <= LRG_MED_REGS) m = lrg_median_block_regs<48>(pts, S->cur_idx, F, nc, sh_med);
+            else {
+                const int k2 = nc >> 1, k1r = (nc & 1) ? k2 : k2 - 1;
+                uint32_t ka, kb;
+                lrg_select2(nullptr, false, points, S->cur_idx, F, ch, nc, k1r, k2, sh_med, &ka, &kb);
+                const float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
+                m = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+            }
+            if (tid == 0) sh_c[ch] = m;
+        }
+    }
+    __syncthreads();
+    TRACE2(s, 5);
+    if (tid < 16) a.center[s * 16 + tid] = sh_c[tid];       // the next update un-centres x, y with it (:271,:275)
+    const int offi = sh_off[0], offn = sh_off[1];
+    // ---- per-row tags: owning slot and the ground-truth flags input_remove / input_add (:230-231,:248,:254) ----
+    const int target = S->target;
+    for (int j = tid; j < rin; j += bd) {
+        a.row_slot_in[offi + j] = s;
+        a.gt_in[offi + j] = obj ? (uint8_t)(obj[sh_src[0][j]] != target) : 0;
+    }
+    for (int j = tid; j < rnb; j += bd) {
+        a.row_slot_nb[offn + j] = s;
+        a.gt_nb[offn + j] = obj ? (uint8_t)(obj[sh_src[1][j]] == target) : 0;
+    }
+    TRACE2(s, 6);
+    // ---- gather + centre (:242-254), element-wise so that loads and stores of a row are contiguous across lanes ----
+    for (int side = 0; side < 2; ++side) {
+        const int k = side ? rnb : rin;
+        float *out = side ? a.x_nb + (long)offn * F : a.x_in + (long)offi * F;
+        const int nel = k * F;
+        for (int e0 = tid; e0 < nel; e0 += 8 * bd) {       // 8 independent row loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + u * bd, nel - 1);
+                const int j = e / F, f = e - j * F;
+                v[u] = __fsub_rn(points[(long)sh_src[side][j] * F + f], sh_c[f]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * bd;
+                if (e < nel) out[e] = v[u];
+            }
+        }
+    }
+}
+
+// MODE bits: 1 = mask update + stop decision, 2 = commit / next seed for single-slot groups (greedy growing), 4 = box query +
+// preparation.  Greedy growing runs all three in one launch; restart groups put lrg_advance_kernel (one workgroup per
+// GROUP) between a MODE 1 and a MODE 4 launch.
+template <int MODE>
+__global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
+                                                                       LrgGrowParams prm, LrgFrontArgs a) {
+    __shared__ uint8_t sh_flags[LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS];
+    __shared__ int sh_tab[512], sh_tabc[512], sh_tabe[512];
+    __shared__ int sh_src[2][LRG_FRONT_MAXSAMPLE];
+    __shared__ float sh_c[16];
+    __shared__ int red[16 * 8];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    LrgSlot *S = &slots[s];
+    const int room = S->room;
+    if ((MODE & 1) && a.pooled)      // the last evaluation's pooled feature has been consumed: zero for the next one
+        for (int c = tid; c < a.pooled_stride; c += blockDim.x) a.pooled[(long)s * a.pooled_stride + c] = 0.f;
+    if (room < 0) {
+        if ((MODE & 4) && tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; }
+        return;
+    }
+    LrgRoom *R = &rooms[room];
+    TRACE2(s, 0);
+    if ((MODE & 1) && S->status == LRG_ACTIVE) lrg_front_update(S, R, s, prm, a, &sh_src[0][0], red);
+    TRACE2(s, 1);
+    if (MODE & 2) {
+        __syncthreads();
+        lrg_advance_group<false>(slots, rooms, n_slots, prm, a.stats, s);
+        __syncthreads();
+    }
+    TRACE2(s, 2);
+    if (MODE & 4) {
+        bool active = S->status == LRG_ACTIVE;
+        if (active && S->pad != 1) {
+            lrg_front_query(S, R, prm, sh_flags, sh_tab, sh_tabc, sh_tabe);
+            active = S->status == LRG_ACTIVE;
+        }
+        TRACE2(s, 3);
+        if (!active) {
+            if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; }
+            return;
+        }
+        lrg_front_prepare(S, R, s, prm, a, sh_src, sh_c, red);
+        TRACE2(s, 7);
+#if LRG_TRACE
+        if (tid == 0 && g_lrg_trace2) { g_lrg_trace2[(long)s * 16 + 8] = S->nc; }
+#endif
+    }
+}

@@ -26,6 +26,11 @@ struct LrgFusedProb {
     const int *tile_count; // nullable pair: *tile_count live tiles, tile_list[b] = instance * 64 + tile of workgroup b
     const int *tile_list;
     float *zero_pool;    // nullable: after the stack, the tile-0 workgroup of instance i clears zero_pool[i*zero_count .. +zero_count)
+    // packed rows (lrg_forward_packed): x holds the distinct rows of ALL instances back to back, *nrows of them; row r belongs
+    // to instance row_inst[r].  Tiles are 32 consecutive packed rows and may span instances: the max-pool and the
+    // per-instance bias are applied per run of equal row_inst inside the tile.
+    const int *nrows;    // nullable: device count of packed rows (non-NULL selects the packed formulation)
+    const int *row_inst; // [capacity] instance of each packed row
     long rows;
     int ldx, Kin, rows_per_inst, pool_stride, nlayers, zero_count;
     LrgFusedLayer L[LRG_FUSED_MAXL];
@@ -37,3 +42,6 @@ struct LrgFusedArgs {
 
 int lrg_fused_branches(const LrgFusedArgs &a, int nprob, hipStream_t st);
 int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st);
+// packed-row variants: P.rows = row capacity (multiple of 32), P.nrows / P.row_inst set
+int lrg_fused_branches_packed(const LrgFusedArgs &a, int nprob, hipStream_t st);
+int lrg_fused_heads_packed(const LrgFusedArgs &a, int nprob, hipStream_t st);

@@ -103,20 +103,32 @@ __device__ __forceinline__ void tile_mfma_first(f32x16 (&acc)[RT], const float *
 
 // DIRECT: also compile the register-to-HBM copy of layers that do not stay in LDS (LRG_FWD_KEEP_ACTS on the pooled layer
 // and on an in-place head layer; parity tests only) -- it costs ~25 VGPRs, which is the third wave per SIMD.
-template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT>
+// PACKED: the rows of all instances are stored back to back (only the distinct ones, lrg_front_kernel); a tile is 32
+// consecutive packed rows and may hold rows of several instances -- the runs of equal row_inst inside it.
+template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false>
 __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFusedArgs args) {
     constexpr int FM = 32 * RT;      // rows (points) per workgroup
+    static_assert(!PACKED || RT == 1, "packed rows use 32-row tiles");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *buf0 = smem;                       // outputs of even layers
     float *buf1 = smem + CAP0;                // the staged input and outputs of odd layers
     float *poolbuf = smem + CAP0 + CAP1;      // [512] running column maxima of the pooled layer / final-layer weights
+    int *run_start = reinterpret_cast<int *>(poolbuf + 512);   // PACKED: [FM + 1] first row of each run (and the end)
+    int *run_inst = run_start + FM + 1;                        //         [FM] instance of each run, -1 = dead rows past *nrows
+    int *run_count = run_inst + FM;                            //         [1]
 
     const LrgFusedProb &P = args.p[blockIdx.y];
     // Tile-major block order (instance fastest): block b runs on XCD b % 8, and with duplicate-row skipping mostly the
     // FIRST tiles of the instances survive -- instance-major order would put all of them on one XCD.
     const int ninst = (int)(P.rows / P.rows_per_inst);
     int inst, tile, nvalid = 0x7fffffff;
-    if (P.tile_list) {
+    int nrows_packed = 0;
+    if (PACKED) {
+        nrows_packed = *P.nrows;
+        if ((long)blockIdx.x * FM >= nrows_packed) return;
+        inst = 0;
+        tile = blockIdx.x;
+    } else if (P.tile_list) {
         // a compacted list of the live tiles (lrg_prepare): workgroups 0 .. count-1 work, the rest leave at once -- the
         // dispatcher deals consecutive workgroups round the XCDs and CUs, so the live ones are spread evenly
         if ((int)blockIdx.x >= *P.tile_count) return;
@@ -131,8 +143,8 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
         // (the count is fetched here and tested after the input rows are staged: one memory round trip instead of two)
         if (P.valid) nvalid = P.valid[inst];
     }
-    if (tile * FM >= P.rows_per_inst) return;
-    const long r0 = (long)inst * P.rows_per_inst + (long)tile * FM;
+    if (!PACKED && tile * FM >= P.rows_per_inst) return;
+    const long r0 = PACKED ? (long)tile * FM : (long)inst * P.rows_per_inst + (long)tile * FM;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -150,6 +162,7 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     // bias of column c of layer L for this lane (a per-instance row when the layer carries the hoisted pooled product)
     auto bias_of = [&](const LrgFusedLayer &L, int c) -> float {
         if (!L.bias) return 0.f;
+        if (PACKED && (L.flags & LRG_FL_INST_BIAS)) return 0.f;       // added per run of rows in the epilogue
         return (L.flags & LRG_FL_INST_BIAS) ? L.bias[(long)inst * L.N + c + li] : L.bias[c + li];
     };
     float4 bq[FD], bf[2];
@@ -187,8 +200,23 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     if (P.fw) { for (int i = tid; i < 2 * P.L[P.nlayers - 1].N; i += FTHREADS) poolbuf[i] = P.fw[i]; }
     else { for (int i = tid; i < 512; i += FTHREADS) poolbuf[i] = 0.f; }
     if (tile * FM >= nvalid) return;             // workgroup-uniform
+    if (PACKED && tid < 64) {
+        // runs of equal instance among the tile's rows (rows past *nrows: instance -1), found by wave 0 with one ballot
+        const int row = tid & 31;
+        const int mine = (r0 + row < nrows_packed) ? P.row_inst[r0 + row] : -1;
+        const int prev = __shfl_up(mine, 1);
+        const bool start = tid < 32 && (row == 0 || mine != prev);
+        const unsigned long long m = __ballot(start);
+        if (start) {
+            const int k = __popcll(m & ((1ull << row) - 1ull));
+            run_start[k] = row;
+            run_inst[k] = mine;
+        }
+        if (tid == 0) { const int n = __popcll(m); run_start[n] = FM; *run_count = n; }
+    }
     __syncthreads();
     TRACE(1);
+    const int nruns = PACKED ? *run_count : 1;
 
     const int nlayers = P.nlayers;
     int prevN = Kp;
@@ -259,6 +287,20 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
                 // a layer that stays in LDS is copied to HBM from there after the barrier (coalesced); only the
                 // parity-test copy of a layer that does not (KEEP_ACTS on the pooled layer) is stored from registers
                 float *gdirect = (DIRECT && L.gout && (!(L.flags & LRG_FL_KEEP) || inplace)) ? L.gout + r0 * L.N : nullptr;
+                if constexpr (PACKED) {
+                    // per-instance bias (the hoisted pooled product of a head, :128-141): one value per run of rows
+                    if ((L.flags & LRG_FL_INST_BIAS) && L.bias) {
+                        for (int k = 0; k < nruns; ++k) {
+                            const int lo = run_start[k], hi = run_start[k + 1], ins = run_inst[k];
+                            const float b = ins >= 0 ? L.bias[(long)ins * L.N + col] : 0.f;
+#pragma unroll
+                            for (int rr = 0; rr < 16; ++rr) {
+                                const int rl = 4 * lh + (rr & 3) + 8 * (rr >> 2);
+                                if (rl >= lo && rl < hi) acc[0][rr] += b;
+                            }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
                     if (t < ntile) {
@@ -269,15 +311,32 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
                             if (L.flags & LRG_FL_RELU) v = fmaxf(v, 0.f);
                             if (L.flags & LRG_FL_KEEP) act_out[rl * ld_out + col] = v;
                             if (DIRECT && gdirect) gdirect[(unsigned)(rl * L.N + col)] = v;
+                            if (PACKED) acc[t][rr] = v;
                             cmax = fmaxf(cmax, v);
                         }
                     }
                 }
                 if (L.flags & LRG_FL_POOL) {
-                    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-                    if (lh == 0) {
-                        if (m22) atomicMax(reinterpret_cast<int *>(&poolbuf[col]), __float_as_int(cmax));   // two waves share the column (values >= 0)
-                        else poolbuf[col] = fmaxf(poolbuf[col], cmax);                                      // this wave owns the column
+                    if constexpr (PACKED) {
+                        // column maxima per run of rows, straight into that instance's pooled feature (values >= 0)
+                        for (int k = 0; k < nruns; ++k) {
+                            const int lo = run_start[k], hi = run_start[k + 1], ins = run_inst[k];
+                            float m = 0.f;
+#pragma unroll
+                            for (int rr = 0; rr < 16; ++rr) {
+                                const int rl = 4 * lh + (rr & 3) + 8 * (rr >> 2);
+                                if (rl >= lo && rl < hi) m = fmaxf(m, acc[0][rr]);
+                            }
+                            m = fmaxf(m, __shfl_xor(m, 32));
+                            if (lh == 0 && ins >= 0 && m > 0.f)
+                                atomicMax(reinterpret_cast<int *>(P.pool + (long)ins * P.pool_stride + col), __float_as_int(m));
+                        }
+                    } else {
+                        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+                        if (lh == 0) {
+                            if (m22) atomicMax(reinterpret_cast<int *>(&poolbuf[col]), __float_as_int(cmax));   // two waves share the column (values >= 0)
+                            else poolbuf[col] = fmaxf(poolbuf[col], cmax);                                      // this wave owns the column
+                        }
                     }
                 }
             }
@@ -300,7 +359,7 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     }
 
     // ---- pooled maxima of this tile -> the instance's pooled feature (:122-125) ----
-    if ((lastflags & LRG_FL_POOL) && P.pool) {
+    if (!PACKED && (lastflags & LRG_FL_POOL) && P.pool) {
         float *dst = P.pool + (r0 / P.rows_per_inst) * P.pool_stride;
         for (int c = tid; c < lastN; c += FTHREADS) atomicMax(reinterpret_cast<int *>(&dst[c]), __float_as_int(poolbuf[c]));
     }
@@ -329,18 +388,19 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
         if (q == 0) *reinterpret_cast<float2 *>(P.fout + (r0 + row) * 2) = make_float2(s0 + P.fb[0], s1 + P.fb[1]);
     }
     // ---- leave the pooled feature of this instance zero for the next evaluation (it was consumed by the GEMV) ----
-    if (P.zero_pool && tile == 0)
+    if (!PACKED && P.zero_pool && tile == 0)
         for (int c = tid; c < P.zero_count; c += FTHREADS) P.zero_pool[(long)inst * P.zero_count + c] = 0.f;
     TRACE(20);
 }
 
-template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT>
+template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false>
 static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     constexpr int FM = 32 * RT;
     long maxrows = 0;
     for (int i = 0; i < nprob; ++i) {
         const LrgFusedProb &P = a.p[i];
-        if (P.rows % FM != 0 || P.rows_per_inst % FM != 0) return LRG_EINVAL - 30;
+        if (P.rows % FM != 0 || (!PACKED && P.rows_per_inst % FM != 0)) return LRG_EINVAL - 30;
+        if (PACKED != (P.nrows != nullptr) || (PACKED && !P.row_inst)) return LRG_EINVAL - 30;
         if (P.nlayers < 1 || P.nlayers > LRG_FUSED_MAXL) return LRG_EINVAL - 31;
         const int Kp = (P.Kin + 7) & ~7;
         if (FM * (Kp + 4) > CAP1) return LRG_EINVAL - 32;
@@ -359,13 +419,14 @@ static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
         if (P.rows > maxrows) maxrows = P.rows;
     }
     if (maxrows == 0) return 0;
-    const size_t lds = (size_t)(CAP0 + CAP1 + 512) * sizeof(float);
-    auto kern = lrg_fused_stack_kernel<CAP0, CAP1, RT, FD, OCC, DIRECT>;
-    static bool attr_done = false;      // raising the dynamic-LDS cap is idempotent
-    if (!attr_done) {
+    const size_t lds = (size_t)(CAP0 + CAP1 + 512 + (PACKED ? 2 * FM + 8 : 0)) * sizeof(float);
+    auto kern = lrg_fused_stack_kernel<CAP0, CAP1, RT, FD, OCC, DIRECT, PACKED>;
+    static bool attr_done[LRG_MAX_DEVICES] = {};      // per instantiation, per device
+    const int dev = lrg_current_device();
+    if (!attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
-        attr_done = true;
+        attr_done[dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM), nprob), dim3(FTHREADS), lds, st, a);
     LRG_LAUNCH_CHECK();
@@ -397,4 +458,15 @@ int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     // 64 -> 256 -> 128 (-> 2); the last hidden layer is written in place
     if (needs_direct(a, nprob)) return launch_stack<32 * 260, 32 * 68, 1, 4, 2, true>(a, nprob, st);
     return launch_stack<32 * 260, 32 * 68, 1, 4, 3, false>(a, nprob, st);
+}
+
+int lrg_fused_branches_packed(const LrgFusedArgs &a, int nprob, hipStream_t st) {
+    // lite 1: conv[1] is the pooled layer itself -- it does not stay in LDS, so its HBM copy (read by the heads) is stored
+    // from the accumulators
+    if (needs_direct(a, nprob)) return launch_stack<32 * 68, 32 * 132, 1, 4, 2, true, true>(a, nprob, st);
+    return launch_stack<32 * 68, 32 * 132, 1, 4, 4, false, true>(a, nprob, st);
+}
+
+int lrg_fused_heads_packed(const LrgFusedArgs &a, int nprob, hipStream_t st) {
+    return launch_stack<32 * 260, 32 * 68, 1, 4, 3, false, true>(a, nprob, st);
 }

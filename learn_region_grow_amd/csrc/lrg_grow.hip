@@ -220,14 +220,14 @@ __device__ void lrg_reset_slot(LrgSlot *S, const LrgRoom *R, int seed, int resta
 }
 
 #define LRG_SEED_TRIES 64   // isolated seeds committed per call before the search is resumed by the next one
-template <bool FUSE_SCAN>     // FUSE_SCAN: do lrg_bbox_stop's scan here (one workgroup per slot; lrg_grow_step, greedy growing)
-__global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
-                                                                        LrgGrowParams prm, int64_t *stats) {
+// The body of lrg_advance for the group whose first slot is g0, run by one 1024-thread workgroup (every return is
+// workgroup-uniform).  FUSE_SCAN: do lrg_bbox_stop's scan here (one workgroup per slot; lrg_grow_step, greedy growing).
+template <bool FUSE_SCAN>
+__device__ void lrg_advance_group(LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams &prm, int64_t *stats, int g0) {
     __shared__ int sh_next;
     __shared__ int sh_flag;
     __shared__ int sh_list[32];
     const int G = prm.group_size, RST = prm.restarts;
-    const int g0 = blockIdx.x * G;
     if (g0 >= n_slots) return;
     LrgSlot *S0 = &slots[g0];
     if (S0->room < 0) return;
@@ -426,6 +426,12 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *
         __syncthreads();
     }
     TRACE2(g0, 15);
+}
+
+template <bool FUSE_SCAN>
+__global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_advance_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
+                                                                        LrgGrowParams prm, int64_t *stats) {
+    lrg_advance_group<FUSE_SCAN>(slots, rooms, n_slots, prm, stats, blockIdx.x * prm.group_size);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -776,7 +782,7 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
 #pragma unroll
         for (int r = 0; r < KT; ++r) key[r] = (r * 1024 + tid < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
     }
-    // sh[0] = min, sh[1] = max, sh[2..35] = one counter per bisection step (+ below-count), sh[36] = max below
+    // sh[0] = min, sh[1] = max, sh[2..49] = three counters per bisection step, sh[50] = below-count, sh[51] = max below
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
     for (int r = 0; r < KT; ++r)
@@ -795,22 +801,25 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
     // A pair that reaches into the common prefix needs no special case: a threshold that would flip a common bit counts
     // either every key or the same keys as a lower threshold.  The step cost is the barrier, not the compares.
     int slot = 2;
-    for (int bit = ((hb + 1) & ~1) - 2; bit >= 0; bit -= 2, slot += 2) {
+    for (int bit = ((hb + 1) & ~1) - 2; bit >= 0; bit -= 2, slot += 3) {
         const uint32_t t1 = rb | (1u << bit), t2 = rb | (2u << bit), t3 = rb | (3u << bit);
-        int c12 = 0, c3 = 0;
+        // three counters, each up to 48 Ki: kept apart (packing two into 16 + 16 bits would overflow the low half)
+        int c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
         for (int r = 0; r < KT; ++r) {
-            c12 += (key[r] < t1 ? 1 : 0) + (key[r] < t2 ? 0x10000 : 0);
+            c1 += key[r] < t1 ? 1 : 0;
+            c2 += key[r] < t2 ? 1 : 0;
             c3 += key[r] < t3 ? 1 : 0;
         }
-        c12 = lrg_wave_sum_i32(c12);
+        c1 = lrg_wave_sum_i32(c1);
+        c2 = lrg_wave_sum_i32(c2);
         c3 = lrg_wave_sum_i32(c3);
-        if (lane == 0) { if (c12) atomicAdd(&sh[slot], c12); if (c3) atomicAdd(&sh[slot + 1], c3); }
+        if (lane == 0) { if (c1) atomicAdd(&sh[slot], c1); if (c2) atomicAdd(&sh[slot + 1], c2); if (c3) atomicAdd(&sh[slot + 2], c3); }
         __syncthreads();
-        const int s12 = sh[slot], s3 = sh[slot + 1];
+        const int s1 = sh[slot], s2 = sh[slot + 1], s3 = sh[slot + 2];
         if (s3 <= k2) rb = t3;
-        else if ((int)((unsigned)s12 >> 16) <= k2) rb = t2;
-        else if ((s12 & 0xFFFF) <= k2) rb = t1;
+        else if (s2 <= k2) rb = t2;
+        else if (s1 <= k2) rb = t1;
     }
     float hi = lrg_key2f(rb);
     if (nc & 1) return hi;
@@ -821,9 +830,9 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
         if (key[r] < rb) { ++below; mx = max(mx, key[r]); }
     below = lrg_wave_sum_i32(below);
     mx = lrg_wave_max_u32(mx);
-    if (lane == 0) { if (below) atomicAdd(&sh[34], below); atomicMax(reinterpret_cast<unsigned *>(&sh[35]), mx); }
+    if (lane == 0) { if (below) atomicAdd(&sh[50], below); atomicMax(reinterpret_cast<unsigned *>(&sh[51]), mx); }
     __syncthreads();
-    float lo = sh[34] >= k2 ? lrg_key2f((uint32_t)sh[35]) : hi;
+    float lo = sh[50] >= k2 ? lrg_key2f((uint32_t)sh[51]) : hi;
     return __fmul_rn(__fadd_rn(lo, hi), 0.5f);
 }
 
@@ -836,7 +845,7 @@ __device__ __forceinline__ int lrg_centred_channel(int y, int F) { const int ch 
 __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                                  float *center, int min_points, int32_t *tile_total) {
     if (tile_total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { tile_total[0] = 0; tile_total[1] = 0; }   // lrg_prepare (next launch) fills the lists
-    __shared__ int sh[40];
+    __shared__ int sh[64];
     const int s = blockIdx.x;
     const LrgSlot *S = &slots[s];
     const int F = prm.feature_size;
@@ -851,7 +860,7 @@ __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *s
         if (threadIdx.x == 0) center[s * 16 + ch] = m;
         return;
     }
-    if (threadIdx.x < 40) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;         // sh[0] = 0xFFFFFFFF (min identity)
+    if (threadIdx.x < 64) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;         // sh[0] = 0xFFFFFFFF (min identity)
     __syncthreads();
     const float *pts = R->points + ch;
     const float med = nc <= 4096 ? lrg_median_block_regs<4>(pts, S->cur_idx, F, nc, sh)
@@ -873,7 +882,7 @@ __global__ __launch_bounds__(1024) void lrg_median_large_kernel(const LrgSlot *s
     const int nc = S->nc;
     if (nc <= LRG_MED_REGS) return;
     const LrgRoom *R = &rooms[S->room];
-    if (threadIdx.x < 40) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;         // sh[0] = 0xFFFFFFFF (min identity)
+    if (threadIdx.x < 64) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;         // sh[0] = 0xFFFFFFFF (min identity)
     __syncthreads();
     const bool cached = nc <= LRG_MED_LARGE;
     if (cached) {
@@ -1158,6 +1167,8 @@ __global__ void lrg_nn1_write_kernel(const int32_t *label_in, int n, const unsig
     label_out[i] = k == ~0ull ? 0 : label_in[(int)(k & 0xFFFFFFFFull)];
 }
 
+#include "lrg_front.inl"
+
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -1236,11 +1247,12 @@ static int launch_block_medians(const LrgSlot *slots, const LrgRoom *rooms, int 
     LRG_LAUNCH_CHECK();
     if (max_points > LRG_MED_REGS) {
         const size_t lds_large = LRG_MED_LARGE * 4 + 256;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static bool attr_done[LRG_MAX_DEVICES] = {};
+        const int dev = lrg_current_device();
+        if (!attr_done[dev]) {
             LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_median_large_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_large));
-            attr_done = true;
+            attr_done[dev] = true;
         }
         hipLaunchKernelGGL(lrg_median_large_kernel, dim3(n_slots, ncentred), dim3(1024), lds_large, st, slots, rooms, *params, center);
         LRG_LAUNCH_CHECK();
@@ -1365,6 +1377,91 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
     return lrg_mask_update(slots, rooms, n_slots, params, b->inlier, b->neighbor, b->center, b->add_logits,
                            b->rmv_logits, b->gt_remove, b->gt_add, nullptr, nullptr, rows ? b->sample_in : nullptr,
                            rows ? b->sample_nb : nullptr, b->stats, stream);
+}
+
+int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                         const LrgWeights *weights, const LrgPackedBuffers *b, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || !weights || !b || n_slots <= 0 || max_points <= 0) return LRG_EINVAL - 1;
+    if (weights->feature_size != params->feature_size) return LRG_EINVAL - 2;
+    if (n_slots % params->group_size != 0) return LRG_EINVAL - 1;
+    if (max_points > LRG_FRONT_MAXCHUNK * LRG_SCAN_CHUNK) return LRG_EINVAL - 3;       // larger rooms: lrg_grow_step
+    if (params->n_inlier > LRG_FRONT_MAXSAMPLE || params->n_neighbor > LRG_FRONT_MAXSAMPLE) return LRG_EINVAL - 3;
+    if (!b->center || !b->sample_in || !b->sample_nb || !b->x_in || !b->x_nb || !b->row_slot_in || !b->row_slot_nb || !b->gt_in ||
+        !b->gt_nb || !b->rmv_logits || !b->add_logits || !b->slot_rows || !b->counters || !b->workspace)
+        return LRG_EINVAL - 4;
+    if (b->row_cap % LRG_ROW_TILE != 0 || (long)b->row_cap < (long)n_slots * max(params->n_inlier, params->n_neighbor))
+        return LRG_EINVAL - 5;
+    size_t poff = 0, pcnt = 0;
+    if ((rc = lrg_forward_packed_pooled_view(weights, n_slots, b->row_cap, &poff, &pcnt))) return rc;
+    if (b->workspace_bytes < lrg_forward_packed_workspace_bytes(weights, n_slots, b->row_cap)) return LRG_EINVAL - 6;
+    LrgFrontArgs a;
+    a.center = b->center; a.sample_in = b->sample_in; a.sample_nb = b->sample_nb;
+    a.x_in = b->x_in; a.x_nb = b->x_nb; a.row_slot_in = b->row_slot_in; a.row_slot_nb = b->row_slot_nb;
+    a.gt_in = b->gt_in; a.gt_nb = b->gt_nb; a.rmv_logits = b->rmv_logits; a.add_logits = b->add_logits;
+    a.slot_rows = b->slot_rows; a.counters = b->counters;
+    a.pooled = static_cast<float *>(b->workspace) + poff; a.pooled_stride = (int)(pcnt / (size_t)n_slots);
+    a.stats = b->stats;
+    hipStream_t st = (hipStream_t)stream;
+    if (params->group_size == 1) {
+        hipLaunchKernelGGL(lrg_front_kernel<7>, dim3(n_slots), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots, *params, a);
+        LRG_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(lrg_front_kernel<1>, dim3(n_slots), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots, *params, a);
+        LRG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(lrg_advance_kernel<false>, dim3(n_slots / params->group_size), dim3(LRG_SCAN_THREADS), 0, st, slots, rooms,
+                           n_slots, *params, b->stats);
+        LRG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(lrg_front_kernel<4>, dim3(n_slots), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots, *params, a);
+        LRG_LAUNCH_CHECK();
+    }
+    return lrg_forward_packed(weights, b->x_in, b->x_nb, b->row_slot_in, b->row_slot_nb, b->counters, b->counters + 2, n_slots,
+                              b->row_cap, b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes, LRG_FWD_POOL_ZEROED, stream);
+}
+
+// `iterations` lock-step iterations captured once into a HIP graph: every kernel argument of lrg_grow_step_packed is a device
+// pointer or a constant, so a replay is the same work with one host call instead of 4-6 launches per iteration.
+struct LrgStepGraph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    int iterations;
+};
+
+int lrg_step_graph_create(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                          const LrgWeights *weights, const LrgPackedBuffers *buffers, int iterations, void *stream, void **graph_out) {
+    if (!graph_out || iterations < 1 || !stream) return LRG_EINVAL - 1;      // (the null stream cannot be captured)
+    if (!weights || !weights->packed) return LRG_EINVAL - 2;                 // re-packing the weights per step has no place in a graph
+    hipStream_t st = (hipStream_t)stream;
+    LRG_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (int i = 0; i < iterations && rc == 0; ++i)
+        rc = lrg_grow_step_packed(slots, rooms, n_slots, max_points, params, weights, buffers, stream);
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return -(int)e;
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); return -(int)e; }
+    LrgStepGraph *g = new LrgStepGraph{graph, exec, iterations};
+    *graph_out = g;
+    return 0;
+}
+
+int lrg_step_graph_launch(void *graph, void *stream) {
+    if (!graph) return LRG_EINVAL - 1;
+    LRG_HIP_CHECK(hipGraphLaunch(static_cast<LrgStepGraph *>(graph)->exec, (hipStream_t)stream));
+    return 0;
+}
+
+int lrg_step_graph_destroy(void *graph) {
+    if (!graph) return 0;
+    LrgStepGraph *g = static_cast<LrgStepGraph *>(graph);
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return 0;
 }
 
 size_t lrg_nn1_fill_workspace_bytes(int n) { return n <= 0 ? 0 : lrg_align_up((size_t)n * 4 + 64, 256) + (size_t)n * 8; }

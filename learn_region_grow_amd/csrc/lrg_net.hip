@@ -234,6 +234,9 @@ struct LrgGemvArgs {
     const float *bias[2];
     float *hb[2];
     int ldw, B, P, C;
+    int *cnt_src, *cnt_dst;   // nullable pair (packed rows): block (0,0,0) copies cnt_src[0..1] to cnt_dst[0..1] and zeroes cnt_src --
+                              // the branch kernels are done with the row counts, the heads read the copy, the next front kernel
+                              // allocates from zero again
 };
 
 // 64 output columns x TB instances per 512-thread block; the 8 waves split K and their partial sums are
@@ -245,6 +248,10 @@ __global__ __launch_bounds__(64 * LRG_GEMV_WAVES) void lrg_head_gemv_kernel(LrgG
     const int b0 = blockIdx.y * LRG_GEMV_TB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
+    if (a.cnt_src && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 2) {
+        a.cnt_dst[threadIdx.x] = a.cnt_src[threadIdx.x];
+        a.cnt_src[threadIdx.x] = 0;
+    }
     const int nb = min(LRG_GEMV_TB, a.B - b0);
     for (int i = threadIdx.x; i < LRG_GEMV_TB * a.P; i += 64 * LRG_GEMV_WAVES) {
         int bi = i / a.P;
@@ -290,6 +297,10 @@ __global__ __launch_bounds__(64 * LRG_GEMM_WAVES) void lrg_head_gemm_kernel(LrgG
     __shared__ float part[LRG_GEMM_WAVES][32][33];
     const int z = blockIdx.z, c0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    if (a.cnt_src && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 2) {
+        a.cnt_dst[threadIdx.x] = a.cnt_src[threadIdx.x];
+        a.cnt_src[threadIdx.x] = 0;
+    }
     const int k0 = wave * 8 * NG;
     const int row = min(b0 + li, a.B - 1);                                   // rows past the batch repeat the last one
     const float *ap = a.pooled + (long)row * a.P + k0 + 4 * lh;
@@ -628,6 +639,163 @@ static int forward_fused(const LrgWeights *w, const float *inlier, const float *
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// packed-row evaluation (the grow loop's formulation): the distinct rows of all instances back to back
+// ------------------------------------------------------------------------------------------------
+struct LrgPackedLayout {
+    size_t conv1[2];     // float offsets: conv[1] of the packed inlier / neighbour rows (:130,:134)
+    size_t pooled;       // [n_inst, 2*C_last]
+    size_t hb[2];        // [n_inst, head_ch[0]] hoisted pooled product of the add / remove head
+    size_t packed;       // lrg_pack_weights image when the caller supplies none
+    size_t total;
+    int P;
+};
+
+static int packed_layout(const LrgWeights *w, int n_inst, int row_cap, LrgPackedLayout *L) {
+    if (!w || n_inst <= 0 || row_cap <= 0 || row_cap % LRG_ROW_TILE != 0) return LRG_EINVAL - 1;
+    if (w->n_conv < 2 || w->n_conv > LRG_MAX_CONV || w->n_head < 2 || w->n_head > LRG_MAX_HEAD) return LRG_EINVAL - 2;
+    if (w->head_ch[w->n_head - 1] != 2) return LRG_EINVAL - 3;
+    size_t off = 0;
+    for (int br = 0; br < 2; ++br) { L->conv1[br] = off; off = lrg_align_up(off + (size_t)row_cap * w->conv_ch[1], 64); }
+    L->P = 2 * w->conv_ch[w->n_conv - 1];
+    L->pooled = off;
+    off = lrg_align_up(off + (size_t)n_inst * L->P, 64);
+    for (int hd = 0; hd < 2; ++hd) { L->hb[hd] = off; off = lrg_align_up(off + (size_t)n_inst * w->head_ch[0], 64); }
+    LrgPackLayout PL;
+    int rc = pack_layout(w, &PL);
+    if (rc) return rc;
+    L->packed = off;
+    off = lrg_align_up(off + PL.total, 64);
+    L->total = off;
+    return 0;
+}
+
+static int forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const int32_t *row_inst_in,
+                          const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
+                          float *add_logits, float *rmv_logits, float *ws, const LrgPackedLayout &L, bool pool_zeroed,
+                          hipStream_t st) {
+    const int nc = w->n_conv, nh = w->n_head;
+    const int Clast = w->conv_ch[nc - 1];
+    if (!pool_zeroed) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)n_inst * L.P * sizeof(float), st));
+    LrgPackLayout PL;
+    int prc = pack_layout(w, &PL);
+    if (prc) return prc;
+    const float *pk = static_cast<const float *>(w->packed);
+    if (!pk) {
+        if ((prc = pack_weights(w, ws + L.packed, st))) return prc;
+        pk = ws + L.packed;
+    }
+    {
+        LrgFusedArgs a = {};
+        for (int br = 0; br < 2; ++br) {
+            LrgFusedProb &P = a.p[br];
+            P.x = br == 0 ? x_in : x_nb;
+            P.ldx = w->feature_size; P.Kin = w->feature_size;
+            P.rows = row_cap; P.rows_per_inst = row_cap;
+            P.nrows = nrows + br; P.row_inst = br == 0 ? row_inst_in : row_inst_nb;
+            P.pool = ws + L.pooled + (br == 0 ? 0 : Clast); P.pool_stride = L.P;
+            P.nlayers = nc;
+            for (int i = 0; i < nc; ++i) {
+                LrgFusedLayer &F = P.L[i];
+                F.w = pk + PL.conv[br][i];
+                F.bias = br == 0 ? w->inlier_b[i] : w->neighbor_b[i];
+                F.K = i == 0 ? w->feature_size : w->conv_ch[i - 1];
+                F.N = w->conv_ch[i]; F.ng = lrg_kgroups(F.K);
+                F.flags = LRG_FL_RELU | (i + 1 < nc ? LRG_FL_KEEP : LRG_FL_POOL);
+                F.gout = i == 1 ? ws + L.conv1[br] : nullptr;
+            }
+        }
+        int rc = lrg_fused_branches_packed(a, 2, st);
+        if (rc) return rc;
+    }
+    const int C0 = w->head_ch[0];
+    {
+        LrgGemvArgs g = {};
+        g.pooled = ws + L.pooled;
+        g.w[0] = w->add_w[0]; g.w[1] = w->rmv_w[0];
+        g.bias[0] = w->add_b[0]; g.bias[1] = w->rmv_b[0];
+        g.hb[0] = ws + L.hb[0]; g.hb[1] = ws + L.hb[1];
+        g.ldw = C0; g.B = n_inst; g.P = L.P; g.C = C0;
+        if (nrows_heads) { g.cnt_src = nrows; g.cnt_dst = nrows_heads; }
+        int grc = launch_head_gemv(g, 2, st);
+        if (grc) return grc;
+    }
+    {
+        const int hbr[2] = {1, 0};      // head 0 = add on the neighbour rows, head 1 = remove on the inlier rows
+        const int32_t *cnt = nrows_heads ? nrows_heads : nrows;
+        LrgFusedArgs a = {};
+        for (int hd = 0; hd < 2; ++hd) {
+            const int br = hbr[hd];
+            LrgFusedProb &P = a.p[hd];
+            P.x = ws + L.conv1[br];
+            P.ldx = w->conv_ch[1]; P.Kin = w->conv_ch[1];
+            P.rows = row_cap; P.rows_per_inst = row_cap;
+            P.nrows = cnt + br; P.row_inst = br == 0 ? row_inst_in : row_inst_nb;
+            P.nlayers = nh - 1;
+            for (int i = 0; i < nh - 1; ++i) {
+                LrgFusedLayer &F = P.L[i];
+                F.N = w->head_ch[i];
+                F.w = pk + PL.head[hd][i];
+                if (i == 0) {
+                    F.bias = ws + L.hb[hd];
+                    F.K = w->conv_ch[1];
+                    F.flags = LRG_FL_RELU | LRG_FL_KEEP | LRG_FL_INST_BIAS;
+                } else {
+                    F.bias = hd == 0 ? w->add_b[i] : w->rmv_b[i];
+                    F.K = w->head_ch[i - 1];
+                    F.flags = LRG_FL_RELU | LRG_FL_KEEP;
+                    if (i == nh - 2 && (i & 1) && F.N > 64) F.flags |= LRG_FL_INPLACE;
+                }
+                F.ng = lrg_kgroups(F.K);
+            }
+            P.fw = hd == 0 ? w->add_w[nh - 1] : w->rmv_w[nh - 1];
+            P.fb = hd == 0 ? w->add_b[nh - 1] : w->rmv_b[nh - 1];
+            P.fout = hd == 0 ? add_logits : rmv_logits;
+        }
+        return lrg_fused_heads_packed(a, 2, st);
+    }
+}
+
+extern "C" {
+
+size_t lrg_forward_packed_workspace_bytes(const LrgWeights *w, int n_inst, int row_cap) {
+    LrgPackedLayout L;
+    if (packed_layout(w, n_inst, row_cap, &L) != 0) return 0;
+    return L.total * sizeof(float);
+}
+
+int lrg_forward_packed_pooled_view(const LrgWeights *w, int n_inst, int row_cap, size_t *offset_floats, size_t *count_floats) {
+    LrgPackedLayout L;
+    int rc = packed_layout(w, n_inst, row_cap, &L);
+    if (rc) return rc;
+    if (!offset_floats || !count_floats) return LRG_EINVAL - 4;
+    *offset_floats = L.pooled;
+    *count_floats = (size_t)n_inst * L.P;
+    return 0;
+}
+
+int lrg_forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const int32_t *row_inst_in,
+                       const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
+                       float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes, unsigned flags,
+                       void *stream) {
+    LrgPackedLayout L;
+    int rc = packed_layout(w, n_inst, row_cap, &L);
+    if (rc) return rc;
+    if (!x_in || !x_nb || !row_inst_in || !row_inst_nb || !nrows || !add_logits || !rmv_logits || !workspace) return LRG_EINVAL - 5;
+    if (workspace_bytes < L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return LRG_EINVAL - 6;
+    // the shapes the fused kernels are instantiated for (lite 0/1/2), as lrg_forward_rows checks them
+    const int nc = w->n_conv, nh = w->n_head;
+    for (int i = 0; i < nc; ++i)
+        if (w->conv_ch[i] % 64 != 0 || (i + 1 < nc && w->conv_ch[i] > 128)) return LRG_EINVAL - 7;
+    for (int i = 0; i < nh - 1; ++i)
+        if (w->head_ch[i] % 64 != 0 || w->head_ch[i] > ((i & 1) ? 128 : 256) || ((i & 1) && w->head_ch[i] > 64 && i != nh - 2))
+            return LRG_EINVAL - 7;
+    return forward_packed(w, x_in, x_nb, row_inst_in, row_inst_nb, nrows, nrows_heads, n_inst, row_cap, add_logits, rmv_logits,
+                          static_cast<float *>(workspace), L, (flags & LRG_FWD_POOL_ZEROED) != 0, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
 extern "C" {
 
 int lrg_abi_version(void) { return LRG_ABI_VERSION; }
@@ -638,6 +806,8 @@ size_t lrg_struct_size(int which) {
     case 1: return sizeof(LrgRoom);
     case 2: return sizeof(LrgSlot);
     case 3: return sizeof(LrgGrowParams);
+    case 4: return sizeof(LrgStepBuffers);
+    case 5: return sizeof(LrgPackedBuffers);
     }
     return 0;
 }

@@ -57,6 +57,46 @@ def gather_room_labels(local_ids, local_labels, n_rooms, device=None, group=None
     return out
 
 
+def gather_flat_labels(local_ids, local_lens, flat, n_rooms, device=None, group=None):
+    """gather_room_labels for labels that are still on the GPU: `flat` is one int32 tensor holding the labels of rooms
+    `local_ids` back to back (`local_lens` points each).  With the nccl backend the flat buffer goes into the all_gather as
+    it is (device to device over xGMI); gloo stages it through the host.  Returns a list of n_rooms arrays."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        host = flat.cpu().numpy()
+        out, o = [None] * n_rooms, 0
+        for i, n in zip(local_ids, local_lens):
+            out[i] = host[o:o + n]
+            o += n
+        return out
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    meta = torch.full((n_rooms, 2), -1, dtype=torch.int64)
+    if len(local_ids):
+        meta[:len(local_ids), 0] = torch.tensor(list(local_ids), dtype=torch.int64)
+        meta[:len(local_ids), 1] = torch.tensor(list(local_lens), dtype=torch.int64)
+    meta = meta.to(device)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    totals = [int(m[:, 1].clamp(min=0).sum()) for m in metas]
+    buf = torch.zeros(max(max(totals), 1), dtype=torch.int32, device=device)
+    mine = int(sum(local_lens))
+    if mine:
+        buf[:mine] = flat[:mine].to(device=device, dtype=torch.int32)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    out = [None] * n_rooms
+    for m, f in zip(metas, bufs):
+        m, f = m.cpu().numpy(), f.cpu().numpy()
+        o = 0
+        for i, n in m:
+            if i < 0:
+                continue
+            out[int(i)] = f[o:o + int(n)].copy()
+            o += int(n)
+    return out
+
+
 def allreduce_sum(values, device=None, group=None):
     """Sum a small list of numbers over ranks (throughput accounting)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LRG_ACTIVE, LRG_DONE, LRG_WAIT, LRG_IDLE,
+from ._lib import (LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LRG_ACTIVE, LRG_DONE, LRG_WAIT, LRG_IDLE,
                    LRG_STATS_WORDS, LRG_DONE_RING, REASON_NAMES)
 from .lrgnet import _ptr, _stream_ptr
 
@@ -49,7 +49,10 @@ class RoomResult:
 class RegionGrower:
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
-                 skip_duplicate_rows=True, poll_every=4):
+                 skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0):
+        """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
+        one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
+        graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*)."""
         self.lib = _lib.load()
         self.net = net
         self.dev = net.device
@@ -81,6 +84,10 @@ class RegionGrower:
         self.policy = policy
         # evaluate LrgNet only on the distinct leading rows of each stacked set (the rest are copies, :240,:252)
         self.skip_duplicate_rows = bool(skip_duplicate_rows) and rng == 'counter' and net.mode == 'fused'
+        self.want_packed = packed
+        self.graph_iterations = int(graph_iterations)
+        self.packed = False
+        self._graph = None
         self.debug_hook = None      # tests: called once per active slot per legacy iteration with the step's data
         self._rooms_loaded = False
 
@@ -110,7 +117,7 @@ class RegionGrower:
         self.d_hkeys = torch.empty(int(hoffs[-1]), dtype=torch.int64, device=dev)
         self.d_hvals = torch.zeros(int(hoffs[-1]), dtype=torch.int32, device=dev)
         self.d_dup = torch.zeros(1, dtype=torch.int32, device=dev)
-        st = _stream_ptr()
+        st = _stream_ptr(self.dev)
         _lib.check(self.lib.lrg_voxelize(_ptr(self.d_points), tot, F, ctypes.c_float(self.params.resolution),
                                          _ptr(self.d_vox), st), 'lrg_voxelize')
         self.h_rooms = (LrgRoom * len(rooms))()
@@ -143,7 +150,7 @@ class RegionGrower:
         self.room_ids = [int(self.h_rooms[r].room_id) for r in range(len(rooms))]
         self.d_rooms = torch.from_numpy(np.frombuffer(bytes(self.h_rooms), dtype=np.uint8).copy()).to(dev)
         # ---- slots ----
-        cap = max(ns)
+        cap = (max(ns) + 15) // 16 * 16           # (lrg_grow_step_packed sets mask bytes with word-wide atomics)
         self.cap = cap
         self.d_cur = torch.zeros((S, cap), dtype=torch.uint8, device=dev)
         self.d_best = torch.zeros((S, cap), dtype=torch.uint8, device=dev)
@@ -192,6 +199,40 @@ class RegionGrower:
         if self.skip_duplicate_rows:
             sb.rows_in, sb.rows_nb = self.b_rows_in.data_ptr(), self.b_rows_nb.data_ptr()
         self.step_buffers = sb
+        self._release_graph()
+        can_pack = (self.rng == 'counter' and self.net.mode == 'fused' and max(ns) <= _lib.LRG_PACKED_MAX_POINTS and
+                    max(Ni, Nn) <= 1024 and self.skip_duplicate_rows and
+                    self.lib.lrg_forward_packed_workspace_bytes(ctypes.byref(self.net._w), S, 32) > 0)
+        if self.want_packed and not can_pack:
+            raise ValueError('packed iterations need the counter stream, the fused network and rooms of at most %d points'
+                             % _lib.LRG_PACKED_MAX_POINTS)
+        self.packed = can_pack if self.want_packed is None else bool(self.want_packed)
+        if self.packed:
+            cap_rows = (S * max(Ni, Nn) + 31) // 32 * 32
+            self.row_cap = cap_rows
+            self.p_xin = torch.zeros((cap_rows, F), dtype=torch.float32, device=dev)
+            self.p_xnb = torch.zeros((cap_rows, F), dtype=torch.float32, device=dev)
+            self.p_rsin = torch.zeros(cap_rows, dtype=torch.int32, device=dev)
+            self.p_rsnb = torch.zeros(cap_rows, dtype=torch.int32, device=dev)
+            self.p_gtin = torch.zeros(cap_rows, dtype=torch.uint8, device=dev)
+            self.p_gtnb = torch.zeros(cap_rows, dtype=torch.uint8, device=dev)
+            self.p_rmv = torch.zeros((cap_rows, 2), dtype=torch.float32, device=dev)
+            self.p_add = torch.zeros((cap_rows, 2), dtype=torch.float32, device=dev)
+            self.p_slot_rows = torch.zeros((S, 4), dtype=torch.int32, device=dev)
+            self.p_counters = torch.zeros(4, dtype=torch.int32, device=dev)
+            pbytes = self.lib.lrg_forward_packed_workspace_bytes(ctypes.byref(self.net._w), S, cap_rows)
+            self.p_ws = torch.zeros(pbytes, dtype=torch.uint8, device=dev)
+            pb = LrgPackedBuffers()
+            pb.center, pb.sample_in, pb.sample_nb = self.b_center.data_ptr(), self.b_sin.data_ptr(), self.b_snb.data_ptr()
+            pb.x_in, pb.x_nb = self.p_xin.data_ptr(), self.p_xnb.data_ptr()
+            pb.row_slot_in, pb.row_slot_nb = self.p_rsin.data_ptr(), self.p_rsnb.data_ptr()
+            pb.gt_in, pb.gt_nb = self.p_gtin.data_ptr(), self.p_gtnb.data_ptr()
+            pb.rmv_logits, pb.add_logits = self.p_rmv.data_ptr(), self.p_add.data_ptr()
+            pb.slot_rows, pb.counters = self.p_slot_rows.data_ptr(), self.p_counters.data_ptr()
+            pb.workspace, pb.workspace_bytes = self.p_ws.data_ptr(), self.p_ws.numel()
+            pb.stats = self.d_stats.data_ptr()
+            pb.row_cap = cap_rows
+            self.packed_buffers = pb
         self.h_stats = [torch.zeros(LRG_STATS_WORDS, dtype=torch.int64).pin_memory() for _ in range(self.depth)]
         self.ev = [torch.cuda.Event() for _ in range(self.depth)]
         self.group_room = [-1] * self.n_groups
@@ -246,22 +287,67 @@ class RegionGrower:
         _lib.check(self.lib.lrg_nn1_fill_ws(ctypes.c_void_p(self.d_points.data_ptr() + o * F * 4), n, F,
                                             ctypes.c_void_p(self.d_label.data_ptr() + o * 4),
                                             ctypes.c_void_p(self.d_filled.data_ptr() + o * 4), _ptr(self._fill_ws),
-                                            self._fill_ws.numel(), _stream_ptr()), 'lrg_nn1_fill_ws')
+                                            self._fill_ws.numel(), _stream_ptr(self.dev)), 'lrg_nn1_fill_ws')
 
     # ------------------------------------------------------------------------------------------
+    def _release_graph(self):
+        if getattr(self, '_graph', None):
+            self.lib.lrg_step_graph_destroy(self._graph)
+        self._graph = None
+
+    def __del__(self):
+        try:
+            self._release_graph()
+        except Exception:
+            pass
+
+    def _record_poll(self):
+        k = self._polls % self.depth
+        self.h_stats[k].copy_(self.d_stats, non_blocking=True)
+        self.ev[k].record()
+        self._polls += 1
+
     def enqueue_iteration(self):
         """One lock-step iteration, device-side randomness (no host sync)."""
-        flags = self.net.forward_flags | (_lib.LRG_FWD_POOL_ZEROED if self.net.mode == 'fused' else 0)
-        rc = self.lib.lrg_grow_step(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, self.cap, ctypes.byref(self.params),
-                                    ctypes.byref(self.net._w), ctypes.byref(self.step_buffers), self.advance_rounds,
-                                    flags, _stream_ptr())
-        _lib.check(rc, 'lrg_grow_step')
+        if self.packed:
+            rc = self.lib.lrg_grow_step_packed(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, self.cap, ctypes.byref(self.params),
+                                               ctypes.byref(self.net._w), ctypes.byref(self.packed_buffers), _stream_ptr(self.dev))
+            _lib.check(rc, 'lrg_grow_step_packed')
+        else:
+            flags = self.net.forward_flags | (_lib.LRG_FWD_POOL_ZEROED if self.net.mode == 'fused' else 0)
+            rc = self.lib.lrg_grow_step(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, self.cap, ctypes.byref(self.params),
+                                        ctypes.byref(self.net._w), ctypes.byref(self.step_buffers), self.advance_rounds,
+                                        flags, _stream_ptr(self.dev))
+            _lib.check(rc, 'lrg_grow_step')
         self.iterations += 1
         if self.iterations % self.poll_every == 0:
-            k = self._polls % self.depth
-            self.h_stats[k].copy_(self.d_stats, non_blocking=True)
-            self.ev[k].record()
-            self._polls += 1
+            self._record_poll()
+
+    def enqueue_graph(self):
+        """`graph_iterations` packed iterations with one host call (HIP graph replay); the graph is captured on first use,
+        on the stream that is current then, and replayed on the current stream."""
+        if not self.packed or self.graph_iterations <= 0:
+            raise _lib.LrgHipError('enqueue_graph needs packed iterations and graph_iterations > 0')
+        st = torch.cuda.current_stream(self.dev)
+        if self._graph is None:
+            if st.cuda_stream == 0:
+                raise _lib.LrgHipError('a HIP graph cannot be captured on the null stream: enter torch.cuda.stream(...) first')
+            g = ctypes.c_void_p()
+            rc = self.lib.lrg_step_graph_create(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, self.cap, ctypes.byref(self.params),
+                                                ctypes.byref(self.net._w), ctypes.byref(self.packed_buffers), self.graph_iterations,
+                                                ctypes.c_void_p(st.cuda_stream), ctypes.byref(g))
+            _lib.check(rc, 'lrg_step_graph_create')
+            self._graph = g
+        _lib.check(self.lib.lrg_step_graph_launch(self._graph, ctypes.c_void_p(st.cuda_stream)), 'lrg_step_graph_launch')
+        self.iterations += self.graph_iterations
+        self._record_poll()
+
+    def enqueue(self):
+        """The next batch of iterations by the cheapest route: a graph replay when one is configured, else one iteration."""
+        if self.packed and self.graph_iterations > 0 and torch.cuda.current_stream(self.dev).cuda_stream != 0:
+            self.enqueue_graph()
+        else:
+            self.enqueue_iteration()
 
     def poll_done(self, wait=False):
         """Groups whose room finished, as seen `depth-1` read-backs ago (or at the latest one, if wait)."""
@@ -287,8 +373,34 @@ class RegionGrower:
         return out
 
     # ------------------------------------------------------------------------------------------
+    def reset_state(self):
+        """Forget the read-back history (a fresh pass over loaded rooms): the done ring restarts from the device's current count."""
+        torch.cuda.current_stream(self.dev).synchronize()
+        st = self.d_stats.cpu()
+        self._seen_done = int(st[1])
+        self._polls = 0
+        self._polls_seen = -1
+
+    def grow_loaded(self, fill=True):
+        """Counter stream: grow (and fill in) every loaded room from its current state; labels final on the device on return."""
+        assert self.rng == 'counter'
+        self.reset_state()
+        queue = list(range(self.n_rooms))
+        for g in range(self.n_groups):
+            self.bind(g, queue.pop(0) if queue else -1)
+        finished = 0
+        while finished < self.n_rooms:
+            self.enqueue()
+            for g in self.poll_done():
+                if fill:
+                    self.fill(self.group_room[g])
+                finished += 1
+                self.bind(g, queue.pop(0) if queue else -1)
+        torch.cuda.current_stream(self.dev).synchronize()
+        return self.n_rooms
+
     def _legacy_iteration(self, streams):
-        lib, st, P = self.lib, _stream_ptr(), ctypes.byref(self.params)
+        lib, st, P = self.lib, _stream_ptr(self.dev), ctypes.byref(self.params)
         S, Ni, Nn = self.S, self.net.num_inlier_points, self.net.num_neighbor_points
         _lib.check(lib.lrg_bbox_stop(_ptr(self.d_slots), _ptr(self.d_rooms), S, self.cap, P, st), 'lrg_bbox_stop')
         for _ in range(self.advance_rounds):
@@ -370,6 +482,10 @@ class RegionGrower:
     # ------------------------------------------------------------------------------------------
     def run(self, rooms, fill=True, max_iterations=None, legacy_seeds=None):
         """Grow every room once; returns a RoomResult per room (in input order)."""
+        with torch.cuda.device(self.dev):
+            return self._run(rooms, fill, max_iterations, legacy_seeds)
+
+    def _run(self, rooms, fill, max_iterations, legacy_seeds):
         self.load_rooms(rooms)
         queue = list(range(self.n_rooms))
         for g in range(self.n_groups):
@@ -391,7 +507,7 @@ class RegionGrower:
                     break
         else:
             while finished < self.n_rooms:
-                self.enqueue_iteration()
+                self.enqueue()
                 for g in self.poll_done():
                     r = self.group_room[g]
                     if fill:
@@ -467,6 +583,8 @@ class LanedRegionGrower:
             parts[k].append(room)
         for k, gr in enumerate(self.growers):
             gr.n_rooms = 0
+            gr.room_index = [i for i in range(len(rooms)) if self.where[i][0] == k]      # input index of the lane's rooms,
+            gr.room_index.sort(key=lambda i: self.where[i][1])                            #   in the lane's order
             if parts[k]:
                 with torch.cuda.stream(self.streams[k]):
                     gr.load_rooms(parts[k])
@@ -475,11 +593,18 @@ class LanedRegionGrower:
     def run(self, rooms, fill=True):
         """Grow every room once; RoomResults in input order."""
         self.load_rooms(rooms)
+        self.grow_loaded(fill)
+        return self.collect(fill)
+
+    def grow_loaded(self, fill=True):
+        """Grow (and fill in) every loaded room, device-resident from start to end: on return the labels are final in each
+        lane's d_label / d_filled.  Returns the number of rooms grown."""
         queues, finished = [], 0
         for k, gr in enumerate(self.growers):
             with torch.cuda.stream(self.streams[k]):
                 q = list(range(gr.n_rooms))
                 if gr.n_rooms:
+                    gr.reset_state()
                     for g in range(gr.n_groups):
                         gr.bind(g, q.pop(0) if q else -1)
                 queues.append(q)
@@ -491,7 +616,7 @@ class LanedRegionGrower:
                 if not live[k]:
                     continue
                 with torch.cuda.stream(self.streams[k]):
-                    gr.enqueue_iteration()
+                    gr.enqueue()
                     for g in gr.poll_done():
                         r = gr.group_room[g]
                         if fill:
@@ -501,7 +626,7 @@ class LanedRegionGrower:
                         gr.bind(g, queues[k].pop(0) if queues[k] else -1)
                     live[k] = done[k] < gr.n_rooms
         torch.cuda.synchronize()
-        return self.collect(fill)
+        return total
 
     def collect(self, fill=True):
         per_lane = []

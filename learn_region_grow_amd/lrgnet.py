@@ -21,8 +21,10 @@ CONV_CHANNELS = {0: [64, 64, 64, 128, 512], 1: [64, 64], 2: [64, 64, 256]}     #
 CONV2_CHANNELS = {0: [256, 128], 1: [64], 2: [64, 64]}
 
 
-def _stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream_ptr(device=None):
+    """The current stream OF `device` (None: of the current device).  Kernels are launched on the current device, so
+    callers that work on another device than the current one wrap their launches in ``torch.cuda.device(device)``."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _ptr(t):
@@ -120,7 +122,7 @@ class LrgNetHIP:
             raise _lib.LrgHipError('lrg_packed_weights_bytes rejected the configuration')
         self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.lrg_pack_weights(ctypes.byref(w), _ptr(self._packed), nbytes, _stream_ptr()),
+            _lib.check(self.lib.lrg_pack_weights(ctypes.byref(w), _ptr(self._packed), nbytes, _stream_ptr(self.device)),
                        'lrg_pack_weights')
         w.packed = self._packed.data_ptr()
 
@@ -152,12 +154,36 @@ class LrgNetHIP:
         if rmv_out is None:
             rmv_out = torch.empty((B, self.num_inlier_points, 2), dtype=torch.float32, device=self.device)
         flags = self.forward_flags
-        rc = self.lib.lrg_forward_rows(ctypes.byref(self._w), _ptr(inlier), _ptr(neighbor), B, self.num_inlier_points,
-                                       self.num_neighbor_points, _ptr(rows_in), _ptr(rows_nb), _ptr(add_out),
-                                       _ptr(rmv_out), _ptr(ws), ws.numel(), flags, _stream_ptr())
+        with torch.cuda.device(self.device):
+            rc = self.lib.lrg_forward_rows(ctypes.byref(self._w), _ptr(inlier), _ptr(neighbor), B, self.num_inlier_points,
+                                           self.num_neighbor_points, _ptr(rows_in), _ptr(rows_nb), _ptr(add_out),
+                                           _ptr(rmv_out), _ptr(ws), ws.numel(), flags, _stream_ptr(self.device))
         _lib.check(rc, 'lrg_forward_rows')
         self.add_output, self.remove_output = add_out, rmv_out
         return add_out, rmv_out
+
+    def forward_packed(self, x_in, x_nb, row_inst_in, row_inst_nb, nrows, n_inst):
+        """LrgNet on packed rows (lrg_forward_packed): x_in / x_nb [row_cap,F] hold nrows[0] / nrows[1] valid rows, row r of
+        a side belonging to instance row_inst_*[r] (rows of an instance contiguous).  Returns (add [row_cap,2] per neighbour
+        row, rmv [row_cap,2] per inlier row, pooled [n_inst, 2*C_last]).  The grow loop's formulation; here for tests."""
+        cap = x_in.shape[0]
+        assert x_nb.shape[0] == cap and cap % _lib.LRG_ROW_TILE == 0 and nrows.dtype == torch.int32 and nrows.numel() >= 2
+        nbytes = self.lib.lrg_forward_packed_workspace_bytes(ctypes.byref(self._w), n_inst, cap)
+        if nbytes == 0:
+            raise _lib.LrgHipError('lrg_forward_packed_workspace_bytes rejected the configuration')
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        add = torch.zeros((cap, 2), dtype=torch.float32, device=self.device)
+        rmv = torch.zeros((cap, 2), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.lrg_forward_packed(ctypes.byref(self._w), _ptr(x_in), _ptr(x_nb), _ptr(row_inst_in), _ptr(row_inst_nb),
+                                             _ptr(nrows), None, n_inst, cap, _ptr(add), _ptr(rmv), _ptr(ws), ws.numel(), 0,
+                                             _stream_ptr(self.device))
+        _lib.check(rc, 'lrg_forward_packed')
+        off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(self.lib.lrg_forward_packed_pooled_view(ctypes.byref(self._w), n_inst, cap, ctypes.byref(off), ctypes.byref(cnt)),
+                   'lrg_forward_packed_pooled_view')
+        pooled = ws.view(torch.float32)[off.value:off.value + cnt.value].view(n_inst, -1)
+        return add, rmv, pooled
 
     def intermediate(self, kind, index, B):
         """View of a workspace intermediate after forward(): kind in conv|neighbor_conv|pooled|add_hidden|remove_hidden."""

@@ -30,3 +30,18 @@ def cuda_device(hip_lib):
     if not torch.cuda.is_available():
         pytest.fail('GPU test selected but no GPU is visible (there is no CPU fallback)')
     return torch.device('cuda:0')
+
+
+def seed_without_near_tie(run_oracle, seeds, margin):
+    """Parity under the Bernoulli policy (test_region_grow.py:266-267) is exact unless a draw u sits within float32
+    noise of its confidence; the oracle reports the closest draw of a run (GrowResult.min_rel_margin).  Rather than
+    skip such a run, walk the seeds until the oracle runs of ALL rooms keep their distance: returns (seed, results).
+    run_oracle(seed) -> list of oracle results."""
+    worst = []
+    for seed in seeds:
+        res = run_oracle(seed)
+        m = min(r.min_rel_margin for r in res)
+        if m >= margin:
+            return seed, res
+        worst.append((seed, m))
+    pytest.fail('every seed tried has a near-tie draw: %s' % worst)

@@ -19,7 +19,8 @@ def close(got, want, what):
     assert got.shape == want.shape, (what, got.shape, want.shape)
     scale = max(1.0, float(np.abs(want).max()))
     err = np.abs(got - want)
-    tol = 1e-4 * scale + 1e-5 * np.abs(want)
+    tol = 1e-4 + 1e-5 * np.abs(want)         # SURVEY.md 8d, as stated: absolute 1e-4 plus 1e-5 relative, no scale factor
+    print('%-16s max |err| %.3e  (max |x| %.3e)' % (what, err.max(), scale))
     assert (err <= tol).all(), '%s: max err %.3e (scale %.3e) at %s' % (what, err.max(), scale, np.unravel_index(err.argmax(), err.shape))
 
 
@@ -214,3 +215,53 @@ def test_packed_weight_image(cuda_device, hip_lib, lite, F):
     net._w.packed = keep
     np.testing.assert_array_equal(a0, a1)
     np.testing.assert_array_equal(r0, r1)
+
+
+@pytest.mark.parametrize('lite,F', [(0, 13), (1, 13), (2, 12)])
+def test_forward_packed_equals_dense_rows(cuda_device, lite, F):
+    """lrg_forward_packed (the loop's formulation: the distinct rows of all instances back to back, dense 32-row tiles that
+    span instances, max-pool and hoisted bias per run of rows) gives the bits of lrg_forward_rows on the same rows: ragged
+    row counts including 0 (skipped instance), 1, tile multiples and full sets."""
+    import torch
+    net, w = make_net(cuda_device, lite, F, 512, 512, 'fused')
+    rs = np.random.RandomState(5)
+    rows_in = np.array([57, 1, 0, 512, 33, 64, 7, 300, 31, 1, 2, 96], dtype=np.int32)
+    rows_nb = np.array([26, 200, 0, 512, 5, 1, 64, 17, 480, 3, 1, 32], dtype=np.int32)
+    B = len(rows_in)
+    xi = (rs.randn(B, 512, F) * 0.5).astype(np.float32)
+    xn = (rs.randn(B, 512, F) * 0.5).astype(np.float32)
+    for b in range(B):                      # the padding rule (:240,:252): rows past the count are copies of earlier ones
+        if rows_in[b]:
+            xi[b, rows_in[b]:] = xi[b, rs.randint(0, rows_in[b], 512 - rows_in[b])]
+        if rows_nb[b]:
+            xn[b, rows_nb[b]:] = xn[b, rs.randint(0, rows_nb[b], 512 - rows_nb[b])]
+    dxi, dxn = torch.from_numpy(xi).to(cuda_device), torch.from_numpy(xn).to(cuda_device)
+    add_d, rmv_d = net.forward(dxi, dxn, rows_in=torch.from_numpy(rows_in).to(cuda_device), rows_nb=torch.from_numpy(rows_nb).to(cuda_device))
+    add_d, rmv_d = add_d.cpu().numpy(), rmv_d.cpu().numpy()
+    cap = B * 512
+    order = rs.permutation(B)               # instances in arbitrary order in the packed arrays (allocation order is not slot order)
+    pin, pnb = np.zeros((cap, F), np.float32), np.zeros((cap, F), np.float32)
+    rin, rnb = np.full(cap, -7, np.int32), np.full(cap, -7, np.int32)
+    off_in, off_nb, oi, on = {}, {}, 0, 0
+    for b in order:
+        off_in[b], off_nb[b] = oi, on
+        pin[oi:oi + rows_in[b]] = xi[b, :rows_in[b]]; rin[oi:oi + rows_in[b]] = b; oi += rows_in[b]
+        pnb[on:on + rows_nb[b]] = xn[b, :rows_nb[b]]; rnb[on:on + rows_nb[b]] = b; on += rows_nb[b]
+    pin[oi:] = np.nan                       # whatever lies past the counts must not matter
+    pnb[on:] = np.nan
+    t = lambda a: torch.from_numpy(a).to(cuda_device)
+    add_p, rmv_p, pooled = net.forward_packed(t(pin), t(pnb), t(rin), t(rnb), t(np.array([oi, on], np.int32)), B)
+    torch.cuda.synchronize()
+    add_p, rmv_p, pooled = add_p.cpu().numpy(), rmv_p.cpu().numpy(), pooled.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(add_p[off_nb[b]:off_nb[b] + rows_nb[b]], add_d[b, :rows_nb[b]], err_msg='add, instance %d' % b)
+        np.testing.assert_array_equal(rmv_p[off_in[b]:off_in[b] + rows_in[b]], rmv_d[b, :rows_in[b]], err_msg='rmv, instance %d' % b)
+    # the pooled features against the oracle's max over the distinct rows
+    C = net.conv_channels[-1]
+    for b in range(B):
+        if rows_in[b] == 0:
+            assert not pooled[b].any()
+            continue
+        _, _, acts = lrgnet_ref.forward(w, xi[b:b + 1, :rows_in[b]], xn[b:b + 1, :rows_nb[b]], lite=lite, dtype=np.float64,
+                                        return_acts=True)
+        close(pooled[b], acts['pooled'][0], 'pooled, instance %d' % b)
