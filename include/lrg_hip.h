@@ -145,6 +145,7 @@ enum {
                                 fresh group in (with seed = -1) so that lrg_advance picks the first seed    */
 };
 
+#define LRG_LOG_WORDS 8
 /* One room, device-resident.  Arrays are per equalised point (n of them). */
 typedef struct LrgRoom {
     const float *points;     /* [n,F] features as stacked at test_region_grow.py:165-172                    */
@@ -155,7 +156,9 @@ typedef struct LrgRoom {
     int32_t *label;          /* [n] cluster_label before fill-in (:176)                                      */
     const uint64_t *hash_keys; /* voxel hash table (open addressing), hash_mask+1 entries                    */
     const int32_t *hash_vals;
-    int32_t *region_log;     /* [n,6] per committed seed: seed, steps, points, reason, labeled, restart      */
+    int32_t *region_log;     /* [n,LRG_LOG_WORDS] per committed seed: seed, steps, points, reason, labeled, restart, and the
+                                number of sample slots whose argmax matched input_add / input_remove at the region's last
+                                evaluated step (add_acc, remove_acc of learn_region_grow_util.py:175,180 times 512; -1: none) */
     int32_t n;
     int32_t hash_mask;
     int32_t next_cluster_id; /* (:177)                                                                      */
@@ -164,6 +167,10 @@ typedef struct LrgRoom {
     int32_t done;
     int32_t room_id;         /* RNG stream key and log tag                                                   */
     int32_t pad;
+    const uint32_t *pvox;    /* nullable: [n] voxels relative to vox_origin packed x | y << 11 | z << 22 (lrg_voxel_pack); the
+                                arrays visited / pvox must then start 16-byte aligned (word-wide loads of 4 points)   */
+    int32_t vox_origin[3];   /* per-axis minimum voxel of the room                                           */
+    int32_t pad2;
 } LrgRoom;
 
 /* One growing region instance.  A *group* of `group_size` consecutive slots shares one room and one seed
@@ -196,6 +203,8 @@ typedef struct LrgSlot {
     int32_t scan_mn[3];      /*   reset) by lrg_advance                                                               */
     int32_t scan_mx[3];
     int32_t query;           /* lrg_box_query scratch: 1 if this call re-derives the slot's lists                     */
+    int32_t acc_add;         /* sample slots whose argmax(add logits) == input_add at the last evaluated step (:175), -1 none */
+    int32_t acc_rmv;         /* likewise for the remove head (:180)                                                     */
 } LrgSlot;
 
 #define LRG_SCAN_CHUNK 4096  /* points per workgroup of the chunked mask scans */
@@ -215,6 +224,11 @@ typedef struct LrgGrowParams {
 
 /* voxels[i,0..2] = rint(points[i,0..2] / resolution)   (test_region_grow.py:175) */
 int lrg_voxelize(const float *points, int n, int F, float resolution, int32_t *voxels, void *stream);
+
+/* pvox[i] = (vx - ox) | (vy - oy) << 11 | (vz - oz) << 22 for the room's voxels: one word per point for the box query and the
+ * bounding-box passes of lrg_grow_step_packed.  (ox, oy, oz) = the per-axis minimum voxel; the room must span at most
+ * 2048 x 2048 x 1024 voxels (the caller checks; out-of-range coordinates are clamped and set *overflow_flag, device int). */
+int lrg_voxel_pack(const int32_t *voxels, int n, int ox, int oy, int oz, uint32_t *pvox, int32_t *overflow_flag, void *stream);
 
 /* Build the room's voxel -> point-index table (replaces the tuple sets of :273,:277,:283-286).
  * keys must hold hash_mask+1 entries; *dup_flag (device int, zeroed by the caller) is set when two points
@@ -355,7 +369,13 @@ typedef struct LrgPackedBuffers {
     size_t workspace_bytes;
     int64_t *stats;         /* LRG_STATS_WORDS x int64, as LrgStepBuffers                                      */
     int32_t row_cap;        /* multiple of LRG_ROW_TILE, >= n_slots * max(n_inlier, n_neighbor)                */
-    int32_t reserved;
+    int32_t rooms_have_pvox; /* 1: every room carries pvox (and 16-byte aligned visited / pvox): enables the single-launch greedy
+                                front kernel with word-wide room scans                                          */
+    int32_t *slot_big;      /* nullable with rooms_have_pvox = 0: [n_slots,2] zero-filled scratch (regions above 1024 points get
+                                their medians from a second, (slot, channel)-parallel launch)                     */
+    int64_t *phase_ticks;   /* nullable: [n_slots,2] accumulators of wall_clock64() ticks the slot's workgroup spent in (0) mask
+                                update / stop decision / commit -- the reference's 'inlier' bucket, test_region_grow.py:260-306 --
+                                and (1) box query / median / sampling / gather -- its 'neighbor' bucket, :219-254            */
 } LrgPackedBuffers;
 
 /* One lock-step iteration, packed rows: lrg_front_kernel (mask update of the previous evaluation :262-288, stop decision
@@ -364,6 +384,11 @@ typedef struct LrgPackedBuffers {
  * rooms of up to 131072 points, n_inlier / n_neighbor <= 1024; larger: lrg_grow_step. */
 int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                          const LrgWeights *weights, const LrgPackedBuffers *buffers, void *stream);
+/* The two halves of lrg_grow_step_packed as separate calls (so that a caller can put events between them):
+ * lrg_front_step = everything up to the packed rows; then lrg_forward_packed(weights, x_in, x_nb, row_slot_in, row_slot_nb,
+ * counters, counters + 2, n_slots, row_cap, add_logits, rmv_logits, workspace, workspace_bytes, LRG_FWD_POOL_ZEROED, stream). */
+int lrg_front_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                   const LrgWeights *weights, const LrgPackedBuffers *buffers, void *stream);
 
 /* `iterations` calls of lrg_grow_step_packed captured into a HIP graph on `stream` (not the null stream; weights->packed
  * set).  Nothing runs at creation.  lrg_step_graph_launch replays them with one host call. */

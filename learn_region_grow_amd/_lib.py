@@ -42,7 +42,8 @@ class LrgRoom(ctypes.Structure):
                 ('hash_keys', _fp), ('hash_vals', _fp), ('region_log', _fp),
                 ('n', ctypes.c_int32), ('hash_mask', ctypes.c_int32), ('next_cluster_id', ctypes.c_int32),
                 ('seed_cursor', ctypes.c_int32), ('n_regions', ctypes.c_int32), ('done', ctypes.c_int32),
-                ('room_id', ctypes.c_int32), ('pad', ctypes.c_int32)]
+                ('room_id', ctypes.c_int32), ('pad', ctypes.c_int32), ('pvox', _fp), ('vox_origin', ctypes.c_int32 * 3),
+                ('pad2', ctypes.c_int32)]
 
 
 class LrgSlot(ctypes.Structure):
@@ -55,7 +56,8 @@ class LrgSlot(ctypes.Structure):
                 ('mn', ctypes.c_int32 * 3), ('mx', ctypes.c_int32 * 3),
                 ('seq_mn', ctypes.c_int32 * 3), ('seq_mx', ctypes.c_int32 * 3),
                 ('target', ctypes.c_int32), ('pad', ctypes.c_int32), ('chunk_cnt', _fp), ('scan_cnt', ctypes.c_int32),
-                ('scan_mn', ctypes.c_int32 * 3), ('scan_mx', ctypes.c_int32 * 3), ('query', ctypes.c_int32)]
+                ('scan_mn', ctypes.c_int32 * 3), ('scan_mx', ctypes.c_int32 * 3), ('query', ctypes.c_int32),
+                ('acc_add', ctypes.c_int32), ('acc_rmv', ctypes.c_int32)]
 
 
 LRG_SCAN_CHUNK = 4096
@@ -78,10 +80,11 @@ class LrgPackedBuffers(ctypes.Structure):
     _fields_ = [('center', _fp), ('sample_in', _fp), ('sample_nb', _fp), ('x_in', _fp), ('x_nb', _fp),
                 ('row_slot_in', _fp), ('row_slot_nb', _fp), ('gt_in', _fp), ('gt_nb', _fp), ('rmv_logits', _fp),
                 ('add_logits', _fp), ('slot_rows', _fp), ('counters', _fp), ('workspace', _fp),
-                ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('row_cap', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('row_cap', ctypes.c_int32), ('rooms_have_pvox', ctypes.c_int32), ('slot_big', _fp), ('phase_ticks', _fp)]
 
 
 LRG_ROW_TILE = 32
+LRG_LOG_WORDS = 8
 LRG_PACKED_MAX_POINTS = 32 * 4096      # lrg_grow_step_packed: rooms up to 131072 points
 LRG_DONE_RING = 1020
 LRG_STATS_WORDS = 4 + LRG_DONE_RING
@@ -128,6 +131,7 @@ _SIGS = {
     'lrg_head_pool_gemv': (ctypes.c_int, [_fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     'lrg_head_final': (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_long, ctypes.c_int, _fp]),
     'lrg_voxelize': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _fp, _fp]),
+    'lrg_voxel_pack': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
     'lrg_voxel_hash_build': (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, _fp]),
     'lrg_bbox_stop': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp]),
     'lrg_advance': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp]),
@@ -149,6 +153,8 @@ _SIGS = {
                                           _fp, _fp, _fp, ctypes.c_size_t, ctypes.c_uint, _fp]),
     'lrg_grow_step_packed': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
                                             ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgPackedBuffers), _fp]),
+    'lrg_front_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
+                                      ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgPackedBuffers), _fp]),
     'lrg_step_graph_create': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
                                              ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgPackedBuffers), ctypes.c_int, _fp,
                                              ctypes.POINTER(ctypes.c_void_p)]),

@@ -56,8 +56,9 @@ __device__ __forceinline__ int lrg_hash_lookup(const uint64_t *keys, const int32
     if (key == LRG_HASH_EMPTY) return -1;
     unsigned h = (unsigned)lrg_fmix64(key) & (unsigned)mask;
     for (int probe = 0; probe <= mask; ++probe) {
-        uint64_t k = keys[h];
-        if (k == key) return vals[h];
+        const uint64_t k = keys[h];
+        const int v = vals[h];               // requested together with the key: one memory round trip per probe, not two
+        if (k == key) return v;
         if (k == LRG_HASH_EMPTY) return -1;
         h = (h + 1) & (unsigned)mask;
     }

@@ -32,6 +32,7 @@ struct LrgFrontArgs {
     float *pooled;           // [n_slots, pooled_stride] pooled features of the network workspace (zeroed here per slot)
     int pooled_stride;
     int64_t *stats;
+    int64_t *phase_ticks;    // nullable: [n_slots,2] wall-clock ticks per slot: (0) update / stop / commit, (1) query / median / gather
 };
 
 // ---- (1) mask update of the evaluation just finished + count / bounding box of the new mask + stop decision ----
@@ -40,7 +41,7 @@ struct LrgFrontArgs {
 // update switched on -- so :292-293 cost O(region), not O(room).
 __device__ void lrg_front_update(LrgSlot *S, const LrgRoom *R, int s, const LrgGrowParams &prm, const LrgFrontArgs &a,
                                  int *sh_added, int *red) {
-    __shared__ int sh_upd, sh_nadd;
+    __shared__ int sh_upd, sh_nadd, sh_acc[2];
     const int tid = threadIdx.x, bd = blockDim.x;
     const int F = prm.feature_size, Ni = prm.n_inlier, Nn = prm.n_neighbor;
     const int nc = S->nc, ne = S->ne;
@@ -50,11 +51,12 @@ __device__ void lrg_front_update(LrgSlot *S, const LrgRoom *R, int s, const LrgG
     const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
     const uint32_t seed = (uint32_t)S->seed, restart = (uint32_t)S->restart, step = (uint32_t)S->step;
     uint8_t *cur = S->cur;
-    if (tid == 0) { sh_upd = 0; sh_nadd = 0; }
+    if (tid == 0) { sh_upd = 0; sh_nadd = 0; sh_acc[0] = 0; sh_acc[1] = 0; }
     __syncthreads();
     // ---- add pass (:266,:270-273,:283-285): sample slot j draws for itself, its logits / coordinates are its source row's ----
     for (int j = tid; j < Nn; j += bd) {
         const long row = offn + (ne < Nn ? a.sample_nb[(long)s * Nn + j] : j);
+        if ((a.add_logits[2 * row + 1] > a.add_logits[2 * row] ? 1 : 0) == (a.gt_nb[row] != 0 ? 1 : 0)) atomicAdd(&sh_acc[0], 1);   // add_acc
         bool take;
         if (prm.policy == 2) take = a.gt_nb[row] != 0;
         else {
@@ -80,6 +82,7 @@ __device__ void lrg_front_update(LrgSlot *S, const LrgRoom *R, int s, const LrgG
     // ---- remove pass (:267,:274-277,:286-287) ----
     for (int j = tid; j < Ni; j += bd) {
         const long row = offi + (nc < Ni ? a.sample_in[(long)s * Ni + j] : j);
+        if ((a.rmv_logits[2 * row + 1] > a.rmv_logits[2 * row] ? 1 : 0) == (a.gt_in[row] != 0 ? 1 : 0)) atomicAdd(&sh_acc[1], 1);   // remove_acc
         bool take;
         if (prm.policy == 2) take = a.gt_in[row] != 0;
         else {
@@ -135,6 +138,7 @@ __device__ void lrg_front_update(LrgSlot *S, const LrgRoom *R, int s, const LrgG
         S->pad = 0;
         S->step += 1;
         S->steps_total += 1;                                                    // :288
+        S->acc_add = sh_acc[0]; S->acc_rmv = sh_acc[1];
         if (a.stats) atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[2]), 1ULL);
         lrg_stop_logic(S);                                                      // :291-306
     }
@@ -392,4 +396,548 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
         if (tid == 0 && g_lrg_trace2) { g_lrg_trace2[(long)s * 16 + 8] = S->nc; }
 #endif
     }
+}
+
+// =================================================================================================
+// Greedy growing (group_size = restarts = 1), n_inlier / n_neighbor <= 512, rooms with packed voxel words: the whole
+// front of an iteration in one launch, written for the number of DEPENDENT memory round trips (a first-touch load costs
+// ~1 us here: everything a kernel reads was written by a kernel on another XCD), not for the amount of work:
+//   * everything addressed by the slot number alone is requested at once (slot, row table, centre, this thread's sample);
+//   * the 512 add slots and the 512 remove slots are decided side by side by the two halves of the workgroup, and the
+//     old index list with its voxel words is fetched while their hash probes are in flight;
+//   * commit and reset walk the region's index lists (O(region)) instead of the room;
+//   * the box query reads 4 points per load (mask word, visited word, four packed voxel words);
+//   * regions above LRG_FRONT_SMALL points leave their nine channel medians to lrg_front_big_kernel, one workgroup per
+//     (slot, channel) -- the single slow step whose cost grows with the region (its last-arriving workgroup gathers).
+// =================================================================================================
+#define LRG_FRONT_SMALL 1024
+
+#define LRG_PVX(p) ((int)((p) & 0x7FFu))
+#define LRG_PVY(p) ((int)(((p) >> 11) & 0x7FFu))
+#define LRG_PVZ(p) ((int)((p) >> 22))
+
+// tags + gather of the slot's distinct rows (shared by the front kernel and the last workgroup of lrg_front_big_kernel)
+__device__ __forceinline__ void lrg_front_gather(const LrgSlot *S, const float *points, const int32_t *obj, int s, int F,
+                                                 const LrgFrontArgs &a, const int (*sh_src)[512], const float *sh_c, int rin,
+                                                 int rnb, int offi, int offn) {
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int target = S->target;
+    for (int j = tid; j < rin; j += bd) {
+        a.row_slot_in[offi + j] = s;
+        a.gt_in[offi + j] = obj ? (uint8_t)(obj[sh_src[0][j]] != target) : 0;              // :231,:248
+    }
+    for (int j = tid; j < rnb; j += bd) {
+        a.row_slot_nb[offn + j] = s;
+        a.gt_nb[offn + j] = obj ? (uint8_t)(obj[sh_src[1][j]] == target) : 0;              // :230,:254
+    }
+    for (int side = 0; side < 2; ++side) {
+        const int k = side ? rnb : rin;
+        float *out = side ? a.x_nb + (long)offn * F : a.x_in + (long)offi * F;
+        const int nel = k * F;
+        for (int e0 = tid; e0 < nel; e0 += 8 * bd) {       // 8 independent row loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + u * bd, nel - 1);
+                const int j = e / F, f = e - j * F;
+                v[u] = __fsub_rn(points[(long)sh_src[side][j] * F + f], sh_c[f]);           // :243-247
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * bd;
+                if (e < nel) out[e] = v[u];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
+                                                                              LrgGrowParams prm, LrgFrontArgs a, int32_t *big) {
+    __shared__ uint8_t sh_flags[LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS];
+    __shared__ int sh_tab[512], sh_tabc[512], sh_tabe[512];
+    __shared__ int sh_src[2][512];         // during the update: [0] = indices switched on by this step
+    __shared__ float sh_c[16];
+    __shared__ int red[16 * 8];
+    __shared__ int sh_i[8];                // 0 updated, 1 added count, 2 status, 3 seed-search minimum, 4 probe count, 5 add_acc, 6 remove_acc
+    __shared__ int sh_list[32];
+    __shared__ int wt_c[8], wt_e[8];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    LrgSlot *S = &slots[s];
+    const int F = prm.feature_size, Ni = prm.n_inlier, Nn = prm.n_neighbor;
+    // ---- round trip 1: everything addressed by the slot number alone ----
+    const int room = S->room;
+    int status = S->status;
+    const int nc0 = S->nc, ne0 = S->ne;
+    uint8_t *cur = S->cur;
+    int32_t *cur_idx = S->cur_idx, *cand_idx = S->cand_idx;
+    const int rows_off_in = a.slot_rows[4 * s + 2], rows_off_nb = a.slot_rows[4 * s + 3];
+    const float c0 = a.center[s * 16 + 0], c1 = a.center[s * 16 + 1];
+    const int half = tid >> 9, j = tid & 511;                    // first half: add slot j, second half: remove slot j
+    const bool mine = j < (half ? Ni : Nn);
+    int sj = 0;
+    if (mine) sj = (half ? a.sample_in : a.sample_nb)[(long)s * (half ? Ni : Nn) + j];
+    if (a.pooled)                    // the last evaluation's pooled feature has been consumed: zero for the next one
+        for (int c = tid; c < a.pooled_stride; c += LRG_FRONT_THREADS) a.pooled[(long)s * a.pooled_stride + c] = 0.f;
+    if (room < 0) {
+        if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
+        return;
+    }
+    // ---- round trip 2: the room ----
+    LrgRoom *R = &rooms[room];
+    const int n = R->n;
+    const float *points = R->points;
+    const int32_t *obj = R->obj_id;
+    const uint32_t *pvox = R->pvox;
+    uint8_t *visited = R->visited;
+    const int ox = R->vox_origin[0], oy = R->vox_origin[1], oz = R->vox_origin[2];
+    const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
+    const int entry_status = status;
+    TRACE2(s, 0);
+    const long long tick0 = a.phase_ticks ? wall_clock64() : 0;
+
+    // =========================== (1) mask update of the evaluation just finished (:262-288) ===========================
+    int id0[4];                      // the first 4096 entries of the old index list and their voxel words, kept for the commit
+    uint32_t pv0[4];
+    int al0 = 0;                     // bit k: entry k is still a member after the update
+    if (status == LRG_ACTIVE) {
+        if (tid == 0) { sh_i[0] = 0; sh_i[1] = 0; sh_i[5] = 0; sh_i[6] = 0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) id0[k] = cur_idx[min(tid + k * LRG_FRONT_THREADS, nc0 - 1)];
+        const int nside = half ? nc0 : ne0, Nside = half ? Ni : Nn;
+        const long row = (half ? rows_off_in : rows_off_nb) + (nside < Nside ? sj : j);      // a padded slot reads its source row
+        int idx = -1;
+        int correct = 0;
+        if (mine) {
+            const float *p = (half ? a.x_in : a.x_nb) + row * F;
+            const float px = p[0], py = p[1], pz = p[2];
+            const float *lg = (half ? a.rmv_logits : a.add_logits) + 2 * row;
+            const int gtf = (half ? a.gt_in : a.gt_nb)[row] != 0;
+            correct = (lg[1] > lg[0] ? 1 : 0) == gtf;                                        // add_acc / remove_acc (util:174-180)
+            bool take;
+            if (prm.policy == 2) take = gtf != 0;                                            // :268-269
+            else {
+                const float conf = lrg_conf(lg);                                             // :262-263
+                if (prm.policy == 1) take = conf > 0.5f;                                     // :264-265
+                else take = lrg_uniform01(lrg_rng_word((uint32_t)j, half ? LRG_PURPOSE_RMV : LRG_PURPOSE_ADD, (uint32_t)S->seed,
+                                                       (uint32_t)S->restart, (uint32_t)S->step, k0, k1)) < conf;   // :266-267
+            }
+            if (take) {
+                const int vx = lrg_voxel_of(__fadd_rn(px, c0), prm.resolution);              // :271-272 / :275-276
+                const int vy = lrg_voxel_of(__fadd_rn(py, c1), prm.resolution);
+                const int vz = lrg_voxel_of(pz, prm.resolution);
+                idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(vx, vy, vz));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv0[k] = pvox[id0[k]];
+        {
+            const int wsum = lrg_wave_sum_i32(correct);          // a wavefront lies in one half (512 = 8 wavefronts)
+            __syncthreads();
+            if (lane == 0 && wsum) atomicAdd(&sh_i[5 + half], wsum);
+        }
+        if (!half && idx >= 0) {                                                             // :283-285
+            unsigned *w = reinterpret_cast<unsigned *>(cur + (idx & ~3));
+            const unsigned bit = 1u << (8 * (idx & 3));
+            if (!(atomicOr(w, bit) & bit)) { sh_i[0] = 1; sh_src[0][atomicAdd(&sh_i[1], 1)] = idx; }
+        }
+        __syncthreads();
+        if (half && idx >= 0) cur[idx] = 0;                                                  // :286-287
+        __syncthreads();
+        // members and bounding box of the new mask (:292-293): surviving old members + surviving new ones
+        const int nadd = sh_i[1];
+        int cnt = 0;
+        int mn0 = INT_MAX, mn1 = INT_MAX, mn2 = INT_MAX, mx0 = INT_MIN, mx1 = INT_MIN, mx2 = INT_MIN;
+        {
+            int al[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) al[k] = cur[id0[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tid + k * LRG_FRONT_THREADS < nc0 && al[k]) {
+                    al0 |= 1 << k;
+                    ++cnt;
+                    const int x = LRG_PVX(pv0[k]), y = LRG_PVY(pv0[k]), z = LRG_PVZ(pv0[k]);
+                    mn0 = min(mn0, x); mn1 = min(mn1, y); mn2 = min(mn2, z);
+                    mx0 = max(mx0, x); mx1 = max(mx1, y); mx2 = max(mx2, z);
+                }
+        }
+        for (int i0 = 4 * LRG_FRONT_THREADS; i0 < nc0; i0 += 4 * LRG_FRONT_THREADS) {       // regions above 4096 points
+            int id[4], al[4];
+            uint32_t pv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) id[k] = cur_idx[min(i0 + k * LRG_FRONT_THREADS + tid, nc0 - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { al[k] = cur[id[k]]; pv[k] = pvox[id[k]]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k * LRG_FRONT_THREADS + tid < nc0 && al[k]) {
+                    ++cnt;
+                    const int x = LRG_PVX(pv[k]), y = LRG_PVY(pv[k]), z = LRG_PVZ(pv[k]);
+                    mn0 = min(mn0, x); mn1 = min(mn1, y); mn2 = min(mn2, z);
+                    mx0 = max(mx0, x); mx1 = max(mx1, y); mx2 = max(mx2, z);
+                }
+        }
+        for (int k = tid; k < nadd; k += LRG_FRONT_THREADS) {
+            const int idx2 = sh_src[0][k];
+            const uint32_t pv = pvox[idx2];
+            if (cur[idx2]) {                                          // (a point added and removed in the same step stays out)
+                ++cnt;
+                const int x = LRG_PVX(pv), y = LRG_PVY(pv), z = LRG_PVZ(pv);
+                mn0 = min(mn0, x); mn1 = min(mn1, y); mn2 = min(mn2, z);
+                mx0 = max(mx0, x); mx1 = max(mx1, y); mx2 = max(mx2, z);
+            }
+        }
+        lrg_block_bbox(cnt, mn0, mn1, mn2, mx0, mx1, mx2, red);
+        if (tid == 0) {
+            S->scan_cnt = cnt;
+            S->scan_mn[0] = cnt ? mn0 + ox : INT_MAX; S->scan_mn[1] = cnt ? mn1 + oy : INT_MAX; S->scan_mn[2] = cnt ? mn2 + oz : INT_MAX;
+            S->scan_mx[0] = cnt ? mx0 + ox : INT_MIN; S->scan_mx[1] = cnt ? mx1 + oy : INT_MIN; S->scan_mx[2] = cnt ? mx2 + oz : INT_MIN;
+            S->updated = sh_i[0];
+            S->pad = 0;
+            S->step += 1;
+            S->steps_total += 1;                                                             // :288
+            S->acc_add = sh_i[5]; S->acc_rmv = sh_i[6];
+            if (a.stats) atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[2]), 1ULL);
+            lrg_stop_logic(S);                                                               // :291-306
+            sh_i[2] = S->status;
+        }
+        __syncthreads();
+        status = sh_i[2];
+    }
+    TRACE2(s, 1);
+
+    // =========================== (2) commit (:210-217), next seed (:186-188), reset (:197-204) ===========================
+    if (lrg_is_stop(status)) {
+        // members of the finished region: after an update, the survivors found above; after a stop taken by the box query
+        // ('noneighbor', step cap), the list that query compacted (every entry a member)
+        const bool from_update = entry_status == LRG_ACTIVE;
+        const int count = S->count;
+        const int labeled = count > prm.cluster_threshold;                                   // :213
+        const int cid = R->next_cluster_id;
+        int32_t *label = R->label;
+        if (from_update) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (al0 >> k & 1) { visited[id0[k]] = 1; if (labeled) label[id0[k]] = cid; cur[id0[k]] = 0; }   // :212,:214 + reset
+            for (int i = 4 * LRG_FRONT_THREADS + tid; i < nc0; i += LRG_FRONT_THREADS) {
+                const int id = cur_idx[i];
+                if (cur[id]) { visited[id] = 1; if (labeled) label[id] = cid; cur[id] = 0; }
+            }
+            const int nadd = sh_i[1];
+            for (int k = tid; k < nadd; k += LRG_FRONT_THREADS) {
+                const int id = sh_src[0][k];
+                if (cur[id]) { visited[id] = 1; if (labeled) label[id] = cid; cur[id] = 0; }
+            }
+        } else {
+            for (int i = tid; i < nc0; i += LRG_FRONT_THREADS) {
+                const int id = cur_idx[i];
+                visited[id] = 1; if (labeled) label[id] = cid; cur[id] = 0;
+            }
+        }
+        if (tid == 0) {
+            int32_t *log = R->region_log + LRG_LOG_WORDS * (long)R->n_regions;
+            log[0] = S->seed; log[1] = S->steps_total; log[2] = count; log[3] = S->last_reason; log[4] = labeled; log[5] = 0;
+            log[6] = S->acc_add; log[7] = S->acc_rmv;
+            R->n_regions += 1;
+            if (labeled) R->next_cluster_id = cid + 1;                                       // :215
+            if (a.stats) atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[0]), 1ULL);
+        }
+        __syncthreads();
+        status = LRG_WAIT;
+    }
+    if (status == LRG_WAIT) {
+        // next unvisited seed in curvature order; its first box query (a one-voxel box) is answered from the voxel hash, and a
+        // seed without neighbours is committed on the spot (see lrg_advance_group)
+        int cursor = R->seed_cursor;
+        int seed = -1, n_cand = 0;
+        const int32_t *order = R->order;
+        for (int tries = 0; tries < LRG_SEED_TRIES; ++tries) {
+            int found = -1;
+            while (cursor < n) {
+                const int pos = cursor + tid;
+                int cand = INT_MAX;
+                if (pos < n && !visited[order[pos]]) cand = pos;
+                if (tid == 0) sh_i[3] = INT_MAX;
+                __syncthreads();
+                if (cand != INT_MAX) atomicMin(&sh_i[3], cand);
+                __syncthreads();
+                const int best = sh_i[3];
+                __syncthreads();
+                if (best != INT_MAX) { found = best; break; }
+                cursor += LRG_FRONT_THREADS;
+            }
+            if (found < 0) {
+                if (tid == 0) {
+                    R->seed_cursor = n;
+                    R->done = 1;
+                    S->status = LRG_DONE;
+                    if (a.stats) {
+                        unsigned long long k = atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[1]), 1ULL);
+                        a.stats[4 + (k % LRG_DONE_RING)] = s;
+                    }
+                    a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0;
+                }
+                return;
+            }
+            const int sd = order[found];
+            cursor = found + 1;
+            if (tid < 64) {
+                int idx = -1;
+                if (tid < 27 && tid != 13) {
+                    const int dx = tid / 9 - 1, dy = (tid / 3) % 3 - 1, dz = tid % 3 - 1;
+                    const int32_t *v = R->voxels + 3 * (long)sd;
+                    idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(v[0] + dx, v[1] + dy, v[2] + dz));
+                    if (idx >= 0 && (visited[idx] || idx == sd)) idx = -1;
+                }
+                int rank = 0, total = 0;
+                for (int l = 0; l < 27; ++l) {
+                    const int o = __shfl(idx, l);
+                    if (o >= 0) { ++total; if (idx >= 0 && o < idx) ++rank; }
+                }
+                if (idx >= 0) sh_list[rank] = idx;
+                if (tid == 0) sh_i[4] = total;
+            }
+            __syncthreads();
+            const int total = sh_i[4];
+            __syncthreads();
+            if (total > 0) { seed = sd; n_cand = total; break; }
+            if (tid == 0) {                                          // no neighbour: the region is the seed alone (:233-235)
+                const int labeled = 1 > prm.cluster_threshold;
+                visited[sd] = 1;
+                if (labeled) { R->label[sd] = R->next_cluster_id; R->next_cluster_id += 1; }
+                int32_t *log = R->region_log + LRG_LOG_WORDS * (long)R->n_regions;
+                log[0] = sd; log[1] = 0; log[2] = 1; log[3] = LRG_STOP_NONEIGHBOR; log[4] = labeled; log[5] = 0; log[6] = -1; log[7] = -1;
+                R->n_regions += 1;
+                if (a.stats) atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[0]), 1ULL);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) R->seed_cursor = cursor;
+        if (seed < 0) {              // try budget spent on isolated points: the next call continues the search
+            if (tid == 0) {
+                S->seed = -1; S->status = LRG_WAIT; S->count = -1;
+                a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0;
+            }
+            return;
+        }
+        // the slot's mask is all zero here (every region clears its members at commit; the host zeroes it when binding)
+        if ((int)tid < n_cand) cand_idx[tid] = sh_list[tid];
+        if (tid == 0) {
+            cur[seed] = 1;                                                                   // :197-198
+            cur_idx[0] = seed;
+            S->seed = seed; S->restart = 0; S->step = 0; S->stuck = 0; S->updated = -1;
+            S->nc = 1; S->ne = n_cand; S->count = 1;
+            for (int d = 0; d < 3; ++d) {
+                const int v = R->voxels[3 * seed + d];
+                S->mn[d] = v; S->mx[d] = v; S->seq_mn[d] = v; S->seq_mx[d] = v;             // :199-202
+            }
+            S->target = obj ? obj[seed] : 0;
+            S->pad = 1;                                                                      // lists ready
+            S->scan_cnt = 0;
+            S->scan_mn[0] = S->scan_mn[1] = S->scan_mn[2] = INT_MAX;
+            S->scan_mx[0] = S->scan_mx[1] = S->scan_mx[2] = INT_MIN;
+            S->steps_total = 0; S->best_count = -1; S->best_restart = INT_MAX; S->last_reason = 0;
+            S->acc_add = -1; S->acc_rmv = -1;
+            S->status = LRG_ACTIVE;
+        }
+        __syncthreads();
+        status = LRG_ACTIVE;
+    }
+    TRACE2(s, 2);
+    const long long tick1 = a.phase_ticks ? wall_clock64() : 0;
+    if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 0] += tick1 - tick0;
+    if (status != LRG_ACTIVE) {      // DONE / IDLE
+        if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
+        return;
+    }
+
+    // =========================== (3) dilated voxel-box query with ordered compaction (:221-235) ===========================
+    if (S->pad != 1) {
+        const int nchunk = (n + LRG_SCAN_CHUNK - 1) / LRG_SCAN_CHUNK;
+        const int lo0 = max(S->mn[0] - 1 - ox, 0), lo1 = max(S->mn[1] - 1 - oy, 0), lo2 = max(S->mn[2] - 1 - oz, 0);     // :222-225
+        const int hi0 = S->mx[0] + 1 - ox, hi1 = S->mx[1] + 1 - oy, hi2 = S->mx[2] + 1 - oz;
+        const int ilast = (n - 1) & ~3;
+        for (int cb = 0; cb < nchunk; cb += 4) {                 // 16 points per thread per trip: 3 loads per 4 points
+            unsigned cw[4], vw[4];
+            uint4 pw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = min((cb + q) * LRG_SCAN_CHUNK + 4 * tid, ilast);
+                cw[q] = *reinterpret_cast<const unsigned *>(cur + i);
+                vw[q] = *reinterpret_cast<const unsigned *>(visited + i);
+                pw[q] = *reinterpret_cast<const uint4 *>(pvox + i);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cb + q;
+                if (c < nchunk) {                               // workgroup-uniform
+                    const int ib = c * LRG_SCAN_CHUNK + 4 * tid;
+                    const unsigned pq[4] = {pw[q].x, pw[q].y, pw[q].z, pw[q].w};
+                    int fc = 0, fe = 0;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        if (ib + kk < n) {
+                            const int x = LRG_PVX(pq[kk]), y = LRG_PVY(pq[kk]), z = LRG_PVZ(pq[kk]);
+                            if (cw[q] >> (8 * kk) & 0xFF) fc |= 1 << kk;
+                            else if (!(vw[q] >> (8 * kk) & 0xFF) && x >= lo0 && x <= hi0 && y >= lo1 && y <= hi1 && z >= lo2 && z <= hi2)
+                                fe |= 1 << kk;                                               // :226-228
+                        }
+                    }
+                    sh_flags[c * LRG_FRONT_THREADS + tid] = (uint8_t)(fc | (fe << 4));
+                    const int packed = lrg_wave_sum_i32(__popc(fc) | (__popc(fe) << 16));
+                    if (lane == 0) sh_tab[c * 16 + wave] = packed;
+                }
+            }
+        }
+        __syncthreads();
+        const int nent = nchunk * 16;
+        int vcn = 0, ven = 0;
+        if (tid < 512 && tid < nent) { const int p = sh_tab[tid]; vcn = p & 0xFFFF; ven = (int)((unsigned)p >> 16); }
+        const int ic = lrg_wave_incl_scan_i32(vcn), ie = lrg_wave_incl_scan_i32(ven);
+        if (tid < 512 && lane == 63) { wt_c[wave] = ic; wt_e[wave] = ie; }
+        __syncthreads();
+        int totc = 0, tote = 0;
+        {
+            int oc = 0, oe = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                if (w < wave) { oc += wt_c[w]; oe += wt_e[w]; }
+                totc += wt_c[w]; tote += wt_e[w];
+            }
+            if (tid < 512) { sh_tabc[tid] = oc + ic - vcn; sh_tabe[tid] = oe + ie - ven; }
+        }
+        __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            const int f = sh_flags[c * LRG_FRONT_THREADS + tid];
+            const int fc = f & 15, fe = f >> 4;
+            const int mine2 = __popc(fc) | (__popc(fe) << 16);
+            const int excl = lrg_wave_incl_scan_i32(mine2) - mine2;
+            int pc = sh_tabc[c * 16 + wave] + (excl & 0xFFFF), pe = sh_tabe[c * 16 + wave] + (int)((unsigned)excl >> 16);
+            const int ib = c * LRG_SCAN_CHUNK + 4 * tid;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (fc >> k & 1) cur_idx[pc++] = ib + k;
+                if (fe >> k & 1) cand_idx[pe++] = ib + k;
+            }
+        }
+        if (tid == 0) {
+            S->pad = 1;
+            S->nc = totc;
+            S->ne = tote;
+            int st = LRG_ACTIVE;
+            if (tote == 0) st = LRG_STOP_NONEIGHBOR;                                         // :233-235
+            else if (prm.max_region_steps > 0 && S->step >= prm.max_region_steps) st = LRG_STOP_MAXSTEPS;
+            if (st != LRG_ACTIVE) { S->status = st; S->last_reason = st; S->count = totc; }
+            sh_i[2] = st;
+        }
+        __syncthreads();
+        if (sh_i[2] != LRG_ACTIVE) {
+            if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
+            return;
+        }
+    }
+    TRACE2(s, 3);
+
+    // =========================== (4) sampling (:237-252), centre (:241), gather (:242-254) ===========================
+    __shared__ int sh_off[2];
+    const int nc = S->nc, ne = S->ne;
+    const int rin = min(nc, Ni), rnb = min(ne, Nn);
+    const bool is_big = nc > LRG_FRONT_SMALL;
+    if (tid == 0) {
+        const int oi = atomicAdd(&a.counters[0], rin), on = atomicAdd(&a.counters[1], rnb);
+        sh_off[0] = oi; sh_off[1] = on;
+        a.slot_rows[4 * s + 0] = rin; a.slot_rows[4 * s + 1] = rnb; a.slot_rows[4 * s + 2] = oi; a.slot_rows[4 * s + 3] = on;
+        big[2 * s] = is_big ? 1 : 0;
+    }
+    if (mine) {
+        const int nn = half ? nc : ne, kk = half ? Ni : Nn;      // (here the first half samples the neighbours, the second the inliers)
+        const int pos = (int)lrg_sample_position((uint32_t)j, (uint32_t)nn, (uint32_t)kk, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
+                                                 (uint32_t)S->seed, (uint32_t)S->restart, (uint32_t)S->step, k0, k1);
+        (half ? a.sample_in : a.sample_nb)[(long)s * kk + j] = pos;
+        if (!is_big && j < min(nn, kk)) sh_src[half ? 0 : 1][j] = (half ? cur_idx : cand_idx)[pos];
+    }
+    if (is_big) {
+        if (tid < 16) a.center[s * 16 + tid] = 0.f;             // lrg_front_big_kernel fills the centred channels, then gathers
+        if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
+        return;
+    }
+    if (tid < 16) sh_c[tid] = 0.f;
+    __syncthreads();
+    TRACE2(s, 4);
+    if (wave < 9) {                                              // one wavefront per centred channel, keys in registers
+        const int ch = lrg_centred_channel(wave, F);
+        if (ch >= 0) {
+            const float *pts = points + ch;
+            const float m = nc <= 256 ? lrg_median_wave_r<4>(pts, cur_idx, F, nc) : lrg_median_wave_r<16>(pts, cur_idx, F, nc);
+            if (lane == 0) sh_c[ch] = m;
+        }
+    }
+    __syncthreads();
+    TRACE2(s, 5);
+    if (tid < 16) a.center[s * 16 + tid] = sh_c[tid];           // the next update un-centres x, y with it (:271,:275)
+    TRACE2(s, 6);
+    lrg_front_gather(S, points, obj, s, F, a, sh_src, sh_c, rin, rnb, sh_off[0], sh_off[1]);
+    if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
+    TRACE2(s, 7);
+#if LRG_TRACE
+    if (tid == 0 && g_lrg_trace2) { g_lrg_trace2[(long)s * 16 + 8] = nc; g_lrg_trace2[(long)s * 16 + 14] = lrg_is_stop(entry_status) || entry_status == LRG_WAIT || (entry_status == LRG_ACTIVE && S->step == 0); }
+#endif
+}
+
+// Medians of regions above LRG_FRONT_SMALL points: one workgroup per (slot, centred channel), keys in registers (two
+// global round trips), two bits per bisection step; the workgroup that arrives last at the slot's counter has all nine
+// medians in reach and gathers the slot's rows.
+__global__ __launch_bounds__(1024) void lrg_front_big_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
+                                                              LrgFrontArgs a, int32_t *big) {
+    __shared__ int sh[64];
+    __shared__ int sh_last;
+    __shared__ int sh_src[2][512];
+    __shared__ float sh_c[16];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (big[2 * s] == 0) return;
+    const long long tickb = a.phase_ticks ? wall_clock64() : 0;
+    const LrgSlot *S = &slots[s];
+    const LrgRoom *R = &rooms[S->room];
+    const int F = prm.feature_size, Ni = prm.n_inlier, Nn = prm.n_neighbor;
+    const int nc = S->nc, ne = S->ne;
+    const int ch = lrg_centred_channel(blockIdx.y, F);
+    // what the gather needs besides the centre is requested now by every workgroup of the slot (the one that arrives last
+    // then only waits for the medians): row table, sample positions -> source indices
+    const int rin = a.slot_rows[4 * s + 0], rnb = a.slot_rows[4 * s + 1], offi = a.slot_rows[4 * s + 2], offn = a.slot_rows[4 * s + 3];
+    for (int u = tid; u < rin + rnb; u += blockDim.x) {
+        const int side = u >= rin, j = side ? u - rin : u;
+        const int pos = (side ? a.sample_nb : a.sample_in)[(long)s * (side ? Nn : Ni) + j];
+        sh_src[side][j] = (side ? S->cand_idx : S->cur_idx)[pos];
+    }
+    if (ch >= 0) {
+        if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
+        __syncthreads();
+        const float *pts = R->points + ch;
+        float m;
+        if (nc <= 4096) m = lrg_median_block_regs<4>(pts, S->cur_idx, F, nc, sh);
+        else if (nc <= 16 * 1024) m = lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh);
+        else if (nc <= LRG_MED_REGS) m = lrg_median_block_regs<48>(pts, S->cur_idx, F, nc, sh);
+        else {
+            const int k2 = nc >> 1, k1r = (nc & 1) ? k2 : k2 - 1;
+            uint32_t ka, kb;
+            lrg_select2(nullptr, false, R->points, S->cur_idx, F, ch, nc, k1r, k2, sh, &ka, &kb);
+            const float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
+            m = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+        }
+        if (tid == 0) __hip_atomic_store(&a.center[s * 16 + ch], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        sh_last = atomicAdd(&big[2 * s + 1], 1) == (int)gridDim.y - 1;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    if (tid == 0) big[2 * s + 1] = 0;
+    __threadfence();
+    if (tid < 16) sh_c[tid] = __hip_atomic_load(&a.center[s * 16 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    lrg_front_gather(S, R->points, R->obj_id, s, F, a, sh_src, sh_c, rin, rnb, offi, offn);
+    if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tickb;
+    (void)ne;
 }

@@ -32,6 +32,14 @@ __global__ void lrg_voxelize_kernel(const float *points, int n, int F, float res
     vox[3 * i + 2] = lrg_voxel_of(points[(long)i * F + 2], res);
 }
 
+__global__ void lrg_voxel_pack_kernel(const int32_t *vox, int n, int ox, int oy, int oz, uint32_t *pvox, int32_t *overflow) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = vox[3 * i] - ox, y = vox[3 * i + 1] - oy, z = vox[3 * i + 2] - oz;
+    if ((unsigned)x > 2047u || (unsigned)y > 2047u || (unsigned)z > 1023u) atomicOr(overflow, 1);
+    pvox[i] = (uint32_t)min(max(x, 0), 2047) | ((uint32_t)min(max(y, 0), 2047) << 11) | ((uint32_t)min(max(z, 0), 1023) << 22);
+}
+
 __global__ void lrg_hash_build_kernel(const int32_t *vox, int n, uint64_t *keys, int32_t *vals, int mask, int32_t *dup) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -211,6 +219,7 @@ __device__ void lrg_reset_slot(LrgSlot *S, const LrgRoom *R, int seed, int resta
             S->mn[d] = v; S->mx[d] = v; S->seq_mn[d] = v; S->seq_mx[d] = v;
         }
         S->target = R->obj_id ? R->obj_id[seed] : 0;
+        S->acc_add = -1; S->acc_rmv = -1;
         S->pad = 0;
         S->scan_cnt = 0;
         S->scan_mn[0] = S->scan_mn[1] = S->scan_mn[2] = INT_MAX;
@@ -320,9 +329,10 @@ __device__ void lrg_advance_group(LrgSlot *slots, LrgRoom *rooms, int n_slots, c
             // reason printed by the reference is that of the call completing the seed: restart ordinal RST-1
             int last_slot = (RST - 1) % G;
             if (g0 + last_slot >= n_slots) last_slot = 0;
-            int32_t *log = R->region_log + 6 * (long)R->n_regions;
+            int32_t *log = R->region_log + LRG_LOG_WORDS * (long)R->n_regions;
             log[0] = S0->seed; log[1] = steps; log[2] = wcount; log[3] = slots[g0 + last_slot].last_reason;
             log[4] = labeled; log[5] = wrest;
+            log[6] = slots[g0 + last_slot].acc_add; log[7] = slots[g0 + last_slot].acc_rmv;
             R->n_regions += 1;
             if (labeled) R->next_cluster_id = cid + 1;                            // :215
             if (stats) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), 1ULL);
@@ -394,8 +404,8 @@ __device__ void lrg_advance_group(LrgSlot *slots, LrgRoom *rooms, int n_slots, c
             const int labeled = 1 > prm.cluster_threshold;
             R->visited[sd] = 1;
             if (labeled) { R->label[sd] = R->next_cluster_id; R->next_cluster_id += 1; }
-            int32_t *log = R->region_log + 6 * (long)R->n_regions;
-            log[0] = sd; log[1] = 0; log[2] = 1; log[3] = LRG_STOP_NONEIGHBOR; log[4] = labeled; log[5] = 0;
+            int32_t *log = R->region_log + LRG_LOG_WORDS * (long)R->n_regions;
+            log[0] = sd; log[1] = 0; log[2] = 1; log[3] = LRG_STOP_NONEIGHBOR; log[4] = labeled; log[5] = 0; log[6] = -1; log[7] = -1;
             R->n_regions += 1;
             if (stats) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), 1ULL);
         }
@@ -985,9 +995,11 @@ __global__ __launch_bounds__(512) void lrg_mask_update_kernel(LrgSlot *slots, co
                                                                const uint8_t *rmv_mask, const int32_t *sample_in,
                                                                const int32_t *sample_nb, int64_t *stats) {
     __shared__ int sh_upd;
+    __shared__ int sh_acc[2];
     const int s = blockIdx.x;
     LrgSlot *S = &slots[s];
     if (S->status != LRG_ACTIVE || S->room < 0) return;
+    if (threadIdx.x < 2) sh_acc[threadIdx.x] = 0;
     const LrgRoom *R = &rooms[S->room];
     const int F = prm.feature_size;
     const float res = prm.resolution;
@@ -997,9 +1009,14 @@ __global__ __launch_bounds__(512) void lrg_mask_update_kernel(LrgSlot *slots, co
     if (threadIdx.x == 0) sh_upd = 0;
     __syncthreads();
     // ---- add pass (:266,:270-273,:283-285) ----
+    const bool have_acc = add_logits && rmv_logits && gt_add && gt_remove;
     for (int j = threadIdx.x; j < prm.n_neighbor; j += blockDim.x) {
         bool take;
         const long o = (long)s * prm.n_neighbor + j;
+        if (have_acc) {                                                        // add_acc (learn_region_grow_util.py:174-175)
+            const long lo = (sample_nb && S->ne < prm.n_neighbor) ? (long)s * prm.n_neighbor + sample_nb[o] : o;
+            if ((add_logits[2 * lo + 1] > add_logits[2 * lo] ? 1 : 0) == (gt_add[o] != 0 ? 1 : 0)) atomicAdd(&sh_acc[0], 1);
+        }
         if (prm.policy == 2) take = gt_add[o] != 0;
         else if (add_mask) take = add_mask[o] != 0;
         else {
@@ -1024,6 +1041,10 @@ __global__ __launch_bounds__(512) void lrg_mask_update_kernel(LrgSlot *slots, co
     for (int j = threadIdx.x; j < prm.n_inlier; j += blockDim.x) {
         bool take;
         const long o = (long)s * prm.n_inlier + j;
+        if (have_acc) {                                                        // remove_acc (:179-180)
+            const long lo = (sample_in && S->nc < prm.n_inlier) ? (long)s * prm.n_inlier + sample_in[o] : o;
+            if ((rmv_logits[2 * lo + 1] > rmv_logits[2 * lo] ? 1 : 0) == (gt_remove[o] != 0 ? 1 : 0)) atomicAdd(&sh_acc[1], 1);
+        }
         if (prm.policy == 2) take = gt_remove[o] != 0;
         else if (rmv_mask) take = rmv_mask[o] != 0;
         else {
@@ -1048,6 +1069,8 @@ __global__ __launch_bounds__(512) void lrg_mask_update_kernel(LrgSlot *slots, co
         S->pad = 0;
         S->step += 1;
         S->steps_total += 1;                                                    // :288
+        S->acc_add = have_acc ? sh_acc[0] : -1;
+        S->acc_rmv = have_acc ? sh_acc[1] : -1;
         if (stats) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[2]), 1ULL);
     }
 }
@@ -1177,6 +1200,15 @@ int lrg_voxelize(const float *points, int n, int F, float resolution, int32_t *v
     if (n == 0) return 0;
     hipLaunchKernelGGL(lrg_voxelize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, points, n, F,
                        resolution, voxels);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_voxel_pack(const int32_t *voxels, int n, int ox, int oy, int oz, uint32_t *pvox, int32_t *overflow_flag, void *stream) {
+    if (!voxels || !pvox || !overflow_flag || n < 0) return LRG_EINVAL - 1;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(lrg_voxel_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, voxels, n, ox, oy, oz, pvox,
+                       overflow_flag);
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -1379,8 +1411,8 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
                            rows ? b->sample_nb : nullptr, b->stats, stream);
 }
 
-int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
-                         const LrgWeights *weights, const LrgPackedBuffers *b, void *stream) {
+int lrg_front_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                   const LrgWeights *weights, const LrgPackedBuffers *b, void *stream) {
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || !weights || !b || n_slots <= 0 || max_points <= 0) return LRG_EINVAL - 1;
@@ -1403,8 +1435,17 @@ int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_po
     a.slot_rows = b->slot_rows; a.counters = b->counters;
     a.pooled = static_cast<float *>(b->workspace) + poff; a.pooled_stride = (int)(pcnt / (size_t)n_slots);
     a.stats = b->stats;
+    a.phase_ticks = b->phase_ticks;
     hipStream_t st = (hipStream_t)stream;
-    if (params->group_size == 1) {
+    if (params->group_size == 1 && params->restarts == 1 && b->rooms_have_pvox && b->slot_big && params->n_inlier <= 512 &&
+        params->n_neighbor <= 512) {
+        const int ncentred = params->feature_size <= 2 ? params->feature_size : params->feature_size <= 6 ? 2 : params->feature_size - 4;
+        hipLaunchKernelGGL(lrg_front_greedy_kernel, dim3(n_slots), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots, *params, a,
+                           b->slot_big);
+        LRG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(lrg_front_big_kernel, dim3(n_slots, ncentred), dim3(1024), 0, st, slots, rooms, *params, a, b->slot_big);
+        LRG_LAUNCH_CHECK();
+    } else if (params->group_size == 1) {
         hipLaunchKernelGGL(lrg_front_kernel<7>, dim3(n_slots), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots, *params, a);
         LRG_LAUNCH_CHECK();
     } else {
@@ -1416,9 +1457,17 @@ int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_po
         hipLaunchKernelGGL(lrg_front_kernel<4>, dim3(n_slots), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots, *params, a);
         LRG_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                         const LrgWeights *weights, const LrgPackedBuffers *b, void *stream) {
+    int rc = lrg_front_step(slots, rooms, n_slots, max_points, params, weights, b, stream);
+    if (rc) return rc;
     return lrg_forward_packed(weights, b->x_in, b->x_nb, b->row_slot_in, b->row_slot_nb, b->counters, b->counters + 2, n_slots,
                               b->row_cap, b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes, LRG_FWD_POOL_ZEROED, stream);
 }
+
 
 // `iterations` lock-step iterations captured once into a HIP graph: every kernel argument of lrg_grow_step_packed is a device
 // pointer or a constant, so a replay is the same work with one host call instead of 4-6 launches per iteration.

@@ -98,32 +98,59 @@ class RegionGrower:
         per-room voxel tables."""
         dev, F, S = self.dev, self.net.feature_size, self.S
         ns = [int(len(r['points'])) for r in rooms]
-        offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+        # every room starts at a multiple of 16 points in the arenas: the packed iteration reads masks, visited flags and packed
+        # voxel words four points per load
+        pad = [(n + 15) // 16 * 16 for n in ns]
+        offs = np.concatenate([[0], np.cumsum(pad)]).astype(np.int64)
         tot = int(offs[-1])
         self.room_n, self.room_off, self.n_rooms = ns, offs, len(rooms)
         self._fill_ws = None
-        pts = np.concatenate([np.ascontiguousarray(r['points'], dtype=np.float32) for r in rooms], axis=0)
-        assert pts.shape[1] == F
+        pts = np.zeros((tot, F), dtype=np.float32)
+        obj = np.zeros(tot, dtype=np.int32)
+        order = np.zeros(tot, dtype=np.int32)
+        for r, room in enumerate(rooms):
+            o, n = int(offs[r]), ns[r]
+            p_ = np.asarray(room['points'], dtype=np.float32)
+            assert p_.shape == (n, F), (p_.shape, F)
+            pts[o:o + n] = p_
+            obj[o:o + n] = np.asarray(room['obj_id']).astype(np.int32)
+            order[o:o + n] = np.asarray(room['order']).astype(np.int32)
         self.d_points = torch.from_numpy(pts).to(dev)
-        self.d_obj = torch.from_numpy(np.concatenate([np.asarray(r['obj_id']).astype(np.int32) for r in rooms])).to(dev)
-        self.d_order = torch.from_numpy(np.concatenate([np.asarray(r['order']).astype(np.int32) for r in rooms])).to(dev)
+        self.d_obj = torch.from_numpy(obj).to(dev)
+        self.d_order = torch.from_numpy(order).to(dev)
         self.d_vox = torch.empty((tot, 3), dtype=torch.int32, device=dev)
+        self.d_pvox = torch.zeros(tot, dtype=torch.int32, device=dev)
         self.d_visited = torch.zeros(tot, dtype=torch.uint8, device=dev)
         self.d_label = torch.zeros(tot, dtype=torch.int32, device=dev)
         self.d_filled = torch.zeros(tot, dtype=torch.int32, device=dev)
-        self.d_rlog = torch.zeros((tot, 6), dtype=torch.int32, device=dev)
+        self.d_rlog = torch.zeros((tot, _lib.LRG_LOG_WORDS), dtype=torch.int32, device=dev)
         caps = [max(16, 1 << int(np.ceil(np.log2(2 * n + 1)))) for n in ns]
         hoffs = np.concatenate([[0], np.cumsum(caps)]).astype(np.int64)
         self.d_hkeys = torch.empty(int(hoffs[-1]), dtype=torch.int64, device=dev)
         self.d_hvals = torch.zeros(int(hoffs[-1]), dtype=torch.int32, device=dev)
         self.d_dup = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_povf = torch.zeros(1, dtype=torch.int32, device=dev)
         st = _stream_ptr(self.dev)
         _lib.check(self.lib.lrg_voxelize(_ptr(self.d_points), tot, F, ctypes.c_float(self.params.resolution),
                                          _ptr(self.d_vox), st), 'lrg_voxelize')
+        # packed voxel words (one per point, relative to the room's minimum voxel) when every room fits 2048 x 2048 x 1024 voxels
+        h_vox = self.d_vox.cpu().numpy()
+        origins, self.have_pvox = [], True
+        for r in range(len(rooms)):
+            v = h_vox[int(offs[r]):int(offs[r]) + ns[r]]
+            lo, hi = (v.min(axis=0), v.max(axis=0)) if ns[r] else (np.zeros(3, np.int64), np.zeros(3, np.int64))
+            origins.append([int(x) for x in lo])
+            if ns[r] and ((hi - lo) > np.array([2047, 2047, 1023])).any():
+                self.have_pvox = False
         self.h_rooms = (LrgRoom * len(rooms))()
         for r, room in enumerate(rooms):
             o, n, ho = int(offs[r]), ns[r], int(hoffs[r])
             R = self.h_rooms[r]
+            if self.have_pvox:
+                R.pvox = self.d_pvox.data_ptr() + o * 4
+                R.vox_origin[0], R.vox_origin[1], R.vox_origin[2] = origins[r]
+                _lib.check(self.lib.lrg_voxel_pack(ctypes.c_void_p(self.d_vox.data_ptr() + o * 12), n, origins[r][0], origins[r][1],
+                                                   origins[r][2], ctypes.c_void_p(R.pvox), _ptr(self.d_povf), st), 'lrg_voxel_pack')
             R.points = self.d_points.data_ptr() + o * F * 4
             R.voxels = self.d_vox.data_ptr() + o * 12
             R.obj_id = self.d_obj.data_ptr() + o * 4
@@ -132,7 +159,7 @@ class RegionGrower:
             R.label = self.d_label.data_ptr() + o * 4
             R.hash_keys = self.d_hkeys.data_ptr() + ho * 8
             R.hash_vals = self.d_hvals.data_ptr() + ho * 4
-            R.region_log = self.d_rlog.data_ptr() + o * 24
+            R.region_log = self.d_rlog.data_ptr() + o * 4 * _lib.LRG_LOG_WORDS
             R.n = n
             R.hash_mask = caps[r] - 1
             R.next_cluster_id = 1
@@ -232,6 +259,9 @@ class RegionGrower:
             pb.workspace, pb.workspace_bytes = self.p_ws.data_ptr(), self.p_ws.numel()
             pb.stats = self.d_stats.data_ptr()
             pb.row_cap = cap_rows
+            self.p_big = torch.zeros((S, 2), dtype=torch.int32, device=dev)
+            pb.slot_big = self.p_big.data_ptr()
+            pb.rooms_have_pvox = 1 if self.have_pvox else 0
             self.packed_buffers = pb
         self.h_stats = [torch.zeros(LRG_STATS_WORDS, dtype=torch.int64).pin_memory() for _ in range(self.depth)]
         self.ev = [torch.cuda.Event() for _ in range(self.depth)]
@@ -266,6 +296,7 @@ class RegionGrower:
             sl.seed = -1
             sl.restart = sl.step = sl.steps_total = sl.stuck = 0
             sl.updated = -1
+            sl.acc_add = sl.acc_rmv = -1
             sl.count = -1
             sl.best_count = -1
             sl.pad = 0
@@ -276,6 +307,10 @@ class RegionGrower:
         a, b = group * self.G, (group + 1) * self.G
         buf = np.frombuffer(bytes(self.h_slots), dtype=np.uint8)[a * sz:b * sz].copy()
         self.d_slots[a * sz:b * sz].copy_(torch.from_numpy(buf))
+        if self.packed:
+            # the packed iteration clears a finished region's members, not the whole mask: a slot that left its last room in
+            # mid-growth (an aborted run) must not carry bits over
+            self.d_cur[a:b].zero_()
         self.group_room[group] = r
 
     def fill(self, r):
@@ -532,7 +567,10 @@ class RegionGrower:
                 row = rlog[o + k]
                 regs.append(dict(seed=int(row[0]), steps=int(row[1]), points=int(row[2]),
                                  reason=REASON_NAMES.get(int(row[3]), str(int(row[3]))), labeled=bool(row[4]),
-                                 restart=int(row[5])))
+                                 restart=int(row[5]),
+                                 # add_acc / remove_acc of the region's last evaluated step (learn_region_grow_util.py:175,180)
+                                 add_acc=(int(row[6]) / float(self.net.num_neighbor_points)) if row[6] >= 0 else float('nan'),
+                                 rmv_acc=(int(row[7]) / float(self.net.num_inlier_points)) if row[7] >= 0 else float('nan')))
             out.append(RoomResult(self.room_ids[r], label[o:o + n].astype(np.int64),
                                   filled[o:o + n].astype(np.int64) if fill else None, regs))
         return out

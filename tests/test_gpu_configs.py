@@ -1,0 +1,125 @@
+"""GPU: BASELINE.json's named configurations, each checked on labels (not only timed):
+  configs[1]  the benchmark configuration itself -- 68 Area-5-shaped rooms in flight over two lanes;
+  configs[2]  ScanNet-shaped rooms, 8 in flight;
+  configs[3]  test_random_restart.py --scoring np with 16 restarts per seed batched per launch (1088 slots for the 68-room set).
+Exact parity where the oracle finishes in seconds (ground-truth masks do not depend on the logits; small rooms under the
+reference's Bernoulli policy), size-independent invariants elsewhere."""
+import numpy as np
+import pytest
+
+from conftest import seed_without_near_tie
+from learn_region_grow_amd import preprocess, synthetic, workloads
+from oracle import grow_ref, rng_ref
+from test_gpu_fullsize import check_invariants, zero_net
+
+pytestmark = pytest.mark.gpu
+WEIGHT_KW = dict(seed=0, gain=2.0, bias_std=0.2, add_bias_shift=0.0, rmv_bias_shift=-3.0)
+CACHE = '/tmp/lrg_cache'
+
+
+@pytest.fixture(scope='module')
+def net(cuda_device):
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    return LrgNetHIP(1, 1, 512, 512, 13, 0, device=cuda_device).load_weights(synthetic.make_synthetic_weights(**WEIGHT_KW))
+
+
+def gpu_net_fn(net):
+    def fn(xi, xn):
+        _, add, _, rmv, _ = net.run(xi, xn)
+        return add, rmv
+    return fn
+
+
+def small_room(seed, n_raw, furniture=0, room_id=0):
+    raw = (synthetic.area5_shaped_room(n_raw, seed, n_furniture=furniture) if furniture
+           else synthetic.generate_room_points(n_raw, seed)).astype(np.float32)
+    p = preprocess.preprocess_room(raw[:, :6], raw[:, 6].astype(int), raw[:, 7].astype(int))
+    return dict(points=p['points'], obj_id=p['obj_id'], order=p['order'], room_id=room_id)
+
+
+def regions_of(res):
+    return [(r['seed'], r['steps'], r['points'], r['reason'], r['labeled']) for r in res.regions]
+
+
+# ---- configs[3]: 16 restarts per seed, batched ---------------------------------------------------------------------------
+def test_sixteen_restarts_batched_match_the_oracle(net):
+    """R = 16 restarts of every seed in one launch (G = 16 slots per room), the reference's Bernoulli policy: regions, restart
+    step totals and labels equal oracle.grow_room(restarts=16) evaluating the same GPU network (test_random_restart.py:169-197)."""
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = [small_room(430 + i, 500 + 250 * i, furniture=2 * i, room_id=60 + i) for i in range(2)]
+
+    def oracle(seed):
+        return [grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.CounterStream(seed, room['room_id']),
+                                   net_fn=gpu_net_fn(net), restarts=16) for room in rooms]
+    seed, wants = seed_without_near_tie(oracle, range(31, 37), 5e-7)
+    got = RegionGrower(net, rooms_in_flight=2, rng='counter', seed=seed, restarts=16, group_size=16).run(rooms)
+    for res, want in zip(got, wants):
+        assert regions_of(res) == regions_of(want)
+        np.testing.assert_array_equal(res.cluster_label, want.cluster_label)
+        np.testing.assert_array_equal(res.filled_label, want.filled_label)
+
+
+def test_sixteen_restarts_full_configuration(net):
+    """The configuration as benchmarked: the 68-room Area-5-shaped set, 16 restarts per seed batched, 1088 slots in flight.
+    Ground-truth masks: every room passes the invariants; two Area-5-size rooms equal the oracle's restart loop exactly."""
+    from learn_region_grow_amd.grow import LanedRegionGrower
+    rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir=CACHE)
+    lg = LanedRegionGrower(net, rooms_in_flight=68, rng='counter', seed=17, policy='gt', restarts=16)
+    assert sum(g.S for g in lg.growers) == 68 * 16
+    got = lg.run(rooms)
+    for room, res in zip(rooms, got):
+        check_invariants(room, res)
+        assert all(0 <= x['restart'] < 16 for x in res.regions)
+    by_size = np.argsort([len(r['points']) for r in rooms])
+    for i in (int(by_size[0]), int(by_size[len(by_size) // 2])):        # the smallest and the median-size room (2.2 k / 9.3 k points)
+        room = rooms[i]
+        want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.CounterStream(17, room['room_id']),
+                                  net_fn=zero_net, policy='gt', restarts=16)
+        assert regions_of(got[i]) == regions_of(want)
+        np.testing.assert_array_equal(got[i].filled_label, want.filled_label)
+
+
+# ---- configs[2]: ScanNet shape ---------------------------------------------------------------------------------------------
+def test_scannet_shaped_rooms(net):
+    """workloads.scannet_rooms(8), all eight in flight (one per GPU in the named case; here one GPU holds them): ground-truth
+    masks exactly equal to the oracle, the Bernoulli policy through the invariants + independence from what else is in flight."""
+    from learn_region_grow_amd.grow import LanedRegionGrower, RegionGrower
+    rooms = workloads.scannet_rooms(8, seed_base=7000, cache_dir=CACHE)
+    got = LanedRegionGrower(net, rooms_in_flight=8, lanes=2, rng='counter', seed=23, policy='gt').run(rooms)
+    for room, res in zip(rooms, got):
+        want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.CounterStream(23, room['room_id']),
+                                  net_fn=zero_net, policy='gt')
+        assert regions_of(res) == regions_of(want)
+        np.testing.assert_array_equal(res.cluster_label, want.cluster_label)
+        np.testing.assert_array_equal(res.filled_label, want.filled_label)
+        check_invariants(room, res)
+    a = RegionGrower(net, rooms_in_flight=8, rng='counter', seed=23, policy='net').run(rooms)
+    b = RegionGrower(net, rooms_in_flight=3, rng='counter', seed=23, policy='net').run(rooms[::-1])[::-1]
+    for room, x, y in zip(rooms, a, b):
+        check_invariants(room, x)
+        np.testing.assert_array_equal(x.filled_label, y.filled_label)
+
+
+# ---- configs[1]: the benchmark configuration --------------------------------------------------------------------------------
+def test_benchmark_configuration_labels(net):
+    """68 Area-5-shaped rooms in flight over two lanes with HIP-graph replays (what bench.py times): every room passes the
+    invariants; the labels of eight rooms -- the 45 k-point one, the smallest, the median and five more -- equal single-room
+    oracle runs."""
+    import torch
+    from learn_region_grow_amd.grow import LanedRegionGrower
+    rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir=CACHE)
+    lg = LanedRegionGrower(net, rooms_in_flight=68, lanes=2, rng='counter', seed=0, policy='gt', graph_iterations=4)
+    got = lg.run(rooms)
+    assert all(g.packed and g._graph is not None for g in lg.growers)
+    for room, res in zip(rooms, got):
+        check_invariants(room, res)
+    by_size = [int(i) for i in np.argsort([len(r['points']) for r in rooms])]
+    assert len(rooms[by_size[-1]]['points']) > 40000
+    picks = [by_size[-1], by_size[0], by_size[len(by_size) // 2]] + by_size[5:60:11]
+    for i in picks:
+        room = rooms[i]
+        want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.CounterStream(0, room['room_id']),
+                                  net_fn=zero_net, policy='gt')
+        assert regions_of(got[i]) == regions_of(want), 'room %d (%d points)' % (i, len(room['points']))
+        np.testing.assert_array_equal(got[i].cluster_label, want.cluster_label)
+        np.testing.assert_array_equal(got[i].filled_label, want.filled_label)
