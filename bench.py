@@ -358,7 +358,9 @@ def main():
         lg.grow_loaded(fill=bool(args.fill))
         tf_grow = time.perf_counter() - tf0
         # the final gather: every rank ends up with every room's labels (one table + one flat int32 buffer, all_gather)
-        flat = torch.cat([gr.d_filled for gr in lg.growers if gr.n_rooms]) if job_rooms else torch.zeros(0, dtype=torch.int32, device=dev)
+        # (rooms start at multiples of 16 points in a lane's arena: take each room's own span)
+        flat = torch.cat([gr.d_filled[int(gr.room_off[k]):int(gr.room_off[k]) + gr.room_n[k]] for gr in lg.growers for k in range(gr.n_rooms)]) \
+            if job_rooms else torch.zeros(0, dtype=torch.int32, device=dev)
         ids = [mine[i] for gr in lg.growers if gr.n_rooms for i in gr.room_index]
         lens = [n for gr in lg.growers if gr.n_rooms for n in gr.room_n]
         tg0 = time.perf_counter()

@@ -205,6 +205,8 @@ typedef struct LrgSlot {
     int32_t query;           /* lrg_box_query scratch: 1 if this call re-derives the slot's lists                     */
     int32_t acc_add;         /* sample slots whose argmax(add logits) == input_add at the last evaluated step (:175), -1 none */
     int32_t acc_rmv;         /* likewise for the remove head (:180)                                                     */
+    double ml_score;         /* --scoring ml: log-likelihood of the masks sampled in the restart in progress (restart :251-271) */
+    double ml_best;          /* ... of the banked restart                                                                */
 } LrgSlot;
 
 #define LRG_SCAN_CHUNK 4096  /* points per workgroup of the chunked mask scans */
@@ -220,6 +222,10 @@ typedef struct LrgGrowParams {
     int32_t max_region_steps;/* <= 0: no cap                                                                 */
     uint32_t rng_seed;       /* counter-stream key word 0 (key word 1 = room_id)                             */
     int32_t policy;          /* 0 net (:266-267), 1 threshold (:264-265), 2 ground truth (:268-269)          */
+    int32_t scoring;         /* restart score (test_random_restart.py:171-174): 0 = 'np' points of the mask, 1 = 'ml' summed
+                                log-likelihood of the sampled add / remove masks, one scalar per restart (upstream resets the
+                                accumulator to a list at :194-196, which breaks it from the second restart on; implemented as
+                                evidently intended).  'ml' is computed by lrg_grow_step_packed only.                        */
 } LrgGrowParams;
 
 /* voxels[i,0..2] = rint(points[i,0..2] / resolution)   (test_region_grow.py:175) */

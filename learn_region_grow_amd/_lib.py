@@ -57,7 +57,7 @@ class LrgSlot(ctypes.Structure):
                 ('seq_mn', ctypes.c_int32 * 3), ('seq_mx', ctypes.c_int32 * 3),
                 ('target', ctypes.c_int32), ('pad', ctypes.c_int32), ('chunk_cnt', _fp), ('scan_cnt', ctypes.c_int32),
                 ('scan_mn', ctypes.c_int32 * 3), ('scan_mx', ctypes.c_int32 * 3), ('query', ctypes.c_int32),
-                ('acc_add', ctypes.c_int32), ('acc_rmv', ctypes.c_int32)]
+                ('acc_add', ctypes.c_int32), ('acc_rmv', ctypes.c_int32), ('ml_score', ctypes.c_double), ('ml_best', ctypes.c_double)]
 
 
 LRG_SCAN_CHUNK = 4096
@@ -67,7 +67,7 @@ class LrgGrowParams(ctypes.Structure):
     _fields_ = [('resolution', ctypes.c_float), ('feature_size', ctypes.c_int32), ('n_inlier', ctypes.c_int32),
                 ('n_neighbor', ctypes.c_int32), ('cluster_threshold', ctypes.c_int32), ('restarts', ctypes.c_int32),
                 ('group_size', ctypes.c_int32), ('max_region_steps', ctypes.c_int32), ('rng_seed', ctypes.c_uint32),
-                ('policy', ctypes.c_int32)]
+                ('policy', ctypes.c_int32), ('scoring', ctypes.c_int32)]
 
 
 class LrgStepBuffers(ctypes.Structure):

@@ -29,6 +29,11 @@ class BeamSearchGrower(RegionGrower):
                          packed=False)     # the levels are driven through the separate entry points
         self.cluster_threshold = cluster_threshold
 
+    def enqueue_iteration(self):
+        raise _lib.LrgHipError('BeamSearchGrower advances level by level (run()); the lock-step iteration of RegionGrower does not apply')
+
+    enqueue = enqueue_graph = grow_loaded = enqueue_iteration
+
     # ---- host-side room state -------------------------------------------------------------------------------------------
     def load_rooms(self, rooms):
         super().load_rooms(rooms)
@@ -193,7 +198,8 @@ class BeamSearchGrower(RegionGrower):
     def _finish_room(self, g, st):
         r = st['room']
         self.results[r] = st['regions']
-        self.fill(r)
+        if self._fill:
+            self.fill(r)
         self._done += 1
         nxt = self._queue.pop(0) if self._queue else None
         if nxt is None:
@@ -205,6 +211,7 @@ class BeamSearchGrower(RegionGrower):
     def run(self, rooms, fill=True):
         """Grow every room once with beam search; RoomResults in input order."""
         self.load_rooms(rooms)
+        self._fill = bool(fill)
         self.state = [None] * self.n_groups
         self.results = [None] * self.n_rooms
         self._queue = list(range(self.n_rooms))
@@ -216,10 +223,10 @@ class BeamSearchGrower(RegionGrower):
             pass
         torch.cuda.synchronize()
         label = self.d_label.cpu().numpy()
-        filled = self.d_filled.cpu().numpy()
+        filled = self.d_filled.cpu().numpy() if fill else None
         out = []
         for r in range(self.n_rooms):
             o, n = int(self.room_off[r]), self.room_n[r]
-            out.append(RoomResult(self.room_ids[r], label[o:o + n].astype(np.int64), filled[o:o + n].astype(np.int64),
-                                  self.results[r]))
+            out.append(RoomResult(self.room_ids[r], label[o:o + n].astype(np.int64),
+                                  filled[o:o + n].astype(np.int64) if fill else None, self.results[r]))
         return out

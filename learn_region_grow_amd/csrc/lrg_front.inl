@@ -145,6 +145,59 @@ __device__ void lrg_front_update(LrgSlot *S, const LrgRoom *R, int s, const LrgG
     __syncthreads();
 }
 
+// ---- --scoring ml (test_random_restart.py:251-271): log-likelihood of the masks this step sampled ----
+// Every sample slot i contributes log(conf_i) / 512 if its (un-centred, re-voxelised) point lies in the set of voxels whose
+// draw fired, else log(1 - conf_i) / 512 -- membership is by VOXEL, so a copy of an added point counts as added whatever its own
+// draw said.  float32 terms as NumPy computes them, summed in double in a fixed order (deterministic).  Both sides divide by
+// NUM_NEIGHBOR_POINT (:261,:269).  Accumulated per restart in slot.ml_score (upstream's reset to a list at :194-196 breaks the
+// accumulation from the second restart on; this is the scalar accumulator it evidently meant).
+__device__ void lrg_front_ml_score(LrgSlot *S, const LrgRoom *R, int s, const LrgGrowParams &prm, const LrgFrontArgs &a) {
+    __shared__ unsigned long long sh_key[LRG_FRONT_MAXSAMPLE];
+    __shared__ double sh_part[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = prm.feature_size;
+    const float c0 = a.center[s * 16 + 0], c1 = a.center[s * 16 + 1];
+    const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
+    const uint32_t seed = (uint32_t)S->seed, restart = (uint32_t)S->restart, step = (uint32_t)S->step;
+    double total = 0.0;
+    for (int side = 0; side < 2; ++side) {                      // 0: add head on the neighbour slots, 1: remove head on the inlier slots
+        const int N = side ? prm.n_inlier : prm.n_neighbor, nside = side ? S->nc : S->ne;
+        const int off = a.slot_rows[4 * s + (side ? 2 : 3)];
+        const bool have = tid < N;
+        unsigned long long key = LRG_HASH_EMPTY;
+        float conf = 0.f;
+        bool take = false;
+        if (have) {
+            const long row = off + (nside < N ? (side ? a.sample_in : a.sample_nb)[(long)s * N + tid] : tid);
+            conf = lrg_conf((side ? a.rmv_logits : a.add_logits) + 2 * row);
+            if (prm.policy == 2) take = (side ? a.gt_in : a.gt_nb)[row] != 0;
+            else if (prm.policy == 1) take = conf > 0.5f;
+            else take = lrg_uniform01(lrg_rng_word((uint32_t)tid, side ? LRG_PURPOSE_RMV : LRG_PURPOSE_ADD, seed, restart, step, k0, k1)) < conf;
+            const float *p = (side ? a.x_in : a.x_nb) + row * F;
+            key = lrg_pack_voxel(lrg_voxel_of(__fadd_rn(p[0], c0), prm.resolution), lrg_voxel_of(__fadd_rn(p[1], c1), prm.resolution),
+                                 lrg_voxel_of(p[2], prm.resolution));
+        }
+        sh_key[tid] = (have && take) ? key : LRG_HASH_EMPTY;
+        __syncthreads();
+        double t = 0.0;
+        if (have) {
+            bool in = take;
+            if (key != LRG_HASH_EMPTY)
+                for (int k = 0; k < N; ++k) in |= sh_key[k] == key;     // every lane reads the same word: an LDS broadcast
+            const float term = __fdiv_rn(in ? logf(conf) : logf(__fsub_rn(1.f, conf)), (float)prm.n_neighbor);
+            t = (double)term;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) sh_part[wave] = t;
+        __syncthreads();
+        if (tid == 0)
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += sh_part[w];
+        __syncthreads();
+    }
+    if (tid == 0) S->ml_score += total;
+}
+
 // ---- (2) dilated voxel-box query with ordered compaction (:221-235) by ONE workgroup ----
 // Pass 1 reads the room once, coalesced, 8 points per thread in flight: a byte of flags per (4096-point chunk, thread)
 // goes to LDS, a packed (current | candidate << 16) count per (chunk, wavefront) to a table.  One exclusive scan of that
@@ -371,6 +424,9 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
     }
     LrgRoom *R = &rooms[room];
     TRACE2(s, 0);
+    if constexpr (MODE == 1) {
+        if (prm.scoring == 1 && S->status == LRG_ACTIVE) lrg_front_ml_score(S, R, s, prm, a);
+    }
     if ((MODE & 1) && S->status == LRG_ACTIVE) lrg_front_update(S, R, s, prm, a, &sh_src[0][0], red);
     TRACE2(s, 1);
     if (MODE & 2) {

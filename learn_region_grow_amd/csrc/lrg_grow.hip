@@ -220,6 +220,7 @@ __device__ void lrg_reset_slot(LrgSlot *S, const LrgRoom *R, int seed, int resta
         }
         S->target = R->obj_id ? R->obj_id[seed] : 0;
         S->acc_add = -1; S->acc_rmv = -1;
+        S->ml_score = 0.0;
         S->pad = 0;
         S->scan_cnt = 0;
         S->scan_mn[0] = S->scan_mn[1] = S->scan_mn[2] = INT_MAX;
@@ -275,12 +276,12 @@ __device__ void lrg_advance_group(LrgSlot *slots, LrgRoom *rooms, int n_slots, c
         int st = S->status;   // uniform across the block
         if (!lrg_is_stop(st)) continue;
         if (RST > 1) {
-            bool better = S->best_count < 0 || S->count > S->best_count;   // first max wins (numpy.argmax, :177)
+            bool better = S->best_count < 0 || (prm.scoring == 1 ? S->ml_score > S->ml_best : S->count > S->best_count);   // first max wins (numpy.argmax, :177)
             if (better) {
                 for (int i = threadIdx.x; i < n; i += blockDim.x) S->best[i] = S->cur[i];
             }
             __syncthreads();
-            if (threadIdx.x == 0 && better) { S->best_count = S->count; S->best_restart = S->restart; }
+            if (threadIdx.x == 0 && better) { S->best_count = S->count; S->best_restart = S->restart; S->ml_best = S->ml_score; }
         }
         int next_restart = S->restart + G;
         __syncthreads();
@@ -306,13 +307,18 @@ __device__ void lrg_advance_group(LrgSlot *slots, LrgRoom *rooms, int n_slots, c
     if (S0->seed >= 0) {
         // winner: max score, earliest restart ordinal (restart :177); greedy: the slot's own mask
         int win = 0, wcount = -1, wrest = INT_MAX, steps = 0;
+        double wscore = 0.0;
+        const bool ml = prm.scoring == 1 && RST > 1;
         for (int s = 0; s < G && g0 + s < n_slots; ++s) {
             const LrgSlot *S = &slots[g0 + s];
             steps += S->steps_total;
             int c = RST > 1 ? S->best_count : S->count;
             int r = RST > 1 ? S->best_restart : S->restart;
             if (c < 0) continue;
-            if (c > wcount || (c == wcount && r < wrest)) { win = s; wcount = c; wrest = r; }
+            const bool first = wcount < 0;
+            const bool wins = ml ? (first || S->ml_best > wscore || (S->ml_best == wscore && r < wrest))
+                                 : (c > wcount || (c == wcount && r < wrest));
+            if (wins) { win = s; wcount = c; wrest = r; wscore = S->ml_best; }
         }
         const LrgSlot *W = &slots[g0 + win];
         const uint8_t *mask = RST > 1 ? W->best : W->cur;
@@ -1228,7 +1234,8 @@ int lrg_voxel_hash_build(const int32_t *voxels, int n, uint64_t *keys, int32_t *
 
 static int check_params(const LrgGrowParams *p) {
     if (!p || p->feature_size < 3 || p->feature_size > 16 || p->n_inlier <= 0 || p->n_neighbor <= 0 ||
-        p->restarts < 1 || p->group_size < 1 || !(p->resolution > 0.f) || p->policy < 0 || p->policy > 2)
+        p->restarts < 1 || p->group_size < 1 || !(p->resolution > 0.f) || p->policy < 0 || p->policy > 2 || p->scoring < 0 ||
+        p->scoring > 1)
         return LRG_EINVAL - 20;
     return 0;
 }
@@ -1375,6 +1382,7 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
     if (rc) return rc;
     if (!slots || !rooms || !weights || !b || n_slots <= 0 || advance_rounds < 1) return LRG_EINVAL - 1;
     if (weights->feature_size != params->feature_size) return LRG_EINVAL - 2;
+    if (params->scoring == 1 && params->restarts > 1) return LRG_EINVAL - 7;    // the 'ml' score is accumulated by lrg_grow_step_packed only
     const bool fuse_scan = params->group_size == 1 && max_points <= 65536;     // (one workgroup scanning a 100 k-point scene is slower
                                                                                //  than the chunked launch)
     if (fuse_scan) {

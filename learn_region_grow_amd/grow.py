@@ -49,7 +49,7 @@ class RoomResult:
 class RegionGrower:
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
-                 skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0):
+                 skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np'):
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
         graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*)."""
@@ -80,6 +80,12 @@ class RegionGrower:
         p.max_region_steps = max_region_steps
         p.rng_seed = seed & 0xFFFFFFFF
         p.policy = POLICIES[policy]
+        if scoring not in ('np', 'ml'):
+            raise ValueError(scoring)
+        if scoring == 'ml' and (rng != 'counter' or packed is False):
+            raise ValueError("scoring='ml' is accumulated on the device by the packed iteration (counter stream)")
+        p.scoring = 1 if scoring == 'ml' and restarts > 1 else 0
+        self.scoring = scoring
         self.params = p
         self.policy = policy
         # evaluate LrgNet only on the distinct leading rows of each stacked set (the rest are copies, :240,:252)
@@ -234,6 +240,8 @@ class RegionGrower:
             raise ValueError('packed iterations need the counter stream, the fused network and rooms of at most %d points'
                              % _lib.LRG_PACKED_MAX_POINTS)
         self.packed = can_pack if self.want_packed is None else bool(self.want_packed)
+        if self.params.scoring == 1 and not self.packed:
+            raise ValueError("scoring='ml' needs the packed iteration (fused network, rooms of at most %d points)" % _lib.LRG_PACKED_MAX_POINTS)
         if self.packed:
             cap_rows = (S * max(Ni, Nn) + 31) // 32 * 32
             self.row_cap = cap_rows
@@ -297,6 +305,7 @@ class RegionGrower:
             sl.restart = sl.step = sl.steps_total = sl.stuck = 0
             sl.updated = -1
             sl.acc_add = sl.acc_rmv = -1
+            sl.ml_score = sl.ml_best = 0.0
             sl.count = -1
             sl.best_count = -1
             sl.pad = 0
@@ -434,6 +443,55 @@ class RegionGrower:
         torch.cuda.current_stream(self.dev).synchronize()
         return self.n_rooms
 
+    def run_timed(self, rooms, fill=True):
+        """One room at a time (the reference's own schedule) with HIP events round the two halves of every iteration, for the
+        reference's timing buckets (test_region_grow.py:40-51): 'net' = the LrgNet launches; the front kernel's time is split into
+        'inlier' (mask update, bounding box, stop decision, commit -- :260-306) and 'neighbor' (box query, median, sampling,
+        stacking -- :219-254) in proportion to the wall-clock ticks its workgroup spent in either part.
+        Returns (results, buckets): buckets[r] = dict(neighbor, net, inlier in seconds, iter_* = per-iteration lists)."""
+        assert self.rng == 'counter' and self.n_groups == 1 and self.G == 1
+        results, buckets = [], []
+        with torch.cuda.device(self.dev):
+            for room in rooms:
+                self.load_rooms([room])
+                if not (self.packed and self.have_pvox):
+                    raise _lib.LrgHipError('run_timed needs the packed greedy iteration')
+                ticks = torch.zeros((self.S, 2), dtype=torch.int64, device=self.dev)
+                self.packed_buffers.phase_ticks = ticks.data_ptr()
+                self.reset_state()
+                self.bind(0, 0)
+                st = _stream_ptr(self.dev)
+                pb, evs = self.packed_buffers, []
+                while True:
+                    for _ in range(32):
+                        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                        e[0].record()
+                        _lib.check(self.lib.lrg_front_step(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, self.cap, ctypes.byref(self.params),
+                                                           ctypes.byref(self.net._w), ctypes.byref(pb), st), 'lrg_front_step')
+                        e[1].record()
+                        _lib.check(self.lib.lrg_forward_packed(ctypes.byref(self.net._w), pb.x_in, pb.x_nb, pb.row_slot_in, pb.row_slot_nb,
+                                                               pb.counters, ctypes.c_void_p(pb.counters + 8), self.S, pb.row_cap, pb.add_logits,
+                                                               pb.rmv_logits, pb.workspace, pb.workspace_bytes, _lib.LRG_FWD_POOL_ZEROED, st),
+                                   'lrg_forward_packed')
+                        e[2].record()
+                        evs.append(e)
+                        self.iterations += 1
+                    torch.cuda.current_stream(self.dev).synchronize()
+                    if int(self.d_stats[1].item()) > self._seen_done:
+                        break
+                if fill:
+                    self.fill(0)
+                torch.cuda.current_stream(self.dev).synchronize()
+                front = np.array([e[0].elapsed_time(e[1]) for e in evs]) * 1e-3
+                netw = np.array([e[1].elapsed_time(e[2]) for e in evs]) * 1e-3
+                tk = ticks.cpu().numpy()[0].astype(np.float64)
+                share = tk[1] / max(tk.sum(), 1.0)
+                buckets.append(dict(neighbor=float(front.sum() * share), net=float(netw.sum()), inlier=float(front.sum() * (1.0 - share)),
+                                    iter_neighbor=(front * share).tolist(), iter_net=netw.tolist(), iter_inlier=(front * (1.0 - share)).tolist()))
+                self.packed_buffers.phase_ticks = None
+                results.append(self.collect(fill)[0])
+        return results, buckets
+
     def _legacy_iteration(self, streams):
         lib, st, P = self.lib, _stream_ptr(self.dev), ctypes.byref(self.params)
         S, Ni, Nn = self.S, self.net.num_inlier_points, self.net.num_neighbor_points
@@ -515,20 +573,28 @@ class RegionGrower:
         return (LrgRoom * self.n_rooms).from_buffer_copy(raw)
 
     # ------------------------------------------------------------------------------------------
-    def run(self, rooms, fill=True, max_iterations=None, legacy_seeds=None):
-        """Grow every room once; returns a RoomResult per room (in input order)."""
+    def run(self, rooms, fill=True, max_iterations=None, legacy_seeds=None, legacy_shared_seed=None):
+        """Grow every room once; returns a RoomResult per room (in input order).
+        rng='legacy': one numpy.random.RandomState per room, seeded with legacy_seeds[r] (default: the room id).  The reference
+        script seeds ONCE (numpy.random.seed(0), test_region_grow.py:21) and draws all rooms of a file from that one stream in
+        file order: legacy_shared_seed=0 with rooms_in_flight=1 reproduces exactly that."""
         with torch.cuda.device(self.dev):
-            return self._run(rooms, fill, max_iterations, legacy_seeds)
+            return self._run(rooms, fill, max_iterations, legacy_seeds, legacy_shared_seed)
 
-    def _run(self, rooms, fill, max_iterations, legacy_seeds):
+    def _run(self, rooms, fill, max_iterations, legacy_seeds, legacy_shared_seed=None):
         self.load_rooms(rooms)
         queue = list(range(self.n_rooms))
         for g in range(self.n_groups):
             self.bind(g, queue.pop(0) if queue else -1)
         finished = 0
         if self.rng == 'legacy':
-            seeds = legacy_seeds if legacy_seeds is not None else [self.room_ids[r] for r in range(self.n_rooms)]
-            streams = [np.random.RandomState(sd) for sd in seeds]
+            if legacy_shared_seed is not None:
+                if self.n_groups != 1:
+                    raise ValueError('one shared stream is consumed room after room: rooms_in_flight must be 1')
+                streams = [np.random.RandomState(legacy_shared_seed)] * self.n_rooms
+            else:
+                seeds = legacy_seeds if legacy_seeds is not None else [self.room_ids[r] for r in range(self.n_rooms)]
+                streams = [np.random.RandomState(sd) for sd in seeds]
             while finished < self.n_rooms:
                 slots = self._legacy_iteration(streams)
                 for g in range(self.n_groups):

@@ -14,22 +14,14 @@ from . import h5lite
 
 
 def loadFromH5(filename, load_labels=True):
+    """Rooms of an HDF5 room file: 'points' holds every room's rows back to back, 'count_room' how many belong to each room.
+    Returns the per-room arrays, or (features, object ids, class ids) per room with the last two columns split off."""
     f = h5lite.File(filename)
-    all_points = f['points'].read()
-    count_room = f['count_room'].read()
-    tmp_points = []
-    idp = 0
-    for i in range(len(count_room)):
-        tmp_points.append(all_points[idp:idp + count_room[i], :])
-        idp += count_room[i]
+    rows, counts = f['points'].read(), f['count_room'].read()
+    rooms = np.split(rows, np.cumsum(counts)[:-1]) if len(counts) else []
     if not load_labels:
-        return tmp_points
-    room, labels, class_labels = [], [], []
-    for p in tmp_points:
-        room.append(p[:, :-2])
-        labels.append(p[:, -2].astype(int))
-        class_labels.append(p[:, -1].astype(int))
-    return room, labels, class_labels
+        return rooms
+    return ([r[:, :-2] for r in rooms], [r[:, -2].astype(int) for r in rooms], [r[:, -1].astype(int) for r in rooms])
 
 
 def saveToH5(filename, rooms):

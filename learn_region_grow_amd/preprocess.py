@@ -21,6 +21,12 @@ def voxel_keys(xyz, resolution):
     return v, ((v[:, 0] + VOX_OFF) << 42) | ((v[:, 1] + VOX_OFF) << 21) | (v[:, 2] + VOX_OFF)
 
 
+def equalized_count(xyz, resolution=0.1):
+    """Number of points a room keeps after equalisation (one per resolution-sized voxel, test_region_grow.py:125-134) -- the
+    size by which rooms are dealt to GPUs -- without the rest of the preprocessing."""
+    return int(len(np.unique(voxel_keys(np.asarray(xyz)[:, :3], resolution)[1])))
+
+
 def preprocess_room(unequalized_points, obj_id, cls_id, resolution=0.1, feature_size=13, chunk=4096, return_cov=False):
     raw = np.asarray(unequalized_points)
     vox, keys = voxel_keys(raw[:, :3], resolution)

@@ -43,6 +43,7 @@ class GrowResult:
                                        # difference it takes to flip the closest Bernoulli draw.  Same logits, other
                                        # exp/divide: errors ~1e-7; another fp32 evaluation of the network: ~1e-5..1e-4
         self.lines = []                # reference-format log lines (:217)
+        self.min_score_gap = np.inf    # --scoring ml: smallest relative lead of a winning restart over the runner-up
 
 
 def _format_region(room_id, r, class_name):
@@ -53,9 +54,15 @@ def _format_region(room_id, r, class_name):
 def grow_room(points, obj_id, order, weights, stream, *, cls_id=None, classes=None, room_id=0,
               resolution=0.1, lite=0, num_inlier=512, num_neighbor=512, cluster_threshold=10,
               policy='net', restarts=0, faithful=False, net_fn=None, hook=None, max_region_steps=None,
-              fill=True):
+              fill=True, scoring='np'):
     """Grow all regions of one room.  restarts=0 -> test_region_grow.py; restarts=R>0 ->
-    test_random_restart.py with NUM_RESTARTS=R and --scoring np."""
+    test_random_restart.py with NUM_RESTARTS=R and --scoring np (default) or ml.
+
+    scoring='ml' (test_random_restart.py:171-172,251-271): the restart score is the summed log-likelihood of the add / remove
+    masks sampled along the restart.  Upstream initialises the accumulator with 0 (:164) but resets it to a LIST between restarts
+    (:194-196), so from the second restart on ``maskLogProb += float`` no longer accumulates a scalar and ``argmax`` (:177)
+    sees a ragged list: only the first restart is scored as written.  Restated here as evidently intended -- one scalar per
+    restart, reset to 0 -- which is a documented divergence."""
     points = np.ascontiguousarray(points, dtype=np.float32)
     obj_id = np.asarray(obj_id)
     N, F = points.shape
@@ -84,6 +91,7 @@ def grow_room(points, obj_id, order, weights, stream, *, cls_id=None, classes=No
         restart_score, restart_mask = [], []
         last_reason = None
         for restart in range(R):
+            maskLogProb = 0.0                                     # restart :164 (and, as intended, per restart)
             currentMask = np.zeros(N, dtype=bool)                 # :197-198 / restart :188-189
             currentMask[seed_id] = True
             minDims = seed_voxel.copy()
@@ -148,6 +156,16 @@ def grow_room(points, obj_id, order, weights, stream, *, cls_id=None, classes=No
                     rmv_mask = input_remove.astype(bool)
                 else:
                     raise ValueError(policy)
+                if scoring == 'ml':                                              # restart :251-271
+                    with np.errstate(divide='ignore'):
+                        for pts_, conf_, mask_ in ((neighbor_points[0], add_conf, add_mask), (inlier_points[0], rmv_conf, rmv_mask)):
+                            q = pts_.copy()
+                            q[:, :2] += center[:2]                               # :256 / :264 (row by row upstream; same float32 adds)
+                            keys_ = pack_voxels(voxelize(q[:, :3], resolution))
+                            in_set = np.isin(keys_, keys_[mask_]) if mask_.any() else np.zeros(len(keys_), bool)
+                            c32 = np.asarray(conf_, dtype=np.float32)
+                            term = np.where(in_set, np.log(c32), np.log(np.float32(1.0) - c32)) / np.float32(num_neighbor)   # :259-261 (both / NUM_NEIGHBOR_POINT)
+                            maskLogProb += float(np.sum(term.astype(np.float64)))
                 addPoints = neighbor_points[0, :, :][add_mask]                   # :270
                 addPoints[:, :2] += center[:2]                                   # :271
                 addVoxels = voxelize(addPoints[:, :3], resolution)               # :272
@@ -202,8 +220,13 @@ def grow_room(points, obj_id, order, weights, stream, *, cls_id=None, classes=No
                     reason = 'noexpand'                                          # :304-306
                     break
             last_reason = reason
-            restart_score.append(int(np.sum(currentMask)))        # restart :173-175 (--scoring np)
+            restart_score.append(maskLogProb if scoring == 'ml' else int(np.sum(currentMask)))   # restart :171-174
             restart_mask.append(currentMask)
+        if scoring == 'ml' and len(restart_score) > 1:
+            # how far the winner is ahead: GPU and NumPy logarithms differ in the last bit, so a near-tie may legitimately flip
+            sc = np.sort(np.asarray(restart_score, dtype=np.float64))[::-1]
+            if np.isfinite(sc[0]) and sc[0] != sc[1]:
+                res.min_score_gap = min(res.min_score_gap, float((sc[0] - sc[1]) / (abs(sc[0]) + 1e-12)) if np.isfinite(sc[1]) else np.inf)
         bestMask = restart_mask[int(np.argmax(restart_score))]    # restart :177 (first max); R=1 -> the mask itself
         visited[bestMask] = True                                  # :212
         labeled = bool(np.sum(bestMask) > cluster_threshold)      # :213

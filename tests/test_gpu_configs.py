@@ -123,3 +123,27 @@ def test_benchmark_configuration_labels(net):
         assert regions_of(got[i]) == regions_of(want), 'room %d (%d points)' % (i, len(room['points']))
         np.testing.assert_array_equal(got[i].cluster_label, want.cluster_label)
         np.testing.assert_array_equal(got[i].filled_label, want.filled_label)
+
+
+def test_restarts_scoring_ml_matches_the_oracle(net):
+    """test_random_restart.py --scoring ml (as evidently intended): the restart with the largest summed
+    log-likelihood of its sampled masks wins.  GPU (logf, fixed-order double sums) against the oracle (NumPy float32 log,
+    float64 sum) on the same GPU network; seeds whose winner leads by less than 1e-4 relative are passed over."""
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = [small_room(450 + i, 600 + 300 * i, furniture=2, room_id=70 + i) for i in range(2)]
+
+    def oracle(seed):
+        out = [grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.CounterStream(seed, room['room_id']),
+                                  net_fn=gpu_net_fn(net), restarts=4, scoring='ml') for room in rooms]
+        for o in out:                                      # fold the score lead into the margin the seed search looks at
+            o.min_rel_margin = min(o.min_rel_margin, 5e-7 * o.min_score_gap / 1e-4)
+        return out
+    seed, wants = seed_without_near_tie(oracle, range(41, 49), 5e-7)
+    got = RegionGrower(net, rooms_in_flight=2, rng='counter', seed=seed, restarts=4, group_size=2, scoring='ml').run(rooms)
+    np_scored = RegionGrower(net, rooms_in_flight=2, rng='counter', seed=seed, restarts=4, group_size=2).run(rooms)
+    differs = False
+    for res, want, other in zip(got, wants, np_scored):
+        assert regions_of(res) == regions_of(want)
+        np.testing.assert_array_equal(res.filled_label, want.filled_label)
+        differs |= not np.array_equal(res.cluster_label, other.cluster_label)
+    assert differs, "'ml' and 'np' scoring picked the same restart everywhere: the test rooms do not exercise the score"
