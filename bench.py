@@ -310,7 +310,9 @@ def main():
             pb = g_.packed_buffers
 
             def fwd():
-                _lib.check(g_.lib.lrg_forward_packed(ctypes.byref(net._w), pb.x_in, pb.x_nb, pb.row_slot_in, pb.row_slot_nb, _ptr(nr), None,
+                _lib.check(g_.lib.lrg_forward_packed(ctypes.byref(net._w), pb.x_in, pb.x_nb,
+                                                     g_.lib.lrg_packed_rows_center(ctypes.byref(g_.params), ctypes.byref(pb)),
+                                                     pb.row_slot_in, pb.row_slot_nb, _ptr(nr), None,
                                                      g_.S, pb.row_cap, pb.add_logits, pb.rmv_logits, pb.workspace, pb.workspace_bytes, 0,
                                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'lrg_forward_packed')
             fwd()

@@ -228,6 +228,13 @@ typedef struct LrgGrowParams {
                                 evidently intended).  'ml' is computed by lrg_grow_step_packed only.                        */
 } LrgGrowParams;
 
+/* Bind the slots [first_slot, first_slot + group_size) to room `room` (-1: leave them idle), on the device: every slot
+ * waits with seed -1, so the next advance picks the room's first seed (:186-188).  reset_room != 0 first returns the room to
+ * its pristine state (visited / labels cleared, cursor at 0, :176-178); clear_masks != 0 clears the slots' masks over the
+ * room they are leaving.  One launch, no host-to-device copy: safe to issue while other streams keep the host busy. */
+int lrg_bind_group(LrgSlot *slots, LrgRoom *rooms, int first_slot, int group_size, int room, int reset_room, int clear_masks,
+                   void *stream);
+
 /* voxels[i,0..2] = rint(points[i,0..2] / resolution)   (test_region_grow.py:175) */
 int lrg_voxelize(const float *points, int n, int F, float resolution, int32_t *voxels, void *stream);
 
@@ -342,6 +349,9 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
  * ---------------------------------------------------------------------------------------------- */
 
 /* LrgNet on packed rows.  x_in / x_nb [row_cap,F] hold nrows[0] / nrows[1] valid rows (device int32 pair);
+ * center (nullable, [n_inst,16]): when given, the rows are stored UNCENTRED and row r enters the network as
+ * x[r,c] - center[row_inst[r]*16 + c] (test_region_grow.py:243-247 applied while the rows are staged; center is 0 on the
+ * channels the reference leaves alone);
  * row_inst_in / row_inst_nb [row_cap] name the instance (0 <= . < n_inst) of each row, rows of one instance being
  * contiguous; row_cap is a multiple of LRG_ROW_TILE.  add_logits [row_cap,2] (per neighbour row, net.add_output :149),
  * rmv_logits [row_cap,2] (per inlier row, net.remove_output :162).
@@ -351,7 +361,7 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
  * Needs the layer widths the fused kernels are built for (lite 0/1/2). */
 size_t lrg_forward_packed_workspace_bytes(const LrgWeights *w, int n_inst, int row_cap);
 int lrg_forward_packed_pooled_view(const LrgWeights *w, int n_inst, int row_cap, size_t *offset_floats, size_t *count_floats);
-int lrg_forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const int32_t *row_inst_in,
+int lrg_forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const float *center, const int32_t *row_inst_in,
                        const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
                        float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes, unsigned flags,
                        void *stream);
@@ -391,10 +401,13 @@ typedef struct LrgPackedBuffers {
 int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                          const LrgWeights *weights, const LrgPackedBuffers *buffers, void *stream);
 /* The two halves of lrg_grow_step_packed as separate calls (so that a caller can put events between them):
- * lrg_front_step = everything up to the packed rows; then lrg_forward_packed(weights, x_in, x_nb, row_slot_in, row_slot_nb,
- * counters, counters + 2, n_slots, row_cap, add_logits, rmv_logits, workspace, workspace_bytes, LRG_FWD_POOL_ZEROED, stream). */
+ * lrg_front_step = everything up to the packed rows; then lrg_forward_packed(weights, x_in, x_nb, centre, row_slot_in,
+ * row_slot_nb, counters, counters + 2, n_slots, row_cap, add_logits, rmv_logits, workspace, workspace_bytes,
+ * LRG_FWD_POOL_ZEROED, stream) with centre = lrg_packed_rows_center(params, buffers): the buffers' centre array when the front
+ * kernels store uncentred rows (greedy growing on rooms with packed voxel words), NULL when they store centred rows. */
 int lrg_front_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                    const LrgWeights *weights, const LrgPackedBuffers *buffers, void *stream);
+const float *lrg_packed_rows_center(const LrgGrowParams *params, const LrgPackedBuffers *buffers);
 
 /* `iterations` calls of lrg_grow_step_packed captured into a HIP graph on `stream` (not the null stream; weights->packed
  * set).  Nothing runs at creation.  lrg_step_graph_launch replays them with one host call. */

@@ -131,6 +131,7 @@ _SIGS = {
     'lrg_head_pool_gemv': (ctypes.c_int, [_fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     'lrg_head_final': (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_long, ctypes.c_int, _fp]),
     'lrg_voxelize': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _fp, _fp]),
+    'lrg_bind_group': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     'lrg_voxel_pack': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
     'lrg_voxel_hash_build': (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, _fp]),
     'lrg_bbox_stop': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp]),
@@ -149,8 +150,9 @@ _SIGS = {
     'lrg_forward_packed_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(LrgWeights), ctypes.c_int, ctypes.c_int]),
     'lrg_forward_packed_pooled_view': (ctypes.c_int, [ctypes.POINTER(LrgWeights), ctypes.c_int, ctypes.c_int,
                                                       ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
-    'lrg_forward_packed': (ctypes.c_int, [ctypes.POINTER(LrgWeights), _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
+    'lrg_forward_packed': (ctypes.c_int, [ctypes.POINTER(LrgWeights), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
                                           _fp, _fp, _fp, ctypes.c_size_t, ctypes.c_uint, _fp]),
+    'lrg_packed_rows_center': (ctypes.c_void_p, [ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgPackedBuffers)]),
     'lrg_grow_step_packed': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
                                             ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgPackedBuffers), _fp]),
     'lrg_front_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),

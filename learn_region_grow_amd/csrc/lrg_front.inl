@@ -473,10 +473,14 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
 #define LRG_PVZ(p) ((int)((p) >> 22))
 
 // tags + gather of the slot's distinct rows (shared by the front kernel and the last workgroup of lrg_front_big_kernel)
+// (first, nthreads): the threads [first, first + nthreads) of the workgroup do the work, so that other wavefronts can compute
+// the medians meanwhile.  The rows are stored UNCENTRED: the branch kernels subtract the centre while staging them
+// (lrg_forward_packed, `center`), the next update re-derives the centred value -- so the gather does not wait for the medians.
 __device__ __forceinline__ void lrg_front_gather(const LrgSlot *S, const float *points, const int32_t *obj, int s, int F,
-                                                 const LrgFrontArgs &a, const int (*sh_src)[512], const float *sh_c, int rin,
-                                                 int rnb, int offi, int offn) {
-    const int tid = threadIdx.x, bd = blockDim.x;
+                                                 const LrgFrontArgs &a, const int (*sh_src)[512], int rin,
+                                                 int rnb, int offi, int offn, int first, int nthreads) {
+    const int tid = (int)threadIdx.x - first, bd = nthreads;
+    if (tid < 0 || tid >= nthreads) return;
     const int target = S->target;
     for (int j = tid; j < rin; j += bd) {
         a.row_slot_in[offi + j] = s;
@@ -496,7 +500,7 @@ __device__ __forceinline__ void lrg_front_gather(const LrgSlot *S, const float *
             for (int u = 0; u < 8; ++u) {
                 const int e = min(e0 + u * bd, nel - 1);
                 const int j = e / F, f = e - j * F;
-                v[u] = __fsub_rn(points[(long)sh_src[side][j] * F + f], sh_c[f]);           // :243-247
+                v[u] = points[(long)sh_src[side][j] * F + f];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -578,8 +582,10 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
                                                        (uint32_t)S->restart, (uint32_t)S->step, k0, k1)) < conf;   // :266-267
             }
             if (take) {
-                const int vx = lrg_voxel_of(__fadd_rn(px, c0), prm.resolution);              // :271-272 / :275-276
-                const int vy = lrg_voxel_of(__fadd_rn(py, c1), prm.resolution);
+                // the rows are stored uncentred: (x - c) + c in float32, as the reference centres (:243,:246) and un-centres
+                // (:271,:275) the row -- not x itself
+                const int vx = lrg_voxel_of(__fadd_rn(__fsub_rn(px, c0), c0), prm.resolution);   // :271-272 / :275-276
+                const int vy = lrg_voxel_of(__fadd_rn(__fsub_rn(py, c1), c1), prm.resolution);
                 const int vz = lrg_voxel_of(pz, prm.resolution);
                 idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(vx, vy, vz));
             }
@@ -910,16 +916,19 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         const int pos = (int)lrg_sample_position((uint32_t)j, (uint32_t)nn, (uint32_t)kk, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
                                                  (uint32_t)S->seed, (uint32_t)S->restart, (uint32_t)S->step, k0, k1);
         (half ? a.sample_in : a.sample_nb)[(long)s * kk + j] = pos;
-        if (!is_big && j < min(nn, kk)) sh_src[half ? 0 : 1][j] = (half ? cur_idx : cand_idx)[pos];
-    }
-    if (is_big) {
-        if (tid < 16) a.center[s * 16 + tid] = 0.f;             // lrg_front_big_kernel fills the centred channels, then gathers
-        if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
-        return;
+        if (j < min(nn, kk)) sh_src[half ? 0 : 1][j] = (half ? cur_idx : cand_idx)[pos];
     }
     if (tid < 16) sh_c[tid] = 0.f;
     __syncthreads();
     TRACE2(s, 4);
+    if (is_big) {
+        // the nine medians of a region above LRG_FRONT_SMALL points come from lrg_front_big_kernel (one workgroup per channel);
+        // nothing here waits for them: the rows go out uncentred
+        if (tid < 16) a.center[s * 16 + tid] = 0.f;
+        lrg_front_gather(S, points, obj, s, F, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
+        if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
+        return;
+    }
     if (wave < 9) {                                              // one wavefront per centred channel, keys in registers
         const int ch = lrg_centred_channel(wave, F);
         if (ch >= 0) {
@@ -927,12 +936,13 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
             const float m = nc <= 256 ? lrg_median_wave_r<4>(pts, cur_idx, F, nc) : lrg_median_wave_r<16>(pts, cur_idx, F, nc);
             if (lane == 0) sh_c[ch] = m;
         }
+    } else {
+        lrg_front_gather(S, points, obj, s, F, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
     }
     __syncthreads();
     TRACE2(s, 5);
-    if (tid < 16) a.center[s * 16 + tid] = sh_c[tid];           // the next update un-centres x, y with it (:271,:275)
+    if (tid < 16) a.center[s * 16 + tid] = sh_c[tid];           // the branch kernels and the next update centre with it (:243-247,:271,:275)
     TRACE2(s, 6);
-    lrg_front_gather(S, points, obj, s, F, a, sh_src, sh_c, rin, rnb, sh_off[0], sh_off[1]);
     if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
     TRACE2(s, 7);
 #if LRG_TRACE
@@ -941,59 +951,35 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
 }
 
 // Medians of regions above LRG_FRONT_SMALL points: one workgroup per (slot, centred channel), keys in registers (two
-// global round trips), two bits per bisection step; the workgroup that arrives last at the slot's counter has all nine
-// medians in reach and gathers the slot's rows.
+// global round trips), two bits per bisection step.  Nothing but the centre is written: the rows were gathered uncentred.
 __global__ __launch_bounds__(1024) void lrg_front_big_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                               LrgFrontArgs a, int32_t *big) {
     __shared__ int sh[64];
-    __shared__ int sh_last;
-    __shared__ int sh_src[2][512];
-    __shared__ float sh_c[16];
     const int s = blockIdx.x, tid = threadIdx.x;
     if (big[2 * s] == 0) return;
     const long long tickb = a.phase_ticks ? wall_clock64() : 0;
     const LrgSlot *S = &slots[s];
     const LrgRoom *R = &rooms[S->room];
-    const int F = prm.feature_size, Ni = prm.n_inlier, Nn = prm.n_neighbor;
-    const int nc = S->nc, ne = S->ne;
+    const int F = prm.feature_size;
+    const int nc = S->nc;
     const int ch = lrg_centred_channel(blockIdx.y, F);
-    // what the gather needs besides the centre is requested now by every workgroup of the slot (the one that arrives last
-    // then only waits for the medians): row table, sample positions -> source indices
-    const int rin = a.slot_rows[4 * s + 0], rnb = a.slot_rows[4 * s + 1], offi = a.slot_rows[4 * s + 2], offn = a.slot_rows[4 * s + 3];
-    for (int u = tid; u < rin + rnb; u += blockDim.x) {
-        const int side = u >= rin, j = side ? u - rin : u;
-        const int pos = (side ? a.sample_nb : a.sample_in)[(long)s * (side ? Nn : Ni) + j];
-        sh_src[side][j] = (side ? S->cand_idx : S->cur_idx)[pos];
-    }
-    if (ch >= 0) {
-        if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
-        __syncthreads();
-        const float *pts = R->points + ch;
-        float m;
-        if (nc <= 4096) m = lrg_median_block_regs<4>(pts, S->cur_idx, F, nc, sh);
-        else if (nc <= 16 * 1024) m = lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh);
-        else if (nc <= LRG_MED_REGS) m = lrg_median_block_regs<48>(pts, S->cur_idx, F, nc, sh);
-        else {
-            const int k2 = nc >> 1, k1r = (nc & 1) ? k2 : k2 - 1;
-            uint32_t ka, kb;
-            lrg_select2(nullptr, false, R->points, S->cur_idx, F, ch, nc, k1r, k2, sh, &ka, &kb);
-            const float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
-            m = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
-        }
-        if (tid == 0) __hip_atomic_store(&a.center[s * 16 + ch], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (ch < 0) return;
+    if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
     __syncthreads();
+    const float *pts = R->points + ch;
+    float m;
+    if (nc <= 4096) m = lrg_median_block_regs<4>(pts, S->cur_idx, F, nc, sh);
+    else if (nc <= 16 * 1024) m = lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh);
+    else if (nc <= LRG_MED_REGS) m = lrg_median_block_regs<48>(pts, S->cur_idx, F, nc, sh);
+    else {
+        const int k2 = nc >> 1, k1r = (nc & 1) ? k2 : k2 - 1;
+        uint32_t ka, kb;
+        lrg_select2(nullptr, false, R->points, S->cur_idx, F, ch, nc, k1r, k2, sh, &ka, &kb);
+        const float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
+        m = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+    }
     if (tid == 0) {
-        __threadfence();
-        sh_last = atomicAdd(&big[2 * s + 1], 1) == (int)gridDim.y - 1;
+        a.center[s * 16 + ch] = m;
+        if (a.phase_ticks && blockIdx.y == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tickb;
     }
-    __syncthreads();
-    if (!sh_last) return;
-    if (tid == 0) big[2 * s + 1] = 0;
-    __threadfence();
-    if (tid < 16) sh_c[tid] = __hip_atomic_load(&a.center[s * 16 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    lrg_front_gather(S, R->points, R->obj_id, s, F, a, sh_src, sh_c, rin, rnb, offi, offn);
-    if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tickb;
-    (void)ne;
 }

@@ -31,6 +31,8 @@ struct LrgFusedProb {
     // per-instance bias are applied per run of equal row_inst inside the tile.
     const int *nrows;    // nullable: device count of packed rows (non-NULL selects the packed formulation)
     const int *row_inst; // [capacity] instance of each packed row
+    const float *center; // nullable (packed): [instances,16] per-instance centre; the staged value of row r, column c is
+                         // x[r,c] - center[row_inst[r]*16 + c]  (the rows are stored uncentred, test_region_grow.py:243-247 applied here)
     long rows;
     int ldx, Kin, rows_per_inst, pool_stride, nlayers, zero_count;
     LrgFusedLayer L[LRG_FUSED_MAXL];

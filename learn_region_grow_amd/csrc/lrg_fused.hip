@@ -182,13 +182,25 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     const int Kin = P.Kin;
     const int Kp = (Kin + 7) & ~7;
     const int ld_x = Kp + 4;
-    if ((P.ldx & 3) == 0 && (Kin & 3) == 0 && (((uintptr_t)P.x) & 15) == 0) {
+    if ((P.ldx & 3) == 0 && (Kin & 3) == 0 && (((uintptr_t)P.x) & 15) == 0 && !(PACKED && P.center)) {
         const int q = Kp >> 2;
         for (int idx = tid; idx < FM * q; idx += FTHREADS) {
             int row = idx / q, c4 = idx - row * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (4 * c4 < Kin) v = *reinterpret_cast<const float4 *>(P.x + (r0 + row) * P.ldx + 4 * c4);
             *reinterpret_cast<float4 *>(&buf1[row * ld_x + 4 * c4]) = v;
+        }
+    } else if (PACKED && P.center) {
+        // uncentred rows: subtract the owning instance's centre while staging (same float32 subtraction the gather would do)
+        for (int idx = tid; idx < FM * Kp; idx += FTHREADS) {
+            int row = idx / Kp, c = idx - row * Kp;
+            float v = 0.f;
+            if (c < Kin) {
+                const int ins = (r0 + row < nrows_packed) ? P.row_inst[r0 + row] : -1;
+                const float xv = P.x[(r0 + row) * P.ldx + c];
+                v = ins >= 0 ? __fsub_rn(xv, P.center[ins * 16 + c]) : 0.f;
+            }
+            buf1[row * ld_x + c] = v;
         }
     } else {
         for (int idx = tid; idx < FM * Kp; idx += FTHREADS) {

@@ -57,6 +57,41 @@ __global__ void lrg_hash_build_kernel(const int32_t *vox, int n, uint64_t *keys,
 }
 
 // ------------------------------------------------------------------------------------------------
+// (re)binding a slot group to a room on the device: what a host-side struct upload would do, without the upload (a
+// pageable host-to-device copy blocks the host until the stream has drained, which starves the other lanes)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void lrg_bind_group_kernel(LrgSlot *slots, LrgRoom *rooms, int first_slot, int group_size, int room,
+                                                              int reset_room, int clear_masks) {
+    const int tid = threadIdx.x;
+    if (room >= 0 && reset_room) {                                            // test_region_grow.py:176-178 for a fresh pass
+        LrgRoom *R = &rooms[room];
+        const int n = R->n;
+        for (int i = tid; i < n; i += blockDim.x) { R->visited[i] = 0; R->label[i] = 0; }
+        if (tid == 0) { R->next_cluster_id = 1; R->seed_cursor = 0; R->n_regions = 0; R->done = 0; }
+    }
+    for (int s = first_slot; s < first_slot + group_size; ++s) {
+        LrgSlot *S = &slots[s];
+        if (clear_masks && S->room >= 0) {                                    // the room the slot is leaving bounds what can be set
+            const int n = rooms[S->room].n;
+            for (int i = tid; i < n; i += blockDim.x) S->cur[i] = 0;
+        }
+    }
+    __syncthreads();
+    if (tid == 0)
+        for (int s = first_slot; s < first_slot + group_size; ++s) {
+            LrgSlot *S = &slots[s];
+            S->room = room;
+            S->status = room >= 0 ? LRG_WAIT : LRG_IDLE;                      // lrg_advance / the front kernel pick the first seed
+            S->seed = -1;
+            S->restart = 0; S->step = 0; S->steps_total = 0; S->stuck = 0;
+            S->updated = -1; S->count = -1; S->best_count = -1; S->pad = 0;
+            S->acc_add = -1; S->acc_rmv = -1; S->ml_score = 0.0; S->ml_best = 0.0;
+            S->scan_cnt = 0; S->query = 0;
+            for (int d = 0; d < 3; ++d) { S->scan_mn[d] = INT_MAX; S->scan_mx[d] = INT_MIN; }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // block helpers (1024 threads = 16 waves)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lrg_block_sum(int v, int *red) {
@@ -1210,6 +1245,15 @@ int lrg_voxelize(const float *points, int n, int F, float resolution, int32_t *v
     return 0;
 }
 
+int lrg_bind_group(LrgSlot *slots, LrgRoom *rooms, int first_slot, int group_size, int room, int reset_room, int clear_masks,
+                   void *stream) {
+    if (!slots || !rooms || first_slot < 0 || group_size < 1) return LRG_EINVAL - 1;
+    hipLaunchKernelGGL(lrg_bind_group_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, slots, rooms, first_slot, group_size, room,
+                       reset_room, clear_masks);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
 int lrg_voxel_pack(const int32_t *voxels, int n, int ox, int oy, int oz, uint32_t *pvox, int32_t *overflow_flag, void *stream) {
     if (!voxels || !pvox || !overflow_flag || n < 0) return LRG_EINVAL - 1;
     if (n == 0) return 0;
@@ -1419,6 +1463,15 @@ int lrg_grow_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, c
                            rows ? b->sample_nb : nullptr, b->stats, stream);
 }
 
+static bool lrg_uses_greedy_front(const LrgGrowParams *params, const LrgPackedBuffers *b) {
+    return params->group_size == 1 && params->restarts == 1 && b->rooms_have_pvox && b->slot_big && params->n_inlier <= 512 &&
+           params->n_neighbor <= 512;
+}
+
+const float *lrg_packed_rows_center(const LrgGrowParams *params, const LrgPackedBuffers *b) {
+    return (params && b && lrg_uses_greedy_front(params, b)) ? b->center : nullptr;
+}
+
 int lrg_front_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                    const LrgWeights *weights, const LrgPackedBuffers *b, void *stream) {
     int rc = check_params(params);
@@ -1445,8 +1498,7 @@ int lrg_front_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     a.stats = b->stats;
     a.phase_ticks = b->phase_ticks;
     hipStream_t st = (hipStream_t)stream;
-    if (params->group_size == 1 && params->restarts == 1 && b->rooms_have_pvox && b->slot_big && params->n_inlier <= 512 &&
-        params->n_neighbor <= 512) {
+    if (lrg_uses_greedy_front(params, b)) {
         const int ncentred = params->feature_size <= 2 ? params->feature_size : params->feature_size <= 6 ? 2 : params->feature_size - 4;
         hipLaunchKernelGGL(lrg_front_greedy_kernel, dim3(n_slots), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots, *params, a,
                            b->slot_big);
@@ -1472,8 +1524,9 @@ int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_po
                          const LrgWeights *weights, const LrgPackedBuffers *b, void *stream) {
     int rc = lrg_front_step(slots, rooms, n_slots, max_points, params, weights, b, stream);
     if (rc) return rc;
-    return lrg_forward_packed(weights, b->x_in, b->x_nb, b->row_slot_in, b->row_slot_nb, b->counters, b->counters + 2, n_slots,
-                              b->row_cap, b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes, LRG_FWD_POOL_ZEROED, stream);
+    return lrg_forward_packed(weights, b->x_in, b->x_nb, lrg_packed_rows_center(params, b), b->row_slot_in, b->row_slot_nb, b->counters,
+                              b->counters + 2, n_slots, b->row_cap, b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes,
+                              LRG_FWD_POOL_ZEROED, stream);
 }
 
 

@@ -670,7 +670,7 @@ static int packed_layout(const LrgWeights *w, int n_inst, int row_cap, LrgPacked
     return 0;
 }
 
-static int forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const int32_t *row_inst_in,
+static int forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const float *center, const int32_t *row_inst_in,
                           const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
                           float *add_logits, float *rmv_logits, float *ws, const LrgPackedLayout &L, bool pool_zeroed,
                           hipStream_t st) {
@@ -693,6 +693,7 @@ static int forward_packed(const LrgWeights *w, const float *x_in, const float *x
             P.ldx = w->feature_size; P.Kin = w->feature_size;
             P.rows = row_cap; P.rows_per_inst = row_cap;
             P.nrows = nrows + br; P.row_inst = br == 0 ? row_inst_in : row_inst_nb;
+            P.center = center;
             P.pool = ws + L.pooled + (br == 0 ? 0 : Clast); P.pool_stride = L.P;
             P.nlayers = nc;
             for (int i = 0; i < nc; ++i) {
@@ -774,7 +775,7 @@ int lrg_forward_packed_pooled_view(const LrgWeights *w, int n_inst, int row_cap,
     return 0;
 }
 
-int lrg_forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const int32_t *row_inst_in,
+int lrg_forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const float *center, const int32_t *row_inst_in,
                        const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
                        float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes, unsigned flags,
                        void *stream) {
@@ -790,7 +791,7 @@ int lrg_forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb
     for (int i = 0; i < nh - 1; ++i)
         if (w->head_ch[i] % 64 != 0 || w->head_ch[i] > ((i & 1) ? 128 : 256) || ((i & 1) && w->head_ch[i] > 64 && i != nh - 2))
             return LRG_EINVAL - 7;
-    return forward_packed(w, x_in, x_nb, row_inst_in, row_inst_nb, nrows, nrows_heads, n_inst, row_cap, add_logits, rmv_logits,
+    return forward_packed(w, x_in, x_nb, center, row_inst_in, row_inst_nb, nrows, nrows_heads, n_inst, row_cap, add_logits, rmv_logits,
                           static_cast<float *>(workspace), L, (flags & LRG_FWD_POOL_ZEROED) != 0, (hipStream_t)stream);
 }
 

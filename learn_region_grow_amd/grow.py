@@ -274,6 +274,7 @@ class RegionGrower:
         self.h_stats = [torch.zeros(LRG_STATS_WORDS, dtype=torch.int64).pin_memory() for _ in range(self.depth)]
         self.ev = [torch.cuda.Event() for _ in range(self.depth)]
         self.group_room = [-1] * self.n_groups
+        self._reset_pending = set()
         self.iterations = 0
         self._seen_done = 0
         self._polls = 0
@@ -284,6 +285,9 @@ class RegionGrower:
     # ------------------------------------------------------------------------------------------
     def reset_room(self, r):
         """Return room r to its pristine state (visited / labels cleared, cursor at 0)."""
+        if self.rng == 'counter':
+            self._reset_pending.add(r)          # folded into the device-side bind that follows (one launch, no upload)
+            return
         o, n = int(self.room_off[r]), self.room_n[r]
         self.d_visited[o:o + n].zero_()
         self.d_label[o:o + n].zero_()
@@ -296,6 +300,15 @@ class RegionGrower:
     def bind(self, group, r):
         """Bind slot group `group` to room r: every slot waits with seed -1, so the next lrg_advance
         picks the room's first seed (:186-188)."""
+        if self.rng == 'counter' and type(self).__name__ == 'RegionGrower':
+            # on the device (lrg_bind_group): a pageable host-to-device copy would block the host until this lane's stream has
+            # drained, and the other lanes would starve meanwhile
+            reset = 1 if r in self._reset_pending else 0
+            self._reset_pending.discard(r)
+            _lib.check(self.lib.lrg_bind_group(_ptr(self.d_slots), _ptr(self.d_rooms), group * self.G, self.G, int(r), reset,
+                                               1 if self.packed else 0, _stream_ptr(self.dev)), 'lrg_bind_group')
+            self.group_room[group] = r
+            return
         sz = ctypes.sizeof(LrgSlot)
         for s in range(group * self.G, (group + 1) * self.G):
             sl = self.h_slots[s]
@@ -317,8 +330,6 @@ class RegionGrower:
         buf = np.frombuffer(bytes(self.h_slots), dtype=np.uint8)[a * sz:b * sz].copy()
         self.d_slots[a * sz:b * sz].copy_(torch.from_numpy(buf))
         if self.packed:
-            # the packed iteration clears a finished region's members, not the whole mask: a slot that left its last room in
-            # mid-growth (an aborted run) must not carry bits over
             self.d_cur[a:b].zero_()
         self.group_room[group] = r
 
@@ -469,7 +480,9 @@ class RegionGrower:
                         _lib.check(self.lib.lrg_front_step(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, self.cap, ctypes.byref(self.params),
                                                            ctypes.byref(self.net._w), ctypes.byref(pb), st), 'lrg_front_step')
                         e[1].record()
-                        _lib.check(self.lib.lrg_forward_packed(ctypes.byref(self.net._w), pb.x_in, pb.x_nb, pb.row_slot_in, pb.row_slot_nb,
+                        _lib.check(self.lib.lrg_forward_packed(ctypes.byref(self.net._w), pb.x_in, pb.x_nb,
+                                                               self.lib.lrg_packed_rows_center(ctypes.byref(self.params), ctypes.byref(pb)),
+                                                               pb.row_slot_in, pb.row_slot_nb,
                                                                pb.counters, ctypes.c_void_p(pb.counters + 8), self.S, pb.row_cap, pb.add_logits,
                                                                pb.rmv_logits, pb.workspace, pb.workspace_bytes, _lib.LRG_FWD_POOL_ZEROED, st),
                                    'lrg_forward_packed')
@@ -647,8 +660,9 @@ class RegionGrower:
 
 
 def auto_lanes(slots_in_flight):
-    """Two lanes pay from about 64 slots in flight (one MI355X: +7 % at 68 rooms, -9 % at 39, -20 % at 8)."""
-    return 2 if slots_in_flight >= 64 else 1
+    """Lanes pay from about 64 slots in flight (one MI355X, 68 rooms, packed iteration: 1 lane 452 k instance-steps/s, 2 lanes
+    469 k, 3 lanes 489 k; 4 lanes need a fifth hardware queue and fall behind)."""
+    return 3 if slots_in_flight >= 64 else 1
 
 
 class LanedRegionGrower:

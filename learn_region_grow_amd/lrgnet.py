@@ -162,9 +162,10 @@ class LrgNetHIP:
         self.add_output, self.remove_output = add_out, rmv_out
         return add_out, rmv_out
 
-    def forward_packed(self, x_in, x_nb, row_inst_in, row_inst_nb, nrows, n_inst):
+    def forward_packed(self, x_in, x_nb, row_inst_in, row_inst_nb, nrows, n_inst, center=None):
         """LrgNet on packed rows (lrg_forward_packed): x_in / x_nb [row_cap,F] hold nrows[0] / nrows[1] valid rows, row r of
-        a side belonging to instance row_inst_*[r] (rows of an instance contiguous).  Returns (add [row_cap,2] per neighbour
+        a side belonging to instance row_inst_*[r] (rows of an instance contiguous); with center [n_inst,16] the rows are
+        uncentred and enter the network as x - center[instance].  Returns (add [row_cap,2] per neighbour
         row, rmv [row_cap,2] per inlier row, pooled [n_inst, 2*C_last]).  The grow loop's formulation; here for tests."""
         cap = x_in.shape[0]
         assert x_nb.shape[0] == cap and cap % _lib.LRG_ROW_TILE == 0 and nrows.dtype == torch.int32 and nrows.numel() >= 2
@@ -175,7 +176,7 @@ class LrgNetHIP:
         add = torch.zeros((cap, 2), dtype=torch.float32, device=self.device)
         rmv = torch.zeros((cap, 2), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            rc = self.lib.lrg_forward_packed(ctypes.byref(self._w), _ptr(x_in), _ptr(x_nb), _ptr(row_inst_in), _ptr(row_inst_nb),
+            rc = self.lib.lrg_forward_packed(ctypes.byref(self._w), _ptr(x_in), _ptr(x_nb), _ptr(center), _ptr(row_inst_in), _ptr(row_inst_nb),
                                              _ptr(nrows), None, n_inst, cap, _ptr(add), _ptr(rmv), _ptr(ws), ws.numel(), 0,
                                              _stream_ptr(self.device))
         _lib.check(rc, 'lrg_forward_packed')

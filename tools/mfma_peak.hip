@@ -13,8 +13,9 @@ __global__ __launch_bounds__(256, 2) void k(const float *w, float *out, int iter
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, li = lane & 31, lh = lane >> 5;
     for (int i = tid; i < 64 * 132; i += 256) smem[i] = (float)(i & 7) * 0.125f;
     __syncthreads();
-    f32x16 acc[RT];
+    f32x16 acc[RT], acc2;
     for (int t = 0; t < RT; ++t) for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
     const float *ap = smem + li * 132 + 4 * lh;
     float4 a[RT];
     for (int t = 0; t < RT; ++t) a[t] = make_float4(1.f, 2.f, 3.f, 4.f);
@@ -35,6 +36,14 @@ __global__ __launch_bounds__(256, 2) void k(const float *w, float *out, int iter
 #pragma unroll
                 for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const float4 *>(ap + t * 32 * 132 + 8 * g);
             const float4 b = bq[g % FD];
+            if (MODE & 8) {       // one tile, two accumulator chains: the MFMAs of a k-group alternate between them
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b.x, acc[0], 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b.y, acc2, 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b.z, acc[0], 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b.w, acc2, 0, 0, 0);
+                if (MODE & 2) bq[g % FD] = (g + FD < 16) ? loadb(wrow, g + FD) : loadb(wnext, g + FD - 16);
+                continue;
+            }
 #pragma unroll
             for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b.x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void k(const float *w, float *out, int iter
         }
     }
     float s = 0.f;
-    for (int t = 0; t < RT; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i];
+    for (int t = 0; t < RT; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i] + acc2[i];
     for (int g = 0; g < FD; ++g) s += bq[g].x;
     if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
 }
@@ -93,6 +102,9 @@ int main() {
             run<3, 1, 8>("RT=1 A lds + B 4x dword ring", w, out, grid, wgs);
             run<7, 1, 4>("RT=1 A lds + B packed dwordx4 ring", w, out, grid, wgs);
             run<7, 1, 8>("RT=1 A lds + B packed dwordx4 ring", w, out, grid, wgs);
+            run<0, 1, 4>("RT=1 registers only, one chain", w, out, grid, wgs);
+            run<8, 1, 4>("RT=1 registers only, two chains", w, out, grid, wgs);
+            run<15, 1, 4>("RT=1 A lds + B packed ring, two chains", w, out, grid, wgs);
         }
     }
     return 0;
