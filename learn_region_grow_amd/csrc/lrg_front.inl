@@ -466,7 +466,10 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
 //   * regions above LRG_FRONT_SMALL points leave their nine channel medians to lrg_front_big_kernel, one workgroup per
 //     (slot, channel) -- the single slow step whose cost grows with the region (its last-arriving workgroup gathers).
 // =================================================================================================
-#define LRG_FRONT_SMALL 1024
+#define LRG_FRONT_SMALL 0       // regions above this many points get their medians from lrg_front_big_kernel.  0 = all of them:
+                                // that launch runs in (almost) every iteration anyway -- with 68 slots some region is nearly
+                                // always large -- and its duration is set by the largest region, so the small ones ride along
+                                // for free and the front kernel loses its median phase (trace: 8.7 k of 44 k cycles per slot)
 
 #define LRG_PVX(p) ((int)((p) & 0x7FFu))
 #define LRG_PVY(p) ((int)(((p) >> 11) & 0x7FFu))
@@ -964,9 +967,18 @@ __global__ __launch_bounds__(1024) void lrg_front_big_kernel(const LrgSlot *slot
     const int nc = S->nc;
     const int ch = lrg_centred_channel(blockIdx.y, F);
     if (ch < 0) return;
+    const float *pts = R->points + ch;
+    if (nc <= 256) {                                 // one wavefront, keys in registers, no barrier
+        if (tid >= 64) return;
+        const float mw = lrg_median_wave_r<4>(pts, S->cur_idx, F, nc);
+        if (tid == 0) {
+            a.center[s * 16 + ch] = mw;
+            if (a.phase_ticks && blockIdx.y == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tickb;
+        }
+        return;
+    }
     if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
     __syncthreads();
-    const float *pts = R->points + ch;
     float m;
     if (nc <= 4096) m = lrg_median_block_regs<4>(pts, S->cur_idx, F, nc, sh);
     else if (nc <= 16 * 1024) m = lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh);
