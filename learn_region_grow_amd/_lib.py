@@ -172,6 +172,7 @@ _SIGS = {
                                        _fp, _fp]),
     'lrg_group_point_grad': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
                                             _fp, _fp, _fp]),
+    'lrg_knn_topk': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]),
     'lrg_pairwise_sqdist': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
     'lrg_preprocess_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
     'lrg_preprocess': (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp,

@@ -51,6 +51,16 @@ __global__ void lrg_group_point_kernel(long total, int n, int c, int m, int nsam
     out[e] = points[(bi * n + ii) * c + l];
 }
 
+// the same gather moving 16 bytes per thread with 32-bit index arithmetic (c a multiple of 4, fewer than 2^31 elements)
+__global__ void lrg_group_point_vec4_kernel(unsigned total4, int n, int c4, int m_ns, const float4 *points, const int *idx, float4 *out) {
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total4) return;
+    const unsigned g = e / (unsigned)c4;
+    const unsigned l = e - g * (unsigned)c4;
+    const unsigned bi = g / (unsigned)m_ns;
+    out[e] = points[((size_t)bi * n + idx[g]) * c4 + l];
+}
+
 // ---- scatter-add gradient (tf_grouping_g.cu:61-78) ----
 __global__ void lrg_group_point_grad_kernel(long total, int n, int c, int m, int nsample, const float *grad_out,
                                             const int *idx, float *grad_points) {
@@ -96,6 +106,112 @@ __global__ __launch_bounds__(256) void lrg_selection_sort_kernel(long rows, int 
     }
 }
 
+
+// ---- partial selection sort with the row in REGISTERS (tf_grouping_g.cu:83-123, exact swap sequence) ----
+// One wavefront per row: position t lives in register t / 64 of lane t % 64, so a pass is NR compares per lane, one wave
+// arg-min and a two-element swap -- no memory traffic inside the k passes (the first version re-read the row from HBM in
+// every pass and serialised on a fence).  The original indices ride in a ushort array in LDS, touched by lane 0 only.
+//   FUSED = false: selectionSortLauncher semantics -- the row comes from dist[b,m,n]; the whole permuted row and index array
+//                  are written back (the reference op's outputs are full-size, only the first k are meaningful);
+//   FUSED = true:  knn_point (tf_grouping.py:48-73) in one kernel -- the row is computed from the coordinates as
+//                  sum_c (xyz1 - xyz2)^2 (same order as lrg_pairwise_sqdist) and only the first k (value, index) pairs are
+//                  written: the b x m x n matrix never exists.
+// The reference scans t = s+1 .. n-1 keeping `min` while dist[t] < dist[min] (strict): the FIRST minimum, NaNs never
+// preferred, and a NaN at position s stays put.
+template <int NR, bool FUSED>
+__global__ __launch_bounds__(256) void lrg_rowselect_kernel(long rows, int n, int m, int c, int k, const float *dist, const float *xyz1,
+                                                             const float *xyz2, int *outi, float *out) {
+    __shared__ unsigned short orig[4][NR * 64];
+    const int w = threadIdx.x >> 6, L = lrg_lane();
+    const long q = (long)blockIdx.x * 4 + w;
+    if (q >= rows) return;
+    float v[NR];
+    if (FUSED) {
+        const long bi = q / m;
+        const float *p1 = xyz1 + bi * n * c, *p2 = xyz2 + q * c;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int t = r * 64 + L;
+            float acc = INFINITY;
+            if (t < n) {
+                for (int l = 0; l < c; ++l) {
+                    const float d = __fsub_rn(p1[(long)t * c + l], p2[l]);
+                    const float sq = __fmul_rn(d, d);
+                    acc = l == 0 ? sq : __fadd_rn(acc, sq);
+                }
+            }
+            v[r] = acc;
+        }
+    } else {
+        const float *d = dist + q * n;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { const int t = r * 64 + L; v[r] = t < n ? d[t] : INFINITY; }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) orig[w][r * 64 + L] = (unsigned short)(r * 64 + L);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int kk = min(k, n);
+#pragma unroll
+    for (int rs = 0; rs < NR; ++rs) {
+        if (rs * 64 >= kk) break;
+        for (int ls = 0; ls < 64; ++ls) {
+            const int s = rs * 64 + ls;
+            if (s >= kk) break;
+            const float vs = __shfl(v[rs], ls);                      // the value at position s
+            // first minimum over the positions >= s held by this lane (registers ascend with the position)
+            float best = INFINITY; int bt = INT_MAX;
+            if (L >= ls && v[rs] < best) { best = v[rs]; bt = rs * 64 + L; }
+#pragma unroll
+            for (int r = rs + 1; r < NR; ++r)
+                if (v[r] < best) { best = v[r]; bt = r * 64 + L; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(best, off); const int ot = __shfl_xor(bt, off);
+                if (ot != INT_MAX && (bt == INT_MAX || ov < best || (ov == best && ot < bt))) { best = ov; bt = ot; }
+            }
+            // nothing below +inf (all remaining +inf / NaN), or a NaN at s (nothing compares below it): position s stays
+            const int p = (bt == INT_MAX || vs != vs) ? s : bt;
+            if (p != s) {
+                if (L == ls) v[rs] = best;
+                const int lp = p & 63, rp = p >> 6;
+#pragma unroll
+                for (int r = rs; r < NR; ++r)
+                    if (r == rp && L == lp) v[r] = vs;
+                if (L == 0) { const unsigned short t0 = orig[w][p]; orig[w][p] = orig[w][s]; orig[w][s] = t0; }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (FUSED) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int t = r * 64 + L;
+            if (t < kk) { out[q * k + t] = v[r]; outi[q * k + t] = orig[w][t]; }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int t = r * 64 + L;
+            if (t < n) { out[q * n + t] = v[r]; outi[q * n + t] = orig[w][t]; }
+        }
+    }
+}
+
+template <bool FUSED>
+static int launch_rowselect(long rows, int n, int m, int c, int k, const float *dist, const float *xyz1, const float *xyz2, int *outi,
+                            float *out, hipStream_t st) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (n <= 512) hipLaunchKernelGGL((lrg_rowselect_kernel<8, FUSED>), grid, block, 0, st, rows, n, m, c, k, dist, xyz1, xyz2, outi, out);
+    else if (n <= 1024) hipLaunchKernelGGL((lrg_rowselect_kernel<16, FUSED>), grid, block, 0, st, rows, n, m, c, k, dist, xyz1, xyz2, outi, out);
+    else if (n <= 2048) hipLaunchKernelGGL((lrg_rowselect_kernel<32, FUSED>), grid, block, 0, st, rows, n, m, c, k, dist, xyz1, xyz2, outi, out);
+    else if (n <= 4096) hipLaunchKernelGGL((lrg_rowselect_kernel<64, FUSED>), grid, block, 0, st, rows, n, m, c, k, dist, xyz1, xyz2, outi, out);
+    else return 1;                      // rows above 4096 entries: the caller takes the memory-resident formulation
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- squared-distance matrix of knn_point (tf_grouping.py:62-65) ----
 __global__ void lrg_pairwise_sqdist_kernel(int b, int n, int m, int c, const float *xyz1, const float *xyz2,
                                            float *dist) {
@@ -133,10 +249,21 @@ int lrg_selection_sort(int b, int n, int m, int k, const float *dist, int *outi,
     if (b < 0 || n <= 0 || m < 0 || k < 0 || !dist || !outi || !out) return LRG_EINVAL - 1;
     long rows = (long)b * m;
     if (rows == 0) return 0;
+    const int rc = launch_rowselect<false>(rows, n, m, 0, k, dist, nullptr, nullptr, outi, out, (hipStream_t)stream);
+    if (rc <= 0) return rc;
     hipLaunchKernelGGL(lrg_selection_sort_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        rows, n, k, dist, outi, out);
     LRG_LAUNCH_CHECK();
     return 0;
+}
+
+int lrg_knn_topk(int b, int n, int m, int c, int k, const float *xyz1, const float *xyz2, float *val, int *idx, void *stream) {
+    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || !xyz1 || !xyz2 || !val || !idx) return LRG_EINVAL - 1;
+    if (n > 4096) return LRG_EINVAL - 2;          // larger rows: lrg_pairwise_sqdist + lrg_selection_sort
+    long rows = (long)b * m;
+    if (rows == 0) return 0;
+    const int rc = launch_rowselect<true>(rows, n, m, c, k, nullptr, xyz1, xyz2, idx, val, (hipStream_t)stream);
+    return rc > 0 ? LRG_EINVAL - 2 : rc;
 }
 
 int lrg_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,
@@ -144,6 +271,13 @@ int lrg_group_point(int b, int n, int c, int m, int nsample, const float *points
     if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || !points || !idx || !out) return LRG_EINVAL - 1;
     long total = (long)b * m * nsample * c;
     if (total == 0) return 0;
+    if (c % 4 == 0 && total / 4 < 0x7fffffffL && (((uintptr_t)points | (uintptr_t)out) & 15) == 0 && (long)m * nsample < 0x7fffffffL) {
+        const unsigned total4 = (unsigned)(total / 4);
+        hipLaunchKernelGGL(lrg_group_point_vec4_kernel, dim3((total4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, total4, n, c / 4,
+                           m * nsample, reinterpret_cast<const float4 *>(points), idx, reinterpret_cast<float4 *>(out));
+        LRG_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(lrg_group_point_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        total, n, c, m, nsample, points, idx, out);
     LRG_LAUNCH_CHECK();

@@ -74,13 +74,23 @@ def group_point_grad(points, idx, grad_out):
     return gp
 
 
-def knn_point(k, xyz1, xyz2):
+def knn_point(k, xyz1, xyz2, fused=None):
     """xyz1 (b,n,c) dataset, xyz2 (b,m,c) queries -> val (b,m,k) squared L2, idx (b,m,k) int32
-    (tf_grouping.py:48-73: distance matrix + select_top_k + slice)."""
+    (tf_grouping.py:48-73: distance matrix + select_top_k + slice).  fused=None: lrg_knn_topk (distances and the selection in
+    registers, no b x m x n matrix) whenever n <= 4096, else the reference's three steps; fused=False forces those."""
     xyz1 = _chk(xyz1, 3, torch.float32, 'xyz1')
     xyz2 = _chk(xyz2, 3, torch.float32, 'xyz2')
     b, n, c = xyz1.shape
     m = xyz2.shape[1]
+    if xyz2.shape[0] != b or xyz2.shape[2] != c or not 0 < k <= n:
+        raise ValueError('knn_point expects (b,n,c) and (b,m,c) with 0 < k <= n')
+    if fused is None:
+        fused = n <= 4096
+    if fused:
+        val = torch.empty((b, m, k), dtype=torch.float32, device=xyz1.device)
+        idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
+        _lib.check(_lib.load().lrg_knn_topk(b, n, m, c, k, _ptr(xyz1), _ptr(xyz2), _ptr(val), _ptr(idx), _stream_ptr()), 'lrg_knn_topk')
+        return val, idx
     dist = torch.empty((b, m, n), dtype=torch.float32, device=xyz1.device)
     _lib.check(_lib.load().lrg_pairwise_sqdist(b, n, m, c, _ptr(xyz1), _ptr(xyz2), _ptr(dist), _stream_ptr()),
                'lrg_pairwise_sqdist')

@@ -10,7 +10,7 @@ from conftest import REPO
 def declared_functions():
     src = open(os.path.join(REPO, 'include', 'lrg_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    names = re.findall(r'^\s*(?:int|size_t|const char \*)\s*\*?\s*(lrg_\w+)\s*\(', src, flags=re.M)
+    names = re.findall(r'^\s*(?:int|size_t|const char \*|const float \*)\s*\*?\s*(lrg_\w+)\s*\(', src, flags=re.M)
     return sorted(set(names))
 
 

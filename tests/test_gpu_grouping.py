@@ -55,16 +55,54 @@ def test_selection_sort_known_answer_and_ties(cuda_device):
     np.testing.assert_array_equal(o.cpu().numpy(), wo)
 
 
-def test_knn_point(cuda_device):
+@pytest.mark.parametrize('b,n,m,c,k', [(2, 500, 40, 3, 8), (3, 2048, 33, 3, 128), (1, 64, 5, 3, 64), (2, 1300, 17, 6, 40), (1, 4096, 9, 3, 70),
+                                        (2, 70, 64, 1, 1)])
+def test_knn_point_fused_and_unfused(cuda_device, b, n, m, c, k):
+    """knn_point (tf_grouping.py:48-73): the fused lrg_knn_topk (distances + selection in registers) and the reference's three steps
+    (distance matrix, select_top_k, slice) against the C oracle's selection sort -- same swap sequence, so the same order among
+    EQUAL distances too (duplicate dataset points, a grid of coordinates)."""
     from learn_region_grow_amd import grouping
-    rs = np.random.RandomState(2)
-    x1 = rs.randn(2, 500, 3).astype(np.float32)
-    x2 = rs.randn(2, 40, 3).astype(np.float32)
-    val, idx = grouping.knn_point(8, dev(x1, cuda_device), dev(x2, cuda_device))
+    rs = np.random.RandomState(n + k)
+    x1 = rs.randn(b, n, c).astype(np.float32)
+    x2 = rs.randn(b, m, c).astype(np.float32)
+    x1[:, 5] = x1[:, 9]                                    # exact ties: duplicated dataset points ...
+    x1[:, n // 2] = x1[:, 3]
+    if n >= 500:
+        x1[0, :64] = np.round(x1[0, :64])                  # ... and a lattice: many equal distances to a lattice query
+        x2[0, 0] = 0.0
     dist = G.knn_dist(x1, x2)
-    wi, wo = G.selection_sort(8, dist)
-    np.testing.assert_array_equal(idx.cpu().numpy(), wi[:, :, :8])
-    np.testing.assert_array_equal(val.cpu().numpy(), wo[:, :, :8])
+    wi, wo = G.selection_sort(k, dist)
+    for fused in (True, False):
+        val, idx = grouping.knn_point(k, dev(x1, cuda_device), dev(x2, cuda_device), fused=fused)
+        np.testing.assert_array_equal(idx.cpu().numpy(), wi[:, :, :k], err_msg='fused=%s' % fused)
+        np.testing.assert_array_equal(val.cpu().numpy(), wo[:, :, :k], err_msg='fused=%s' % fused)
+
+
+def test_selection_sort_full_rows_large(cuda_device):
+    """select_top_k keeps the reference op's full-size outputs: every one of the n positions (values and indices) after k passes
+    equals the oracle's, at the harness shape of tf_ops/grouping/test/selection_sort.cu (n = 2048, k = 128), with NaN / inf entries."""
+    from learn_region_grow_amd import grouping
+    rs = np.random.RandomState(7)
+    d = rs.rand(2, 24, 2048).astype(np.float32)
+    d[0, 1, 3] = np.nan
+    d[0, 1, 700] = np.inf
+    d[0, 2, :] = np.inf
+    d[0, 3, 0] = np.nan
+    d[1, 0, 100:140] = 0.25
+    oi, o = grouping.select_top_k(128, dev(d, cuda_device))
+    wi, wo = G.selection_sort(128, d)
+    np.testing.assert_array_equal(oi.cpu().numpy(), wi)
+    np.testing.assert_array_equal(o.cpu().numpy(), wo)
+
+
+def test_group_point_wide_rows(cuda_device):
+    """c a multiple of 4: the 16-byte path (the harness shape of tf_ops/grouping/test/query_ball_point.cpp: c = 64)."""
+    from learn_region_grow_amd import grouping
+    rs = np.random.RandomState(3)
+    pts = rs.rand(4, 512, 64).astype(np.float32)
+    idx = rs.randint(0, 512, (4, 128, 64)).astype(np.int32)
+    out = grouping.group_point(dev(pts, cuda_device), dev(idx, cuda_device))
+    np.testing.assert_array_equal(out.cpu().numpy(), G.group_point(pts, idx))
 
 
 @pytest.mark.parametrize('F', [6, 13])

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""tf_ops/grouping replacements at the reference's own harness shapes:
+    query_ball_point.cpp:88   b=32 n=512  m=128 nsample=64 c=64      G1 ball query, G3 group point, G4 its gradient
+    selection_sort.cu:55      b=32 n=2048 m=512 k=128                 G2 selection sort, knn_point fused / unfused
+GPU: HIP events round `reps` launches.  CPU: the reference's OWN functions (tf_ops/grouping/test/*.cpp compiled into oracle/_ref by
+oracle/Makefile) on a bounded share of the batch, scaled.  Bytes: the algorithmic HBM bytes of SURVEY.md 8d, against 8 TB/s.
+Prints one JSON object (also importable: grouping_rates())."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+HBM = 8000e9
+
+
+class _quiet_stdout:
+    """The reference's test functions printf their results: keep file descriptor 1 clean for the JSON."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        self.null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self.null, 1)
+
+    def __exit__(self, *a):
+        os.dup2(self.saved, 1)
+        os.close(self.null)
+        os.close(self.saved)
+
+
+def _time_gpu(fn, reps=20):
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def grouping_rates(device='cuda:0', cpu=True, reps=20):
+    import torch
+    from learn_region_grow_amd import grouping
+    from oracle import grouping_ref as G         # CPU side: the reference's compiled functions (oracle/_ref)
+    dev = torch.device(device)
+    rs = np.random.RandomState(0)
+    out = {}
+    # ---- query_ball_point.cpp:88 shape ----
+    b, n, m, ns, c, radius = 32, 512, 128, 64, 64, 0.1
+    x1, x2 = rs.rand(b, n, 3).astype(np.float32), rs.rand(b, m, 3).astype(np.float32)
+    pts = rs.rand(b, n, c).astype(np.float32)
+    d1, d2, dp = (torch.from_numpy(a).to(dev) for a in (x1, x2, pts))
+    idx, cnt = grouping.query_ball_point(radius, ns, d1, d2)
+    go = torch.rand((b, m, ns, c), device=dev)
+    rows = []
+    rows.append(('G1 query_ball_point', _time_gpu(lambda: grouping.query_ball_point(radius, ns, d1, d2), reps),
+                 b * (n + m) * 12 + b * m * (ns + 1) * 4, lambda k: G.query_ball_point(radius, ns, x1[:k], x2[:k], use_reference=True)))
+    rows.append(('G3 group_point', _time_gpu(lambda: grouping.group_point(dp, idx), reps),
+                 2 * b * m * ns * c * 4 + b * m * ns * 4, lambda k: G.group_point(pts[:k], idx.cpu().numpy()[:k], use_reference=True)))
+    rows.append(('G4 group_point_grad', _time_gpu(lambda: grouping.group_point_grad(dp, idx, go), reps),
+                 2 * b * m * ns * c * 4 + b * m * ns * 4 + b * n * c * 4,
+                 lambda k: G.group_point_grad(go.cpu().numpy()[:k], idx.cpu().numpy()[:k], n, use_reference=True)))
+    shape1 = dict(b=b, n=n, m=m, nsample=ns, c=c, radius=radius)
+    for name, t, nbytes, cpu_fn in rows:
+        e = dict(gpu_us=t * 1e6, algorithmic_bytes=nbytes, GBps=nbytes / t / 1e9, frac_of_hbm_peak=nbytes / t / HBM, shape=shape1)
+        if cpu:
+            kb = 4
+            with _quiet_stdout():
+                t0 = time.time(); cpu_fn(kb); tc = time.time() - t0
+            e['cpu_reference_us'] = tc * 1e6 * b / kb
+            e['cpu_sample'] = 'the reference\'s tf_ops/grouping/test function on %d of %d batch items, scaled' % (kb, b)
+        out[name] = e
+    # ---- selection_sort.cu:55 shape ----
+    b, n, m, k = 32, 2048, 512, 128
+    x1, x2 = rs.rand(b, n, 3).astype(np.float32), rs.rand(b, m, 3).astype(np.float32)
+    d1, d2 = torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev)
+    dist = torch.empty((b, m, n), device=dev)
+    from learn_region_grow_amd import _lib
+    from learn_region_grow_amd.lrgnet import _ptr, _stream_ptr
+    lib = _lib.load()
+
+    def pair():
+        _lib.check(lib.lrg_pairwise_sqdist(b, n, m, 3, _ptr(d1), _ptr(d2), _ptr(dist), _stream_ptr()), 'pairwise')
+    shape2 = dict(b=b, n=n, m=m, k=k, c=3)
+    t_pair = _time_gpu(pair, reps)
+    t_sel = _time_gpu(lambda: grouping.select_top_k(k, dist), 5)
+    t_fused = _time_gpu(lambda: grouping.knn_point(k, d1, d2, fused=True), 5)
+    t_unf = _time_gpu(lambda: grouping.knn_point(k, d1, d2, fused=False), 5)
+    bytes_sel = 3 * b * m * n * 4 + b * m * n * 4            # read dist, write out + outi (full size, the op's contract)
+    bytes_fused = b * (n + m) * 12 + b * m * k * 8            # coordinates in, k (value, index) pairs out
+    out['G2 select_top_k (full-size outputs)'] = dict(gpu_us=t_sel * 1e6, algorithmic_bytes=bytes_sel, GBps=bytes_sel / t_sel / 1e9,
+                                                      frac_of_hbm_peak=bytes_sel / t_sel / HBM, shape=shape2)
+    out['knn_point fused (lrg_knn_topk)'] = dict(gpu_us=t_fused * 1e6, algorithmic_bytes=bytes_fused, GBps=bytes_fused / t_fused / 1e9,
+                                                 frac_of_hbm_peak=bytes_fused / t_fused / HBM, shape=shape2,
+                                                 selection_compares=b * m * k * n,
+                                                 note='bound by the k x n compares of the selection the op is defined by, not by its bytes')
+    out['knn_point unfused (distance matrix + select_top_k + slice)'] = dict(
+        gpu_us=t_unf * 1e6, pairwise_us=t_pair * 1e6, algorithmic_bytes=bytes_sel + b * m * n * 4 + b * (n + m) * 12, shape=shape2)
+    if cpu:
+        kb = 1
+        dh = G.knn_dist(x1[:kb], x2[:kb, :64])
+        with _quiet_stdout():
+            t0 = time.time(); G.selection_sort(k, dh, use_reference=True); tc = time.time() - t0
+        out['G2 select_top_k (full-size outputs)']['cpu_reference_us'] = tc * 1e6 * b * m / (kb * 64)
+        out['G2 select_top_k (full-size outputs)']['cpu_sample'] = "the reference's selection_sort_cpu on 64 of %d rows, scaled" % (b * m)
+    return out
+
+
+if __name__ == '__main__':
+    print(json.dumps(grouping_rates(), indent=1))
