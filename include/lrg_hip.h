@@ -449,6 +449,37 @@ int lrg_knn_topk(int b, int n, int m, int c, int k, const float *xyz1, const flo
 int lrg_pairwise_sqdist(int b, int n, int m, int c, const float *xyz1, const float *xyz2, float *dist, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training side: the pieces of the backward pass and of AdamOptimizer
+ * (learn_region_grow_util.py:165-189) that the forward entry points do not cover.  The step is sequenced by the host
+ * mirror (learn_region_grow_amd/train.py: LrgNetTrainer.train_step = sess.run([net.train_op, net.loss, ...]) at
+ * train_region_grow.py:175).
+ * ---------------------------------------------------------------------------------------------- */
+/* C[M,N] = op(A)[M,K] op(B)[K,N] in fp32 on the matrix cores.  transA: A is stored [K,M] (row stride lda), else [M,K];
+ * transB: B is stored [N,K] (row stride ldb), else [K,N].  Epilogue: C = acc + addend (nullable, [M,N] with row stride ldc),
+ * then C = 0 where mask <= 0 (nullable, same shape: the ReLU gradient of the layer whose output the result is the gradient of).
+ * split_k > 1: the reduction is split over that many workgroup layers which ADD into C -- the caller zeroes C first, and no
+ * epilogue is allowed.  dX = dZ W^T is (transB = 1); dW = X^T dZ over all rows is (transA = 1, split_k ~ rows / 1024). */
+int lrg_gemm_f32(int M, int N, int K, const float *A, int lda, int transA, const float *B, int ldb, int transB, float *C, int ldc,
+                 const float *addend, const float *mask, int split_k, void *stream);
+/* d(loss)/d(logits) of a sparse softmax cross entropy over `rows` two-class slots with per-class weights
+ * (add head :174: w_pos = w_neg = 1 / rows; remove head :166-172: 1 / #positive and 1 / #negative slots of the batch).
+ * stats (device double[8], ACCUMULATED): 0 weighted loss, 1 slots with argmax == label, 2 true positives, 3 predicted
+ * positives, 4 labelled positives, 5 rows (the numerators of add_acc, add_prc, add_rcl ... at :175-184). */
+int lrg_ce_grad(const float *logits, const int32_t *labels, long rows, float w_pos, float w_neg, float *dlogits, double *stats,
+                void *stream);
+/* Gradient of the column max over each instance's rows (:122-123) followed by the pooled layer's ReLU: y [B,rows,C] is that
+ * layer's output, dpool [B, dpool_stride] the gradient of its column maxima; dy [B,rows,C] gets dpool / (number of rows that tie
+ * for the maximum) on those rows -- tf.reduce_max's rule -- and 0 elsewhere (and 0 everywhere when the maximum is 0). */
+int lrg_pool_backward(const float *y, const float *dpool, int B, int rows, int C, int dpool_stride, float *dy, void *stream);
+/* out[s, n] = sum of x[s*seg_rows + r, n] over r < seg_rows, for s < n_seg (bias gradients, the gradient of the tiled pooled
+ * feature: the sum over an instance's rows). */
+int lrg_segment_colsum(const float *x, long n_seg, int seg_rows, int N, float *out, void *stream);
+/* One AdamOptimizer update of n parameters as TensorFlow 1 applies it (:188): m += (g - m)(1 - beta1); v += (g^2 - v)(1 - beta2);
+ * p -= lr_t m / (sqrt(v) + epsilon), with lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t) computed by the caller. */
+int lrg_adam_step(float *params, const float *grads, float *m, float *v, long n, float lr_t, float beta1, float beta2, float epsilon,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Room preprocessing P0 (replaces the per-room block test_region_grow.py:119-173: equalisation, per-point PCA normals and
  * curvature, feature stack).  SURVEY.md section 8f, row f1.
  *

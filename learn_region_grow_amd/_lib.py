@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(HERE, 'liblrg_hip.so')
-SOURCES = ['lrg_net.hip', 'lrg_fused.hip', 'lrg_grow.hip', 'lrg_grouping.hip', 'lrg_preprocess.hip']
+SOURCES = ['lrg_net.hip', 'lrg_fused.hip', 'lrg_grow.hip', 'lrg_grouping.hip', 'lrg_preprocess.hip', 'lrg_train.hip']
 
 LRG_MAX_CONV = 5
 LRG_MAX_HEAD = 3
@@ -174,6 +174,12 @@ _SIGS = {
                                             _fp, _fp, _fp]),
     'lrg_knn_topk': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]),
     'lrg_pairwise_sqdist': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
+    'lrg_gemm_f32': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
+                                    _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp]),
+    'lrg_ce_grad': (ctypes.c_int, [_fp, _fp, ctypes.c_long, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp]),
+    'lrg_pool_backward': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
+    'lrg_segment_colsum': (ctypes.c_int, [_fp, ctypes.c_long, ctypes.c_int, ctypes.c_int, _fp, _fp]),
+    'lrg_adam_step': (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_long, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp]),
     'lrg_preprocess_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
     'lrg_preprocess': (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp,
                                       ctypes.c_size_t, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),

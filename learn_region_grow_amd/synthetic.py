@@ -201,3 +201,10 @@ def make_synthetic_weights(seed=0, feature_size=13, lite=0, gain=2.0, bias_std=0
     w['lrg_add_bias%d' % last][1] += np.float32(add_bias_shift)
     w['lrg_remove_bias%d' % last][1] += np.float32(rmv_bias_shift)
     return w
+
+
+def make_reference_init_weights(seed=0, feature_size=13, lite=0):
+    """The state a fresh LrgNet starts training from (learn_region_grow_util.py:107-108,...): kernels from
+    VarianceScaling(1.0, 'fan_avg', 'uniform') -- U(-a, a) with a = sqrt(6 / (fan_in + fan_out)) -- and zero biases."""
+    return make_synthetic_weights(seed=seed, feature_size=feature_size, lite=lite, gain=1.0, bias_std=0.0, add_bias_shift=0.0,
+                                  rmv_bias_shift=0.0)
