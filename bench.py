@@ -50,11 +50,15 @@ def parse():
     ap.add_argument('--restarts', type=int, default=1)
     ap.add_argument('--workload', default='area5', choices=['area5', 'kitti', 'scannet'],
                     help='area5: 68 Area-5-shaped rooms (configs[1]); kitti: 100 k-point scenes at 0.3 m (configs[4])')
-    ap.add_argument('--policy', default='gt', choices=['net', 'gt', 'threshold'],
+    ap.add_argument('--policy', default='net', choices=['net', 'gt', 'threshold'],
                     help="mask policy: 'net' = the reference's Bernoulli draws against the network's confidence "
                          "(test_region_grow.py:266-267); 'gt' = its commented-out ground-truth masks (:268-269). "
-                         "The network is evaluated every step either way; with synthetic weights only 'gt' gives "
-                         "Area-5-like region dynamics (regions per room, steps per region)")
+                         "The network is evaluated every step either way")
+    ap.add_argument('--weights', default='trained', choices=['trained', 'random'],
+                    help="'trained': LrgNet trained by this repository's own training path on synthetic Area-5-shaped rooms "
+                         "(learn_region_grow_amd/weights, tools/train_synthetic.py) -- the reference's policy then gives Area-5-like "
+                         "dynamics (~100 labeled regions and ~1 500 steps per room); 'random': seeded random weights (growth degenerates "
+                         "under 'net': use --policy gt with them)")
     ap.add_argument('--net-mode', default='fused', choices=['fused', 'streamed'])
     ap.add_argument('--packed', type=int, default=1, help='1: lrg_grow_step_packed (front kernel + packed rows); 0: the nine-launch lrg_grow_step')
     ap.add_argument('--graph', type=int, default=4, help='packed iterations replayed per host call from a HIP graph (0 = plain launches)')
@@ -203,7 +207,7 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         backend = dist.get_backend()
 
-    weights = synthetic.make_synthetic_weights(seed=0)
+    weights = synthetic.load_trained_weights() if args.weights == 'trained' else synthetic.make_synthetic_weights(seed=0)
     resolution = 0.1
     if args.workload == 'kitti':
         resolution = 0.3
@@ -411,7 +415,9 @@ def main():
                        'iterations_per_step': args.iters_per_step, 'timed_iterations': iterations,
                        'rooms_in_flight_per_gpu': len(rooms), 'slots_per_gpu': S, 'lanes': n_lanes, 'policy': args.policy,
                        'restarts': args.restarts, 'points': '512 inlier + 512 neighbour x 13 features',
-                       'rng': 'counter (Philox) stream', 'weights': 'synthetic, seed 0', 'net_mode': args.net_mode,
+                       'rng': 'counter (Philox) stream',
+                       'weights': ('trained on synthetic Area-5-shaped rooms by train_region_grow.py (learn_region_grow_amd/weights)'
+                                   if args.weights == 'trained' else 'random, seed 0'), 'net_mode': args.net_mode,
                        'iteration': 'lrg_grow_step_packed (front kernel + branch / GEMM / head on packed rows)' if packed else 'lrg_grow_step',
                        'hip_graph_iterations': graph,
                        'active_fraction': inst_steps / (iterations * S * world)},

@@ -150,3 +150,25 @@ def load_staged(filename, feature_size=13):
     A = np.split(add, np.cumsum(ncount)[:-1]) if len(ncount) else []
     keep = [i for i in range(len(ncount)) if ncount[i] > 0]
     return dict(points=[P[i] for i in keep], remove=[R[i] for i in keep], neighbor_points=[Q[i] for i in keep], add=[A[i] for i in keep])
+
+
+def assemble_batch(data, order, rs, batch_size=100, n_inlier=512, n_neighbor=512):
+    """train_region_grow.py:156-175: every tuple of the batch padded / subsampled to the network's point counts with the legacy
+    generator in the reference's call order (inlier choice, then neighbour choice, per tuple).
+    -> inlier [B,Ni,F], neighbor [B,Nn,F] float32, input_add [B,Nn], input_remove [B,Ni] int32."""
+    F = data['points'][0].shape[1]
+    xi = np.zeros((batch_size, n_inlier, F), dtype=np.float32)
+    xn = np.zeros((batch_size, n_neighbor, F), dtype=np.float32)
+    ia = np.zeros((batch_size, n_neighbor), dtype=np.int32)
+    ir = np.zeros((batch_size, n_inlier), dtype=np.int32)
+    for i in range(batch_size):
+        k = order[i]
+        N = len(data['points'][k])
+        subset = rs.choice(N, n_inlier, replace=False) if N >= n_inlier else list(range(N)) + list(rs.choice(N, n_inlier - N, replace=True))
+        xi[i] = data['points'][k][subset]
+        ir[i] = np.asarray(data['remove'][k])[subset]
+        N = len(data['neighbor_points'][k])
+        subset = rs.choice(N, n_neighbor, replace=False) if N >= n_neighbor else list(range(N)) + list(rs.choice(N, n_neighbor - N, replace=True))
+        xn[i] = data['neighbor_points'][k][subset]
+        ia[i] = np.asarray(data['add'][k])[subset]
+    return xi, xn, ia, ir

@@ -11,6 +11,8 @@ axis-aligned cuboid "furniture" instances, with the sampling density chosen so t
 models/lrgnet_model5.ckpt.index (learn_region_grow_util.py:107-159); the trained blob is not
 distributed with the reference.
 """
+import os
+
 import numpy as np
 
 # tools/generate_synthetic_rooms.py:35-39
@@ -208,3 +210,16 @@ def make_reference_init_weights(seed=0, feature_size=13, lite=0):
     VarianceScaling(1.0, 'fan_avg', 'uniform') -- U(-a, a) with a = sqrt(6 / (fan_in + fan_out)) -- and zero biases."""
     return make_synthetic_weights(seed=seed, feature_size=feature_size, lite=lite, gain=1.0, bias_std=0.0, add_bias_shift=0.0,
                                   rmv_bias_shift=0.0)
+
+
+TRAINED_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'weights', 'lrgnet_synthetic_area5.npz')
+
+
+def load_trained_weights():
+    """LrgNet (lite 0, 13 features) trained by THIS repository's training path (tools/train_synthetic.py: 32 Area-5-shaped synthetic
+    rooms staged twice by learn_region_grow_amd.stage -- 124 k tuples -- and 12 epochs of train_region_grow.py on one MI355X;
+    profiles/r02_train_synthetic.log).  The reference's trained checkpoints are not distributed (models/*.data-* are missing
+    upstream), and randomly initialised weights give degenerate growth under the reference's Bernoulli policy; with these the
+    policy of test_region_grow.py:266-267 segments the synthetic Area-5-shaped rooms into ~100 regions of ~1 500 steps per room."""
+    z = np.load(TRAINED_WEIGHTS)
+    return {k: z[k] for k in z.files}
