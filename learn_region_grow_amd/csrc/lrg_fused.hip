@@ -472,13 +472,25 @@ int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     return launch_stack<32 * 260, 32 * 68, 1, 4, 3, false>(a, nprob, st);
 }
 
+// Build-time knobs of the packed-row kernels (tools/r02_fd2.sh): depth of the weight ring and workgroups per CU.  Measured on
+// the loop (profiles/r02_weight_ring_depth_experiment*.txt): 4 / 8 k-groups in flight give the same kernel durations both at
+// ~2 tiles per CU and at < 1 tile per CU -- the lone tile is bound by its per-pass epilogues and layer barriers, not by weights.
+#ifndef LRG_PACKED_FD
+#define LRG_PACKED_FD 4
+#endif
+#ifndef LRG_PACKED_OCC
+#define LRG_PACKED_OCC 4
+#endif
+#ifndef LRG_PACKED_HEAD_FD
+#define LRG_PACKED_HEAD_FD 4
+#endif
 int lrg_fused_branches_packed(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     // lite 1: conv[1] is the pooled layer itself -- it does not stay in LDS, so its HBM copy (read by the heads) is stored
     // from the accumulators
     if (needs_direct(a, nprob)) return launch_stack<32 * 68, 32 * 132, 1, 4, 2, true, true>(a, nprob, st);
-    return launch_stack<32 * 68, 32 * 132, 1, 4, 4, false, true>(a, nprob, st);
+    return launch_stack<32 * 68, 32 * 132, 1, LRG_PACKED_FD, LRG_PACKED_OCC, false, true>(a, nprob, st);
 }
 
 int lrg_fused_heads_packed(const LrgFusedArgs &a, int nprob, hipStream_t st) {
-    return launch_stack<32 * 260, 32 * 68, 1, 4, 3, false, true>(a, nprob, st);
+    return launch_stack<32 * 260, 32 * 68, 1, LRG_PACKED_HEAD_FD, 3, false, true>(a, nprob, st);
 }

@@ -7,9 +7,10 @@ from learn_region_grow_amd import synthetic, workloads, _lib
 from learn_region_grow_amd.lrgnet import LrgNetHIP
 from learn_region_grow_amd.grow import RegionGrower
 dev = torch.device('cuda:0')
-rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir='/tmp/lrg_cache')
-net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev).load_weights(synthetic.make_synthetic_weights(seed=0))
-gr = RegionGrower(net, rooms_in_flight=68, rng='counter', seed=0, policy='gt')
+NR = int(sys.argv[1]) if len(sys.argv) > 1 else 68
+rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir='/tmp/lrg_cache')[:NR]
+net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev).load_weights(synthetic.load_trained_weights())
+gr = RegionGrower(net, rooms_in_flight=NR, rng='counter', seed=0, policy='net')
 gr.load_rooms(rooms)
 for g in range(gr.n_groups):
     gr.bind(g, g)
