@@ -64,7 +64,8 @@ def parse():
     ap.add_argument('--graph', type=int, default=4, help='packed iterations replayed per host call from a HIP graph (0 = plain launches)')
     ap.add_argument('--fill', type=int, default=1, help='1: finished rooms get their 1-NN fill-in before they are recycled')
     ap.add_argument('--lanes', type=int, default=0, help='groups of slots on their own HIP streams; 0 = auto')
-    ap.add_argument('--fixed-rooms', type=int, default=544, help='room jobs of the fixed-work leg over ALL ranks (0 = skip)')
+    ap.add_argument('--fixed-rooms', type=int, default=-1,
+                    help='room jobs of the fixed-work leg over ALL ranks (0 = skip; default: 8 jobs per geometry = 544 for the Area-5 set)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
     ap.add_argument('--p0-rooms', type=int, default=4, help='rooms of the preprocessing (P0) side measurement (0 = skip)')
@@ -220,7 +221,8 @@ def main():
         rooms = workloads.area5_rooms(args.rooms, seed_base=1000 + 100 * rank, cache_dir=args.cache)
         base = workloads.area5_rooms(args.rooms, seed_base=1000, cache_dir=args.cache) if rank else rooms
     net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, mode=args.net_mode).load_weights(weights)
-    packed = bool(args.packed) and args.net_mode == 'fused' and max(len(r['points']) for r in rooms) <= _lib.LRG_PACKED_MAX_POINTS
+    packed = bool(args.packed) and args.net_mode == 'fused' and max(len(r['points']) for r in rooms) <= (
+        _lib.LRG_PACKED_MAX_POINTS if args.packed > 1 else _lib.LRG_PACKED_AUTO_POINTS)      # --packed 2 forces it up to 131072 points
     graph = args.graph if packed else 0
     if graph and args.iters_per_step % graph:
         raise SystemExit('--iters-per-step must be a multiple of --graph')
@@ -346,6 +348,8 @@ def main():
     # fixed-work leg: R room jobs over all ranks, reset -> final labels (grow + fill-in) -> RCCL gather
     # ------------------------------------------------------------------------------------------------------------------
     fixed = None
+    if args.fixed_rooms < 0:
+        args.fixed_rooms = 8 * len(base)
     if args.fixed_rooms > 0 and args.restarts == 1:
         for g_ in growers:
             g_._release_graph()

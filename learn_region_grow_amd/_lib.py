@@ -86,6 +86,9 @@ class LrgPackedBuffers(ctypes.Structure):
 LRG_ROW_TILE = 32
 LRG_LOG_WORDS = 8
 LRG_PACKED_MAX_POINTS = 32 * 4096      # lrg_grow_step_packed: rooms up to 131072 points
+LRG_PACKED_AUTO_POINTS = 65536         # ... chosen by default up to this size: its front kernel walks a room with ONE workgroup per
+                                       # slot, which loses to the chunk-parallel scans of lrg_grow_step on 100 k-point scenes (KITTI shape:
+                                       # 41 k vs 57 k instance-steps/s, profiles/r02_kitti_*)
 LRG_DONE_RING = 1020
 LRG_STATS_WORDS = 4 + LRG_DONE_RING
 

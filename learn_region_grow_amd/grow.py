@@ -239,7 +239,7 @@ class RegionGrower:
         if self.want_packed and not can_pack:
             raise ValueError('packed iterations need the counter stream, the fused network and rooms of at most %d points'
                              % _lib.LRG_PACKED_MAX_POINTS)
-        self.packed = can_pack if self.want_packed is None else bool(self.want_packed)
+        self.packed = (can_pack and max(ns) <= _lib.LRG_PACKED_AUTO_POINTS) if self.want_packed is None else bool(self.want_packed)
         if self.params.scoring == 1 and not self.packed:
             raise ValueError("scoring='ml' needs the packed iteration (fused network, rooms of at most %d points)" % _lib.LRG_PACKED_MAX_POINTS)
         if self.packed:
