@@ -82,8 +82,11 @@ def golden_lrgnet(lite, feature_size, n_in, n_nb, batch, seed):
         d['add_conv%d' % i] = out[k + i]
         d['remove_conv%d' % i] = out[k + nh + i]
     name = 'lrgnet_lite%s_f%d_n%d_b%d.npz' % ('N' if lite is None else lite, feature_size, n_in, batch)
+    import torch_check                                  # second opinion on the stand-in's conv1d: torch.nn.functional.conv1d (CPU)
+    err = torch_check.check_against_torch(d, w)
+    assert err < 5e-5, 'stand-in and torch conv1d disagree: %g' % err
     np.savez_compressed(os.path.join(HERE, name), **d)
-    print('wrote', name)
+    print('wrote %s (torch conv1d cross-check: max relative error %.1e)' % (name, err))
 
 
 def run_reference_script(script, argv, raw_room, tag, init_globals=None):

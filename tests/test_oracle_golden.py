@@ -4,6 +4,7 @@ test_region_grow.py and test_random_restart.py unmodified)."""
 import glob
 import hashlib
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -111,3 +112,19 @@ def test_other_policies_run(policy):
     if policy == 'gt':     # ground-truth masks never mix instances: every labeled region is pure
         for lab in range(1, int(r.cluster_label.max()) + 1):
             assert len(set(g['obj_id'][r.cluster_label == lab].tolist())) == 1
+
+
+@pytest.mark.parametrize('path', sorted(__import__('glob').glob(os.path.join(GOLDEN, 'lrgnet_*.npz'))), ids=os.path.basename)
+def test_reference_goldens_agree_with_torch_conv1d(path):
+    """A second opinion on the stand-in's ``tf.nn.conv1d``: the goldens were made by the reference's
+    LrgNet.__init__ with conv1d evaluated as ``x @ W[0]``; tests/golden/torch_check.py recomputes every layer with
+    torch.nn.functional.conv1d on the CPU -- an independent convolution kernel and an independent reading of the [1, Cin, Cout]
+    filter layout -- from the golden's own inputs (make_golden.py runs the same check when it writes a golden)."""
+    sys.path.insert(0, GOLDEN)
+    import torch_check
+    from learn_region_grow_amd import synthetic
+    g = np.load(path)
+    lite = int(g['lite'])
+    w = synthetic.make_synthetic_weights(feature_size=int(g['feature_size']), lite=None if lite < 0 else lite, seed=0, gain=2.0, bias_std=0.2,
+                                         add_bias_shift=0.0, rmv_bias_shift=-3.0)
+    assert torch_check.check_against_torch(g, w) < 5e-5
