@@ -30,7 +30,7 @@ extern "C" {
 int lrg_abi_version(void);
 /* Name of the code object's target ("gfx950"); a build sanity hook for the loader. */
 const char *lrg_target_arch(void);
-/* sizeof() of the ABI structs as compiled (0 LrgWeights, 1 LrgRoom, 2 LrgSlot, 3 LrgGrowParams, 4 LrgStepBuffers, 5 LrgPackedBuffers), so that a
+/* sizeof() of the ABI structs as compiled (0 LrgWeights, 1 LrgRoom, 2 LrgSlot, 3 LrgGrowParams, 4 LrgStepBuffers, 5 LrgPackedBuffers, 6 LrgBeamGroup), so that a
  * foreign-language binding can verify its mirror of the layout at load time. */
 size_t lrg_struct_size(int which);
 
@@ -416,6 +416,33 @@ int lrg_step_graph_create(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_p
                           void **graph_out);
 int lrg_step_graph_launch(void *graph, void *stream);
 int lrg_step_graph_destroy(void *graph);
+
+/* ------------------------------------------------------------------------------------------------
+ * Beam search (test_beam_search.py:143-290) with the queue on the device.
+ * A room in flight is a group of beam_width * search_width consecutive slots (child (qid, search id) = slot qid * search_width
+ * + search id).  lrg_beam_level = one level of every room in flight: lrg_beam_advance (children of the last level -> next queue
+ * by size, :275-287; stall test / commit of the head, :188-198,:289-293; next seed, :154-174; next children into the slots),
+ * then the loop's kernels over all slots (box query, median, sampling, gather, LrgNet on the distinct rows, mask update, scan of
+ * the updated masks).  No host decision in between; finished rooms appear in the stats ring (first slot of the group).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct LrgBeamGroup {
+    uint8_t *parent;         /* [beam_width, cap] masks of the queue entries                                             */
+    int32_t cap;             /* row stride of parent                                                                     */
+    int32_t room;            /* index into rooms[], -1 = none (the host binds a group by writing room, seed = -1, pending = done = 0) */
+    int32_t seed;            /* seed point in progress, -1 = pick the next                                               */
+    int32_t level, stuck, steps, nq;
+    int32_t pending;         /* 1: the slots hold the evaluated children of the current queue                            */
+    int32_t done;            /* the room has no unvisited seed left                                                      */
+    int32_t seq_mn[3], seq_mx[3];
+    int32_t q_count[16], q_parent[16];       /* queue entries: mask size, parent buffer (-1 = the seed alone)            */
+    int32_t q_mn[16][3], q_mx[16][3];        /* their bounding boxes                                                      */
+    int32_t pad;
+} LrgBeamGroup;
+int lrg_beam_advance(LrgBeamGroup *groups, LrgSlot *slots, LrgRoom *rooms, int n_groups, int beam_width, int search_width,
+                     const LrgGrowParams *params, int64_t *stats, void *stream);
+int lrg_beam_level(LrgBeamGroup *groups, LrgSlot *slots, LrgRoom *rooms, int n_groups, int beam_width, int search_width, int max_points,
+                   const LrgGrowParams *params, const LrgWeights *weights, const LrgStepBuffers *buffers, unsigned forward_flags,
+                   void *stream);
 
 /* 1-NN fill-in of unlabeled points in all F feature dims, first-min ties (:308-316). */
 int lrg_nn1_fill(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *stream);

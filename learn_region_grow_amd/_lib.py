@@ -83,6 +83,14 @@ class LrgPackedBuffers(ctypes.Structure):
                 ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('row_cap', ctypes.c_int32), ('rooms_have_pvox', ctypes.c_int32), ('slot_big', _fp), ('phase_ticks', _fp)]
 
 
+class LrgBeamGroup(ctypes.Structure):
+    _fields_ = [('parent', _fp), ('cap', ctypes.c_int32), ('room', ctypes.c_int32), ('seed', ctypes.c_int32), ('level', ctypes.c_int32),
+                ('stuck', ctypes.c_int32), ('steps', ctypes.c_int32), ('nq', ctypes.c_int32), ('pending', ctypes.c_int32),
+                ('done', ctypes.c_int32), ('seq_mn', ctypes.c_int32 * 3), ('seq_mx', ctypes.c_int32 * 3),
+                ('q_count', ctypes.c_int32 * 16), ('q_parent', ctypes.c_int32 * 16), ('q_mn', ctypes.c_int32 * 48),
+                ('q_mx', ctypes.c_int32 * 48), ('pad', ctypes.c_int32)]
+
+
 LRG_ROW_TILE = 32
 LRG_LOG_WORDS = 8
 LRG_PACKED_MAX_POINTS = 32 * 4096      # lrg_grow_step_packed: rooms up to 131072 points
@@ -100,7 +108,7 @@ class LrgHipError(RuntimeError):
 def build(verbose=False):
     """hipcc --offload-arch=gfx950 -> learn_region_grow_amd/liblrg_hip.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ('lrg_common.h', 'lrg_rng.h', 'lrg_fused.h', 'lrg_front.inl')] + \
+    deps = srcs + [os.path.join(CSRC, h) for h in ('lrg_common.h', 'lrg_rng.h', 'lrg_fused.h', 'lrg_front.inl', 'lrg_beam.inl')] + \
         [os.path.join(os.path.dirname(HERE), 'include', 'lrg_hip.h')]
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
@@ -165,6 +173,9 @@ _SIGS = {
                                              ctypes.POINTER(ctypes.c_void_p)]),
     'lrg_step_graph_launch': (ctypes.c_int, [_fp, _fp]),
     'lrg_step_graph_destroy': (ctypes.c_int, [_fp]),
+    'lrg_beam_advance': (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp]),
+    'lrg_beam_level': (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
+                                      ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgStepBuffers), ctypes.c_uint, _fp]),
     'lrg_nn1_fill': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
     'lrg_nn1_fill_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
     'lrg_nn1_fill_ws': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]),
@@ -211,7 +222,7 @@ def load():
         fn.argtypes = args
     if lib.lrg_abi_version() != 3:
         raise LrgHipError('ABI version mismatch')
-    for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers)):
+    for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LrgBeamGroup)):
         if lib.lrg_struct_size(which) != ctypes.sizeof(st):
             raise LrgHipError('struct layout mismatch for %s: C %d vs ctypes %d' %
                               (st.__name__, lib.lrg_struct_size(which), ctypes.sizeof(st)))

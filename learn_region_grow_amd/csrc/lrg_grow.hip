@@ -1232,6 +1232,7 @@ __global__ void lrg_nn1_write_kernel(const int32_t *label_in, int n, const unsig
 }
 
 #include "lrg_front.inl"
+#include "lrg_beam.inl"
 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -1529,6 +1530,47 @@ int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_po
                               LRG_FWD_POOL_ZEROED, stream);
 }
 
+
+int lrg_beam_advance(LrgBeamGroup *groups, LrgSlot *slots, LrgRoom *rooms, int n_groups, int beam_width, int search_width,
+                     const LrgGrowParams *params, int64_t *stats, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!groups || !slots || !rooms || n_groups <= 0 || beam_width < 1 || beam_width > LRG_BEAM_MAXQ || search_width < 1 ||
+        beam_width * search_width > 64)
+        return LRG_EINVAL - 1;
+    hipLaunchKernelGGL(lrg_beam_advance_kernel, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, groups, slots, rooms, beam_width,
+                       search_width, *params, stats);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+int lrg_beam_level(LrgBeamGroup *groups, LrgSlot *slots, LrgRoom *rooms, int n_groups, int beam_width, int search_width, int max_points,
+                   const LrgGrowParams *params, const LrgWeights *weights, const LrgStepBuffers *b, unsigned forward_flags, void *stream) {
+    int rc = lrg_beam_advance(groups, slots, rooms, n_groups, beam_width, search_width, params, b ? b->stats : nullptr, stream);
+    if (rc) return rc;
+    if (!weights || !b || max_points <= 0) return LRG_EINVAL - 1;
+    const int n_slots = n_groups * beam_width * search_width;
+    if ((rc = lrg_box_query(slots, rooms, n_slots, max_points, params, stream))) return rc;
+    const bool rows = b->rows_in && b->rows_nb && (forward_flags & LRG_FWD_FUSED);
+    int32_t *tile_lists = nullptr;
+    if (rows && params->n_inlier <= 64 * LRG_ROW_TILE && params->n_neighbor <= 64 * LRG_ROW_TILE) {
+        size_t off = 0, cnt = 0;
+        if ((rc = lrg_forward_workspace_view(weights, n_slots, params->n_inlier, params->n_neighbor, 6, 0, &off, &cnt))) return rc;
+        tile_lists = reinterpret_cast<int32_t *>(static_cast<float *>(b->workspace) + off);
+        forward_flags |= LRG_FWD_TILE_LISTS;
+    }
+    if ((rc = prepare_impl(slots, rooms, n_slots, params, b->center, b->sample_in, b->sample_nb, b->inlier, b->neighbor, b->gt_remove,
+                           b->gt_add, rows ? b->rows_in : nullptr, rows ? b->rows_nb : nullptr, tile_lists, max_points, stream)))
+        return rc;
+    if ((rc = lrg_forward_rows(weights, b->inlier, b->neighbor, n_slots, params->n_inlier, params->n_neighbor, rows ? b->rows_in : nullptr,
+                               rows ? b->rows_nb : nullptr, b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes, forward_flags,
+                               stream)))
+        return rc;
+    if ((rc = lrg_mask_update(slots, rooms, n_slots, params, b->inlier, b->neighbor, b->center, b->add_logits, b->rmv_logits, b->gt_remove,
+                              b->gt_add, nullptr, nullptr, rows ? b->sample_in : nullptr, rows ? b->sample_nb : nullptr, b->stats, stream)))
+        return rc;
+    return lrg_bbox_stop(slots, rooms, n_slots, max_points, params, stream);
+}
 
 // `iterations` lock-step iterations captured once into a HIP graph: every kernel argument of lrg_grow_step_packed is a device
 // pointer or a constant, so a replay is the same work with one host call instead of 4-6 launches per iteration.

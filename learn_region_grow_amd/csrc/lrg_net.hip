@@ -809,6 +809,7 @@ size_t lrg_struct_size(int which) {
     case 3: return sizeof(LrgGrowParams);
     case 4: return sizeof(LrgStepBuffers);
     case 5: return sizeof(LrgPackedBuffers);
+    case 6: return sizeof(LrgBeamGroup);
     }
     return 0;
 }

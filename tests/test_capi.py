@@ -28,7 +28,7 @@ def test_abi_and_struct_layout(hip_lib):
     assert hip_lib.lrg_abi_version() == 3
     assert hip_lib.lrg_target_arch() == b'gfx950'
     for which, st in enumerate((_lib.LrgWeights, _lib.LrgRoom, _lib.LrgSlot, _lib.LrgGrowParams, _lib.LrgStepBuffers,
-                               _lib.LrgPackedBuffers)):
+                               _lib.LrgPackedBuffers, _lib.LrgBeamGroup)):
         assert hip_lib.lrg_struct_size(which) == ctypes.sizeof(st)
 
 

@@ -8,7 +8,8 @@ from learn_region_grow_amd.lrgnet import LrgNetHIP
 from learn_region_grow_amd.beam import BeamSearchGrower
 dev = torch.device('cuda:0')
 rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir='/tmp/lrg_cache')
-sel = sorted(rooms, key=lambda r: len(r['points']))[:24]
+NR = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+sel = sorted(rooms, key=lambda r: len(r['points']))[:NR]
 net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev).load_weights(synthetic.make_synthetic_weights(seed=0))
 gr = BeamSearchGrower(net, rooms_in_flight=len(sel), beam_width=3, search_width=3, seed=0, policy='gt')
 t0 = time.perf_counter()
