@@ -40,6 +40,7 @@ struct LrgFusedProb {
 
 struct LrgFusedArgs {
     LrgFusedProb p[2];
+    int nprob;           // set by the packed launchers: problems interleaved in a one-dimensional grid
 };
 
 int lrg_fused_branches(const LrgFusedArgs &a, int nprob, hipStream_t st);

@@ -16,12 +16,20 @@
 #if LRG_TRACE
 __device__ long long *g_lrg_trace = nullptr;
 extern "C" void lrg_set_trace(long long *p) { hipMemcpyToSymbol(HIP_SYMBOL(g_lrg_trace), &p, sizeof(p)); }
-#define TRACE(i) do { if (CAP0 == LRG_TRACE && tid == 0 && g_lrg_trace && blockIdx.x < 2048) g_lrg_trace[((long)blockIdx.y * 2048 + blockIdx.x) * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+// stamps are parked in LDS and written out once at the end: a global store per stamp would sit in the same in-order memory
+// counter as the weight loads and stretch the very phases it measures (~1.6 k cycles per store, seen)
+#define TRACE(i) do { if (CAP0 == LRG_TRACE && tid == 0) lrg_trace_sh[(i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#ifndef LRG_TRACE_LAYER
+#define LRG_TRACE_LAYER 4   // the layer whose passes are stamped one by one (slots 12 + 2 * pass: after the MFMAs, 13 + 2 * pass: after the epilogue)
+#endif
+#define TRACE_PASS(l, cb, k) do { if ((l) == LRG_TRACE_LAYER && (cb) < 4) TRACE(12 + 2 * (cb) + (k)); } while (0)
 #else
 #define TRACE(i)
+#define TRACE_PASS(l, cb, k)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 
 #define FBN 128      // output columns per pass: 4 waves side by side, each a (32*RT)x32 strip (RT 32x32 MFMA tiles sharing B)
 #define FTHREADS 256 // one wave per SIMD per workgroup; 2-3 workgroups per CU interleave without sharing barriers
@@ -110,6 +118,10 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     constexpr int FM = 32 * RT;      // rows (points) per workgroup
     static_assert(!PACKED || RT == 1, "packed rows use 32-row tiles");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#if LRG_TRACE
+    __shared__ long long lrg_trace_sh[32];
+    if (threadIdx.x < 32) lrg_trace_sh[threadIdx.x] = 0;
+#endif
     float *buf0 = smem;                       // outputs of even layers
     float *buf1 = smem + CAP0;                // the staged input and outputs of odd layers
     float *poolbuf = smem + CAP0 + CAP1;      // [512] running column maxima of the pooled layer / final-layer weights
@@ -117,7 +129,16 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     int *run_inst = run_start + FM + 1;                        //         [FM] instance of each run, -1 = dead rows past *nrows
     int *run_count = run_inst + FM;                            //         [1]
 
-    const LrgFusedProb &P = args.p[blockIdx.y];
+    // PACKED: a one-dimensional grid with the problems (the two branches / the two heads) interleaved -- workgroup j is tile
+    // j / nprob of problem j % nprob -- so that the live tiles are the FIRST workgroups of the launch: the dispatcher deals
+    // consecutive workgroups round the XCDs and CUs, and <= 256 live tiles get a CU each.  With a (tiles, problem) grid the
+    // second problem's tiles arrive after ~1000 dead workgroups and double up on CUs of the first's while others idle
+    // (118 of 248 tiles shared a CU and took 75 k cycles instead of 51 k, profiles/r02_branch_tile_placement.txt).
+    // The compacted tile lists of lrg_forward_rows are launched the same way.
+    const int nprob = args.nprob;                 // > 0: interleaved
+    const int prob = nprob > 0 ? (int)(blockIdx.x % nprob) : (int)blockIdx.y;
+    const int bx = nprob > 0 ? (int)(blockIdx.x / nprob) : (int)blockIdx.x;
+    const LrgFusedProb &P = args.p[prob];
     // Tile-major block order (instance fastest): block b runs on XCD b % 8, and with duplicate-row skipping mostly the
     // FIRST tiles of the instances survive -- instance-major order would put all of them on one XCD.
     const int ninst = (int)(P.rows / P.rows_per_inst);
@@ -125,19 +146,19 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     int nrows_packed = 0;
     if (PACKED) {
         nrows_packed = *P.nrows;
-        if ((long)blockIdx.x * FM >= nrows_packed) return;
+        if ((long)bx * FM >= nrows_packed) return;
         inst = 0;
-        tile = blockIdx.x;
+        tile = bx;
     } else if (P.tile_list) {
         // a compacted list of the live tiles (lrg_prepare): workgroups 0 .. count-1 work, the rest leave at once -- the
         // dispatcher deals consecutive workgroups round the XCDs and CUs, so the live ones are spread evenly
-        if ((int)blockIdx.x >= *P.tile_count) return;
-        const int code = P.tile_list[blockIdx.x];
+        if (bx >= *P.tile_count) return;
+        const int code = P.tile_list[bx];
         inst = code >> 6;
         tile = code & 63;
     } else {
-        inst = blockIdx.x % ninst;
-        tile = blockIdx.x / ninst;
+        inst = bx % ninst;
+        tile = bx / ninst;
         // rows beyond valid[instance] are copies of earlier rows (the padding rule, test_region_grow.py:240,:252):
         // their per-point results are identical and the max-pool ignores duplicates, so whole tiles of them are skipped
         // (the count is fetched here and tested after the input rows are staged: one memory round trip instead of two)
@@ -263,6 +284,20 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
                 for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
             const float bv = bvn;
             bvn = bias_of(Lx, coln);
+            // PACKED: the per-instance bias values of the first RB runs start their trip before the MFMAs (a load that the
+            // epilogue issues and waits for costs a full memory round trip per run and pass: the rows were written by the
+            // GEMM kernel on another XCD a moment ago)
+            constexpr int RB = 4;
+            float bk[RB] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (PACKED) {
+                if (wave_on && (L.flags & LRG_FL_INST_BIAS) && L.bias) {
+#pragma unroll
+                    for (int k = 0; k < RB; ++k) {
+                        const int ins = k < nruns ? run_inst[k] : -1;
+                        if (ins >= 0) bk[k] = L.bias[(long)ins * L.N + col0 + li];
+                    }
+                }
+            }
             if (wave_on) {
                 const float4 *wp = wptr(L, col0);
                 if constexpr (RT == 2) {
@@ -291,6 +326,7 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
             } else {
                 prefetch_b<FD>(bq, wpn);      // an idle wave still owes the next pass its first weights
             }
+            TRACE_PASS(l, cb, 0);
             if (inplace) __syncthreads();            // the output overlays this layer's input: everyone must be done reading
             if (wave_on) {
                 // ---- epilogue: bias, ReLU, keep in LDS / copy to HBM / column max ----
@@ -300,50 +336,102 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
                 // parity-test copy of a layer that does not (KEEP_ACTS on the pooled layer) is stored from registers
                 float *gdirect = (DIRECT && L.gout && (!(L.flags & LRG_FL_KEEP) || inplace)) ? L.gout + r0 * L.N : nullptr;
                 if constexpr (PACKED) {
-                    // per-instance bias (the hoisted pooled product of a head, :128-141): one value per run of rows
+                    // One wave per SIMD: every instruction of the epilogue is issue time the matrix pipe idles through
+                    // (~600 instructions = 2.6 k cycles per pass against 4.1 k of MFMAs, profiles/r02_branch_pass_stamps.txt),
+                    // so this path is written for instruction count: flag tests outside the 16-value loops, one unsigned
+                    // compare per value for "row in run", the single-run tile (4 of 5) without any row test.
+                    f32x16 &a = acc[0];
+                    const bool relu = (L.flags & LRG_FL_RELU) != 0, keep = (L.flags & LRG_FL_KEEP) != 0;
+                    const int row4 = 4 * lh;
+                    // per-instance bias (the hoisted pooled product of a head, :128-141): one value per run of rows; the
+                    // first RB runs' values were requested before the MFMAs of this pass
                     if ((L.flags & LRG_FL_INST_BIAS) && L.bias) {
-                        for (int k = 0; k < nruns; ++k) {
-                            const int lo = run_start[k], hi = run_start[k + 1], ins = run_inst[k];
-                            const float b = ins >= 0 ? L.bias[(long)ins * L.N + col] : 0.f;
+                        if (nruns == 1) {
 #pragma unroll
-                            for (int rr = 0; rr < 16; ++rr) {
-                                const int rl = 4 * lh + (rr & 3) + 8 * (rr >> 2);
-                                if (rl >= lo && rl < hi) acc[0][rr] += b;
+                            for (int rr = 0; rr < 16; ++rr) a[rr] += bk[0];
+                        } else {
+                            auto add_run = [&](int k, float b) {
+                                const int lo = run_start[k], len = run_start[k + 1] - lo, d = row4 - lo;
+#pragma unroll
+                                for (int rr = 0; rr < 16; ++rr)
+                                    if ((unsigned)(d + (rr & 3) + 8 * (rr >> 2)) < (unsigned)len) a[rr] += b;
+                            };
+#pragma unroll
+                            for (int k = 0; k < RB; ++k)
+                                if (k < nruns) add_run(k, bk[k]);
+                            for (int k = RB; k < nruns; ++k) {
+                                const int ins = run_inst[k];
+                                add_run(k, ins >= 0 ? L.bias[(long)ins * L.N + col] : 0.f);
                             }
                         }
                     }
-                }
+                    if (relu) {
 #pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    if (t < ntile) {
-#pragma unroll
-                        for (int rr = 0; rr < 16; ++rr) {
-                            const int rl = rbase + t * 32 + 4 * lh + (rr & 3) + 8 * (rr >> 2);
-                            float v = acc[t][rr] + bv;
-                            if (L.flags & LRG_FL_RELU) v = fmaxf(v, 0.f);
-                            if (L.flags & LRG_FL_KEEP) act_out[rl * ld_out + col] = v;
-                            if (DIRECT && gdirect) gdirect[(unsigned)(rl * L.N + col)] = v;
-                            if (PACKED) acc[t][rr] = v;
-                            cmax = fmaxf(cmax, v);
-                        }
-                    }
-                }
-                if (L.flags & LRG_FL_POOL) {
-                    if constexpr (PACKED) {
-                        // column maxima per run of rows, straight into that instance's pooled feature (values >= 0)
-                        for (int k = 0; k < nruns; ++k) {
-                            const int lo = run_start[k], hi = run_start[k + 1], ins = run_inst[k];
-                            float m = 0.f;
-#pragma unroll
-                            for (int rr = 0; rr < 16; ++rr) {
-                                const int rl = 4 * lh + (rr & 3) + 8 * (rr >> 2);
-                                if (rl >= lo && rl < hi) m = fmaxf(m, acc[0][rr]);
-                            }
-                            m = fmaxf(m, __shfl_xor(m, 32));
-                            if (lh == 0 && ins >= 0 && m > 0.f)
-                                atomicMax(reinterpret_cast<int *>(P.pool + (long)ins * P.pool_stride + col), __float_as_int(m));
-                        }
+                        for (int rr = 0; rr < 16; ++rr) a[rr] = fmaxf(a[rr] + bv, 0.f);
                     } else {
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) a[rr] += bv;
+                    }
+                    if (keep) {
+                        float *o = act_out + row4 * ld_out + col;
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) o[((rr & 3) + 8 * (rr >> 2)) * ld_out] = a[rr];
+                    }
+                    if (DIRECT && gdirect) {
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) gdirect[(unsigned)((row4 + (rr & 3) + 8 * (rr >> 2)) * L.N + col)] = a[rr];
+                    }
+                    if (L.flags & LRG_FL_POOL) {
+                        // Column maxima per run of rows.  The values are >= 0, so the maximum is taken on their bit patterns
+                        // as integers (v_max3_i32, no NaN canonicalisation; the same order the atomicMax below relies on).
+                        // They are parked in the layer's own output buffer (free: the pooled layer does not stay in LDS) and
+                        // go to the instances' pooled features after the layer, so that no pass carries an atomic's
+                        // memory-side round trip in the in-order counter its weight loads use.
+                        const int runcap = keep ? 0 : (act_out == buf1 ? CAP1 : CAP0) / L.N;
+                        int *parked = reinterpret_cast<int *>(act_out);
+                        auto put = [&](int k, int m) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)m, (unsigned)m, false, false);
+                            m = max((int)sw[0], (int)sw[1]);                 // both halves of the wave hold rows of the column
+                            if (lh == 0) {
+                                if (k < runcap) parked[k * L.N + col] = m;
+                                else {
+                                    const int ins = run_inst[k];
+                                    if (ins >= 0 && m > 0) atomicMax(reinterpret_cast<int *>(P.pool + (long)ins * P.pool_stride + col), m);
+                                }
+                            }
+                        };
+                        if (nruns == 1) {
+                            int m = 0;
+#pragma unroll
+                            for (int rr = 0; rr < 16; ++rr) m = max(m, __float_as_int(a[rr]));
+                            put(0, m);
+                        } else {
+                            for (int k = 0; k < nruns; ++k) {
+                                const int lo = run_start[k], len = run_start[k + 1] - lo, d = row4 - lo;
+                                int m = 0;
+#pragma unroll
+                                for (int rr = 0; rr < 16; ++rr)
+                                    m = max(m, (unsigned)(d + (rr & 3) + 8 * (rr >> 2)) < (unsigned)len ? __float_as_int(a[rr]) : 0);
+                                put(k, m);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        if (t < ntile) {
+#pragma unroll
+                            for (int rr = 0; rr < 16; ++rr) {
+                                const int rl = rbase + t * 32 + 4 * lh + (rr & 3) + 8 * (rr >> 2);
+                                float v = acc[t][rr] + bv;
+                                if (L.flags & LRG_FL_RELU) v = fmaxf(v, 0.f);
+                                if (L.flags & LRG_FL_KEEP) act_out[rl * ld_out + col] = v;
+                                if (DIRECT && gdirect) gdirect[(unsigned)(rl * L.N + col)] = v;
+                                cmax = fmaxf(cmax, v);
+                            }
+                        }
+                    }
+                    if (L.flags & LRG_FL_POOL) {
                         cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
                         if (lh == 0) {
                             if (m22) atomicMax(reinterpret_cast<int *>(&poolbuf[col]), __float_as_int(cmax));   // two waves share the column (values >= 0)
@@ -352,8 +440,25 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
                     }
                 }
             }
+            TRACE_PASS(l, cb, 1);
         }
         __syncthreads();                             // layer boundary: outputs visible, inputs dead
+        if constexpr (PACKED) {
+            if ((L.flags & LRG_FL_POOL) && !(L.flags & LRG_FL_KEEP)) {
+                // the parked per-run maxima -> the pooled features (:122-125), coalesced, nothing waits for them
+                const int runcap = (act_out == buf1 ? CAP1 : CAP0) / L.N;
+                const int nk = nruns < runcap ? nruns : runcap;
+                for (int k = 0; k < nk; ++k) {
+                    const int ins = run_inst[k];
+                    if (ins < 0) continue;
+                    int *dst = reinterpret_cast<int *>(P.pool + (long)ins * P.pool_stride);
+                    for (int c = tid; c < L.N; c += FTHREADS) {
+                        const int m = reinterpret_cast<const int *>(act_out)[k * L.N + c];
+                        if (m > 0) atomicMax(dst + c, m);
+                    }
+                }
+            }
+        }
         if (L.gout && (L.flags & LRG_FL_KEEP) && !inplace) {
             // HBM copy of a layer the next one reads from LDS (conv[1] for the heads, :130,:134): whole rows, float4
             const int q = L.N >> 2;
@@ -403,6 +508,14 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     if (!PACKED && P.zero_pool && tile == 0)
         for (int c = tid; c < P.zero_count; c += FTHREADS) P.zero_pool[(long)inst * P.zero_count + c] = 0.f;
     TRACE(20);
+#if LRG_TRACE
+    if (CAP0 == LRG_TRACE && tid == 0 && g_lrg_trace && bx < 2048) {
+        lrg_trace_sh[21] = nruns;
+        // where the workgroup ran: HW_ID (wave / simd / cu / sh / se) and XCC_ID
+        lrg_trace_sh[22] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        for (int i = 0; i < 32; ++i) g_lrg_trace[((long)prob * 2048 + bx) * 32 + i] = lrg_trace_sh[i];
+    }
+#endif
 }
 
 template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false>
@@ -440,7 +553,17 @@ static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
         if (e != hipSuccess) return -(int)e;
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM), nprob), dim3(FTHREADS), lds, st, a);
+    bool lists = true;
+    for (int i = 0; i < nprob; ++i) lists = lists && a.p[i].tile_list != nullptr;
+    if (PACKED || lists) {
+        LrgFusedArgs b = a;
+        b.nprob = nprob;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM) * nprob), dim3(FTHREADS), lds, st, b);
+    } else {
+        LrgFusedArgs b = a;
+        b.nprob = 0;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM), nprob), dim3(FTHREADS), lds, st, b);
+    }
     LRG_LAUNCH_CHECK();
     return 0;
 }
@@ -479,7 +602,7 @@ int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st) {
 #define LRG_PACKED_FD 4
 #endif
 #ifndef LRG_PACKED_OCC
-#define LRG_PACKED_OCC 4
+#define LRG_PACKED_OCC 3
 #endif
 #ifndef LRG_PACKED_HEAD_FD
 #define LRG_PACKED_HEAD_FD 4

@@ -2,7 +2,8 @@
 mkdir -p gpurun_out
 R=$(pwd)
 rm -f $R/gpurun_out/fd2.txt
-for V in "4 4 4" "8 3 4" "8 3 8"; do
+IFS=";" read -ra CFGS <<< "${FD_CONFIGS:-4 3 4;8 3 8;12 2 8;16 2 8}"
+for V in "${CFGS[@]}"; do
   set -- $V
   FLAGS="-DLRG_PACKED_FD=$1 -DLRG_PACKED_OCC=$2 -DLRG_PACKED_HEAD_FD=$3"
   rm -rf /tmp/exp_repo; cp -r $R /tmp/exp_repo && cd /tmp/exp_repo

@@ -15,7 +15,7 @@ gr.load_rooms(rooms)
 for g in range(gr.n_groups):
     gr.bind(g, g)
 lib = _lib.load()
-for it in range(300):
+for it in range(int(os.environ.get("LRG_TRACE_WARM", "300"))):
     gr.enqueue_iteration()
     for g in gr.poll_done():
         r = gr.group_room[g]; gr.reset_room(r); gr.bind(g, r)
@@ -26,9 +26,19 @@ lib.lrg_set_trace(ctypes.c_void_p(tr.data_ptr()))
 gr.enqueue_iteration()
 torch.cuda.synchronize()
 t = tr.cpu().numpy().reshape(2, 2048, 32)
+# which compute unit each workgroup ran on (HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID [3:0]) and how many shared it
+live = t[(t[:, :, 20] > 0) & (t[:, :, 0] > 0)]
+hw = live[:, 22]
+cu = ((hw >> 32) & 0xf) * 4096 + ((hw >> 13) & 7) * 64 + ((hw >> 12) & 1) * 32 + ((hw >> 8) & 0xf)
+life_all = live[:, 20] - live[:, 0]
+vals, inv, cnt = np.unique(cu, return_inverse=True, return_counts=True)
+print('%d live workgroups on %d distinct CUs (XCCs used: %s)' % (len(live), len(vals), sorted(set(((hw >> 32) & 0xf).tolist()))))
+for c in sorted(set(cnt.tolist())):
+    sel = cnt[inv] == c
+    print('   workgroups on a CU holding %d of them: %4d, lifetime p50 %d p90 %d max %d' % (c, sel.sum(), np.median(life_all[sel]), np.percentile(life_all[sel], 90), life_all[sel].max()))
 for y in range(2):
     a = t[y]
-    a = a[a[:, 20] > 0]
+    a = a[(a[:, 20] > 0) & (a[:, 0] > 0)]
     if not len(a):
         continue
     t0 = a[:, 0].min()
@@ -39,3 +49,14 @@ for y in range(2):
     d = np.diff(a[:, :13], axis=1)
     names = ['stage'] + [x for l in range(5) for x in ('L%d setup' % l, 'L%d run' % l)]
     print('   median phase cycles:', dict(zip(names, np.median(d, axis=0).astype(int).tolist())))
+    # passes of the stamped layer (LRG_TRACE_LAYER): after the MFMAs / after the epilogue, relative to the layer's start
+    tl = int(os.environ.get('LRG_TRACE_LAYER', '4'))
+    base = a[:, 2 + 2 * tl]
+    ps = a[:, 12:20]
+    ok = (ps > 0).all(axis=0)
+    rel = np.median(ps - base[:, None], axis=0).astype(int)
+    print('   layer %d pass stamps (cycles after the layer began; mfma done / epilogue done):' % tl, [int(r) if o else None for r, o in zip(rel, ok)])
+    nr = a[:, 21]
+    for k in sorted(set(nr.tolist()))[:12]:
+        sel = nr == k
+        print('   tiles with %2d runs: %4d, lifetime p50 %d max %d' % (k, sel.sum(), np.median(life[sel]), life[sel].max()))
