@@ -135,9 +135,23 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     // second problem's tiles arrive after ~1000 dead workgroups and double up on CUs of the first's while others idle
     // (118 of 248 tiles shared a CU and took 75 k cycles instead of 51 k, profiles/r02_branch_tile_placement.txt).
     // The compacted tile lists of lrg_forward_rows are launched the same way.
+    // With two problems of t0 and t1 live tiles the first 2 * min(t0, t1) workgroups alternate and the rest of the longer
+    // problem follows, so the live tiles are exactly the first t0 + t1 workgroups.
     const int nprob = args.nprob;                 // > 0: interleaved
-    const int prob = nprob > 0 ? (int)(blockIdx.x % nprob) : (int)blockIdx.y;
-    const int bx = nprob > 0 ? (int)(blockIdx.x / nprob) : (int)blockIdx.x;
+    int prob = nprob > 0 ? (int)(blockIdx.x % nprob) : (int)blockIdx.y;
+    int bx = nprob > 0 ? (int)(blockIdx.x / nprob) : (int)blockIdx.x;
+    if (nprob == 2) {
+        auto live = [&](const LrgFusedProb &Q) {
+            return PACKED ? (*Q.nrows + FM - 1) / FM : Q.tile_list ? *Q.tile_count : (int)(Q.rows / FM);
+        };
+        const int t0 = live(args.p[0]), t1 = live(args.p[1]);
+        const int m = t0 < t1 ? t0 : t1;
+        if ((int)blockIdx.x >= 2 * m) {
+            prob = t0 > t1 ? 0 : 1;
+            bx = (int)blockIdx.x - m;
+            if (bx >= (t0 > t1 ? t0 : t1)) return;
+        }
+    }
     const LrgFusedProb &P = args.p[prob];
     // Tile-major block order (instance fastest): block b runs on XCD b % 8, and with duplicate-row skipping mostly the
     // FIRST tiles of the instances survive -- instance-major order would put all of them on one XCD.
@@ -170,6 +184,9 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     TRACE(0);
+#if LRG_TRACE
+    if (CAP0 == LRG_TRACE && tid == 0) lrg_trace_sh[23] = (long long)wall_clock64();     // 100 MHz: calibrates the cycle counter
+#endif
 
     // A 64-wide layer of a 64-row tile is laid out 2x2 (each wave one 32x32 tile) instead of 1x4 strips of which only
     // two would have columns: all four SIMDs stay busy through the narrow layers.
@@ -511,6 +528,7 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
 #if LRG_TRACE
     if (CAP0 == LRG_TRACE && tid == 0 && g_lrg_trace && bx < 2048) {
         lrg_trace_sh[21] = nruns;
+        lrg_trace_sh[24] = (long long)wall_clock64();
         // where the workgroup ran: HW_ID (wave / simd / cu / sh / se) and XCC_ID
         lrg_trace_sh[22] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
         for (int i = 0; i < 32; ++i) g_lrg_trace[((long)prob * 2048 + bx) * 32 + i] = lrg_trace_sh[i];

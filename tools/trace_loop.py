@@ -31,6 +31,9 @@ live = t[(t[:, :, 20] > 0) & (t[:, :, 0] > 0)]
 hw = live[:, 22]
 cu = ((hw >> 32) & 0xf) * 4096 + ((hw >> 13) & 7) * 64 + ((hw >> 12) & 1) * 32 + ((hw >> 8) & 0xf)
 life_all = live[:, 20] - live[:, 0]
+wall = (live[:, 24] - live[:, 23]) / 100.0     # us (wall_clock64 ticks at 100 MHz)
+print('cycle counter: %.2f GHz (median over workgroups); workgroup lifetime p50 %.1f us max %.1f us; first start to last end %.1f us' % (
+    np.median(life_all / wall) / 1e3, np.median(wall), wall.max(), (live[:, 24].max() - live[:, 23].min()) / 100.0))
 vals, inv, cnt = np.unique(cu, return_inverse=True, return_counts=True)
 print('%d live workgroups on %d distinct CUs (XCCs used: %s)' % (len(live), len(vals), sorted(set(((hw >> 32) & 0xf).tolist()))))
 for c in sorted(set(cnt.tolist())):
