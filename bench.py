@@ -64,6 +64,7 @@ def parse():
     ap.add_argument('--graph', type=int, default=4, help='packed iterations replayed per host call from a HIP graph (0 = plain launches)')
     ap.add_argument('--fill', type=int, default=1, help='1: finished rooms get their 1-NN fill-in before they are recycled')
     ap.add_argument('--lanes', type=int, default=0, help='groups of slots on their own HIP streams; 0 = auto')
+    ap.add_argument('--cu-partition', type=int, default=-1, help='lanes on disjoint sets of compute units: 1 / 0; -1 = on from two lanes')
     ap.add_argument('--fixed-rooms', type=int, default=-1,
                     help='room jobs of the fixed-work leg over ALL ranks (0 = skip; default: 8 jobs per geometry = 544 for the Area-5 set)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-baseline sample (0 = skip)')
@@ -184,7 +185,7 @@ def main():
     import torch.distributed as dist
     from learn_region_grow_amd import _lib, synthetic, workloads, dist as lrg_dist
     from learn_region_grow_amd.lrgnet import LrgNetHIP, _ptr
-    from learn_region_grow_amd.grow import LanedRegionGrower, RegionGrower, auto_lanes
+    from learn_region_grow_amd.grow import LanedRegionGrower, RegionGrower, auto_lanes, lane_streams
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -235,10 +236,11 @@ def main():
     n_lanes = max(1, min(args.lanes, len(rooms))) if args.lanes > 0 else auto_lanes(len(rooms) * args.restarts)
     by_size = sorted(range(len(rooms)), key=lambda i: -len(rooms[i]['points']))
     parts = [[i for i in by_size[k::n_lanes]] for k in range(n_lanes)]
-    lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
+    cu_part = None if args.cu_partition < 0 else bool(args.cu_partition)
+    lane_streams_, _raw_lane_streams = lane_streams(dev, n_lanes, cu_part)
     growers = []
     for k in range(n_lanes):
-        with torch.cuda.stream(lane_streams[k]):
+        with torch.cuda.stream(lane_streams_[k]):
             g_ = RegionGrower(net, rooms_in_flight=len(parts[k]), seed=rank, **grow_kw)
             g_.load_rooms([rooms[i] for i in parts[k]])
             for g in range(g_.n_groups):
@@ -251,7 +253,7 @@ def main():
         per_call = graph if graph else 1
         for _ in range(0, iters, per_call):
             for lane, g_ in enumerate(growers):
-                with torch.cuda.stream(lane_streams[lane]):
+                with torch.cuda.stream(lane_streams_[lane]):
                     g_.enqueue()
                     for g in g_.poll_done():          # finished rooms get their fill-in (:308-316) and restart at once
                         r = g_.group_room[g]
@@ -361,7 +363,7 @@ def main():
         mine = lrg_dist.shard_rooms_lpt(sizes, world)[rank]
         job_rooms = [dict(base[jobs[j][0]], room_id=100000 + jobs[j][1]) for j in mine]
         slots = min(args.rooms, max(1, len(job_rooms)))
-        lg = LanedRegionGrower(net, rooms_in_flight=slots, lanes=args.lanes if args.lanes > 0 else None, seed=0, **grow_kw)
+        lg = LanedRegionGrower(net, rooms_in_flight=slots, lanes=args.lanes if args.lanes > 0 else None, cu_partition=cu_part, seed=0, **grow_kw)
         lg.load_rooms(job_rooms)
         barrier()
         tf0 = time.perf_counter()

@@ -417,6 +417,13 @@ int lrg_step_graph_create(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_p
 int lrg_step_graph_launch(void *graph, void *stream);
 int lrg_step_graph_destroy(void *graph);
 
+/* A stream whose kernels run only on the compute units set in `mask` (bit i of word i / 32; hipExtStreamCreateWithCUMask).
+ * Lanes (slot groups iterating independently on their own streams, the batched scheduler of north_star) get disjoint CU sets:
+ * every lane's launches hold fewer tiles than it has CUs, and the dispatcher starts each launch on the same CUs -- without
+ * the masks two lanes' tiles double up there while the rest of the chip idles. */
+int lrg_stream_create_cu_mask(const uint32_t *mask, int words, void **stream);
+int lrg_stream_destroy(void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Beam search (test_beam_search.py:143-290) with the queue on the device.
  * A room in flight is a group of beam_width * search_width consecutive slots (child (qid, search id) = slot qid * search_width

@@ -173,6 +173,8 @@ _SIGS = {
                                              ctypes.POINTER(ctypes.c_void_p)]),
     'lrg_step_graph_launch': (ctypes.c_int, [_fp, _fp]),
     'lrg_step_graph_destroy': (ctypes.c_int, [_fp]),
+    'lrg_stream_create_cu_mask': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    'lrg_stream_destroy': (ctypes.c_int, [_fp]),
     'lrg_beam_advance': (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp]),
     'lrg_beam_level': (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
                                       ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgStepBuffers), ctypes.c_uint, _fp]),

@@ -1616,6 +1616,21 @@ int lrg_step_graph_destroy(void *graph) {
     return 0;
 }
 
+int lrg_stream_create_cu_mask(const uint32_t *mask, int words, void **stream) {
+    if (!mask || words <= 0 || !stream) return LRG_EINVAL - 1;
+    hipStream_t st = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+    if (e != hipSuccess) return -(int)e;
+    *stream = st;
+    return 0;
+}
+
+int lrg_stream_destroy(void *stream) {
+    if (!stream) return 0;
+    hipError_t e = hipStreamDestroy(static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 size_t lrg_nn1_fill_workspace_bytes(int n) { return n <= 0 ? 0 : lrg_align_up((size_t)n * 4 + 64, 256) + (size_t)n * 8; }
 
 int lrg_nn1_fill_ws(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *workspace,

@@ -665,6 +665,32 @@ def auto_lanes(slots_in_flight):
     return 3 if slots_in_flight >= 64 else 1
 
 
+def lane_streams(device, lanes, cu_partition=None):
+    """-> (torch streams, raw handles to keep alive).  cu_partition (default: on from two lanes): every lane's stream is
+    confined to its own 1/lanes of the compute units (lrg_stream_create_cu_mask).  A lane's launches hold fewer tiles than it has
+    CUs, and the dispatcher starts every launch on the same CUs: without the masks two lanes' tiles double up there while the
+    rest of the chip idles."""
+    if cu_partition is None:
+        cu_partition = lanes > 1
+    if not cu_partition or lanes <= 1:
+        return [torch.cuda.Stream(device=device) for _ in range(lanes)], []
+    lib = _lib.load()
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    words = (ncu + 31) // 32
+    streams, raw = [], []
+    with torch.cuda.device(device):
+        for k in range(lanes):
+            lo, hi = k * ncu // lanes, (k + 1) * ncu // lanes
+            mask = (ctypes.c_uint32 * words)()
+            for b in range(lo, hi):
+                mask[b // 32] |= 1 << (b % 32)
+            h = ctypes.c_void_p()
+            _lib.check(lib.lrg_stream_create_cu_mask(mask, words, ctypes.byref(h)), 'lrg_stream_create_cu_mask')
+            raw.append(h)
+            streams.append(torch.cuda.ExternalStream(h.value, device=device))
+    return streams, raw
+
+
 class LanedRegionGrower:
     """The rooms in flight dealt over `lanes` RegionGrower instances, each on its own HIP stream.
 
@@ -673,7 +699,7 @@ class LanedRegionGrower:
     other's network evaluation (+8 % instance-steps/s at 68 rooms on one MI355X).  Rooms are independent and the counter
     random stream is keyed by room id, so results do not depend on the lane count (tests/test_gpu_grow.py)."""
 
-    def __init__(self, net, rooms_in_flight=64, lanes=None, **kw):
+    def __init__(self, net, rooms_in_flight=64, lanes=None, cu_partition=None, **kw):
         if kw.get('rng', 'counter') != 'counter':
             raise ValueError("lanes need rng='counter' (the legacy stream is replayed on the host, one iteration at a time)")
         self.net = net
@@ -681,7 +707,7 @@ class LanedRegionGrower:
             lanes = auto_lanes(int(rooms_in_flight) * int(kw.get('restarts', 1)))
         lanes = max(1, min(int(lanes), int(rooms_in_flight)))
         share = [rooms_in_flight // lanes + (1 if k < rooms_in_flight % lanes else 0) for k in range(lanes)]
-        self.streams = [torch.cuda.Stream(device=net.device) for _ in range(lanes)]
+        self.streams, self._raw_streams = lane_streams(net.device, lanes, cu_partition)
         self.growers = []
         for k in range(lanes):
             with torch.cuda.stream(self.streams[k]):

@@ -27,3 +27,18 @@ for q, v in sorted(byq.items()):
     for k in sorted(dur, key=lambda k: -sum(dur[k])):
         print('  %-62s n=%5d  dur p50 %7.1f us  mean %7.1f  | gap before p50 %6.1f us mean %6.1f' % (
             k, len(dur[k]), np.median(dur[k]) / 1e3, np.mean(dur[k]) / 1e3, np.median(gap[k]) / 1e3, np.mean(gap[k]) / 1e3))
+
+# overlap across queues: how many kernels are in flight, by share of the traced span
+ev = []
+for q, v in byq.items():
+    for s, e, _ in sorted(v)[skip:]:
+        ev.append((s, 1)); ev.append((e, -1))
+ev.sort()
+if ev:
+    depth, last, acc = 0, ev[0][0], defaultdict(int)
+    for t, d in ev:
+        acc[depth] += t - last
+        last = t
+        depth += d
+    tot = sum(acc.values())
+    print('kernels in flight over the span: ' + ', '.join('%d: %.1f %%' % (k, 100.0 * acc[k] / tot) for k in sorted(acc)))
