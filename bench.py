@@ -64,7 +64,7 @@ def parse():
     ap.add_argument('--graph', type=int, default=4, help='packed iterations replayed per host call from a HIP graph (0 = plain launches)')
     ap.add_argument('--fill', type=int, default=1, help='1: finished rooms get their 1-NN fill-in before they are recycled')
     ap.add_argument('--lanes', type=int, default=0, help='groups of slots on their own HIP streams; 0 = auto')
-    ap.add_argument('--cu-partition', type=int, default=-1, help='lanes on disjoint sets of compute units: 1 / 0; -1 = on from two lanes')
+    ap.add_argument('--cu-partition', type=int, default=0, help='1: lanes on disjoint sets of compute units')
     ap.add_argument('--fixed-rooms', type=int, default=-1,
                     help='room jobs of the fixed-work leg over ALL ranks (0 = skip; default: 8 jobs per geometry = 544 for the Area-5 set)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-baseline sample (0 = skip)')
@@ -236,8 +236,8 @@ def main():
     n_lanes = max(1, min(args.lanes, len(rooms))) if args.lanes > 0 else auto_lanes(len(rooms) * args.restarts)
     by_size = sorted(range(len(rooms)), key=lambda i: -len(rooms[i]['points']))
     parts = [[i for i in by_size[k::n_lanes]] for k in range(n_lanes)]
-    cu_part = None if args.cu_partition < 0 else bool(args.cu_partition)
-    lane_streams_, _raw_lane_streams = lane_streams(dev, n_lanes, cu_part)
+    cu_part = args.cu_partition > 0
+    lane_streams_ = lane_streams(dev, n_lanes, cu_part)
     growers = []
     for k in range(n_lanes):
         with torch.cuda.stream(lane_streams_[k]):

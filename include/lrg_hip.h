@@ -420,7 +420,7 @@ int lrg_step_graph_destroy(void *graph);
 /* A stream whose kernels run only on the compute units set in `mask` (bit i of word i / 32; hipExtStreamCreateWithCUMask).
  * Lanes (slot groups iterating independently on their own streams, the batched scheduler of north_star) get disjoint CU sets:
  * every lane's launches hold fewer tiles than it has CUs, and the dispatcher starts each launch on the same CUs -- without
- * the masks two lanes' tiles double up there while the rest of the chip idles. */
+ * the masks two lanes' tiles double up there while the rest of the chip idles.  mask = NULL: a plain non-blocking stream. */
 int lrg_stream_create_cu_mask(const uint32_t *mask, int words, void **stream);
 int lrg_stream_destroy(void *stream);
 

@@ -466,7 +466,10 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
 //   * regions above LRG_FRONT_SMALL points leave their nine channel medians to lrg_front_big_kernel, one workgroup per
 //     (slot, channel) -- the single slow step whose cost grows with the region (its last-arriving workgroup gathers).
 // =================================================================================================
-#define LRG_FRONT_SMALL 0       // regions above this many points get their medians from lrg_front_big_kernel.  0 = all of them:
+#ifndef LRG_FRONT_SMALL
+#define LRG_FRONT_SMALL 0
+#endif
+                                // regions above this many points get their medians from lrg_front_big_kernel.  0 = all of them:
                                 // that launch runs in (almost) every iteration anyway -- with 68 slots some region is nearly
                                 // always large -- and its duration is set by the largest region, so the small ones ride along
                                 // for free and the front kernel loses its median phase (trace: 8.7 k of 44 k cycles per slot)
@@ -936,7 +939,9 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         const int ch = lrg_centred_channel(wave, F);
         if (ch >= 0) {
             const float *pts = points + ch;
-            const float m = nc <= 256 ? lrg_median_wave_r<4>(pts, cur_idx, F, nc) : lrg_median_wave_r<16>(pts, cur_idx, F, nc);
+            const float m = nc <= 256 ? lrg_median_wave_r<4>(pts, cur_idx, F, nc)
+                          : nc <= 1024 ? lrg_median_wave_r<16>(pts, cur_idx, F, nc)
+                                       : lrg_median_wave_r64(pts, cur_idx, F, nc);
             if (lane == 0) sh_c[ch] = m;
         }
     } else {

@@ -1617,9 +1617,9 @@ int lrg_step_graph_destroy(void *graph) {
 }
 
 int lrg_stream_create_cu_mask(const uint32_t *mask, int words, void **stream) {
-    if (!mask || words <= 0 || !stream) return LRG_EINVAL - 1;
+    if (!stream || (mask && words <= 0)) return LRG_EINVAL - 1;
     hipStream_t st = nullptr;
-    hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+    hipError_t e = mask ? hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask) : hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (e != hipSuccess) return -(int)e;
     *stream = st;
     return 0;

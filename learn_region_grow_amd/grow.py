@@ -660,35 +660,48 @@ class RegionGrower:
 
 
 def auto_lanes(slots_in_flight):
-    """Lanes pay from about 64 slots in flight (one MI355X, 68 rooms, packed iteration: 1 lane 452 k instance-steps/s, 2 lanes
-    469 k, 3 lanes 489 k; 4 lanes need a fifth hardware queue and fall behind)."""
-    return 3 if slots_in_flight >= 64 else 1
+    """Two lanes from about 64 slots in flight.  At a fixed number of rooms in flight lanes buy little: the loop is a chain of
+    latency-bound launches whose durations hardly depend on the slot count, so halving a lane's slots halves its throughput;
+    what a second lane adds is its fill-in / rebinding in the shadow of the other's iteration (one MI355X, 68 rooms: 1 lane
+    507 k instance-steps/s and 347 rooms/s, 2 lanes 518 k and 357, 3 lanes 499 k and 345 -- two kernels at most run side by
+    side, profiles/r02_stream_overlap.txt)."""
+    return 2 if slots_in_flight >= 64 else 1
 
 
-def lane_streams(device, lanes, cu_partition=None):
-    """-> (torch streams, raw handles to keep alive).  cu_partition (default: on from two lanes): every lane's stream is
-    confined to its own 1/lanes of the compute units (lrg_stream_create_cu_mask).  A lane's launches hold fewer tiles than it has
-    CUs, and the dispatcher starts every launch on the same CUs: without the masks two lanes' tiles double up there while the
-    rest of the chip idles."""
-    if cu_partition is None:
-        cu_partition = lanes > 1
-    if not cu_partition or lanes <= 1:
-        return [torch.cuda.Stream(device=device) for _ in range(lanes)], []
-    lib = _lib.load()
-    ncu = torch.cuda.get_device_properties(device).multi_processor_count
-    words = (ncu + 31) // 32
-    streams, raw = [], []
-    with torch.cuda.device(device):
-        for k in range(lanes):
-            lo, hi = k * ncu // lanes, (k + 1) * ncu // lanes
-            mask = (ctypes.c_uint32 * words)()
-            for b in range(lo, hi):
-                mask[b // 32] |= 1 << (b % 32)
-            h = ctypes.c_void_p()
-            _lib.check(lib.lrg_stream_create_cu_mask(mask, words, ctypes.byref(h)), 'lrg_stream_create_cu_mask')
-            raw.append(h)
-            streams.append(torch.cuda.ExternalStream(h.value, device=device))
-    return streams, raw
+_LANE_STREAMS = {}       # (device index, CU-masked lane count or 0) -> ([torch streams], [raw handles]), one set per process
+
+
+def lane_streams(device, lanes, cu_partition=False):
+    """-> the process-wide streams of lanes 0 .. lanes-1 on `device`.
+
+    One set per process, created once: HIP deals new streams round its hardware queues, and not every pair of queues runs
+    side by side (tools/stream_overlap.hip: two kernels at most are in flight; a second pair of streams created later for the
+    fixed-work leg of bench.py took turns instead: 207 rooms/s against 357 with the first pair reused).
+    cu_partition: every lane's stream confined to its own 1/lanes of the compute units (lrg_stream_create_cu_mask; measured:
+    no gain -- lanes do not compete for CUs -- so off by default)."""
+    device = torch.device(device)
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev_index, lanes if cu_partition and lanes > 1 else 0)
+    streams, raw = _LANE_STREAMS.setdefault(key, ([], []))
+    if key[1] == 0:
+        while len(streams) < lanes:
+            streams.append(torch.cuda.Stream(device=device))
+        return streams[:lanes]
+    if not streams:
+        lib = _lib.load()
+        ncu = torch.cuda.get_device_properties(device).multi_processor_count
+        words = (ncu + 31) // 32
+        with torch.cuda.device(device):
+            for k in range(lanes):
+                lo, hi = k * ncu // lanes, (k + 1) * ncu // lanes
+                mask = (ctypes.c_uint32 * words)()
+                for b in range(lo, hi):
+                    mask[b // 32] |= 1 << (b % 32)
+                h = ctypes.c_void_p()
+                _lib.check(lib.lrg_stream_create_cu_mask(mask, words, ctypes.byref(h)), 'lrg_stream_create_cu_mask')
+                raw.append(h)
+                streams.append(torch.cuda.ExternalStream(h.value, device=device))
+    return streams[:lanes]
 
 
 class LanedRegionGrower:
@@ -699,7 +712,7 @@ class LanedRegionGrower:
     other's network evaluation (+8 % instance-steps/s at 68 rooms on one MI355X).  Rooms are independent and the counter
     random stream is keyed by room id, so results do not depend on the lane count (tests/test_gpu_grow.py)."""
 
-    def __init__(self, net, rooms_in_flight=64, lanes=None, cu_partition=None, **kw):
+    def __init__(self, net, rooms_in_flight=64, lanes=None, cu_partition=False, **kw):
         if kw.get('rng', 'counter') != 'counter':
             raise ValueError("lanes need rng='counter' (the legacy stream is replayed on the host, one iteration at a time)")
         self.net = net
@@ -707,7 +720,7 @@ class LanedRegionGrower:
             lanes = auto_lanes(int(rooms_in_flight) * int(kw.get('restarts', 1)))
         lanes = max(1, min(int(lanes), int(rooms_in_flight)))
         share = [rooms_in_flight // lanes + (1 if k < rooms_in_flight % lanes else 0) for k in range(lanes)]
-        self.streams, self._raw_streams = lane_streams(net.device, lanes, cu_partition)
+        self.streams = lane_streams(net.device, lanes, cu_partition)
         self.growers = []
         for k in range(lanes):
             with torch.cuda.stream(self.streams[k]):
