@@ -474,6 +474,9 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
                                 // always large -- and its duration is set by the largest region, so the small ones ride along
                                 // for free and the front kernel loses its median phase (trace: 8.7 k of 44 k cycles per slot)
 
+#ifndef LRG_QUERY_TRIP
+#define LRG_QUERY_TRIP 4
+#endif
 #define LRG_PVX(p) ((int)((p) & 0x7FFu))
 #define LRG_PVY(p) ((int)(((p) >> 11) & 0x7FFu))
 #define LRG_PVZ(p) ((int)((p) >> 22))
@@ -825,18 +828,22 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         const int lo0 = max(S->mn[0] - 1 - ox, 0), lo1 = max(S->mn[1] - 1 - oy, 0), lo2 = max(S->mn[2] - 1 - oz, 0);     // :222-225
         const int hi0 = S->mx[0] + 1 - ox, hi1 = S->mx[1] + 1 - oy, hi2 = S->mx[2] + 1 - oz;
         const int ilast = (n - 1) & ~3;
-        for (int cb = 0; cb < nchunk; cb += 4) {                 // 16 points per thread per trip: 3 loads per 4 points
-            unsigned cw[4], vw[4];
-            uint4 pw[4];
+        // LRG_QUERY_TRIP chunks per trip (4 points per thread and chunk: 3 loads per 4 points), all loads of a trip in flight
+        // together.  Measured with 8 (one trip up to 32 k points): no change -- the phase grows with the room through the
+        // per-chunk flag / scan / compaction work (11 k cycles up to 10 k points, 24 k above 20 k), not through its round trips.
+        for (int cb = 0; cb < nchunk; cb += LRG_QUERY_TRIP) {
+            unsigned cw[LRG_QUERY_TRIP], vw[LRG_QUERY_TRIP];
+            uint4 pw[LRG_QUERY_TRIP];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < LRG_QUERY_TRIP; ++q) {
+                if (q >= 4 && cb + q >= nchunk) continue;        // small rooms: no loads for chunks they do not have
                 const int i = min((cb + q) * LRG_SCAN_CHUNK + 4 * tid, ilast);
                 cw[q] = *reinterpret_cast<const unsigned *>(cur + i);
                 vw[q] = *reinterpret_cast<const unsigned *>(visited + i);
                 pw[q] = *reinterpret_cast<const uint4 *>(pvox + i);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < LRG_QUERY_TRIP; ++q) {
                 const int c = cb + q;
                 if (c < nchunk) {                               // workgroup-uniform
                     const int ib = c * LRG_SCAN_CHUNK + 4 * tid;
@@ -933,6 +940,10 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         if (tid < 16) a.center[s * 16 + tid] = 0.f;
         lrg_front_gather(S, points, obj, s, F, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
         if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
+        TRACE2(s, 5); TRACE2(s, 6); TRACE2(s, 7);
+#if LRG_TRACE
+        if (tid == 0 && g_lrg_trace2) { g_lrg_trace2[(long)s * 16 + 8] = nc; g_lrg_trace2[(long)s * 16 + 14] = lrg_is_stop(entry_status) || entry_status == LRG_WAIT || (entry_status == LRG_ACTIVE && S->step == 0); }
+#endif
         return;
     }
     if (wave < 9) {                                              // one wavefront per centred channel, keys in registers

@@ -7,21 +7,21 @@ from learn_region_grow_amd import synthetic, workloads, _lib
 from learn_region_grow_amd.lrgnet import LrgNetHIP
 from learn_region_grow_amd.grow import RegionGrower
 dev = torch.device('cuda:0')
-net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev).load_weights(synthetic.make_synthetic_weights(seed=0))
+net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev).load_weights(synthetic.load_trained_weights())
 rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir='/tmp/lrg_cache')
-gr = RegionGrower(net, rooms_in_flight=68, rng='counter', policy='gt')
+gr = RegionGrower(net, rooms_in_flight=68, rng='counter', policy='net')
 gr.load_rooms(rooms)
 for g in range(68): gr.bind(g, g)
 lib = _lib.load()
 tr = torch.zeros(68 * 16, dtype=torch.int64, device=dev)
 lib.lrg_set_trace2.argtypes = [ctypes.c_void_p]
-for it in range(600):
+for it in range(4000):
     gr.enqueue_iteration()
     for g in gr.poll_done():
         r = gr.group_room[g]; gr.reset_room(r); gr.bind(g, r)
 torch.cuda.synchronize()
 lib.lrg_set_trace2(ctypes.c_void_p(tr.data_ptr()))
-names = ['update', 'advance', 'query', 'sample', 'median', 'tags', 'gather']
+names = ['update', 'advance', 'query', 'sample', 'gather', 'tags', 'end']
 rows = []
 n_of = np.array([len(r['points']) for r in rooms])
 worst = []
@@ -42,6 +42,10 @@ rows = np.array(rows, dtype=np.float64)
 print('%d slot-iterations; cycles (p50 / p90 / max)' % len(rows))
 for i, nm in enumerate(names + ['total']):
     print('  %-8s %8d %8d %8d' % (nm, np.median(rows[:, i]), np.percentile(rows[:, i], 90), rows[:, i].max()))
+# the slowest slot of each launch: which phase makes it slow
+slow = []
+per_it = 68
+k = 0
 w = np.array(worst)
 print('per launch: span first-start..last-end p50 %d, slowest workgroup p50 %d cycles' % (np.median(w[:, 0]), np.median(w[:, 1])))
 for lo, hi in ((0, 1024), (1024, 4096), (4096, 1 << 30)):
@@ -55,3 +59,8 @@ for lo, hi in ((0, 10000), (10000, 20000), (20000, 1 << 30)):
 sel = rows[rows[:, 10] > 0]
 if len(sel):
     print('  slots that committed + reseeded: %d samples; ' % len(sel) + ', '.join('%s %d' % (nm, np.median(sel[:, i])) for i, nm in enumerate(names)) + ', total %d' % np.median(sel[:, 7]))
+
+# slowest decile of slot-iterations
+thr = np.percentile(rows[:, 7], 90)
+sel = rows[rows[:, 7] >= thr]
+print('  slowest decile (total >= %d): ' % thr + ', '.join('%s %d' % (nm, np.median(sel[:, i])) for i, nm in enumerate(names)) + '; nc p50 %d, room points p50 %d, committed %.0f %%' % (np.median(sel[:, 9]), np.median(sel[:, 8]), 100 * (sel[:, 10] > 0).mean()))
