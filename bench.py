@@ -345,6 +345,10 @@ def main():
     spath = os.path.join(REPO, 'profiles', 'r02_pmc_sq_loop.json')
     if os.path.exists(spath):
         sq = json.load(open(spath))
+        if in_loop is not None:      # chip-wide matrix-pipe utilisation over the loop's kernels, from the committed SQ counter pass
+            in_loop['mfma_util_chipwide'] = sq.get('mfma_util_chipwide')
+            in_loop['mfma_util_chipwide_source'] = 'profiles/r02_pmc_sq_loop.json (tools/pmc_sq_loop.sh; round 1 by the same definition: %.3f)' % \
+                sq.get('round_1_same_definition', {}).get('mfma_util_chipwide', float('nan'))
 
     # ------------------------------------------------------------------------------------------------------------------
     # fixed-work leg: R room jobs over all ranks, reset -> final labels (grow + fill-in) -> RCCL gather
