@@ -923,6 +923,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         sh_off[0] = oi; sh_off[1] = on;
         a.slot_rows[4 * s + 0] = rin; a.slot_rows[4 * s + 1] = rnb; a.slot_rows[4 * s + 2] = oi; a.slot_rows[4 * s + 3] = on;
         big[2 * s] = is_big ? 1 : 0;
+        if (is_big) big[2 * s + 1] += 1;                 // tag of this iteration's centres (LrgFusedMedians: medians in the branch launch)
     }
     if (mine) {
         const int nn = half ? nc : ne, kk = half ? Ni : Nn;      // (here the first half samples the neighbours, the second the inliers)
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
 // global round trips), two bits per bisection step.  Nothing but the centre is written: the rows were gathered uncentred.
 __global__ __launch_bounds__(1024) void lrg_front_big_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                               LrgFrontArgs a, int32_t *big) {
-    __shared__ int sh[64];
+    __shared__ __attribute__((aligned(16))) int sh[LRG_RADIX_LDS_INTS(1)];
     const int s = blockIdx.x, tid = threadIdx.x;
     if (big[2 * s] == 0) return;
     const long long tickb = a.phase_ticks ? wall_clock64() : 0;
@@ -993,13 +994,15 @@ __global__ __launch_bounds__(1024) void lrg_front_big_kernel(const LrgSlot *slot
         }
         return;
     }
-    if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
-    __syncthreads();
     float m;
-    if (nc <= 4096) m = lrg_median_block_regs<4>(pts, S->cur_idx, F, nc, sh);
-    else if (nc <= 16 * 1024) m = lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh);
-    else if (nc <= LRG_MED_REGS) m = lrg_median_block_regs<48>(pts, S->cur_idx, F, nc, sh);
+    const int chs[1] = {ch};
+    float mm[1];
+    if (nc <= 4096) { lrg_median_block_radix<4, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, mm); m = mm[0]; }
+    else if (nc <= 16 * 1024) { lrg_median_block_radix<16, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, mm); m = mm[0]; }
+    else if (nc <= LRG_MED_REGS) { lrg_median_block_radix<48, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, mm); m = mm[0]; }
     else {
+        if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
+        __syncthreads();
         const int k2 = nc >> 1, k1r = (nc & 1) ? k2 : k2 - 1;
         uint32_t ka, kb;
         lrg_select2(nullptr, false, R->points, S->cur_idx, F, ch, nc, k1r, k2, sh, &ka, &kb);

@@ -1,6 +1,7 @@
 // Internal interface between lrg_net.hip (lrg_forward) and lrg_fused.hip (fused stack kernels).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "lrg_common.h"
 
 #define LRG_FUSED_MAXL 6
 #define LRG_FL_RELU 1
@@ -33,14 +34,35 @@ struct LrgFusedProb {
     const int *row_inst; // [capacity] instance of each packed row
     const float *center; // nullable (packed): [instances,16] per-instance centre; the staged value of row r, column c is
                          // x[r,c] - center[row_inst[r]*16 + c]  (the rows are stored uncentred, test_region_grow.py:243-247 applied here)
+    // medians riding in the same launch (LrgFusedArgs.nmed > 0): the centre of instance i, channel c arrives as the tagged word
+    // ctag[i*16 + c] = (tags[2*i + 1] << 32) | float bits, written by this launch's median workgroups; channels outside cmask
+    // are not centred
+    const unsigned long long *ctag;
+    const int32_t *tags;
+    unsigned cmask;
     long rows;
     int ldx, Kin, rows_per_inst, pool_stride, nlayers, zero_count;
     LrgFusedLayer L[LRG_FUSED_MAXL];
 };
 
+// The nine channel medians of every slot's region (test_region_grow.py:241) computed by the FIRST n_slots * ncentred workgroups
+// of the packed branch launch instead of a launch of their own: they never wait, the tile workgroups behind them (dispatched
+// in order, so every median workgroup is already running or done) pick each centre up as one tagged 64-bit word.
+struct LrgFusedMedians {
+    const LrgSlot *slots;
+    const LrgRoom *rooms;
+    const int32_t *big;          // [n_slots,2]: (rows prepared this iteration, tag) written by lrg_front_greedy_kernel
+    float *center;               // [n_slots,16] plain copy for the next launches (mask update, :271,:275)
+    unsigned long long *ctag;    // [n_slots,16]
+    int64_t *phase_ticks;        // nullable
+    int n_slots, ncentred, F;
+};
+
 struct LrgFusedArgs {
     LrgFusedProb p[2];
     int nprob;           // set by the packed launchers: problems interleaved in a one-dimensional grid
+    int nmed;            // median workgroups in front of the tiles (0: none)
+    LrgFusedMedians med;
 };
 
 int lrg_fused_branches(const LrgFusedArgs &a, int nprob, hipStream_t st);
@@ -48,3 +70,11 @@ int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st);
 // packed-row variants: P.rows = row capacity (multiple of 32), P.nrows / P.row_inst set
 int lrg_fused_branches_packed(const LrgFusedArgs &a, int nprob, hipStream_t st);
 int lrg_fused_heads_packed(const LrgFusedArgs &a, int nprob, hipStream_t st);
+
+int lrg_fused_median_workgroups(int n_slots);       // median workgroups in front of the tiles of a packed branch launch
+
+// lrg_forward_packed with the medians in the branch launch (lrg_net.hip; called by lrg_grow_step_packed)
+int lrg_forward_packed_medians(const LrgWeights *w, const float *x_in, const float *x_nb, const int32_t *row_inst_in,
+                               const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
+                               float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes,
+                               const LrgFusedMedians *med, hipStream_t st);

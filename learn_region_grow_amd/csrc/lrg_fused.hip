@@ -9,6 +9,7 @@
 // parity tests and the "HBM-streamed" roofline figure use.
 #include "lrg_common.h"
 #include "lrg_fused.h"
+#include "lrg_median.h"
 
 #ifndef LRG_TRACE
 #define LRG_TRACE 0     // = CAP0 of the instantiation to trace (4352 / 2176 branch, 8320 head): thread 0 of each workgroup stamps the cycle counter at phase boundaries
@@ -109,11 +110,74 @@ __device__ __forceinline__ void tile_mfma_first(f32x16 (&acc)[RT], const float *
     }
 }
 
+// One median workgroup of the packed branch launch (FTHREADS threads): LRG_MED_SPLIT workgroups per slot, workgroup g taking the
+// centred channels g, g + SPLIT, g + 2 SPLIT, ...  Few workgroups: they sit in front of the tiles in the grid, and every CU slot
+// they hold while the tiles are dealt out is a tile doubled up elsewhere (nine per slot: 56 us instead of 42).
+// Up to 1024 points one wavefront per channel, keys in registers; above, the block bisection channel after channel.  A result
+// goes out twice: plain (centre array, read by later launches) and as a tagged 64-bit word for the tile workgroups of THIS launch
+// (one coherent load gives value and validity together).
+#ifndef LRG_MED_SPLIT
+#define LRG_MED_SPLIT 3
+#endif
+__device__ __forceinline__ void lrg_fused_median_wg(const LrgFusedMedians &M, int id, int *sh) {
+    const int s = id / LRG_MED_SPLIT, g = id - s * LRG_MED_SPLIT, tid = threadIdx.x, wave = tid >> 6;
+    if (M.big[2 * s] == 0) return;                                   // no rows this iteration (idle / finished slot)
+    const long long t0 = M.phase_ticks ? wall_clock64() : 0;
+    const unsigned tag = (unsigned)M.big[2 * s + 1];
+    const LrgSlot *S = &M.slots[s];
+    const LrgRoom *R = &M.rooms[S->room];
+    const int F = M.F, nc = S->nc;
+    const int32_t *idx = S->cur_idx;
+    const float *points = R->points;
+    auto publish = [&](int ch, float m) {
+        M.center[s * 16 + ch] = m;
+        __hip_atomic_store(&M.ctag[s * 16 + ch], ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(m),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (nc <= 1024) {
+        const int y = g + LRG_MED_SPLIT * wave;
+        const int ch = y < M.ncentred ? lrg_centred_channel(y, F) : -1;
+        if (ch >= 0) {
+            const float m = nc <= 256 ? lrg_median_wave_r<4>(points + ch, idx, F, nc) : lrg_median_wave_r<16>(points + ch, idx, F, nc);
+            if ((tid & 63) == 0) publish(ch, m);
+        }
+    } else if (nc <= 16 * FTHREADS && LRG_MED_SPLIT == 3) {
+        // the workgroup's three channels at once (shared index loads and barriers), radix select
+        int chs[3];
+        float m[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const int y = g + 3 * c; chs[c] = y < M.ncentred ? lrg_centred_channel(y, F) : -1; }
+        lrg_median_block_radix<16, FTHREADS, 3>(points, chs, idx, F, nc, sh, m);
+        if (tid < 3 && chs[tid] >= 0) publish(chs[tid], tid == 0 ? m[0] : tid == 1 ? m[1] : m[2]);
+    } else {
+        for (int y = g; y < M.ncentred; y += LRG_MED_SPLIT) {
+            const int ch = lrg_centred_channel(y, F);
+            if (ch < 0) break;
+            __syncthreads();
+            float m;
+            if (nc <= 48 * FTHREADS) {
+                const int chs[1] = {ch};
+                float mm[1];
+                lrg_median_block_radix<48, FTHREADS, 1>(points, chs, idx, F, nc, sh, mm);
+                m = mm[0];
+            } else {
+                const int k2 = nc >> 1, k1 = (nc & 1) ? k2 : k2 - 1;
+                uint32_t ka, kb;
+                lrg_select2(nullptr, false, points, idx, F, ch, nc, k1, k2, sh, &ka, &kb);
+                const float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
+                m = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+            }
+            if (tid == 0) publish(ch, m);
+        }
+    }
+    if (M.phase_ticks && tid == 0 && g == 0) M.phase_ticks[2 * s + 1] += wall_clock64() - t0;
+}
+
 // DIRECT: also compile the register-to-HBM copy of layers that do not stay in LDS (LRG_FWD_KEEP_ACTS on the pooled layer
 // and on an in-place head layer; parity tests only) -- it costs ~25 VGPRs, which is the third wave per SIMD.
 // PACKED: the rows of all instances are stored back to back (only the distinct ones, lrg_front_kernel); a tile is 32
 // consecutive packed rows and may hold rows of several instances -- the runs of equal row_inst inside it.
-template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false>
+template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false, bool MED = false>
 __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFusedArgs args) {
     constexpr int FM = 32 * RT;      // rows (points) per workgroup
     static_assert(!PACKED || RT == 1, "packed rows use 32-row tiles");
@@ -128,6 +192,7 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     int *run_start = reinterpret_cast<int *>(poolbuf + 512);   // PACKED: [FM + 1] first row of each run (and the end)
     int *run_inst = run_start + FM + 1;                        //         [FM] instance of each run, -1 = dead rows past *nrows
     int *run_count = run_inst + FM;                            //         [1]
+    int *row_run = run_count + 1;                              //         [FM] run of each row (medians in the launch)
 
     // PACKED: a one-dimensional grid with the problems (the two branches / the two heads) interleaved -- workgroup j is tile
     // j / nprob of problem j % nprob -- so that the live tiles are the FIRST workgroups of the launch: the dispatcher deals
@@ -137,18 +202,30 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     // The compacted tile lists of lrg_forward_rows are launched the same way.
     // With two problems of t0 and t1 live tiles the first 2 * min(t0, t1) workgroups alternate and the rest of the longer
     // problem follows, so the live tiles are exactly the first t0 + t1 workgroups.
+    int bid = (int)blockIdx.x;
+    if constexpr (PACKED && MED) {
+        // the median workgroups come first in the grid (LrgFusedMedians); an instantiation of its own: their register keys
+        // would cost the plain tile kernels their third and fourth workgroup per CU
+        if (args.nmed > 0) {
+            if (bid < args.nmed) {
+                lrg_fused_median_wg(args.med, bid, reinterpret_cast<int *>(smem));
+                return;
+            }
+            bid -= args.nmed;
+        }
+    }
     const int nprob = args.nprob;                 // > 0: interleaved
-    int prob = nprob > 0 ? (int)(blockIdx.x % nprob) : (int)blockIdx.y;
-    int bx = nprob > 0 ? (int)(blockIdx.x / nprob) : (int)blockIdx.x;
+    int prob = nprob > 0 ? bid % nprob : (int)blockIdx.y;
+    int bx = nprob > 0 ? bid / nprob : (int)blockIdx.x;
     if (nprob == 2) {
         auto live = [&](const LrgFusedProb &Q) {
             return PACKED ? (*Q.nrows + FM - 1) / FM : Q.tile_list ? *Q.tile_count : (int)(Q.rows / FM);
         };
         const int t0 = live(args.p[0]), t1 = live(args.p[1]);
         const int m = t0 < t1 ? t0 : t1;
-        if ((int)blockIdx.x >= 2 * m) {
+        if (bid >= 2 * m) {
             prob = t0 > t1 ? 0 : 1;
-            bx = (int)blockIdx.x - m;
+            bx = bid - m;
             if (bx >= (t0 > t1 ? t0 : t1)) return;
         }
     }
@@ -220,7 +297,56 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     const int Kin = P.Kin;
     const int Kp = (Kin + 7) & ~7;
     const int ld_x = Kp + 4;
-    if ((P.ldx & 3) == 0 && (Kin & 3) == 0 && (((uintptr_t)P.x) & 15) == 0 && !(PACKED && P.center)) {
+    bool runs_done = false;
+    if (PACKED && P.ctag) {
+        // The centres come from this launch's median workgroups.  Runs first (whose centres does the tile need), the raw rows
+        // requested meanwhile, then one coherent load per (run, centred channel) until its tag is this iteration's.
+        constexpr int NE = (FM * 16 + FTHREADS - 1) / FTHREADS;
+        float xv[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * FTHREADS, row = idx / Kp, c = idx - row * Kp;
+            xv[e] = (idx < FM * Kp && c < Kin && r0 + row < nrows_packed) ? P.x[(r0 + row) * P.ldx + c] : 0.f;
+        }
+        if (tid < 64) {
+            const int row = tid & 31;
+            const int mine = (r0 + row < nrows_packed) ? P.row_inst[r0 + row] : -1;
+            const int prev = __shfl_up(mine, 1);
+            const bool start = tid < 32 && (row == 0 || mine != prev);
+            const unsigned long long m = __ballot(start);
+            const int k = __popcll(m & ((2ull << row) - 1ull)) - 1;          // run of this row
+            if (start) { run_start[k] = row; run_inst[k] = mine; }
+            if (tid < 32) row_run[row] = k;
+            if (tid == 0) { const int n = __popcll(m); run_start[n] = FM; *run_count = n; }
+        }
+        __syncthreads();
+        for (int t = tid; t < *run_count * 16; t += FTHREADS) {
+            const int k = t >> 4, c = t & 15;
+            {
+                const int ins = run_inst[k];
+                float cv = 0.f;
+                if (ins >= 0 && (P.cmask >> c & 1u)) {
+                    const unsigned want = (unsigned)P.tags[2 * ins + 1];
+                    unsigned long long v = 0;
+                    for (int spin = 0; spin < (1 << 22); ++spin) {              // (bounded: a lost producer shows as wrong results, not a hang)
+                        v = __hip_atomic_load(&P.ctag[ins * 16 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(v >> 32) == want) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    cv = __uint_as_float((unsigned)v);
+                }
+                poolbuf[t] = cv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * FTHREADS, row = idx / Kp, c = idx - row * Kp;
+            if (idx < FM * Kp)
+                buf1[row * ld_x + c] = (c < Kin && r0 + row < nrows_packed) ? __fsub_rn(xv[e], poolbuf[row_run[row] * 16 + c]) : 0.f;
+        }
+        runs_done = true;
+    } else if ((P.ldx & 3) == 0 && (Kin & 3) == 0 && (((uintptr_t)P.x) & 15) == 0 && !(PACKED && P.center)) {
         const int q = Kp >> 2;
         for (int idx = tid; idx < FM * q; idx += FTHREADS) {
             int row = idx / q, c4 = idx - row * q;
@@ -248,9 +374,9 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
     }
     // poolbuf: running column maxima of a pooled stack, or the final [C,2] layer of a head (C <= 256)
     if (P.fw) { for (int i = tid; i < 2 * P.L[P.nlayers - 1].N; i += FTHREADS) poolbuf[i] = P.fw[i]; }
-    else { for (int i = tid; i < 512; i += FTHREADS) poolbuf[i] = 0.f; }
+    else if (!runs_done) { for (int i = tid; i < 512; i += FTHREADS) poolbuf[i] = 0.f; }      // (PACKED keeps its maxima elsewhere)
     if (tile * FM >= nvalid) return;             // workgroup-uniform
-    if (PACKED && tid < 64) {
+    if (PACKED && !runs_done && tid < 64) {
         // runs of equal instance among the tile's rows (rows past *nrows: instance -1), found by wave 0 with one ballot
         const int row = tid & 31;
         const int mine = (r0 + row < nrows_packed) ? P.row_inst[r0 + row] : -1;
@@ -536,7 +662,7 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
 #endif
 }
 
-template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false>
+template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false, bool MED = false>
 static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     constexpr int FM = 32 * RT;
     long maxrows = 0;
@@ -562,8 +688,8 @@ static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
         if (P.rows > maxrows) maxrows = P.rows;
     }
     if (maxrows == 0) return 0;
-    const size_t lds = (size_t)(CAP0 + CAP1 + 512 + (PACKED ? 2 * FM + 8 : 0)) * sizeof(float);
-    auto kern = lrg_fused_stack_kernel<CAP0, CAP1, RT, FD, OCC, DIRECT, PACKED>;
+    const size_t lds = (size_t)(CAP0 + CAP1 + 512 + (PACKED ? 3 * FM + 8 : 0)) * sizeof(float);
+    auto kern = lrg_fused_stack_kernel<CAP0, CAP1, RT, FD, OCC, DIRECT, PACKED, MED>;
     static bool attr_done[LRG_MAX_DEVICES] = {};      // per instantiation, per device
     const int dev = lrg_current_device();
     if (!attr_done[dev]) {
@@ -576,10 +702,12 @@ static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     if (PACKED || lists) {
         LrgFusedArgs b = a;
         b.nprob = nprob;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM) * nprob), dim3(FTHREADS), lds, st, b);
+        if (!MED) b.nmed = 0;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM) * nprob + (unsigned)b.nmed), dim3(FTHREADS), lds, st, b);
     } else {
         LrgFusedArgs b = a;
         b.nprob = 0;
+        b.nmed = 0;
         hipLaunchKernelGGL(kern, dim3((unsigned)(maxrows / FM), nprob), dim3(FTHREADS), lds, st, b);
     }
     LRG_LAUNCH_CHECK();
@@ -625,9 +753,15 @@ int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st) {
 #ifndef LRG_PACKED_HEAD_FD
 #define LRG_PACKED_HEAD_FD 4
 #endif
+int lrg_fused_median_workgroups(int n_slots) { return n_slots * LRG_MED_SPLIT; }
+
 int lrg_fused_branches_packed(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     // lite 1: conv[1] is the pooled layer itself -- it does not stay in LDS, so its HBM copy (read by the heads) is stored
     // from the accumulators
+    if (a.nmed > 0) {
+        if (needs_direct(a, nprob)) return launch_stack<32 * 68, 32 * 132, 1, 4, 2, true, true, true>(a, nprob, st);
+        return launch_stack<32 * 68, 32 * 132, 1, LRG_PACKED_FD, 2, false, true, true>(a, nprob, st);
+    }
     if (needs_direct(a, nprob)) return launch_stack<32 * 68, 32 * 132, 1, 4, 2, true, true>(a, nprob, st);
     return launch_stack<32 * 68, 32 * 132, 1, LRG_PACKED_FD, LRG_PACKED_OCC, false, true>(a, nprob, st);
 }

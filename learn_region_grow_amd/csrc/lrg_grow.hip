@@ -5,6 +5,8 @@
 // advance in lock-step, one workgroup per slot (or per slot group), all state device-resident.
 #include "lrg_common.h"
 #include "lrg_rng.h"
+#include "lrg_median.h"
+#include "lrg_fused.h"
 
 #define LRG_SCAN_THREADS 1024
 
@@ -589,122 +591,6 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_compact_kernel(LrgSl
 // ------------------------------------------------------------------------------------------------
 #define LRG_MED_SMALL 1024      // lrg_median (stand-alone): up to 16 keys per lane, one wavefront per (slot, channel)
 #define LRG_MED_LARGE 36864     // 144 KB: one workgroup per CU, only launched work for the few big regions
-__device__ __forceinline__ uint32_t lrg_f2key(float f) {
-    uint32_t b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float lrg_key2f(uint32_t k) {
-    uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-    return __uint_as_float(b);
-}
-
-// k-th smallest (0-based) keys for two ranks at once, by bitwise bisection on the key: the answer is the largest r
-// with #(key < r) <= k.  32 counting passes, no atomics, no sorting (regions of 1..10^4 points, test_region_grow.py:241).
-__device__ void lrg_select2(const uint32_t *cache, bool cached, const float *pts, const int32_t *idx, int F, int ch,
-                            int nc, int ka, int kb, int *sh, uint32_t *ra_out, uint32_t *rb_out) {
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int nround = (nc + blockDim.x - 1) / blockDim.x;
-    // The keys of one channel of one region are clustered (coordinates within a room, near-constant normals): their
-    // common high bits cannot discriminate, so find them first (one min/max pass) and bisect only the bits below.
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-    for (int it = 0; it < nround; ++it) {
-        int j = it * blockDim.x + threadIdx.x;
-        if (j < nc) {
-            uint32_t key = cached ? cache[j] : lrg_f2key(pts[(long)idx[j] * F + ch]);
-            kmin = min(kmin, key); kmax = max(kmax, key);
-        }
-    }
-    kmin = lrg_wave_min_u32(kmin);
-    kmax = lrg_wave_max_u32(kmax);
-    if (lrg_lane() == 0) { sh[2 * wave] = (int)kmin; sh[2 * wave + 1] = (int)kmax; }
-    __syncthreads();
-    for (int w = 0; w < nw; ++w) { kmin = min(kmin, (uint32_t)sh[2 * w]); kmax = max(kmax, (uint32_t)sh[2 * w + 1]); }
-    __syncthreads();
-    const uint32_t diff = kmin ^ kmax;
-    const int hb = diff ? 32 - __clz((int)diff) : 0;              // bits [hb,32) are common to every key
-    const uint32_t common = hb >= 32 ? 0u : (kmin >> hb) << hb;
-    uint32_t ra = common, rb = common;
-    for (int bit = hb - 1; bit >= 0; --bit) {
-        const uint32_t ca = ra | (1u << bit), cb = rb | (1u << bit);
-        int cnt_a = 0, cnt_b = 0;
-        for (int it = 0; it < nround; ++it) {
-            int j = it * blockDim.x + threadIdx.x;
-            if (j < nc) {
-                uint32_t key = cached ? cache[j] : lrg_f2key(pts[(long)idx[j] * F + ch]);
-                cnt_a += key < ca ? 1 : 0;
-                cnt_b += key < cb ? 1 : 0;
-            }
-        }
-        cnt_a = lrg_wave_sum_i32(cnt_a);
-        cnt_b = lrg_wave_sum_i32(cnt_b);
-        if (lrg_lane() == 0) { sh[2 * wave] = cnt_a; sh[2 * wave + 1] = cnt_b; }
-        __syncthreads();
-        int ta = 0, tb = 0;
-        for (int w = 0; w < nw; ++w) { ta += sh[2 * w]; tb += sh[2 * w + 1]; }
-        __syncthreads();
-        if (ta <= ka) ra = ca;
-        if (tb <= kb) rb = cb;
-    }
-    *ra_out = ra; *rb_out = rb;
-}
-
-// Bisection select of the two middle ranks over R register keys per lane (padding keys = 0xFFFFFFFF never count):
-// per-lane VALU counters and one DPP wave reduction per step -- no LDS, no barriers, no scalar popcounts.
-template <int R>
-__device__ __forceinline__ float lrg_select_regs(const uint32_t (&key)[R], int nc) {
-    const int lane = lrg_lane();
-    // common high bits of the (clustered) keys cannot discriminate: bisect only below them
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (r * 64 + lane < nc) { kmin = min(kmin, key[r]); kmax = max(kmax, key[r]); }
-    kmin = lrg_wave_min_u32(kmin);
-    kmax = lrg_wave_max_u32(kmax);
-    const uint32_t diff = kmin ^ kmax;
-    const int hb = diff ? 32 - __clz((int)diff) : 0;
-    const uint32_t common = hb >= 32 ? 0u : (kmin >> hb) << hb;
-    // upper median = element of rank k2 = the largest r with #(key < r) <= k2; one compare per key per step
-    const int k2 = nc >> 1;
-    uint32_t rb = common;
-    for (int bit = hb - 1; bit >= 0; --bit) {
-        const uint32_t cb = rb | (1u << bit);
-        int cnt = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) cnt += key[r] < cb ? 1 : 0;        // padding keys (0xFFFFFFFF) never count
-        if (lrg_wave_sum_i32(cnt) <= k2) rb = cb;
-    }
-    float hi = lrg_key2f(rb);
-    if (nc & 1) return hi;
-    // even count: the element of rank k2-1 is rb itself when fewer than k2 keys lie below rb (duplicates of rb span
-    // both ranks), otherwise it is the largest key below rb
-    int below = 0;
-    uint32_t mx = 0u;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (key[r] < rb) { ++below; mx = max(mx, key[r]); }
-    below = lrg_wave_sum_i32(below);
-    mx = lrg_wave_max_u32(mx);
-    float lo = below >= k2 ? lrg_key2f(mx) : hi;
-    return __fmul_rn(__fadd_rn(lo, hi), 0.5f);                          // numpy.mean of the two middle float32 values
-}
-
-// Median of one channel over nc <= 64*R current points by ONE wavefront, keys gathered straight from HBM.
-// All loads are unconditional at clamped positions: predicated loads would each sit in their own branch with a full
-// s_waitcnt behind it (R dependent round trips instead of 2).
-template <int R>
-__device__ __forceinline__ float lrg_median_wave_r(const float *pts, const int32_t *idx, int F, int nc) {
-    const int lane = lrg_lane();
-    uint32_t key[R];
-    {
-        int id[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) id[r] = idx[min(r * 64 + lane, nc - 1)];
-#pragma unroll
-        for (int r = 0; r < R; ++r) key[r] = (r * 64 + lane < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
-    }
-    return lrg_select_regs<R>(key, nc);
-}
-
 __device__ float lrg_median_wave(const float *points, const int32_t *idx, int F, int ch, int nc) {
     const float *pts = points + ch;
     if (nc <= 256) return lrg_median_wave_r<4>(pts, idx, F, nc);       // the common case: the median Area-5 region has 57 points
@@ -820,83 +706,13 @@ __global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const Lrg
     TRACE2(s, 3);
 }
 
-// Larger regions: one 1024-thread workgroup per (slot, channel), KT keys per thread in REGISTERS (two global round
-// trips in all), bisection with per-thread counters, a DPP wave sum and one LDS atomic + one barrier per step.
-template <int KT>
-__device__ __forceinline__ float lrg_median_block_regs(const float *pts, const int32_t *idx, int F, int nc, int *sh) {
-    const int tid = threadIdx.x, lane = lrg_lane();
-    uint32_t key[KT];
-    {
-        int id[KT];
-#pragma unroll
-        for (int r = 0; r < KT; ++r) id[r] = idx[min(r * 1024 + tid, nc - 1)];
-#pragma unroll
-        for (int r = 0; r < KT; ++r) key[r] = (r * 1024 + tid < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
-    }
-    // sh[0] = min, sh[1] = max, sh[2..49] = three counters per bisection step, sh[50] = below-count, sh[51] = max below
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-#pragma unroll
-    for (int r = 0; r < KT; ++r)
-        if (r * 1024 + tid < nc) { kmin = min(kmin, key[r]); kmax = max(kmax, key[r]); }
-    kmin = lrg_wave_min_u32(kmin);
-    kmax = lrg_wave_max_u32(kmax);
-    if (lane == 0) { atomicMin(reinterpret_cast<unsigned *>(&sh[0]), kmin); atomicMax(reinterpret_cast<unsigned *>(&sh[1]), kmax); }
-    __syncthreads();
-    kmin = (uint32_t)sh[0]; kmax = (uint32_t)sh[1];
-    const uint32_t diff = kmin ^ kmax;
-    const int hb = diff ? 32 - __clz((int)diff) : 0;
-    const uint32_t common = hb >= 32 ? 0u : (kmin >> hb) << hb;
-    const int k2 = nc >> 1;
-    uint32_t rb = common;
-    // two bits per step on aligned bit pairs (three thresholds; counts packed 16+16 | 32: a block holds at most 48 Ki keys).
-    // A pair that reaches into the common prefix needs no special case: a threshold that would flip a common bit counts
-    // either every key or the same keys as a lower threshold.  The step cost is the barrier, not the compares.
-    int slot = 2;
-    for (int bit = ((hb + 1) & ~1) - 2; bit >= 0; bit -= 2, slot += 3) {
-        const uint32_t t1 = rb | (1u << bit), t2 = rb | (2u << bit), t3 = rb | (3u << bit);
-        // three counters, each up to 48 Ki: kept apart (packing two into 16 + 16 bits would overflow the low half)
-        int c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-        for (int r = 0; r < KT; ++r) {
-            c1 += key[r] < t1 ? 1 : 0;
-            c2 += key[r] < t2 ? 1 : 0;
-            c3 += key[r] < t3 ? 1 : 0;
-        }
-        c1 = lrg_wave_sum_i32(c1);
-        c2 = lrg_wave_sum_i32(c2);
-        c3 = lrg_wave_sum_i32(c3);
-        if (lane == 0) { if (c1) atomicAdd(&sh[slot], c1); if (c2) atomicAdd(&sh[slot + 1], c2); if (c3) atomicAdd(&sh[slot + 2], c3); }
-        __syncthreads();
-        const int s1 = sh[slot], s2 = sh[slot + 1], s3 = sh[slot + 2];
-        if (s3 <= k2) rb = t3;
-        else if (s2 <= k2) rb = t2;
-        else if (s1 <= k2) rb = t1;
-    }
-    float hi = lrg_key2f(rb);
-    if (nc & 1) return hi;
-    int below = 0;
-    uint32_t mx = 0u;
-#pragma unroll
-    for (int r = 0; r < KT; ++r)
-        if (key[r] < rb) { ++below; mx = max(mx, key[r]); }
-    below = lrg_wave_sum_i32(below);
-    mx = lrg_wave_max_u32(mx);
-    if (lane == 0) { if (below) atomicAdd(&sh[50], below); atomicMax(reinterpret_cast<unsigned *>(&sh[51]), mx); }
-    __syncthreads();
-    float lo = sh[50] >= k2 ? lrg_key2f((uint32_t)sh[51]) : hi;
-    return __fmul_rn(__fadd_rn(lo, hi), 0.5f);
-}
-
 #define LRG_MED_REGS (48 * 1024)   // largest region whose keys fit the registers of one 1024-thread workgroup
-// centred channel of grid row y: 0, 1, 6, 7, ... (:243-247); -1 past the feature count
-__device__ __forceinline__ int lrg_centred_channel(int y, int F) { const int ch = y < 2 ? y : y + 4; return ch < F ? ch : -1; }
-
-// Regions of (min_points, LRG_MED_REGS] points: keys in registers, 160 B of LDS, so the many workgroups that find nothing to
-// do (most slots hold small regions) come and go two per CU instead of queueing for a 147 KB LDS allocation each.
+// Regions of (min_points, LRG_MED_REGS] points: keys in registers, 4 KB of LDS (radix select), so the many workgroups that find
+// nothing to do (most slots hold small regions) come and go two per CU instead of queueing for a 147 KB LDS allocation each.
 __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                                  float *center, int min_points, int32_t *tile_total) {
     if (tile_total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { tile_total[0] = 0; tile_total[1] = 0; }   // lrg_prepare (next launch) fills the lists
-    __shared__ int sh[64];
+    __shared__ __attribute__((aligned(16))) int sh[LRG_RADIX_LDS_INTS(1)];
     const int s = blockIdx.x;
     const LrgSlot *S = &slots[s];
     const int F = prm.feature_size;
@@ -911,13 +727,12 @@ __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *s
         if (threadIdx.x == 0) center[s * 16 + ch] = m;
         return;
     }
-    if (threadIdx.x < 64) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;         // sh[0] = 0xFFFFFFFF (min identity)
-    __syncthreads();
-    const float *pts = R->points + ch;
-    const float med = nc <= 4096 ? lrg_median_block_regs<4>(pts, S->cur_idx, F, nc, sh)
-                    : nc <= 16 * 1024 ? lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh)
-                                      : lrg_median_block_regs<48>(pts, S->cur_idx, F, nc, sh);
-    if (threadIdx.x == 0) center[s * 16 + ch] = med;
+    const int chs[1] = {ch};
+    float med[1];
+    if (nc <= 4096) lrg_median_block_radix<4, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, med);
+    else if (nc <= 16 * 1024) lrg_median_block_radix<16, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, med);
+    else lrg_median_block_radix<48, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, med);
+    if (threadIdx.x == 0) center[s * 16 + ch] = med[0];
 }
 
 // Regions above LRG_MED_REGS points (only rooms that large can hold one: launched when max_points says so)
@@ -1473,8 +1288,16 @@ const float *lrg_packed_rows_center(const LrgGrowParams *params, const LrgPacked
     return (params && b && lrg_uses_greedy_front(params, b)) ? b->center : nullptr;
 }
 
-int lrg_front_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
-                   const LrgWeights *weights, const LrgPackedBuffers *b, void *stream) {
+// Medians of the greedy front in the packed branch launch (LrgFusedMedians) instead of lrg_front_big_kernel: one launch less, but
+// the tiles of the large regions -- the last to start -- then wait for medians computed by 256-thread workgroups with three
+// channels each: branch launch 57.6 us against 41.2 + 8.5 for the two launches (profiles/r02_fused_medians_experiment.txt).
+// Off; build-time switch for A/B measurements.
+#ifndef LRG_FUSE_MEDIANS
+#define LRG_FUSE_MEDIANS 0
+#endif
+
+static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                           const LrgWeights *weights, const LrgPackedBuffers *b, void *stream, bool launch_medians) {
     int rc = check_params(params);
     if (rc) return rc;
     if (!slots || !rooms || !weights || !b || n_slots <= 0 || max_points <= 0) return LRG_EINVAL - 1;
@@ -1504,8 +1327,10 @@ int lrg_front_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         hipLaunchKernelGGL(lrg_front_greedy_kernel, dim3(n_slots), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots, *params, a,
                            b->slot_big);
         LRG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(lrg_front_big_kernel, dim3(n_slots, ncentred), dim3(1024), 0, st, slots, rooms, *params, a, b->slot_big);
-        LRG_LAUNCH_CHECK();
+        if (launch_medians) {
+            hipLaunchKernelGGL(lrg_front_big_kernel, dim3(n_slots, ncentred), dim3(1024), 0, st, slots, rooms, *params, a, b->slot_big);
+            LRG_LAUNCH_CHECK();
+        }
     } else if (params->group_size == 1) {
         hipLaunchKernelGGL(lrg_front_kernel<7>, dim3(n_slots), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots, *params, a);
         LRG_LAUNCH_CHECK();
@@ -1521,10 +1346,28 @@ int lrg_front_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     return 0;
 }
 
+int lrg_front_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                   const LrgWeights *weights, const LrgPackedBuffers *b, void *stream) {
+    return front_step_impl(slots, rooms, n_slots, max_points, params, weights, b, stream, true);
+}
+
 int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                          const LrgWeights *weights, const LrgPackedBuffers *b, void *stream) {
-    int rc = lrg_front_step(slots, rooms, n_slots, max_points, params, weights, b, stream);
+    if (!params || !b) return LRG_EINVAL - 1;
+    const bool fuse = LRG_FUSE_MEDIANS && lrg_uses_greedy_front(params, b);
+    int rc = front_step_impl(slots, rooms, n_slots, max_points, params, weights, b, stream, !fuse);
     if (rc) return rc;
+    if (fuse) {
+        LrgFusedMedians med;
+        med.slots = slots; med.rooms = rooms; med.big = b->slot_big; med.center = b->center; med.ctag = nullptr;
+        med.phase_ticks = b->phase_ticks;
+        med.n_slots = n_slots;
+        med.ncentred = params->feature_size <= 2 ? params->feature_size : params->feature_size <= 6 ? 2 : params->feature_size - 4;
+        med.F = params->feature_size;
+        return lrg_forward_packed_medians(weights, b->x_in, b->x_nb, b->row_slot_in, b->row_slot_nb, b->counters, b->counters + 2, n_slots,
+                                          b->row_cap, b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes, &med,
+                                          (hipStream_t)stream);
+    }
     return lrg_forward_packed(weights, b->x_in, b->x_nb, lrg_packed_rows_center(params, b), b->row_slot_in, b->row_slot_nb, b->counters,
                               b->counters + 2, n_slots, b->row_cap, b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes,
                               LRG_FWD_POOL_ZEROED, stream);

@@ -647,6 +647,7 @@ struct LrgPackedLayout {
     size_t pooled;       // [n_inst, 2*C_last]
     size_t hb[2];        // [n_inst, head_ch[0]] hoisted pooled product of the add / remove head
     size_t packed;       // lrg_pack_weights image when the caller supplies none
+    size_t ctag;         // [n_inst,16] 64-bit tagged centres (LrgFusedMedians), 2 floats each
     size_t total;
     int P;
 };
@@ -666,14 +667,27 @@ static int packed_layout(const LrgWeights *w, int n_inst, int row_cap, LrgPacked
     if (rc) return rc;
     L->packed = off;
     off = lrg_align_up(off + PL.total, 64);
+    L->ctag = off;
+    off = lrg_align_up(off + (size_t)n_inst * 32, 64);
     L->total = off;
+    return 0;
+}
+
+// the shapes the fused kernels are instantiated for (lite 0/1/2), as lrg_forward_rows checks them
+static int packed_shapes(const LrgWeights *w) {
+    const int nc = w->n_conv, nh = w->n_head;
+    for (int i = 0; i < nc; ++i)
+        if (w->conv_ch[i] % 64 != 0 || (i + 1 < nc && w->conv_ch[i] > 128)) return LRG_EINVAL - 7;
+    for (int i = 0; i < nh - 1; ++i)
+        if (w->head_ch[i] % 64 != 0 || w->head_ch[i] > ((i & 1) ? 128 : 256) || ((i & 1) && w->head_ch[i] > 64 && i != nh - 2))
+            return LRG_EINVAL - 7;
     return 0;
 }
 
 static int forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const float *center, const int32_t *row_inst_in,
                           const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
                           float *add_logits, float *rmv_logits, float *ws, const LrgPackedLayout &L, bool pool_zeroed,
-                          hipStream_t st) {
+                          hipStream_t st, const LrgFusedMedians *med = nullptr) {
     const int nc = w->n_conv, nh = w->n_head;
     const int Clast = w->conv_ch[nc - 1];
     if (!pool_zeroed) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)n_inst * L.P * sizeof(float), st));
@@ -693,7 +707,14 @@ static int forward_packed(const LrgWeights *w, const float *x_in, const float *x
             P.ldx = w->feature_size; P.Kin = w->feature_size;
             P.rows = row_cap; P.rows_per_inst = row_cap;
             P.nrows = nrows + br; P.row_inst = br == 0 ? row_inst_in : row_inst_nb;
-            P.center = center;
+            P.center = med ? nullptr : center;
+            if (med) {
+                P.ctag = reinterpret_cast<const unsigned long long *>(ws + L.ctag);
+                P.tags = med->big;
+                unsigned cm = 0;
+                for (int y = 0; y < med->ncentred; ++y) { const int ch = y < 2 ? y : y + 4; if (ch < w->feature_size) cm |= 1u << ch; }
+                P.cmask = cm;
+            }
             P.pool = ws + L.pooled + (br == 0 ? 0 : Clast); P.pool_stride = L.P;
             P.nlayers = nc;
             for (int i = 0; i < nc; ++i) {
@@ -705,6 +726,11 @@ static int forward_packed(const LrgWeights *w, const float *x_in, const float *x
                 F.flags = LRG_FL_RELU | (i + 1 < nc ? LRG_FL_KEEP : LRG_FL_POOL);
                 F.gout = i == 1 ? ws + L.conv1[br] : nullptr;
             }
+        }
+        if (med) {
+            a.med = *med;
+            a.med.ctag = reinterpret_cast<unsigned long long *>(ws + L.ctag);
+            a.nmed = lrg_fused_median_workgroups(med->n_slots);
         }
         int rc = lrg_fused_branches_packed(a, 2, st);
         if (rc) return rc;
@@ -784,18 +810,27 @@ int lrg_forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb
     if (rc) return rc;
     if (!x_in || !x_nb || !row_inst_in || !row_inst_nb || !nrows || !add_logits || !rmv_logits || !workspace) return LRG_EINVAL - 5;
     if (workspace_bytes < L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return LRG_EINVAL - 6;
-    // the shapes the fused kernels are instantiated for (lite 0/1/2), as lrg_forward_rows checks them
-    const int nc = w->n_conv, nh = w->n_head;
-    for (int i = 0; i < nc; ++i)
-        if (w->conv_ch[i] % 64 != 0 || (i + 1 < nc && w->conv_ch[i] > 128)) return LRG_EINVAL - 7;
-    for (int i = 0; i < nh - 1; ++i)
-        if (w->head_ch[i] % 64 != 0 || w->head_ch[i] > ((i & 1) ? 128 : 256) || ((i & 1) && w->head_ch[i] > 64 && i != nh - 2))
-            return LRG_EINVAL - 7;
+    if ((rc = packed_shapes(w))) return rc;
     return forward_packed(w, x_in, x_nb, center, row_inst_in, row_inst_nb, nrows, nrows_heads, n_inst, row_cap, add_logits, rmv_logits,
                           static_cast<float *>(workspace), L, (flags & LRG_FWD_POOL_ZEROED) != 0, (hipStream_t)stream);
 }
 
 }  // extern "C"
+
+int lrg_forward_packed_medians(const LrgWeights *w, const float *x_in, const float *x_nb, const int32_t *row_inst_in,
+                               const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
+                               float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes,
+                               const LrgFusedMedians *med, hipStream_t st) {
+    LrgPackedLayout L;
+    int rc = packed_layout(w, n_inst, row_cap, &L);
+    if (rc) return rc;
+    if (!med || !med->slots || !med->rooms || !med->big || !med->center || med->n_slots != n_inst) return LRG_EINVAL - 5;
+    if (workspace_bytes < L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return LRG_EINVAL - 6;
+    if ((rc = packed_shapes(w))) return rc;
+    return forward_packed(w, x_in, x_nb, nullptr, row_inst_in, row_inst_nb, nrows, nrows_heads, n_inst, row_cap, add_logits, rmv_logits,
+                          static_cast<float *>(workspace), L, true, st, med);
+}
+
 
 extern "C" {
 
