@@ -858,8 +858,13 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
                                 fe |= 1 << kk;                                               // :226-228
                         }
                     }
-                    sh_flags[c * LRG_FRONT_THREADS + tid] = (uint8_t)(fc | (fe << 4));
-                    const int packed = lrg_wave_sum_i32(__popc(fc) | (__popc(fe) << 16));
+                    // a room's points come object after object, so a region and its neighbours sit in few (chunk, wavefront)
+                    // pairs: the empty ones skip the flag store and the reduction here, the scan and the stores below
+                    int packed = 0;
+                    if (__ballot((fc | fe) != 0)) {                                            // (wavefront-uniform)
+                        sh_flags[c * LRG_FRONT_THREADS + tid] = (uint8_t)(fc | (fe << 4));
+                        packed = lrg_wave_sum_i32(__popc(fc) | (__popc(fe) << 16));
+                    }
                     if (lane == 0) sh_tab[c * 16 + wave] = packed;
                 }
             }
@@ -883,6 +888,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         }
         __syncthreads();
         for (int c = 0; c < nchunk; ++c) {
+            if (sh_tab[c * 16 + wave] == 0) continue;
             const int f = sh_flags[c * LRG_FRONT_THREADS + tid];
             const int fc = f & 15, fe = f >> 4;
             const int mine2 = __popc(fc) | (__popc(fe) << 16);

@@ -18,6 +18,3 @@ for r in csv.DictReader(open(f)):
         print('   1 lane  %-70s calls %6s avg %8.1f us' % (r['Name'][:70], r['Calls'], float(r['AverageNs'])/1e3))
 PY
 cd $R
-export LRG_TRACE_WARM=4000
-rm -rf /tmp/trace_repo
-LRG_TRACE_LAYER=4 bash tools/trace_run.sh 2176 68 tools/trace_loop.py 2>&1 | grep -v "amdgpu\|tiles with" | tail -12 | tee gpurun_out/trace9_branch.txt
