@@ -387,8 +387,9 @@ typedef struct LrgPackedBuffers {
     int32_t row_cap;        /* multiple of LRG_ROW_TILE, >= n_slots * max(n_inlier, n_neighbor)                */
     int32_t rooms_have_pvox; /* 1: every room carries pvox (and 16-byte aligned visited / pvox): enables the single-launch greedy
                                 front kernel with word-wide room scans                                          */
-    int32_t *slot_big;      /* nullable with rooms_have_pvox = 0: [n_slots,2] zero-filled scratch (regions above 1024 points get
-                                their medians from a second, (slot, channel)-parallel launch)                     */
+    int32_t *slot_big;      /* nullable with rooms_have_pvox = 0: [n_slots,2] zero-filled ONCE and owned by these buffers for good:
+                                (rows prepared this iteration, running tag of the slot's centres) -- the medians come from a
+                                second, (slot, channel)-parallel launch                                            */
     int64_t *phase_ticks;   /* nullable: [n_slots,2] accumulators of wall_clock64() ticks the slot's workgroup spent in (0) mask
                                 update / stop decision / commit -- the reference's 'inlier' bucket, test_region_grow.py:260-306 --
                                 and (1) box query / median / sampling / gather -- its 'neighbor' bucket, :219-254            */
@@ -396,7 +397,8 @@ typedef struct LrgPackedBuffers {
 
 /* One lock-step iteration, packed rows: lrg_front_kernel (mask update of the previous evaluation :262-288, stop decision
  * :291-306, commit / next seed :186-217, box query :221-235, medians :241, sampling :237-252, gather :242-254) and
- * lrg_forward_packed -- four launches (six with restart groups).  Slot masks (LrgSlot.cur) must be 4-byte aligned;
+ * lrg_forward_packed -- five launches (front, medians, branch stacks, pooled GEMM, head stacks; seven with restart groups).
+ * Slot masks (LrgSlot.cur) must be 4-byte aligned;
  * rooms of up to 131072 points, n_inlier / n_neighbor <= 1024; larger: lrg_grow_step. */
 int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                          const LrgWeights *weights, const LrgPackedBuffers *buffers, void *stream);

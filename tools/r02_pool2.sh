@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 R=$(pwd)
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
-timeout 1200 python -m pytest tests/test_gpu_grow.py tests/test_gpu_fullsize.py -m gpu -q -x --tb=short -p no:cacheprovider 2>&1 | tail -5
+timeout 1200 python -m pytest tests/test_gpu_net.py tests/test_gpu_grow.py tests/test_gpu_fullsize.py tests/test_gpu_configs.py -m gpu -q -x --tb=short -p no:cacheprovider 2>&1 | tail -5
 for L in 1 2; do
   timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --p0-rooms 0 --lanes $L > gpurun_out/pool_bench_l$L.log 2>&1
   echo "lanes $L: $(grep '^{' gpurun_out/pool_bench_l$L.log | tail -1 | cut -c80-330)"
