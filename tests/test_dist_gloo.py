@@ -29,6 +29,11 @@ def _worker(rank, world, port, q):
     labels = [np.arange(sizes[i], dtype=np.int32) + 1000 * i for i in mine]     # stand-in per-room labels
     allrooms = lrg_dist.gather_room_labels(mine, labels, len(sizes))
     ok = all(np.array_equal(allrooms[i], np.arange(sizes[i], dtype=np.int32) + 1000 * i) for i in range(len(sizes)))
+    # the same through the flat device-buffer form the CLI and bench.py use (labels of the rank's rooms back to back)
+    import torch
+    flat = torch.from_numpy(np.concatenate(labels)) if labels else torch.zeros(0, dtype=torch.int32)
+    allflat = lrg_dist.gather_flat_labels(mine, [sizes[i] for i in mine], flat, len(sizes))
+    ok = ok and all(np.array_equal(allflat[i], np.arange(sizes[i], dtype=np.int32) + 1000 * i) for i in range(len(sizes)))
     tot = lrg_dist.allreduce_sum([len(mine), sum(sizes[i] for i in mine)])
     mx = lrg_dist.allreduce_max(float(rank))
     q.put((rank, ok, tot, mx))
@@ -55,5 +60,8 @@ def test_gather_world_size_2_gloo():
 
 
 def test_single_process_gather_is_identity():
+    import torch
     out = lrg_dist.gather_room_labels([1, 0], [np.array([5, 6]), np.array([7])], 3)
+    assert out[0].tolist() == [7] and out[1].tolist() == [5, 6] and out[2] is None
+    out = lrg_dist.gather_flat_labels([1, 0], [2, 1], torch.tensor([5, 6, 7], dtype=torch.int32), 3)
     assert out[0].tolist() == [7] and out[1].tolist() == [5, 6] and out[2] is None
