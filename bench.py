@@ -350,6 +350,12 @@ def main():
             in_loop['mfma_util_chipwide_source'] = 'profiles/r02_pmc_sq_loop.json (tools/pmc_sq_loop.sh; round 1 by the same definition: %.3f)' % \
                 sq.get('round_1_same_definition', {}).get('mfma_util_chipwide', float('nan'))
 
+    lpath = os.path.join(REPO, 'profiles', 'r02_traffic_loop.json')
+    if os.path.exists(lpath) and in_loop is not None:      # HBM bytes of the loop's five launches, from the committed PMC passes
+        lt = json.load(open(lpath))
+        in_loop['hbm_bytes_per_iteration'] = lt.get('hbm_bytes_per_iteration')
+        in_loop['hbm_bytes_source'] = 'profiles/r02_traffic_loop.json (tools/pmc_traffic_loop.sh: FETCH_SIZE / WRITE_SIZE passes, 68 rooms in flight)'
+
     # ------------------------------------------------------------------------------------------------------------------
     # fixed-work leg: R room jobs over all ranks, reset -> final labels (grow + fill-in) -> RCCL gather
     # ------------------------------------------------------------------------------------------------------------------
