@@ -420,9 +420,10 @@ int lrg_step_graph_launch(void *graph, void *stream);
 int lrg_step_graph_destroy(void *graph);
 
 /* A stream whose kernels run only on the compute units set in `mask` (bit i of word i / 32; hipExtStreamCreateWithCUMask).
- * Lanes (slot groups iterating independently on their own streams, the batched scheduler of north_star) get disjoint CU sets:
- * every lane's launches hold fewer tiles than it has CUs, and the dispatcher starts each launch on the same CUs -- without
- * the masks two lanes' tiles double up there while the rest of the chip idles.  mask = NULL: a plain non-blocking stream. */
+ * Meant for lanes (slot groups iterating independently on their own streams, the batched scheduler of north_star) on disjoint CU
+ * sets.  mask = NULL: a plain non-blocking stream.
+ * Measured on one MI355X: no gain at two lanes (lanes do not compete for CUs, profiles/r02_lanes_cu_partition_sweep.txt), and three
+ * masked streams of a spin-kernel microbenchmark did not finish (tools/stream_overlap.hip) -- an option for experiments, off by default. */
 int lrg_stream_create_cu_mask(const uint32_t *mask, int words, void **stream);
 int lrg_stream_destroy(void *stream);
 

@@ -45,8 +45,8 @@ struct LrgFusedProb {
     LrgFusedLayer L[LRG_FUSED_MAXL];
 };
 
-// The nine channel medians of every slot's region (test_region_grow.py:241) computed by the FIRST n_slots * ncentred workgroups
-// of the packed branch launch instead of a launch of their own: they never wait, the tile workgroups behind them (dispatched
+// The nine channel medians of every slot's region (test_region_grow.py:241) computed by the FIRST workgroups (a few per slot,
+// lrg_fused_median_workgroups) of the packed branch launch instead of a launch of their own: they never wait, the tile workgroups behind them (dispatched
 // in order, so every median workgroup is already running or done) pick each centre up as one tagged 64-bit word.
 struct LrgFusedMedians {
     const LrgSlot *slots;
