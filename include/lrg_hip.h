@@ -397,7 +397,8 @@ typedef struct LrgPackedBuffers {
 
 /* One lock-step iteration, packed rows: lrg_front_kernel (mask update of the previous evaluation :262-288, stop decision
  * :291-306, commit / next seed :186-217, box query :221-235, medians :241, sampling :237-252, gather :242-254) and
- * lrg_forward_packed -- five launches (front, medians, branch stacks, pooled GEMM, head stacks; seven with restart groups).
+ * lrg_forward_packed -- five launches (front, medians, branch stacks, pooled GEMM, head stacks; six with restart groups: update,
+ * group commit, query + medians + gather, then the three of the network).
  * Slot masks (LrgSlot.cur) must be 4-byte aligned;
  * rooms of up to 131072 points, n_inlier / n_neighbor <= 1024; larger: lrg_grow_step. */
 int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
