@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define LRG_ABI_VERSION 3
+#define LRG_ABI_VERSION 4
 #define LRG_EINVAL (-1000)
 
 #define LRG_MAX_CONV 5 /* branch layers: lite=0 -> 5, lite=1 -> 2, lite=2 -> 3  (learn_region_grow_util.py:77-85) */
@@ -170,6 +170,18 @@ typedef struct LrgRoom {
     const uint32_t *pvox;    /* nullable: [n] voxels relative to vox_origin packed x | y << 11 | z << 22 (lrg_voxel_pack); the
                                 arrays visited / pvox must then start 16-byte aligned (word-wide loads of 4 points)   */
     int32_t vox_origin[3];   /* per-axis minimum voxel of the room                                           */
+    int32_t chan_stride;     /* floats between two channels of chan_major                                    */
+    const float *chan_major; /* nullable: the centred channels 0, 1, 6 .. F-1 (:243-247) channel-major,
+                                chan_major[y * chan_stride + i] == points[i * F + (y < 2 ? y : y + 4)]: a region's points are
+                                mostly runs of consecutive indices, so the median's keys (:241) come from a few dense lines
+                                instead of one 4-byte word out of every F-float row                          */
+    const int32_t *vgrid;    /* nullable (needs pvox / vox_origin): dense voxel grid of the room, x fastest,
+                                vgrid[((vz - oz) * vgrid_dim[1] + (vy - oy)) * vgrid_dim[0] + (vx - ox)] = index of the point in
+                                that voxel or -1 (lrg_voxel_grid_build).  The box query of a region (:221-229) then reads the cells
+                                of its dilated box -- rows of consecutive ints -- instead of every point of the room, and a voxel
+                                lookup (:273-287) is one load instead of a probe chain: 4 bytes per voxel of the room's bounding
+                                box, a few MB per room out of 288 GB                                          */
+    int32_t vgrid_dim[3];    /* voxels per axis of the room's bounding box                                   */
     int32_t pad2;
 } LrgRoom;
 
@@ -242,6 +254,10 @@ int lrg_voxelize(const float *points, int n, int F, float resolution, int32_t *v
  * bounding-box passes of lrg_grow_step_packed.  (ox, oy, oz) = the per-axis minimum voxel; the room must span at most
  * 2048 x 2048 x 1024 voxels (the caller checks; out-of-range coordinates are clamped and set *overflow_flag, device int). */
 int lrg_voxel_pack(const int32_t *voxels, int n, int ox, int oy, int oz, uint32_t *pvox, int32_t *overflow_flag, void *stream);
+
+/* Dense voxel grid of a room (LrgRoom.vgrid): grid[gx * gy * gz] (x fastest) is filled with -1 and receives the index of the
+ * point of each occupied voxel; (ox, oy, oz) = the per-axis minimum voxel, (gx, gy, gz) = the extent of the bounding box. */
+int lrg_voxel_grid_build(const int32_t *voxels, int n, int ox, int oy, int oz, int gx, int gy, int gz, int32_t *grid, void *stream);
 
 /* Build the room's voxel -> point-index table (replaces the tuple sets of :273,:277,:283-286).
  * keys must hold hash_mask+1 entries; *dup_flag (device int, zeroed by the caller) is set when two points
@@ -375,8 +391,11 @@ typedef struct LrgPackedBuffers {
     float *x_nb;            /* [row_cap,F] packed distinct neighbour rows (:243-244,:253)                    */
     int32_t *row_slot_in;   /* [row_cap] slot of each packed row                                             */
     int32_t *row_slot_nb;
-    uint8_t *gt_in;         /* [row_cap] input_remove of the row's point (:248)                              */
-    uint8_t *gt_nb;         /* [row_cap] input_add (:254)                                                    */
+    float *upd_in;          /* [n_slots,n_inlier,4]   per slot, for its distinct inlier rows j: columns 0..2 of the packed row and
+                                input_remove of its point (:248) as 0.0 / 1.0 -- what the NEXT mask update (:262-288) needs of
+                                the row, in storage of the slot's own (16-byte aligned).  The packed arrays are allocated from row 0
+                                again by every launch: a slot whose workgroup starts late must not look for last iteration's rows there */
+    float *upd_nb;          /* [n_slots,n_neighbor,4] the same for the neighbour rows and input_add (:254)    */
     float *rmv_logits;      /* [row_cap,2] per packed inlier row                                             */
     float *add_logits;      /* [row_cap,2] per packed neighbour row                                          */
     int32_t *slot_rows;     /* [n_slots,4] rows_in, rows_nb, first packed inlier row, first packed neighbour row */

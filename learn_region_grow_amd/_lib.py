@@ -43,6 +43,7 @@ class LrgRoom(ctypes.Structure):
                 ('n', ctypes.c_int32), ('hash_mask', ctypes.c_int32), ('next_cluster_id', ctypes.c_int32),
                 ('seed_cursor', ctypes.c_int32), ('n_regions', ctypes.c_int32), ('done', ctypes.c_int32),
                 ('room_id', ctypes.c_int32), ('pad', ctypes.c_int32), ('pvox', _fp), ('vox_origin', ctypes.c_int32 * 3),
+                ('chan_stride', ctypes.c_int32), ('chan_major', _fp), ('vgrid', _fp), ('vgrid_dim', ctypes.c_int32 * 3),
                 ('pad2', ctypes.c_int32)]
 
 
@@ -78,7 +79,7 @@ class LrgStepBuffers(ctypes.Structure):
 
 class LrgPackedBuffers(ctypes.Structure):
     _fields_ = [('center', _fp), ('sample_in', _fp), ('sample_nb', _fp), ('x_in', _fp), ('x_nb', _fp),
-                ('row_slot_in', _fp), ('row_slot_nb', _fp), ('gt_in', _fp), ('gt_nb', _fp), ('rmv_logits', _fp),
+                ('row_slot_in', _fp), ('row_slot_nb', _fp), ('upd_in', _fp), ('upd_nb', _fp), ('rmv_logits', _fp),
                 ('add_logits', _fp), ('slot_rows', _fp), ('counters', _fp), ('workspace', _fp),
                 ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('row_cap', ctypes.c_int32), ('rooms_have_pvox', ctypes.c_int32), ('slot_big', _fp), ('phase_ticks', _fp)]
 
@@ -97,6 +98,8 @@ LRG_PACKED_MAX_POINTS = 32 * 4096      # lrg_grow_step_packed: rooms up to 13107
 LRG_PACKED_AUTO_POINTS = 65536         # ... chosen by default up to this size: its front kernel walks a room with ONE workgroup per
                                        # slot, which loses to the chunk-parallel scans of lrg_grow_step on 100 k-point scenes (KITTI shape:
                                        # 41 k vs 57 k instance-steps/s, profiles/r02_kitti_*)
+LRG_VGRID_MAX_CELLS = 1 << 26          # dense voxel grid of a room (LrgRoom.vgrid): at most 64 M cells (256 MB) per room ...
+LRG_VGRID_TOTAL_CELLS = 1 << 31        # ... and 8 GB for the rooms of one grower
 LRG_DONE_RING = 1020
 LRG_STATS_WORDS = 4 + LRG_DONE_RING
 
@@ -144,6 +147,7 @@ _SIGS = {
     'lrg_voxelize': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _fp, _fp]),
     'lrg_bind_group': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     'lrg_voxel_pack': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
+    'lrg_voxel_grid_build': (ctypes.c_int, [_fp] + [ctypes.c_int] * 7 + [_fp, _fp]),
     'lrg_voxel_hash_build': (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, _fp]),
     'lrg_bbox_stop': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp]),
     'lrg_advance': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.POINTER(LrgGrowParams), _fp, _fp]),
@@ -222,7 +226,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lrg_abi_version() != 3:
+    if lib.lrg_abi_version() != 4:
         raise LrgHipError('ABI version mismatch')
     for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LrgBeamGroup)):
         if lib.lrg_struct_size(which) != ctypes.sizeof(st):

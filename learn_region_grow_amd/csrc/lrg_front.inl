@@ -25,7 +25,11 @@ struct LrgFrontArgs {
     int32_t *sample_in, *sample_nb;
     float *x_in, *x_nb;
     int32_t *row_slot_in, *row_slot_nb;
-    uint8_t *gt_in, *gt_nb;
+    float4 *upd_in, *upd_nb; // [n_slots, n_inlier] / [n_slots, n_neighbor]: (x, y, z as stored in the packed row, ground-truth flag) of the
+                             // slot's distinct rows -- what the NEXT mask update needs of them, in storage of the slot's own.  The packed
+                             // arrays are re-allocated from row 0 by every launch: a workgroup that starts late (the chip busy with
+                             // another lane's kernels) would find its rows of the last iteration overwritten by the slots that are
+                             // already gathering.
     const float *rmv_logits, *add_logits;
     int32_t *slot_rows;      // [n_slots,4]: rows_in, rows_nb, first packed inlier row, first packed neighbour row
     int32_t *counters;       // [0] packed inlier rows, [1] packed neighbour rows allocated so far in this iteration
@@ -55,20 +59,21 @@ __device__ void lrg_front_update(LrgSlot *S, const LrgRoom *R, int s, const LrgG
     __syncthreads();
     // ---- add pass (:266,:270-273,:283-285): sample slot j draws for itself, its logits / coordinates are its source row's ----
     for (int j = tid; j < Nn; j += bd) {
-        const long row = offn + (ne < Nn ? a.sample_nb[(long)s * Nn + j] : j);
-        if ((a.add_logits[2 * row + 1] > a.add_logits[2 * row] ? 1 : 0) == (a.gt_nb[row] != 0 ? 1 : 0)) atomicAdd(&sh_acc[0], 1);   // add_acc
+        const int srow = ne < Nn ? a.sample_nb[(long)s * Nn + j] : j;
+        const long row = offn + srow;
+        const float4 u = a.upd_nb[(long)s * Nn + srow];
+        if ((a.add_logits[2 * row + 1] > a.add_logits[2 * row] ? 1 : 0) == (u.w != 0.f ? 1 : 0)) atomicAdd(&sh_acc[0], 1);   // add_acc
         bool take;
-        if (prm.policy == 2) take = a.gt_nb[row] != 0;
+        if (prm.policy == 2) take = u.w != 0.f;
         else {
             const float conf = lrg_conf(a.add_logits + 2 * row);
             if (prm.policy == 1) take = conf > 0.5f;
             else take = lrg_uniform01(lrg_rng_word((uint32_t)j, LRG_PURPOSE_ADD, seed, restart, step, k0, k1)) < conf;
         }
         if (take) {
-            const float *p = a.x_nb + row * F;
-            const int vx = lrg_voxel_of(__fadd_rn(p[0], c0), res);      // :271-272: un-centre x,y then rint(/res)
-            const int vy = lrg_voxel_of(__fadd_rn(p[1], c1), res);
-            const int vz = lrg_voxel_of(p[2], res);
+            const int vx = lrg_voxel_of(__fadd_rn(u.x, c0), res);       // :271-272: un-centre x,y then rint(/res)
+            const int vy = lrg_voxel_of(__fadd_rn(u.y, c1), res);
+            const int vz = lrg_voxel_of(u.z, res);
             const int idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(vx, vy, vz));
             if (idx >= 0) {
                 // several sample slots may name the same point: the word-wide atomic elects the one that switches it on
@@ -81,20 +86,21 @@ __device__ void lrg_front_update(LrgSlot *S, const LrgRoom *R, int s, const LrgG
     __syncthreads();
     // ---- remove pass (:267,:274-277,:286-287) ----
     for (int j = tid; j < Ni; j += bd) {
-        const long row = offi + (nc < Ni ? a.sample_in[(long)s * Ni + j] : j);
-        if ((a.rmv_logits[2 * row + 1] > a.rmv_logits[2 * row] ? 1 : 0) == (a.gt_in[row] != 0 ? 1 : 0)) atomicAdd(&sh_acc[1], 1);   // remove_acc
+        const int srow = nc < Ni ? a.sample_in[(long)s * Ni + j] : j;
+        const long row = offi + srow;
+        const float4 u = a.upd_in[(long)s * Ni + srow];
+        if ((a.rmv_logits[2 * row + 1] > a.rmv_logits[2 * row] ? 1 : 0) == (u.w != 0.f ? 1 : 0)) atomicAdd(&sh_acc[1], 1);   // remove_acc
         bool take;
-        if (prm.policy == 2) take = a.gt_in[row] != 0;
+        if (prm.policy == 2) take = u.w != 0.f;
         else {
             const float conf = lrg_conf(a.rmv_logits + 2 * row);
             if (prm.policy == 1) take = conf > 0.5f;
             else take = lrg_uniform01(lrg_rng_word((uint32_t)j, LRG_PURPOSE_RMV, seed, restart, step, k0, k1)) < conf;
         }
         if (take) {
-            const float *p = a.x_in + row * F;
-            const int vx = lrg_voxel_of(__fadd_rn(p[0], c0), res);
-            const int vy = lrg_voxel_of(__fadd_rn(p[1], c1), res);
-            const int vz = lrg_voxel_of(p[2], res);
+            const int vx = lrg_voxel_of(__fadd_rn(u.x, c0), res);
+            const int vy = lrg_voxel_of(__fadd_rn(u.y, c1), res);
+            const int vz = lrg_voxel_of(u.z, res);
             const int idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(vx, vy, vz));
             if (idx >= 0) cur[idx] = 0;
         }
@@ -168,14 +174,15 @@ __device__ void lrg_front_ml_score(LrgSlot *S, const LrgRoom *R, int s, const Lr
         float conf = 0.f;
         bool take = false;
         if (have) {
-            const long row = off + (nside < N ? (side ? a.sample_in : a.sample_nb)[(long)s * N + tid] : tid);
+            const int srow = nside < N ? (side ? a.sample_in : a.sample_nb)[(long)s * N + tid] : tid;
+            const long row = off + srow;
+            const float4 u = (side ? a.upd_in : a.upd_nb)[(long)s * N + srow];
             conf = lrg_conf((side ? a.rmv_logits : a.add_logits) + 2 * row);
-            if (prm.policy == 2) take = (side ? a.gt_in : a.gt_nb)[row] != 0;
+            if (prm.policy == 2) take = u.w != 0.f;
             else if (prm.policy == 1) take = conf > 0.5f;
             else take = lrg_uniform01(lrg_rng_word((uint32_t)tid, side ? LRG_PURPOSE_RMV : LRG_PURPOSE_ADD, seed, restart, step, k0, k1)) < conf;
-            const float *p = (side ? a.x_in : a.x_nb) + row * F;
-            key = lrg_pack_voxel(lrg_voxel_of(__fadd_rn(p[0], c0), prm.resolution), lrg_voxel_of(__fadd_rn(p[1], c1), prm.resolution),
-                                 lrg_voxel_of(p[2], prm.resolution));
+            key = lrg_pack_voxel(lrg_voxel_of(__fadd_rn(u.x, c0), prm.resolution), lrg_voxel_of(__fadd_rn(u.y, c1), prm.resolution),
+                                 lrg_voxel_of(u.z, prm.resolution));
         }
         sh_key[tid] = (have && take) ? key : LRG_HASH_EMPTY;
         __syncthreads();
@@ -337,10 +344,10 @@ __device__ void lrg_front_prepare(const LrgSlot *S, const LrgRoom *R, int s, con
         if (wave < 9) {
             const int ch = lrg_centred_channel(wave, F);
             if (ch >= 0) {
-                const float *pts = points + ch;
-                const float m = nc <= 256 ? lrg_median_wave_r<4>(pts, S->cur_idx, F, nc)
-                              : nc <= 1024 ? lrg_median_wave_r<16>(pts, S->cur_idx, F, nc)
-                                           : lrg_median_wave_r64(pts, S->cur_idx, F, nc);
+                const LrgChanSrc cs = lrg_chan_src(R, wave, ch, F);
+                const float m = nc <= 256 ? lrg_median_wave_r<4>(cs.base, S->cur_idx, cs.stride, nc)
+                              : nc <= 1024 ? lrg_median_wave_r<16>(cs.base, S->cur_idx, cs.stride, nc)
+                                           : lrg_median_wave_r64(cs.base, S->cur_idx, cs.stride, nc);
                 if (lane == 0) sh_c[ch] = m;
             }
         }
@@ -351,14 +358,14 @@ __device__ void lrg_front_prepare(const LrgSlot *S, const LrgRoom *R, int s, con
             __syncthreads();
             if (tid < 64) sh_med[tid] = tid == 0 ? -1 : 0;
             __syncthreads();
-            const float *pts = points + ch;
+            const LrgChanSrc cs = lrg_chan_src(R, y, ch, F);
             float m;
-            if (nc <= 16 * 1024) m = lrg_median_block_regs<16>(pts, S->cur_idx, F, nc, sh_med);
-            else if (nc <= LRG_MED_REGS) m = lrg_median_block_regs<48>(pts, S->cur_idx, F, nc, sh_med);
+            if (nc <= 16 * 1024) m = lrg_median_block_regs<16>(cs.base, S->cur_idx, cs.stride, nc, sh_med);
+            else if (nc <= LRG_MED_REGS) m = lrg_median_block_regs<48>(cs.base, S->cur_idx, cs.stride, nc, sh_med);
             else {
                 const int k2 = nc >> 1, k1r = (nc & 1) ? k2 : k2 - 1;
                 uint32_t ka, kb;
-                lrg_select2(nullptr, false, points, S->cur_idx, F, ch, nc, k1r, k2, sh_med, &ka, &kb);
+                lrg_select2(nullptr, false, cs.base, S->cur_idx, cs.stride, 0, nc, k1r, k2, sh_med, &ka, &kb);
                 const float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
                 m = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
             }
@@ -371,32 +378,40 @@ __device__ void lrg_front_prepare(const LrgSlot *S, const LrgRoom *R, int s, con
     const int offi = sh_off[0], offn = sh_off[1];
     // ---- per-row tags: owning slot and the ground-truth flags input_remove / input_add (:230-231,:248,:254) ----
     const int target = S->target;
+    // (and the slot's own copy of what the next update needs of each row: its first three columns as stored -- centred -- and the flag)
+    // (columns 0..2 follow from the gather loop below)
     for (int j = tid; j < rin; j += bd) {
         a.row_slot_in[offi + j] = s;
-        a.gt_in[offi + j] = obj ? (uint8_t)(obj[sh_src[0][j]] != target) : 0;
+        reinterpret_cast<float *>(a.upd_in)[((long)s * Ni + j) * 4 + 3] = (obj && obj[sh_src[0][j]] != target) ? 1.f : 0.f;
     }
     for (int j = tid; j < rnb; j += bd) {
         a.row_slot_nb[offn + j] = s;
-        a.gt_nb[offn + j] = obj ? (uint8_t)(obj[sh_src[1][j]] == target) : 0;
+        reinterpret_cast<float *>(a.upd_nb)[((long)s * Nn + j) * 4 + 3] = (obj && obj[sh_src[1][j]] == target) ? 1.f : 0.f;
     }
     TRACE2(s, 6);
     // ---- gather + centre (:242-254), element-wise so that loads and stores of a row are contiguous across lanes ----
     for (int side = 0; side < 2; ++side) {
         const int k = side ? rnb : rin;
         float *out = side ? a.x_nb + (long)offn * F : a.x_in + (long)offi * F;
+        float *upd = reinterpret_cast<float *>(side ? a.upd_nb : a.upd_in) + (long)s * (side ? Nn : Ni) * 4;
         const int nel = k * F;
         for (int e0 = tid; e0 < nel; e0 += 8 * bd) {       // 8 independent row loads in flight per thread
             float v[8];
+            int jf[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = min(e0 + u * bd, nel - 1);
                 const int j = e / F, f = e - j * F;
+                jf[u] = f < 3 ? 4 * j + f : -1;
                 v[u] = __fsub_rn(points[(long)sh_src[side][j] * F + f], sh_c[f]);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = e0 + u * bd;
-                if (e < nel) out[e] = v[u];
+                if (e < nel) {
+                    out[e] = v[u];
+                    if (jf[u] >= 0) upd[jf[u]] = v[u];     // the slot's own copy of columns 0..2 for the next update
+                }
             }
         }
     }
@@ -485,40 +500,75 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
 // (first, nthreads): the threads [first, first + nthreads) of the workgroup do the work, so that other wavefronts can compute
 // the medians meanwhile.  The rows are stored UNCENTRED: the branch kernels subtract the centre while staging them
 // (lrg_forward_packed, `center`), the next update re-derives the centred value -- so the gather does not wait for the medians.
-__device__ __forceinline__ void lrg_front_gather(const LrgSlot *S, const float *points, const int32_t *obj, int s, int F,
+__device__ __forceinline__ void lrg_front_gather(const LrgSlot *S, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
                                                  const LrgFrontArgs &a, const int (*sh_src)[512], int rin,
                                                  int rnb, int offi, int offn, int first, int nthreads) {
     const int tid = (int)threadIdx.x - first, bd = nthreads;
     if (tid < 0 || tid >= nthreads) return;
     const int target = S->target;
+    // (and the slot's own copy of what the next update needs of each row: x, y, z as stored -- uncentred -- and the flag)
+    // (x, y, z follow from the gather loop below)
     for (int j = tid; j < rin; j += bd) {
         a.row_slot_in[offi + j] = s;
-        a.gt_in[offi + j] = obj ? (uint8_t)(obj[sh_src[0][j]] != target) : 0;              // :231,:248
+        reinterpret_cast<float *>(a.upd_in)[((long)s * ni + j) * 4 + 3] = (obj && obj[sh_src[0][j]] != target) ? 1.f : 0.f;   // :231,:248
     }
     for (int j = tid; j < rnb; j += bd) {
         a.row_slot_nb[offn + j] = s;
-        a.gt_nb[offn + j] = obj ? (uint8_t)(obj[sh_src[1][j]] == target) : 0;              // :230,:254
+        reinterpret_cast<float *>(a.upd_nb)[((long)s * nn + j) * 4 + 3] = (obj && obj[sh_src[1][j]] == target) ? 1.f : 0.f;   // :230,:254
     }
     for (int side = 0; side < 2; ++side) {
         const int k = side ? rnb : rin;
         float *out = side ? a.x_nb + (long)offn * F : a.x_in + (long)offi * F;
+        float *upd = reinterpret_cast<float *>(side ? a.upd_nb : a.upd_in) + (long)s * (side ? nn : ni) * 4;
         const int nel = k * F;
         for (int e0 = tid; e0 < nel; e0 += 8 * bd) {       // 8 independent row loads in flight per thread
             float v[8];
+            int jf[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = min(e0 + u * bd, nel - 1);
                 const int j = e / F, f = e - j * F;
+                jf[u] = f < 3 ? 4 * j + f : -1;
                 v[u] = points[(long)sh_src[side][j] * F + f];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = e0 + u * bd;
-                if (e < nel) out[e] = v[u];
+                if (e < nel) {
+                    out[e] = v[u];
+                    if (jf[u] >= 0) upd[jf[u]] = v[u];     // the slot's own copy of x, y, z for the next update
+                }
             }
         }
     }
 }
+
+// voxel -> point index: one load from the room's dense grid when it has one, else the probe chain of the hash table
+struct LrgVoxIndex {
+    const int32_t *grid;
+    int gx, gy, gz, ox, oy, oz;
+    const uint64_t *hkeys;
+    const int32_t *hvals;
+    int hmask;
+};
+__device__ __forceinline__ int lrg_voxel_index(const LrgVoxIndex &I, int vx, int vy, int vz) {
+    if (I.grid) {
+        const int x = vx - I.ox, y = vy - I.oy, z = vz - I.oz;
+        if ((unsigned)x >= (unsigned)I.gx || (unsigned)y >= (unsigned)I.gy || (unsigned)z >= (unsigned)I.gz) return -1;
+        return I.grid[((long)z * I.gy + y) * I.gx + x];
+    }
+    return lrg_hash_lookup(I.hkeys, I.hvals, I.hmask, lrg_pack_voxel(vx, vy, vz));
+}
+// v / d for 0 <= v < 2^23, d >= 1 with rcp = 1.0f / d: float estimate, one correction step either way
+__device__ __forceinline__ int lrg_div_small(int v, int d, float rcp) {
+    int q = (int)(((float)v + 0.5f) * rcp);
+    if (q * d > v) --q;
+    else if ((q + 1) * d <= v) ++q;
+    return q;
+}
+#ifndef LRG_GRID_QUERY_CELLS
+#define LRG_GRID_QUERY_CELLS (16 * LRG_FRONT_THREADS)   // dilated boxes up to this many voxels are answered from the grid
+#endif
 
 __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
                                                                               LrgGrowParams prm, LrgFrontArgs a, int32_t *big) {
@@ -529,7 +579,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     __shared__ int red[16 * 8];
     __shared__ int sh_i[8];                // 0 updated, 1 added count, 2 status, 3 seed-search minimum, 4 probe count, 5 add_acc, 6 remove_acc
     __shared__ int sh_list[32];
-    __shared__ int wt_c[8], wt_e[8];
+    __shared__ int wt_c[16], wt_e[16];   // (the grid query scans over all 16 wavefronts)
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     LrgSlot *S = &slots[s];
     const int F = prm.feature_size, Ni = prm.n_inlier, Nn = prm.n_neighbor;
@@ -559,6 +609,10 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     const uint32_t *pvox = R->pvox;
     uint8_t *visited = R->visited;
     const int ox = R->vox_origin[0], oy = R->vox_origin[1], oz = R->vox_origin[2];
+    LrgVoxIndex VI;
+    VI.grid = R->vgrid; VI.gx = R->vgrid_dim[0]; VI.gy = R->vgrid_dim[1]; VI.gz = R->vgrid_dim[2];
+    VI.ox = ox; VI.oy = oy; VI.oz = oz;
+    VI.hkeys = R->hash_keys; VI.hvals = R->hash_vals; VI.hmask = R->hash_mask;
     const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
     const int entry_status = status;
     TRACE2(s, 0);
@@ -573,14 +627,15 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
 #pragma unroll
         for (int k = 0; k < 4; ++k) id0[k] = cur_idx[min(tid + k * LRG_FRONT_THREADS, nc0 - 1)];
         const int nside = half ? nc0 : ne0, Nside = half ? Ni : Nn;
-        const long row = (half ? rows_off_in : rows_off_nb) + (nside < Nside ? sj : j);      // a padded slot reads its source row
+        const int srow = nside < Nside ? sj : j;                                              // a padded slot reads its source row
+        const long row = (half ? rows_off_in : rows_off_nb) + srow;
         int idx = -1;
         int correct = 0;
         if (mine) {
-            const float *p = (half ? a.x_in : a.x_nb) + row * F;
-            const float px = p[0], py = p[1], pz = p[2];
+            const float4 u = (half ? a.upd_in : a.upd_nb)[(long)s * Nside + srow];
+            const float px = u.x, py = u.y, pz = u.z;
             const float *lg = (half ? a.rmv_logits : a.add_logits) + 2 * row;
-            const int gtf = (half ? a.gt_in : a.gt_nb)[row] != 0;
+            const int gtf = u.w != 0.f;
             correct = (lg[1] > lg[0] ? 1 : 0) == gtf;                                        // add_acc / remove_acc (util:174-180)
             bool take;
             if (prm.policy == 2) take = gtf != 0;                                            // :268-269
@@ -596,7 +651,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
                 const int vx = lrg_voxel_of(__fadd_rn(__fsub_rn(px, c0), c0), prm.resolution);   // :271-272 / :275-276
                 const int vy = lrg_voxel_of(__fadd_rn(__fsub_rn(py, c1), c1), prm.resolution);
                 const int vz = lrg_voxel_of(pz, prm.resolution);
-                idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(vx, vy, vz));
+                idx = lrg_voxel_index(VI, vx, vy, vz);
             }
         }
 #pragma unroll
@@ -757,7 +812,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
                 if (tid < 27 && tid != 13) {
                     const int dx = tid / 9 - 1, dy = (tid / 3) % 3 - 1, dz = tid % 3 - 1;
                     const int32_t *v = R->voxels + 3 * (long)sd;
-                    idx = lrg_hash_lookup(R->hash_keys, R->hash_vals, R->hash_mask, lrg_pack_voxel(v[0] + dx, v[1] + dy, v[2] + dz));
+                    idx = lrg_voxel_index(VI, v[0] + dx, v[1] + dy, v[2] + dz);
                     if (idx >= 0 && (visited[idx] || idx == sd)) idx = -1;
                 }
                 int rank = 0, total = 0;
@@ -828,6 +883,73 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         const int lo0 = max(S->mn[0] - 1 - ox, 0), lo1 = max(S->mn[1] - 1 - oy, 0), lo2 = max(S->mn[2] - 1 - oz, 0);     // :222-225
         const int hi0 = S->mx[0] + 1 - ox, hi1 = S->mx[1] + 1 - oy, hi2 = S->mx[2] + 1 - oz;
         const int ilast = (n - 1) & ~3;
+        int totc = 0, tote = 0;
+        // A box of up to LRG_GRID_QUERY_CELLS voxels is answered from the room's dense voxel grid: the cells of the box (rows of
+        // consecutive ints along x: one round trip), the mask and visited bytes of the points found (a second one), two bitmaps
+        // over the room's indices in LDS, and the ordered lists from their popcounts -- O(box) instead of O(room), and the same
+        // lists: every point of the mask lies inside its bounding box, every candidate inside the dilated one (:221-229).
+        const int g0 = min(hi0, VI.gx - 1), g1 = min(hi1, VI.gy - 1), g2 = min(hi2, VI.gz - 1);
+        const int bx = g0 - lo0 + 1, by = g1 - lo1 + 1, bz = g2 - lo2 + 1;
+        const bool by_grid = VI.grid && bx > 0 && by > 0 && bz > 0 && (long)bx * by * bz <= LRG_GRID_QUERY_CELLS;   // (workgroup-uniform)
+        if (by_grid) {
+            const int V = bx * by * bz;
+            const int nwords = (n + 31) >> 5;                                   // <= 4096: two bitmaps = sh_flags
+            unsigned *bm_c = reinterpret_cast<unsigned *>(sh_flags), *bm_e = bm_c + nwords;
+            for (int w = tid; w < 2 * nwords; w += LRG_FRONT_THREADS) bm_c[w] = 0u;
+            __syncthreads();
+            const float rbx = 1.0f / (float)bx, rby = 1.0f / (float)by;
+            for (int v0 = 0; v0 < V; v0 += 8 * LRG_FRONT_THREADS) {
+                int id[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int v = v0 + u * LRG_FRONT_THREADS + tid;
+                    id[u] = -1;
+                    if (v < V) {
+                        const int t = lrg_div_small(v, bx, rbx), x = v - t * bx;
+                        const int z = lrg_div_small(t, by, rby), y = t - z * by;
+                        id[u] = VI.grid[((long)(lo2 + z) * VI.gy + (lo1 + y)) * VI.gx + lo0 + x];
+                    }
+                }
+                int cf[8], vf[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = max(id[u], 0); cf[u] = cur[i]; vf[u] = visited[i]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (id[u] >= 0) {
+                        if (cf[u]) atomicOr(&bm_c[id[u] >> 5], 1u << (id[u] & 31));
+                        else if (!vf[u]) atomicOr(&bm_e[id[u] >> 5], 1u << (id[u] & 31));                                 // :226-228
+                    }
+            }
+            __syncthreads();
+            // thread t owns the words [t * wpt, (t + 1) * wpt): counts, a wavefront scan, the wavefronts' offsets, the indices
+            const int wpt = (nwords + LRG_FRONT_THREADS - 1) / LRG_FRONT_THREADS;     // 1 .. 4
+            unsigned mc[4], me[4];
+            int pcn = 0, pen = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int w = tid * wpt + q;
+                const bool in = q < wpt && w < nwords;
+                mc[q] = in ? bm_c[w] : 0u; me[q] = in ? bm_e[w] : 0u;
+                pcn += __popc(mc[q]); pen += __popc(me[q]);
+            }
+            const int packed = pcn | (pen << 16);                                     // a wavefront covers <= 8192 points
+            const int incl = lrg_wave_incl_scan_i32(packed);
+            if (lane == 63) { wt_c[wave] = incl & 0xFFFF; wt_e[wave] = (int)((unsigned)incl >> 16); }
+            __syncthreads();
+            int oc = 0, oe = 0;
+#pragma unroll
+            for (int w = 0; w < LRG_FRONT_THREADS / 64; ++w) {
+                if (w < wave) { oc += wt_c[w]; oe += wt_e[w]; }
+                totc += wt_c[w]; tote += wt_e[w];
+            }
+            int pc = oc + (incl & 0xFFFF) - pcn, pe = oe + (int)((unsigned)incl >> 16) - pen;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int base = (tid * wpt + q) << 5;
+                for (unsigned m = mc[q]; m; m &= m - 1) cur_idx[pc++] = base + __ffs((int)m) - 1;
+                for (unsigned m = me[q]; m; m &= m - 1) cand_idx[pe++] = base + __ffs((int)m) - 1;
+            }
+        } else {
         // LRG_QUERY_TRIP chunks per trip (4 points per thread and chunk: 3 loads per 4 points), all loads of a trip in flight
         // together.  Measured with 8 (one trip up to 32 k points): no change -- the phase grows with the room through the
         // per-chunk flag / scan / compaction work (11 k cycles up to 10 k points, 24 k above 20 k), not through its round trips.
@@ -876,7 +998,6 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         const int ic = lrg_wave_incl_scan_i32(vcn), ie = lrg_wave_incl_scan_i32(ven);
         if (tid < 512 && lane == 63) { wt_c[wave] = ic; wt_e[wave] = ie; }
         __syncthreads();
-        int totc = 0, tote = 0;
         {
             int oc = 0, oe = 0;
 #pragma unroll
@@ -901,6 +1022,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
                 if (fe >> k & 1) cand_idx[pe++] = ib + k;
             }
         }
+        }      // (room-wide pass)
         if (tid == 0) {
             S->pad = 1;
             S->nc = totc;
@@ -945,7 +1067,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         // the nine medians of a region above LRG_FRONT_SMALL points come from lrg_front_big_kernel (one workgroup per channel);
         // nothing here waits for them: the rows go out uncentred
         if (tid < 16) a.center[s * 16 + tid] = 0.f;
-        lrg_front_gather(S, points, obj, s, F, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
+        lrg_front_gather(S, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
         if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
         TRACE2(s, 5); TRACE2(s, 6); TRACE2(s, 7);
 #if LRG_TRACE
@@ -956,14 +1078,14 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     if (wave < 9) {                                              // one wavefront per centred channel, keys in registers
         const int ch = lrg_centred_channel(wave, F);
         if (ch >= 0) {
-            const float *pts = points + ch;
-            const float m = nc <= 256 ? lrg_median_wave_r<4>(pts, cur_idx, F, nc)
-                          : nc <= 1024 ? lrg_median_wave_r<16>(pts, cur_idx, F, nc)
-                                       : lrg_median_wave_r64(pts, cur_idx, F, nc);
+            const LrgChanSrc cs = lrg_chan_src(R, wave, ch, F);
+            const float m = nc <= 256 ? lrg_median_wave_r<4>(cs.base, cur_idx, cs.stride, nc)
+                          : nc <= 1024 ? lrg_median_wave_r<16>(cs.base, cur_idx, cs.stride, nc)
+                                       : lrg_median_wave_r64(cs.base, cur_idx, cs.stride, nc);
             if (lane == 0) sh_c[ch] = m;
         }
     } else {
-        lrg_front_gather(S, points, obj, s, F, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
+        lrg_front_gather(S, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
     }
     __syncthreads();
     TRACE2(s, 5);
@@ -990,10 +1112,10 @@ __global__ __launch_bounds__(1024) void lrg_front_big_kernel(const LrgSlot *slot
     const int nc = S->nc;
     const int ch = lrg_centred_channel(blockIdx.y, F);
     if (ch < 0) return;
-    const float *pts = R->points + ch;
+    const LrgChanSrc cs = lrg_chan_src(R, blockIdx.y, ch, F);
     if (nc <= 256) {                                 // one wavefront, keys in registers, no barrier
         if (tid >= 64) return;
-        const float mw = lrg_median_wave_r<4>(pts, S->cur_idx, F, nc);
+        const float mw = lrg_median_wave_r<4>(cs.base, S->cur_idx, cs.stride, nc);
         if (tid == 0) {
             a.center[s * 16 + ch] = mw;
             if (a.phase_ticks && blockIdx.y == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tickb;
@@ -1001,17 +1123,27 @@ __global__ __launch_bounds__(1024) void lrg_front_big_kernel(const LrgSlot *slot
         return;
     }
     float m;
-    const int chs[1] = {ch};
+    const int chs[1] = {0};
     float mm[1];
-    if (nc <= 4096) { lrg_median_block_radix<4, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, mm); m = mm[0]; }
-    else if (nc <= 16 * 1024) { lrg_median_block_radix<16, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, mm); m = mm[0]; }
-    else if (nc <= LRG_MED_REGS) { lrg_median_block_radix<48, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, mm); m = mm[0]; }
+    if (nc <= 4096) { lrg_median_block_radix<4, 1024, 1>(cs.base, chs, S->cur_idx, cs.stride, nc, sh, mm); m = mm[0]; }
+    else if (nc <= 16 * 1024) { lrg_median_block_radix<16, 1024, 1>(cs.base, chs, S->cur_idx, cs.stride, nc, sh, mm); m = mm[0]; }
+    else if (nc <= LRG_MED_REGS) {
+#if LRG_MED48_BISECT
+        // 48 keys per thread: a radix pass is 48 LDS atomics per thread (49 k per workgroup), a bisection step 144 compares and
+        // one atomic per wavefront
+        if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
+        __syncthreads();
+        m = lrg_median_block_regs<48>(cs.base, S->cur_idx, cs.stride, nc, sh);
+#else
+        lrg_median_block_radix<48, 1024, 1>(cs.base, chs, S->cur_idx, cs.stride, nc, sh, mm); m = mm[0];
+#endif
+    }
     else {
         if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
         __syncthreads();
         const int k2 = nc >> 1, k1r = (nc & 1) ? k2 : k2 - 1;
         uint32_t ka, kb;
-        lrg_select2(nullptr, false, R->points, S->cur_idx, F, ch, nc, k1r, k2, sh, &ka, &kb);
+        lrg_select2(nullptr, false, cs.base, S->cur_idx, cs.stride, 0, nc, k1r, k2, sh, &ka, &kb);
         const float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
         m = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
     }

@@ -42,6 +42,13 @@ __global__ void lrg_voxel_pack_kernel(const int32_t *vox, int n, int ox, int oy,
     pvox[i] = (uint32_t)min(max(x, 0), 2047) | ((uint32_t)min(max(y, 0), 2047) << 11) | ((uint32_t)min(max(z, 0), 1023) << 22);
 }
 
+__global__ void lrg_voxel_grid_kernel(const int32_t *vox, int n, int ox, int oy, int oz, int gx, int gy, int gz, int32_t *grid) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = vox[3 * i] - ox, y = vox[3 * i + 1] - oy, z = vox[3 * i + 2] - oz;
+    if ((unsigned)x < (unsigned)gx && (unsigned)y < (unsigned)gy && (unsigned)z < (unsigned)gz) grid[((long)z * gy + y) * gx + x] = i;
+}
+
 __global__ void lrg_hash_build_kernel(const int32_t *vox, int n, uint64_t *keys, int32_t *vals, int mask, int32_t *dup) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -591,10 +598,9 @@ __global__ __launch_bounds__(LRG_SCAN_THREADS) void lrg_box_compact_kernel(LrgSl
 // ------------------------------------------------------------------------------------------------
 #define LRG_MED_SMALL 1024      // lrg_median (stand-alone): up to 16 keys per lane, one wavefront per (slot, channel)
 #define LRG_MED_LARGE 36864     // 144 KB: one workgroup per CU, only launched work for the few big regions
-__device__ float lrg_median_wave(const float *points, const int32_t *idx, int F, int ch, int nc) {
-    const float *pts = points + ch;
-    if (nc <= 256) return lrg_median_wave_r<4>(pts, idx, F, nc);       // the common case: the median Area-5 region has 57 points
-    return lrg_median_wave_r<16>(pts, idx, F, nc);
+__device__ float lrg_median_wave(const LrgChanSrc cs, const int32_t *idx, int nc) {
+    if (nc <= 256) return lrg_median_wave_r<4>(cs.base, idx, cs.stride, nc);       // the common case: the median Area-5 region has 57 points
+    return lrg_median_wave_r<16>(cs.base, idx, cs.stride, nc);
 }
 
 __global__ __launch_bounds__(256) void lrg_median_wave_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(256) void lrg_median_wave_kernel(const LrgSlot *slo
     }
     const int nc = S->nc;
     if (nc > LRG_MED_SMALL) return;                                             // the block-level launch owns this slot
-    float med = lrg_median_wave(rooms[S->room].points, S->cur_idx, F, ch, nc);
+    float med = lrg_median_wave(lrg_chan_src(&rooms[S->room], ch < 2 ? ch : ch - 4, ch, F), S->cur_idx, nc);
     if (lrg_lane() == 0) center[s * 16 + ch] = med;
 }
 
@@ -723,15 +729,24 @@ __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *s
     const LrgRoom *R = &rooms[S->room];
     if (nc <= 1024) {                                                          // one wavefront, keys in registers, no barriers
         if (threadIdx.x >= 64) return;
-        const float m = lrg_median_wave(R->points, S->cur_idx, F, ch, nc);
+        const float m = lrg_median_wave(lrg_chan_src(R, blockIdx.y, ch, F), S->cur_idx, nc);
         if (threadIdx.x == 0) center[s * 16 + ch] = m;
         return;
     }
-    const int chs[1] = {ch};
+    const LrgChanSrc cs = lrg_chan_src(R, blockIdx.y, ch, F);
+    const int chs[1] = {0};
     float med[1];
-    if (nc <= 4096) lrg_median_block_radix<4, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, med);
-    else if (nc <= 16 * 1024) lrg_median_block_radix<16, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, med);
-    else lrg_median_block_radix<48, 1024, 1>(R->points, chs, S->cur_idx, F, nc, sh, med);
+    if (nc <= 4096) lrg_median_block_radix<4, 1024, 1>(cs.base, chs, S->cur_idx, cs.stride, nc, sh, med);
+    else if (nc <= 16 * 1024) lrg_median_block_radix<16, 1024, 1>(cs.base, chs, S->cur_idx, cs.stride, nc, sh, med);
+    else {
+#if LRG_MED48_BISECT
+        if (threadIdx.x < 64) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;
+        __syncthreads();
+        med[0] = lrg_median_block_regs<48>(cs.base, S->cur_idx, cs.stride, nc, sh);
+#else
+        lrg_median_block_radix<48, 1024, 1>(cs.base, chs, S->cur_idx, cs.stride, nc, sh, med);
+#endif
+    }
     if (threadIdx.x == 0) center[s * 16 + ch] = med[0];
 }
 
@@ -748,6 +763,7 @@ __global__ __launch_bounds__(1024) void lrg_median_large_kernel(const LrgSlot *s
     const int nc = S->nc;
     if (nc <= LRG_MED_REGS) return;
     const LrgRoom *R = &rooms[S->room];
+    const LrgChanSrc cs = lrg_chan_src(R, blockIdx.y, ch, F);
     if (threadIdx.x < 64) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;         // sh[0] = 0xFFFFFFFF (min identity)
     __syncthreads();
     const bool cached = nc <= LRG_MED_LARGE;
@@ -755,7 +771,8 @@ __global__ __launch_bounds__(1024) void lrg_median_large_kernel(const LrgSlot *s
         // gather 8 values per thread per round: the index load and the dependent feature load of the 8 are independent,
         // so their two global latencies are paid once per round instead of once per element
         const int32_t *idx = S->cur_idx;
-        const float *pts = R->points + ch;
+        const float *pts = cs.base;
+        const int F = cs.stride;
         for (int j0 = threadIdx.x; j0 < nc; j0 += 8 * blockDim.x) {
             int id[8];
             float v[8];
@@ -771,7 +788,7 @@ __global__ __launch_bounds__(1024) void lrg_median_large_kernel(const LrgSlot *s
     const int k2 = nc >> 1;
     const int k1 = (nc & 1) ? k2 : k2 - 1;
     uint32_t ka, kb;
-    lrg_select2(cache, cached, R->points, S->cur_idx, F, ch, nc, k1, k2, sh, &ka, &kb);
+    lrg_select2(cache, cached, cs.base, S->cur_idx, cs.stride, 0, nc, k1, k2, sh, &ka, &kb);
     float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
     float med = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
     if (threadIdx.x == 0) center[s * 16 + ch] = med;
@@ -1079,6 +1096,16 @@ int lrg_voxel_pack(const int32_t *voxels, int n, int ox, int oy, int oz, uint32_
     return 0;
 }
 
+int lrg_voxel_grid_build(const int32_t *voxels, int n, int ox, int oy, int oz, int gx, int gy, int gz, int32_t *grid, void *stream) {
+    if (!voxels || !grid || n < 0 || gx <= 0 || gy <= 0 || gz <= 0) return LRG_EINVAL - 1;
+    LRG_HIP_CHECK(hipMemsetAsync(grid, 0xFF, (size_t)gx * gy * gz * sizeof(int32_t), (hipStream_t)stream));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(lrg_voxel_grid_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, voxels, n, ox, oy, oz, gx, gy, gz,
+                       grid);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
 int lrg_voxel_hash_build(const int32_t *voxels, int n, uint64_t *keys, int32_t *vals, int hash_mask, int32_t *dup_flag,
                          void *stream) {
     if (!voxels || !keys || !vals || !dup_flag || n < 0 || hash_mask < 0 || ((hash_mask + 1) & hash_mask) != 0 ||
@@ -1305,8 +1332,8 @@ static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_
     if (n_slots % params->group_size != 0) return LRG_EINVAL - 1;
     if (max_points > LRG_FRONT_MAXCHUNK * LRG_SCAN_CHUNK) return LRG_EINVAL - 3;       // larger rooms: lrg_grow_step
     if (params->n_inlier > LRG_FRONT_MAXSAMPLE || params->n_neighbor > LRG_FRONT_MAXSAMPLE) return LRG_EINVAL - 3;
-    if (!b->center || !b->sample_in || !b->sample_nb || !b->x_in || !b->x_nb || !b->row_slot_in || !b->row_slot_nb || !b->gt_in ||
-        !b->gt_nb || !b->rmv_logits || !b->add_logits || !b->slot_rows || !b->counters || !b->workspace)
+    if (!b->center || !b->sample_in || !b->sample_nb || !b->x_in || !b->x_nb || !b->row_slot_in || !b->row_slot_nb || !b->upd_in ||
+        !b->upd_nb || !b->rmv_logits || !b->add_logits || !b->slot_rows || !b->counters || !b->workspace)
         return LRG_EINVAL - 4;
     if (b->row_cap % LRG_ROW_TILE != 0 || (long)b->row_cap < (long)n_slots * max(params->n_inlier, params->n_neighbor))
         return LRG_EINVAL - 5;
@@ -1316,7 +1343,7 @@ static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_
     LrgFrontArgs a;
     a.center = b->center; a.sample_in = b->sample_in; a.sample_nb = b->sample_nb;
     a.x_in = b->x_in; a.x_nb = b->x_nb; a.row_slot_in = b->row_slot_in; a.row_slot_nb = b->row_slot_nb;
-    a.gt_in = b->gt_in; a.gt_nb = b->gt_nb; a.rmv_logits = b->rmv_logits; a.add_logits = b->add_logits;
+    a.upd_in = reinterpret_cast<float4 *>(b->upd_in); a.upd_nb = reinterpret_cast<float4 *>(b->upd_nb); a.rmv_logits = b->rmv_logits; a.add_logits = b->add_logits;
     a.slot_rows = b->slot_rows; a.counters = b->counters;
     a.pooled = static_cast<float *>(b->workspace) + poff; a.pooled_stride = (int)(pcnt / (size_t)n_slots);
     a.stats = b->stats;

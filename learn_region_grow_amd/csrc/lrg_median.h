@@ -4,6 +4,10 @@
 #pragma once
 #include "lrg_common.h"
 
+#ifndef LRG_MED48_BISECT
+#define LRG_MED48_BISECT 1      // regions above 16 Ki points (48 register keys per thread): bisection instead of the radix select
+#endif
+
 __device__ __forceinline__ uint32_t lrg_f2key(float f) {
     uint32_t b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -193,6 +197,19 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
 
 // centred channel of grid row y: 0, 1, 6, 7, ... (:243-247); -1 past the feature count
 __device__ __forceinline__ int lrg_centred_channel(int y, int F) { const int ch = y < 2 ? y : y + 4; return ch < F ? ch : -1; }
+
+// Where the keys of centred channel ch = lrg_centred_channel(y, F) of a room come from: value of point i = base[i * stride].
+// With the room's channel-major copy (LrgRoom::chan_major) a region -- mostly runs of consecutive indices, a room's points come
+// object after object -- reads a few dense lines per channel; from the [n,F] rows every key is a line of its own
+// (a 40 k-point region: 160 KB against 5 MB per channel).
+struct LrgChanSrc { const float *base; int stride; };
+__device__ __forceinline__ LrgChanSrc lrg_chan_src(const LrgRoom *R, int y, int ch, int F) {
+    LrgChanSrc c;
+    const float *cm = R->chan_major;
+    if (cm) { c.base = cm + (long)y * R->chan_stride; c.stride = 1; }
+    else { c.base = R->points + ch; c.stride = F; }
+    return c;
+}
 
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ Two sources of randomness:
                  exactly as the reference does (scipy-style softmax, float64 uniforms)    -- parity
 """
 import ctypes
+import os
 import time
 
 import numpy as np
@@ -122,6 +123,12 @@ class RegionGrower:
             obj[o:o + n] = np.asarray(room['obj_id']).astype(np.int32)
             order[o:o + n] = np.asarray(room['order']).astype(np.int32)
         self.d_points = torch.from_numpy(pts).to(dev)
+        # channel-major copy of the centred channels 0, 1, 6 .. F-1 (LrgRoom.chan_major): the medians' keys (:241) of a region
+        # -- mostly runs of consecutive indices -- then come from a few dense lines per channel instead of one word per row
+        cch = [c for c in range(F) if c < 2 or c >= 6]
+        self.d_chan = None
+        if tot and len(cch) * tot < 2 ** 31 and os.environ.get('LRG_NO_CHAN_MAJOR') != '1':
+            self.d_chan = self.d_points[:, cch].t().contiguous()
         self.d_obj = torch.from_numpy(obj).to(dev)
         self.d_order = torch.from_numpy(order).to(dev)
         self.d_vox = torch.empty((tot, 3), dtype=torch.int32, device=dev)
@@ -141,13 +148,22 @@ class RegionGrower:
                                          _ptr(self.d_vox), st), 'lrg_voxelize')
         # packed voxel words (one per point, relative to the room's minimum voxel) when every room fits 2048 x 2048 x 1024 voxels
         h_vox = self.d_vox.cpu().numpy()
-        origins, self.have_pvox = [], True
+        origins, dims, self.have_pvox = [], [], True
         for r in range(len(rooms)):
             v = h_vox[int(offs[r]):int(offs[r]) + ns[r]]
             lo, hi = (v.min(axis=0), v.max(axis=0)) if ns[r] else (np.zeros(3, np.int64), np.zeros(3, np.int64))
             origins.append([int(x) for x in lo])
+            dims.append([int(x) for x in (hi - lo + 1)])
             if ns[r] and ((hi - lo) > np.array([2047, 2047, 1023])).any():
                 self.have_pvox = False
+        # dense voxel grids (LrgRoom.vgrid): 4 bytes per voxel of a room's bounding box -- a few MB per room; rooms whose box
+        # exceeds LRG_VGRID_MAX_CELLS (or a set above LRG_VGRID_TOTAL_CELLS in all) keep the hash table and the room-wide pass
+        cells = [dims[r][0] * dims[r][1] * dims[r][2] if ns[r] else 0 for r in range(len(rooms))]
+        use_grid = [self.have_pvox and 0 < c <= _lib.LRG_VGRID_MAX_CELLS and os.environ.get('LRG_NO_VGRID') != '1' for c in cells]
+        if sum(c for c, u in zip(cells, use_grid) if u) > _lib.LRG_VGRID_TOTAL_CELLS:
+            use_grid = [False] * len(rooms)
+        goffs = np.concatenate([[0], np.cumsum([(c + 15) // 16 * 16 if u else 0 for c, u in zip(cells, use_grid)])]).astype(np.int64)
+        self.d_vgrid = torch.empty(int(goffs[-1]), dtype=torch.int32, device=dev) if goffs[-1] else None
         self.h_rooms = (LrgRoom * len(rooms))()
         for r, room in enumerate(rooms):
             o, n, ho = int(offs[r]), ns[r], int(hoffs[r])
@@ -157,7 +173,16 @@ class RegionGrower:
                 R.vox_origin[0], R.vox_origin[1], R.vox_origin[2] = origins[r]
                 _lib.check(self.lib.lrg_voxel_pack(ctypes.c_void_p(self.d_vox.data_ptr() + o * 12), n, origins[r][0], origins[r][1],
                                                    origins[r][2], ctypes.c_void_p(R.pvox), _ptr(self.d_povf), st), 'lrg_voxel_pack')
+            if use_grid[r]:
+                R.vgrid = self.d_vgrid.data_ptr() + int(goffs[r]) * 4
+                R.vgrid_dim[0], R.vgrid_dim[1], R.vgrid_dim[2] = dims[r]
+                _lib.check(self.lib.lrg_voxel_grid_build(ctypes.c_void_p(self.d_vox.data_ptr() + o * 12), n, origins[r][0], origins[r][1],
+                                                         origins[r][2], dims[r][0], dims[r][1], dims[r][2], ctypes.c_void_p(R.vgrid), st),
+                           'lrg_voxel_grid_build')
             R.points = self.d_points.data_ptr() + o * F * 4
+            if self.d_chan is not None:
+                R.chan_major = self.d_chan.data_ptr() + o * 4
+                R.chan_stride = tot
             R.voxels = self.d_vox.data_ptr() + o * 12
             R.obj_id = self.d_obj.data_ptr() + o * 4
             R.order = self.d_order.data_ptr() + o * 4
@@ -249,8 +274,8 @@ class RegionGrower:
             self.p_xnb = torch.zeros((cap_rows, F), dtype=torch.float32, device=dev)
             self.p_rsin = torch.zeros(cap_rows, dtype=torch.int32, device=dev)
             self.p_rsnb = torch.zeros(cap_rows, dtype=torch.int32, device=dev)
-            self.p_gtin = torch.zeros(cap_rows, dtype=torch.uint8, device=dev)
-            self.p_gtnb = torch.zeros(cap_rows, dtype=torch.uint8, device=dev)
+            self.p_updin = torch.zeros((S, Ni, 4), dtype=torch.float32, device=dev)
+            self.p_updnb = torch.zeros((S, Nn, 4), dtype=torch.float32, device=dev)
             self.p_rmv = torch.zeros((cap_rows, 2), dtype=torch.float32, device=dev)
             self.p_add = torch.zeros((cap_rows, 2), dtype=torch.float32, device=dev)
             self.p_slot_rows = torch.zeros((S, 4), dtype=torch.int32, device=dev)
@@ -261,7 +286,7 @@ class RegionGrower:
             pb.center, pb.sample_in, pb.sample_nb = self.b_center.data_ptr(), self.b_sin.data_ptr(), self.b_snb.data_ptr()
             pb.x_in, pb.x_nb = self.p_xin.data_ptr(), self.p_xnb.data_ptr()
             pb.row_slot_in, pb.row_slot_nb = self.p_rsin.data_ptr(), self.p_rsnb.data_ptr()
-            pb.gt_in, pb.gt_nb = self.p_gtin.data_ptr(), self.p_gtnb.data_ptr()
+            pb.upd_in, pb.upd_nb = self.p_updin.data_ptr(), self.p_updnb.data_ptr()
             pb.rmv_logits, pb.add_logits = self.p_rmv.data_ptr(), self.p_add.data_ptr()
             pb.slot_rows, pb.counters = self.p_slot_rows.data_ptr(), self.p_counters.data_ptr()
             pb.workspace, pb.workspace_bytes = self.p_ws.data_ptr(), self.p_ws.numel()
