@@ -147,3 +147,69 @@ def test_restarts_scoring_ml_matches_the_oracle(net):
         np.testing.assert_array_equal(res.filled_label, want.filled_label)
         differs |= not np.array_equal(res.cluster_label, other.cluster_label)
     assert differs, "'ml' and 'np' scoring picked the same restart everywhere: the test rooms do not exercise the score"
+
+
+def test_benchmark_configuration_with_a_busy_chip(net):
+    """Slots must not depend on when their workgroups start.  The front kernel allocates the packed rows of an iteration from
+    row 0 again, so a slot whose workgroup starts late -- here: while a second stream keeps every CU busy with dense LrgNet
+    evaluations -- would find last iteration's rows overwritten if it still looked for them there (it did, up to ABI 3: with two
+    lanes 13 of 68 rooms gave more than one outcome over eight runs, tools/determinism_check.py).  Two lanes + the hog, twice,
+    against a quiet single-lane run: same regions and labels for all 68 rooms."""
+    import threading
+    import torch
+    from learn_region_grow_amd.grow import LanedRegionGrower
+    rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir=CACHE)
+    kw = dict(rooms_in_flight=68, rng='counter', seed=0, policy='gt')
+    quiet = LanedRegionGrower(net, lanes=1, **kw).run(rooms)
+    dev = net.device
+    rs = np.random.RandomState(0)
+    xi = torch.from_numpy((rs.randn(68, 512, 13) * 0.5).astype(np.float32)).to(dev)
+    xn = torch.from_numpy((rs.randn(68, 512, 13) * 0.5).astype(np.float32)).to(dev)
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    hog_net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev).load_weights(synthetic.make_synthetic_weights(**WEIGHT_KW))
+    hog_stream = torch.cuda.Stream(device=dev)
+    stop = threading.Event()
+
+    def hog():
+        with torch.cuda.stream(hog_stream):
+            while not stop.is_set():
+                for _ in range(8):
+                    hog_net.forward(xi, xn)
+                hog_stream.synchronize()
+    for _ in range(2):
+        stop.clear()
+        th = threading.Thread(target=hog)
+        th.start()
+        try:
+            busy = LanedRegionGrower(net, lanes=2, graph_iterations=4, **kw).run(rooms)
+        finally:
+            stop.set()
+            th.join()
+        for i, (a, b) in enumerate(zip(quiet, busy)):
+            assert regions_of(a) == regions_of(b), 'room %d (%d points)' % (i, len(rooms[i]['points']))
+            np.testing.assert_array_equal(a.cluster_label, b.cluster_label)
+            np.testing.assert_array_equal(a.filled_label, b.filled_label)
+
+
+def test_voxel_grid_and_channel_major_copy_change_nothing(net, monkeypatch):
+    """LrgRoom.vgrid (box queries and voxel lookups from a dense grid) and LrgRoom.chan_major (median keys from a channel-major
+    copy) are layouts, not definitions: rooms loaded without them give the same regions and labels -- Bernoulli policy, a room
+    large enough for regions above 1024 points, the 45 k-point room under ground-truth masks."""
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = [small_room(640 + i, n, furniture=f, room_id=80 + i) for i, (n, f) in enumerate([(700, 1), (2600, 3), (6500, 4)])]
+    big = workloads.make_room(45063, 1057, 57)
+
+    def run():
+        a = RegionGrower(net, rooms_in_flight=3, rng='counter', seed=5, policy='net').run(rooms)
+        b = RegionGrower(net, rooms_in_flight=1, rng='counter', seed=5, policy='gt').run([big])
+        return a + b
+    with_both = run()
+    monkeypatch.setenv('LRG_NO_VGRID', '1')
+    without_grid = run()
+    monkeypatch.setenv('LRG_NO_CHAN_MAJOR', '1')
+    without_either = run()
+    assert max(r['points'] for res in with_both for r in res.regions) > 1024
+    for x, y, z in zip(with_both, without_grid, without_either):
+        assert regions_of(x) == regions_of(y) == regions_of(z)
+        np.testing.assert_array_equal(x.filled_label, y.filled_label)
+        np.testing.assert_array_equal(x.filled_label, z.filled_label)

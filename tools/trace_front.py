@@ -7,15 +7,22 @@ from learn_region_grow_amd import synthetic, workloads, _lib
 from learn_region_grow_amd.lrgnet import LrgNetHIP
 from learn_region_grow_amd.grow import RegionGrower
 dev = torch.device('cuda:0')
-net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev).load_weights(synthetic.load_trained_weights())
-rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir='/tmp/lrg_cache')
-gr = RegionGrower(net, rooms_in_flight=68, rng='counter', policy='net')
+KITTI = os.environ.get('LRG_TRACE_WORKLOAD') == 'kitti'      # 8 KITTI-shaped scenes, ground-truth masks, packed iteration forced
+if KITTI:
+    net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev).load_weights(synthetic.make_synthetic_weights(seed=0))
+    rooms = workloads.kitti_scenes(8, seed_base=5000, cache_dir='/tmp/lrg_cache')
+    gr = RegionGrower(net, rooms_in_flight=8, rng='counter', policy='gt', resolution=0.3, packed=True)
+else:
+    net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev).load_weights(synthetic.load_trained_weights())
+    rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir='/tmp/lrg_cache')
+    gr = RegionGrower(net, rooms_in_flight=68, rng='counter', policy='net')
 gr.load_rooms(rooms)
-for g in range(68): gr.bind(g, g)
+NS = len(rooms)
+for g in range(NS): gr.bind(g, g)
 lib = _lib.load()
-tr = torch.zeros(68 * 16, dtype=torch.int64, device=dev)
+tr = torch.zeros(NS * 16, dtype=torch.int64, device=dev)
 lib.lrg_set_trace2.argtypes = [ctypes.c_void_p]
-for it in range(4000):
+for it in range(1500 if KITTI else 4000):
     gr.enqueue_iteration()
     for g in gr.poll_done():
         r = gr.group_room[g]; gr.reset_room(r); gr.bind(g, r)
@@ -28,8 +35,8 @@ worst = []
 for it in range(60):
     tr.zero_()
     gr.enqueue_iteration(); torch.cuda.synchronize()
-    t = tr.cpu().numpy().reshape(68, 16)
-    for g in range(68):
+    t = tr.cpu().numpy().reshape(NS, 16)
+    for g in range(NS):
         if t[g, 7] > 0:
             d = np.diff(t[g, :8])
             rows.append(np.concatenate([d, [t[g, 7] - t[g, 0], n_of[gr.group_room[g]], t[g, 8], t[g, 14] > 0]]))
