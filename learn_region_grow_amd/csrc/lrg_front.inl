@@ -397,12 +397,10 @@ __device__ void lrg_front_prepare(const LrgSlot *S, const LrgRoom *R, int s, con
         const int nel = k * F;
         for (int e0 = tid; e0 < nel; e0 += 8 * bd) {       // 8 independent row loads in flight per thread
             float v[8];
-            int jf[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = min(e0 + u * bd, nel - 1);
                 const int j = e / F, f = e - j * F;
-                jf[u] = f < 3 ? 4 * j + f : -1;
                 v[u] = __fsub_rn(points[(long)sh_src[side][j] * F + f], sh_c[f]);
             }
 #pragma unroll
@@ -410,7 +408,8 @@ __device__ void lrg_front_prepare(const LrgSlot *S, const LrgRoom *R, int s, con
                 const int e = e0 + u * bd;
                 if (e < nel) {
                     out[e] = v[u];
-                    if (jf[u] >= 0) upd[jf[u]] = v[u];     // the slot's own copy of columns 0..2 for the next update
+                    const int j = e / F, f = e - j * F;
+                    if (f < 3) upd[4 * j + f] = v[u];      // the slot's own copy of columns 0..2 for the next update
                 }
             }
         }
@@ -500,47 +499,67 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
 // (first, nthreads): the threads [first, first + nthreads) of the workgroup do the work, so that other wavefronts can compute
 // the medians meanwhile.  The rows are stored UNCENTRED: the branch kernels subtract the centre while staging them
 // (lrg_forward_packed, `center`), the next update re-derives the centred value -- so the gather does not wait for the medians.
-__device__ __forceinline__ void lrg_front_gather(const LrgSlot *S, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
+// v / d for 0 <= v < 2^23, d >= 1 with rcp = 1.0f / d: float estimate, one correction step either way
+__device__ __forceinline__ int lrg_div_small(int v, int d, float rcp) {
+    int q = (int)(((float)v + 0.5f) * rcp);
+    if (q * d > v) --q;
+    else if ((q + 1) * d <= v) ++q;
+    return q;
+}
+// Workgroup barrier for hand-overs through LDS only: waits for this wavefront's LDS operations, not for the acknowledgement of
+// its global stores (__syncthreads() does, ~1.5 k cycles after a burst of stores that nobody in the workgroup reads back).
+#define LRG_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Both sides in one element space (inlier rows, then neighbour rows): one round trip for all rows, and the obj_id words of the
+// ground-truth flags input_remove / input_add (:230-231,:248,:254) ride along (element 0 of each row).  Besides the packed rows,
+// every row leaves x, y, z (as stored: uncentred) and its flag in the slot's own upd_* arrays for the next mask update.
+// U = loads in flight per thread: two full sets (2 x 512 rows x 13 floats = 13 k elements) still go in one trip with 13.
+template <int U>
+__device__ __forceinline__ void lrg_front_gather_rows(int target, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
+                                                      const LrgFrontArgs &a, const int (*sh_src)[512], int rin, int rnb, int offi, int offn,
+                                                      int tid, int bd) {
+    const int nel_in = rin * F, nel = nel_in + rnb * F;
+    const float rF = 1.0f / (float)F;
+    float *out_in = a.x_in + (long)offi * F, *out_nb = a.x_nb + (long)offn * F;
+    float *upd_in = reinterpret_cast<float *>(a.upd_in) + (long)s * ni * 4, *upd_nb = reinterpret_cast<float *>(a.upd_nb) + (long)s * nn * 4;
+    for (int e0 = tid; e0 < nel; e0 += U * bd) {
+        float v[U];
+        int ob[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = min(e0 + u * bd, nel - 1);
+            const int side = e >= nel_in ? 1 : 0, l = e - (side ? nel_in : 0);
+            const int j = lrg_div_small(l, F, rF), f = l - j * F;
+            const int src = sh_src[side][j];
+            v[u] = points[(long)src * F + f];
+            ob[u] = (f == 0 && obj) ? obj[src] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * bd;                     // (row and column worked out again: registers are for the loads in flight)
+            if (e < nel) {
+                const int side = e >= nel_in ? 1 : 0, l = e - (side ? nel_in : 0);
+                const int j = lrg_div_small(l, F, rF), f = l - j * F;
+                (side ? out_nb : out_in)[l] = v[u];
+                float *upd = (side ? upd_nb : upd_in) + 4 * j;
+                if (f < 3) upd[f] = v[u];
+                if (f == 0) upd[3] = (obj && (side ? ob[u] == target : ob[u] != target)) ? 1.f : 0.f;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void lrg_front_gather(int target, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
                                                  const LrgFrontArgs &a, const int (*sh_src)[512], int rin,
                                                  int rnb, int offi, int offn, int first, int nthreads) {
     const int tid = (int)threadIdx.x - first, bd = nthreads;
     if (tid < 0 || tid >= nthreads) return;
-    const int target = S->target;
-    // (and the slot's own copy of what the next update needs of each row: x, y, z as stored -- uncentred -- and the flag)
-    // (x, y, z follow from the gather loop below)
-    for (int j = tid; j < rin; j += bd) {
-        a.row_slot_in[offi + j] = s;
-        reinterpret_cast<float *>(a.upd_in)[((long)s * ni + j) * 4 + 3] = (obj && obj[sh_src[0][j]] != target) ? 1.f : 0.f;   // :231,:248
-    }
-    for (int j = tid; j < rnb; j += bd) {
-        a.row_slot_nb[offn + j] = s;
-        reinterpret_cast<float *>(a.upd_nb)[((long)s * nn + j) * 4 + 3] = (obj && obj[sh_src[1][j]] == target) ? 1.f : 0.f;   // :230,:254
-    }
-    for (int side = 0; side < 2; ++side) {
-        const int k = side ? rnb : rin;
-        float *out = side ? a.x_nb + (long)offn * F : a.x_in + (long)offi * F;
-        float *upd = reinterpret_cast<float *>(side ? a.upd_nb : a.upd_in) + (long)s * (side ? nn : ni) * 4;
-        const int nel = k * F;
-        for (int e0 = tid; e0 < nel; e0 += 8 * bd) {       // 8 independent row loads in flight per thread
-            float v[8];
-            int jf[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = min(e0 + u * bd, nel - 1);
-                const int j = e / F, f = e - j * F;
-                jf[u] = f < 3 ? 4 * j + f : -1;
-                v[u] = points[(long)sh_src[side][j] * F + f];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * bd;
-                if (e < nel) {
-                    out[e] = v[u];
-                    if (jf[u] >= 0) upd[jf[u]] = v[u];     // the slot's own copy of x, y, z for the next update
-                }
-            }
-        }
-    }
+    for (int j = tid; j < rin; j += bd) a.row_slot_in[offi + j] = s;
+    for (int j = tid; j < rnb; j += bd) a.row_slot_nb[offn + j] = s;
+    const int nel = (rin + rnb) * F;
+    if (nel <= 2 * bd) lrg_front_gather_rows<2>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
+    else if (nel <= 6 * bd) lrg_front_gather_rows<6>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
+    else lrg_front_gather_rows<13>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);   // 2 x 512 rows x 13 floats
 }
 
 // voxel -> point index: one load from the room's dense grid when it has one, else the probe chain of the hash table
@@ -559,15 +578,9 @@ __device__ __forceinline__ int lrg_voxel_index(const LrgVoxIndex &I, int vx, int
     }
     return lrg_hash_lookup(I.hkeys, I.hvals, I.hmask, lrg_pack_voxel(vx, vy, vz));
 }
-// v / d for 0 <= v < 2^23, d >= 1 with rcp = 1.0f / d: float estimate, one correction step either way
-__device__ __forceinline__ int lrg_div_small(int v, int d, float rcp) {
-    int q = (int)(((float)v + 0.5f) * rcp);
-    if (q * d > v) --q;
-    else if ((q + 1) * d <= v) ++q;
-    return q;
-}
 #ifndef LRG_GRID_QUERY_CELLS
-#define LRG_GRID_QUERY_CELLS (16 * LRG_FRONT_THREADS)   // dilated boxes up to this many voxels are answered from the grid
+#define LRG_GRID_QUERY_CELLS (16 * LRG_FRONT_THREADS)   // dilated boxes up to this many voxels are answered from the grid (measured: a
+                                                        // limit of 32 Ki with 12 or 16 cells per trip gains nothing over the room-wide pass)
 #endif
 
 __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
@@ -587,6 +600,13 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     const int room = S->room;
     int status = S->status;
     const int nc0 = S->nc, ne0 = S->ne;
+    // what the stop decision and the random stream need of the slot, requested with the rest of round trip 1 (thread 0 used to walk
+    // through these in dependent loads of its own while 1023 threads waited)
+    const int seed0 = S->seed, restart0 = S->restart, step0 = S->step, stuck0 = S->stuck, steps_total0 = S->steps_total;
+    const int sq0 = S->seq_mn[0], sq1 = S->seq_mn[1], sq2 = S->seq_mn[2], sq3 = S->seq_mx[0], sq4 = S->seq_mx[1], sq5 = S->seq_mx[2];
+    int cur_seed = seed0, cur_restart = restart0, cur_step = step0, cur_target = S->target;
+    bool lists_ready = false;            // a fresh seed: its index lists come from the seed search, no box query
+    __shared__ int sh_box[8];            // bounding box of the mask (S->mn, S->mx) for the box query
     uint8_t *cur = S->cur;
     int32_t *cur_idx = S->cur_idx, *cand_idx = S->cand_idx;
     const int rows_off_in = a.slot_rows[4 * s + 2], rows_off_nb = a.slot_rows[4 * s + 3];
@@ -618,6 +638,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     TRACE2(s, 0);
     const long long tick0 = a.phase_ticks ? wall_clock64() : 0;
 
+    int q_nc = nc0, q_ne = ne0;        // sizes of the lists the sampling below draws from (set by the seed path / the box query)
     // =========================== (1) mask update of the evaluation just finished (:262-288) ===========================
     int id0[4];                      // the first 4096 entries of the old index list and their voxel words, kept for the commit
     uint32_t pv0[4];
@@ -642,8 +663,8 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
             else {
                 const float conf = lrg_conf(lg);                                             // :262-263
                 if (prm.policy == 1) take = conf > 0.5f;                                     // :264-265
-                else take = lrg_uniform01(lrg_rng_word((uint32_t)j, half ? LRG_PURPOSE_RMV : LRG_PURPOSE_ADD, (uint32_t)S->seed,
-                                                       (uint32_t)S->restart, (uint32_t)S->step, k0, k1)) < conf;   // :266-267
+                else take = lrg_uniform01(lrg_rng_word((uint32_t)j, half ? LRG_PURPOSE_RMV : LRG_PURPOSE_ADD, (uint32_t)seed0,
+                                                       (uint32_t)restart0, (uint32_t)step0, k0, k1)) < conf;   // :266-267
             }
             if (take) {
                 // the rows are stored uncentred: (x - c) + c in float32, as the reference centres (:243,:246) and un-centres
@@ -715,19 +736,39 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         }
         lrg_block_bbox(cnt, mn0, mn1, mn2, mx0, mx1, mx2, red);
         if (tid == 0) {
-            S->scan_cnt = cnt;
-            S->scan_mn[0] = cnt ? mn0 + ox : INT_MAX; S->scan_mn[1] = cnt ? mn1 + oy : INT_MAX; S->scan_mn[2] = cnt ? mn2 + oz : INT_MAX;
-            S->scan_mx[0] = cnt ? mx0 + ox : INT_MIN; S->scan_mx[1] = cnt ? mx1 + oy : INT_MIN; S->scan_mx[2] = cnt ? mx2 + oz : INT_MIN;
-            S->updated = sh_i[0];
+            const int upd = sh_i[0];
             S->pad = 0;
-            S->step += 1;
-            S->steps_total += 1;                                                             // :288
+            S->step = step0 + 1;
+            S->steps_total = steps_total0 + 1;                                               // :288
             S->acc_add = sh_i[5]; S->acc_rmv = sh_i[6];
             if (a.stats) atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[2]), 1ULL);
-            lrg_stop_logic(S);                                                               // :291-306
-            sh_i[2] = S->status;
+            // lrg_stop_logic (:291-306) on the values at hand: the same decisions and the same stores, without its loads
+            S->scan_cnt = 0;
+            S->scan_mn[0] = S->scan_mn[1] = S->scan_mn[2] = INT_MAX;
+            S->scan_mx[0] = S->scan_mx[1] = S->scan_mx[2] = INT_MIN;
+            S->updated = -1;
+            S->count = cnt;
+            int st = LRG_ACTIVE;
+            if (!upd) st = LRG_STOP_NOEXPAND;                                                // :304-306
+            else if (cnt == 0) st = LRG_STOP_EMPTY;                                          // :292 would raise
+            else {
+                const int a0 = mn0 + ox, a1 = mn1 + oy, a2 = mn2 + oz, b0 = mx0 + ox, b1 = mx1 + oy, b2 = mx2 + oz;
+                S->mn[0] = a0; S->mn[1] = a1; S->mn[2] = a2; S->mx[0] = b0; S->mx[1] = b1; S->mx[2] = b2;     // :292-293
+                sh_box[0] = a0; sh_box[1] = a1; sh_box[2] = a2; sh_box[3] = b0; sh_box[4] = b1; sh_box[5] = b2;
+                const bool grew = a0 < sq0 || a1 < sq1 || a2 < sq2 || b0 > sq3 || b1 > sq4 || b2 > sq5;        // :294
+                if (!grew && stuck0 >= 1) st = LRG_STOP_STUCK;                               // :295-297
+                else {
+                    S->stuck = grew ? 0 : stuck0 + 1;                                        // :299,:301
+                    S->seq_mn[0] = min(sq0, a0); S->seq_mn[1] = min(sq1, a1); S->seq_mn[2] = min(sq2, a2);
+                    S->seq_mx[0] = max(sq3, b0); S->seq_mx[1] = max(sq4, b1); S->seq_mx[2] = max(sq5, b2);
+                }
+            }
+            if (st != LRG_ACTIVE) { S->status = st; S->last_reason = st; }
+            sh_i[2] = st;
+            sh_box[6] = cnt;
         }
-        __syncthreads();
+        cur_step = step0 + 1;
+        LRG_LDS_BARRIER();           // (status, box and count go through LDS; nobody reads thread 0's stores to the slot before the next full barrier)
         status = sh_i[2];
     }
     TRACE2(s, 1);
@@ -737,7 +778,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         // members of the finished region: after an update, the survivors found above; after a stop taken by the box query
         // ('noneighbor', step cap), the list that query compacted (every entry a member)
         const bool from_update = entry_status == LRG_ACTIVE;
-        const int count = S->count;
+        const int count = from_update ? sh_box[6] : S->count;
         const int labeled = count > prm.cluster_threshold;                                   // :213
         const int cid = R->next_cluster_id;
         int32_t *label = R->label;
@@ -848,6 +889,9 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         }
         // the slot's mask is all zero here (every region clears its members at commit; the host zeroes it when binding)
         if ((int)tid < n_cand) cand_idx[tid] = sh_list[tid];
+        q_nc = 1; q_ne = n_cand;
+        cur_seed = seed; cur_restart = 0; cur_step = 0;
+        lists_ready = true;
         if (tid == 0) {
             cur[seed] = 1;                                                                   // :197-198
             cur_idx[0] = seed;
@@ -857,7 +901,9 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
                 const int v = R->voxels[3 * seed + d];
                 S->mn[d] = v; S->mx[d] = v; S->seq_mn[d] = v; S->seq_mx[d] = v;             // :199-202
             }
-            S->target = obj ? obj[seed] : 0;
+            const int tg = obj ? obj[seed] : 0;
+            S->target = tg;
+            sh_box[7] = tg;
             S->pad = 1;                                                                      // lists ready
             S->scan_cnt = 0;
             S->scan_mn[0] = S->scan_mn[1] = S->scan_mn[2] = INT_MAX;
@@ -868,6 +914,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         }
         __syncthreads();
         status = LRG_ACTIVE;
+        cur_target = sh_box[7];
     }
     TRACE2(s, 2);
     const long long tick1 = a.phase_ticks ? wall_clock64() : 0;
@@ -878,10 +925,10 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     }
 
     // =========================== (3) dilated voxel-box query with ordered compaction (:221-235) ===========================
-    if (S->pad != 1) {
+    if (!lists_ready) {
         const int nchunk = (n + LRG_SCAN_CHUNK - 1) / LRG_SCAN_CHUNK;
-        const int lo0 = max(S->mn[0] - 1 - ox, 0), lo1 = max(S->mn[1] - 1 - oy, 0), lo2 = max(S->mn[2] - 1 - oz, 0);     // :222-225
-        const int hi0 = S->mx[0] + 1 - ox, hi1 = S->mx[1] + 1 - oy, hi2 = S->mx[2] + 1 - oz;
+        const int lo0 = max(sh_box[0] - 1 - ox, 0), lo1 = max(sh_box[1] - 1 - oy, 0), lo2 = max(sh_box[2] - 1 - oz, 0);     // :222-225
+        const int hi0 = sh_box[3] + 1 - ox, hi1 = sh_box[4] + 1 - oy, hi2 = sh_box[5] + 1 - oz;
         const int ilast = (n - 1) & ~3;
         int totc = 0, tote = 0;
         // A box of up to LRG_GRID_QUERY_CELLS voxels is answered from the room's dense voxel grid: the cells of the box (rows of
@@ -898,10 +945,12 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
             for (int w = tid; w < 2 * nwords; w += LRG_FRONT_THREADS) bm_c[w] = 0u;
             __syncthreads();
             const float rbx = 1.0f / (float)bx, rby = 1.0f / (float)by;
-            for (int v0 = 0; v0 < V; v0 += 8 * LRG_FRONT_THREADS) {
-                int id[8];
+            constexpr int GU = 8;                                               // cells per thread and trip
+            for (int v0 = 0; v0 < V; v0 += GU * LRG_FRONT_THREADS) {
+                int id[GU];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < GU; ++u) {
+                    if (u >= 4 && v0 + u * LRG_FRONT_THREADS >= V) { id[u] = -1; continue; }      // (uniform: small boxes issue 4 loads, not 16)
                     const int v = v0 + u * LRG_FRONT_THREADS + tid;
                     id[u] = -1;
                     if (v < V) {
@@ -910,11 +959,14 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
                         id[u] = VI.grid[((long)(lo2 + z) * VI.gy + (lo1 + y)) * VI.gx + lo0 + x];
                     }
                 }
-                int cf[8], vf[8];
+                int cf[GU], vf[GU];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int i = max(id[u], 0); cf[u] = cur[i]; vf[u] = visited[i]; }
+                for (int u = 0; u < GU; ++u) {
+                    if (u >= 4 && v0 + u * LRG_FRONT_THREADS >= V) { cf[u] = 0; vf[u] = 0; continue; }
+                    const int i = max(id[u], 0); cf[u] = cur[i]; vf[u] = visited[i];
+                }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < GU; ++u)
                     if (id[u] >= 0) {
                         if (cf[u]) atomicOr(&bm_c[id[u] >> 5], 1u << (id[u] & 31));
                         else if (!vf[u]) atomicOr(&bm_e[id[u] >> 5], 1u << (id[u] & 31));                                 // :226-228
@@ -1023,13 +1075,14 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
             }
         }
         }      // (room-wide pass)
+        q_nc = totc; q_ne = tote;
         if (tid == 0) {
             S->pad = 1;
             S->nc = totc;
             S->ne = tote;
             int st = LRG_ACTIVE;
             if (tote == 0) st = LRG_STOP_NONEIGHBOR;                                         // :233-235
-            else if (prm.max_region_steps > 0 && S->step >= prm.max_region_steps) st = LRG_STOP_MAXSTEPS;
+            else if (prm.max_region_steps > 0 && cur_step >= prm.max_region_steps) st = LRG_STOP_MAXSTEPS;
             if (st != LRG_ACTIVE) { S->status = st; S->last_reason = st; S->count = totc; }
             sh_i[2] = st;
         }
@@ -1043,31 +1096,35 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
 
     // =========================== (4) sampling (:237-252), centre (:241), gather (:242-254) ===========================
     __shared__ int sh_off[2];
-    const int nc = S->nc, ne = S->ne;
+    const int nc = q_nc, ne = q_ne;                      // (known to every thread: no trip through S->nc / S->ne)
     const int rin = min(nc, Ni), rnb = min(ne, Nn);
     const bool is_big = nc > LRG_FRONT_SMALL;
+    int oi = 0, on = 0;
+    if (tid == 0) {                                      // requested here, needed after the sampling arithmetic
+        oi = atomicAdd(&a.counters[0], rin);
+        on = atomicAdd(&a.counters[1], rnb);
+    }
+    if (mine) {
+        const int nn = half ? nc : ne, kk = half ? Ni : Nn;      // (here the first half samples the neighbours, the second the inliers)
+        const int pos = (int)lrg_sample_position((uint32_t)j, (uint32_t)nn, (uint32_t)kk, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
+                                                 (uint32_t)cur_seed, (uint32_t)cur_restart, (uint32_t)cur_step, k0, k1);
+        (half ? a.sample_in : a.sample_nb)[(long)s * kk + j] = pos;
+        if (j < min(nn, kk)) sh_src[half ? 0 : 1][j] = (half ? cur_idx : cand_idx)[pos];
+    }
     if (tid == 0) {
-        const int oi = atomicAdd(&a.counters[0], rin), on = atomicAdd(&a.counters[1], rnb);
         sh_off[0] = oi; sh_off[1] = on;
         a.slot_rows[4 * s + 0] = rin; a.slot_rows[4 * s + 1] = rnb; a.slot_rows[4 * s + 2] = oi; a.slot_rows[4 * s + 3] = on;
         big[2 * s] = is_big ? 1 : 0;
         if (is_big) big[2 * s + 1] += 1;                 // tag of this iteration's centres (LrgFusedMedians: medians in the branch launch)
     }
-    if (mine) {
-        const int nn = half ? nc : ne, kk = half ? Ni : Nn;      // (here the first half samples the neighbours, the second the inliers)
-        const int pos = (int)lrg_sample_position((uint32_t)j, (uint32_t)nn, (uint32_t)kk, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
-                                                 (uint32_t)S->seed, (uint32_t)S->restart, (uint32_t)S->step, k0, k1);
-        (half ? a.sample_in : a.sample_nb)[(long)s * kk + j] = pos;
-        if (j < min(nn, kk)) sh_src[half ? 0 : 1][j] = (half ? cur_idx : cand_idx)[pos];
-    }
     if (tid < 16) sh_c[tid] = 0.f;
-    __syncthreads();
+    LRG_LDS_BARRIER();               // (the gather reads the source indices and the row offsets from LDS)
     TRACE2(s, 4);
     if (is_big) {
         // the nine medians of a region above LRG_FRONT_SMALL points come from lrg_front_big_kernel (one workgroup per channel);
         // nothing here waits for them: the rows go out uncentred
         if (tid < 16) a.center[s * 16 + tid] = 0.f;
-        lrg_front_gather(S, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
+        lrg_front_gather(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
         if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
         TRACE2(s, 5); TRACE2(s, 6); TRACE2(s, 7);
 #if LRG_TRACE
@@ -1085,7 +1142,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
             if (lane == 0) sh_c[ch] = m;
         }
     } else {
-        lrg_front_gather(S, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
+        lrg_front_gather(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
     }
     __syncthreads();
     TRACE2(s, 5);
