@@ -314,7 +314,9 @@ def main():
             sr = g_.p_slot_rows.cpu().numpy()
             rows += sr[:, :2].sum(axis=0)
             act += int((sr[:, 0] > 0).sum())
-            nr = torch.tensor([int(sr[:, 0].sum()), int(sr[:, 1].sum())], dtype=torch.int32, device=dev)
+            # rows as the loop's last evaluation saw them: the hand-over copy of the allocation counters (a slot's rows are
+            # allocated in multiples of 8, the padding being copies of its last row)
+            nr = g_.p_counters[2:4].clone()
             pb = g_.packed_buffers
 
             def fwd():

@@ -403,7 +403,8 @@ typedef struct LrgPackedBuffers {
     void *workspace;        /* lrg_forward_packed_workspace_bytes(w, n_slots, row_cap), 256-byte aligned       */
     size_t workspace_bytes;
     int64_t *stats;         /* LRG_STATS_WORDS x int64, as LrgStepBuffers                                      */
-    int32_t row_cap;        /* multiple of LRG_ROW_TILE, >= n_slots * max(n_inlier, n_neighbor)                */
+    int32_t row_cap;        /* multiple of LRG_ROW_TILE, >= n_slots * max(n_inlier, n_neighbor) rounded up to 16: a slot's
+                                rows are allocated in multiples of 8, the padding being copies of its last row    */
     int32_t rooms_have_pvox; /* 1: every room carries pvox (and 16-byte aligned visited / pvox): enables the single-launch greedy
                                 front kernel with word-wide room scans                                          */
     int32_t *slot_big;      /* nullable with rooms_have_pvox = 0: [n_slots,2] zero-filled ONCE and owned by these buffers for good:

@@ -506,6 +506,16 @@ __device__ __forceinline__ int lrg_div_small(int v, int d, float rcp) {
     else if ((q + 1) * d <= v) ++q;
     return q;
 }
+// A slot's packed rows are allocated in multiples of LRG_ROW_PAD rows, the padding filled with copies of the set's last row (the
+// copies the reference itself pads a set with, :240,:252: the max-pool ignores duplicates, nobody reads their logits).  A 32-row
+// tile of the network then holds at most 32 / LRG_ROW_PAD runs of rows of different slots: every run costs its epilogue passes
+// a masked maximum and a bias of its own (a tile of 8 runs lived 50 k cycles against 27 k for one run, profiles/r02_head_pass_stamps.txt),
+// and the slowest tile is what a launch lasts.
+#ifndef LRG_ROW_PAD
+#define LRG_ROW_PAD 8
+#endif
+#define LRG_PAD_ROWS(r) (((r) + LRG_ROW_PAD - 1) / LRG_ROW_PAD * LRG_ROW_PAD)
+
 // Workgroup barrier for hand-overs through LDS only: waits for this wavefront's LDS operations, not for the acknowledgement of
 // its global stores (__syncthreads() does, ~1.5 k cycles after a burst of stores that nobody in the workgroup reads back).
 #define LRG_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -518,7 +528,8 @@ template <int U>
 __device__ __forceinline__ void lrg_front_gather_rows(int target, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
                                                       const LrgFrontArgs &a, const int (*sh_src)[512], int rin, int rnb, int offi, int offn,
                                                       int tid, int bd) {
-    const int nel_in = rin * F, nel = nel_in + rnb * F;
+    const int rin_p = LRG_PAD_ROWS(rin), rnb_p = LRG_PAD_ROWS(rnb);      // (rows past the set: copies of its last row)
+    const int nel_in = rin_p * F, nel = nel_in + rnb_p * F;
     const float rF = 1.0f / (float)F;
     float *out_in = a.x_in + (long)offi * F, *out_nb = a.x_nb + (long)offn * F;
     float *upd_in = reinterpret_cast<float *>(a.upd_in) + (long)s * ni * 4, *upd_nb = reinterpret_cast<float *>(a.upd_nb) + (long)s * nn * 4;
@@ -530,7 +541,7 @@ __device__ __forceinline__ void lrg_front_gather_rows(int target, const float *p
             const int e = min(e0 + u * bd, nel - 1);
             const int side = e >= nel_in ? 1 : 0, l = e - (side ? nel_in : 0);
             const int j = lrg_div_small(l, F, rF), f = l - j * F;
-            const int src = sh_src[side][j];
+            const int src = sh_src[side][min(j, (side ? rnb : rin) - 1)];
             v[u] = points[(long)src * F + f];
             ob[u] = (f == 0 && obj) ? obj[src] : 0;
         }
@@ -541,9 +552,11 @@ __device__ __forceinline__ void lrg_front_gather_rows(int target, const float *p
                 const int side = e >= nel_in ? 1 : 0, l = e - (side ? nel_in : 0);
                 const int j = lrg_div_small(l, F, rF), f = l - j * F;
                 (side ? out_nb : out_in)[l] = v[u];
-                float *upd = (side ? upd_nb : upd_in) + 4 * j;
-                if (f < 3) upd[f] = v[u];
-                if (f == 0) upd[3] = (obj && (side ? ob[u] == target : ob[u] != target)) ? 1.f : 0.f;
+                if (j < (side ? rnb : rin)) {
+                    float *upd = (side ? upd_nb : upd_in) + 4 * j;
+                    if (f < 3) upd[f] = v[u];
+                    if (f == 0) upd[3] = (obj && (side ? ob[u] == target : ob[u] != target)) ? 1.f : 0.f;
+                }
             }
         }
     }
@@ -554,9 +567,9 @@ __device__ __forceinline__ void lrg_front_gather(int target, const float *points
                                                  int rnb, int offi, int offn, int first, int nthreads) {
     const int tid = (int)threadIdx.x - first, bd = nthreads;
     if (tid < 0 || tid >= nthreads) return;
-    for (int j = tid; j < rin; j += bd) a.row_slot_in[offi + j] = s;
-    for (int j = tid; j < rnb; j += bd) a.row_slot_nb[offn + j] = s;
-    const int nel = (rin + rnb) * F;
+    for (int j = tid; j < LRG_PAD_ROWS(rin); j += bd) a.row_slot_in[offi + j] = s;
+    for (int j = tid; j < LRG_PAD_ROWS(rnb); j += bd) a.row_slot_nb[offn + j] = s;
+    const int nel = (LRG_PAD_ROWS(rin) + LRG_PAD_ROWS(rnb)) * F;
     if (nel <= 2 * bd) lrg_front_gather_rows<2>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
     else if (nel <= 6 * bd) lrg_front_gather_rows<6>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
     else lrg_front_gather_rows<13>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);   // 2 x 512 rows x 13 floats
@@ -1101,8 +1114,8 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     const bool is_big = nc > LRG_FRONT_SMALL;
     int oi = 0, on = 0;
     if (tid == 0) {                                      // requested here, needed after the sampling arithmetic
-        oi = atomicAdd(&a.counters[0], rin);
-        on = atomicAdd(&a.counters[1], rnb);
+        oi = atomicAdd(&a.counters[0], LRG_PAD_ROWS(rin));
+        on = atomicAdd(&a.counters[1], LRG_PAD_ROWS(rnb));
     }
     if (mine) {
         const int nn = half ? nc : ne, kk = half ? Ni : Nn;      // (here the first half samples the neighbours, the second the inliers)
@@ -1159,7 +1172,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
 // global round trips), two bits per bisection step.  Nothing but the centre is written: the rows were gathered uncentred.
 __global__ __launch_bounds__(1024) void lrg_front_big_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                               LrgFrontArgs a, int32_t *big) {
-    __shared__ __attribute__((aligned(16))) int sh[LRG_RADIX_LDS_INTS(1)];
+    __shared__ __attribute__((aligned(16))) int sh[LRG_SAMPLED_LDS_INTS(1024)];      // (>= LRG_RADIX_LDS_INTS(1))
     const int s = blockIdx.x, tid = threadIdx.x;
     if (big[2 * s] == 0) return;
     const long long tickb = a.phase_ticks ? wall_clock64() : 0;
@@ -1185,9 +1198,11 @@ __global__ __launch_bounds__(1024) void lrg_front_big_kernel(const LrgSlot *slot
     if (nc <= 4096) { lrg_median_block_radix<4, 1024, 1>(cs.base, chs, S->cur_idx, cs.stride, nc, sh, mm); m = mm[0]; }
     else if (nc <= 16 * 1024) { lrg_median_block_radix<16, 1024, 1>(cs.base, chs, S->cur_idx, cs.stride, nc, sh, mm); m = mm[0]; }
     else if (nc <= LRG_MED_REGS) {
-#if LRG_MED48_BISECT
-        // 48 keys per thread: a radix pass is 48 LDS atomics per thread (49 k per workgroup), a bisection step 144 compares and
-        // one atomic per wavefront
+#if LRG_MED48_BISECT == 2
+        // 48 keys per thread: a radix pass is 48 LDS atomics per thread (49 k per workgroup), a bisection step 144 compares per
+        // thread -- two sampled pivots first, then the selection among the eighth of the keys between them
+        m = lrg_median_block_sampled<48>(cs.base, S->cur_idx, cs.stride, nc, sh);
+#elif LRG_MED48_BISECT
         if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
         __syncthreads();
         m = lrg_median_block_regs<48>(cs.base, S->cur_idx, cs.stride, nc, sh);

@@ -718,7 +718,7 @@ __global__ __launch_bounds__(LRG_PREP_THREADS) void lrg_prepare_kernel(const Lrg
 __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                                  float *center, int min_points, int32_t *tile_total) {
     if (tile_total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { tile_total[0] = 0; tile_total[1] = 0; }   // lrg_prepare (next launch) fills the lists
-    __shared__ __attribute__((aligned(16))) int sh[LRG_RADIX_LDS_INTS(1)];
+    __shared__ __attribute__((aligned(16))) int sh[LRG_SAMPLED_LDS_INTS(1024)];      // (>= LRG_RADIX_LDS_INTS(1))
     const int s = blockIdx.x;
     const LrgSlot *S = &slots[s];
     const int F = prm.feature_size;
@@ -739,7 +739,9 @@ __global__ __launch_bounds__(1024) void lrg_median_block_kernel(const LrgSlot *s
     if (nc <= 4096) lrg_median_block_radix<4, 1024, 1>(cs.base, chs, S->cur_idx, cs.stride, nc, sh, med);
     else if (nc <= 16 * 1024) lrg_median_block_radix<16, 1024, 1>(cs.base, chs, S->cur_idx, cs.stride, nc, sh, med);
     else {
-#if LRG_MED48_BISECT
+#if LRG_MED48_BISECT == 2
+        med[0] = lrg_median_block_sampled<48>(cs.base, S->cur_idx, cs.stride, nc, sh);
+#elif LRG_MED48_BISECT
         if (threadIdx.x < 64) sh[threadIdx.x] = threadIdx.x == 0 ? -1 : 0;
         __syncthreads();
         med[0] = lrg_median_block_regs<48>(cs.base, S->cur_idx, cs.stride, nc, sh);
@@ -1335,7 +1337,7 @@ static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_
     if (!b->center || !b->sample_in || !b->sample_nb || !b->x_in || !b->x_nb || !b->row_slot_in || !b->row_slot_nb || !b->upd_in ||
         !b->upd_nb || !b->rmv_logits || !b->add_logits || !b->slot_rows || !b->counters || !b->workspace)
         return LRG_EINVAL - 4;
-    if (b->row_cap % LRG_ROW_TILE != 0 || (long)b->row_cap < (long)n_slots * max(params->n_inlier, params->n_neighbor))
+    if (b->row_cap % LRG_ROW_TILE != 0 || (long)b->row_cap < (long)n_slots * LRG_PAD_ROWS(max(params->n_inlier, params->n_neighbor)))
         return LRG_EINVAL - 5;
     size_t poff = 0, pcnt = 0;
     if ((rc = lrg_forward_packed_pooled_view(weights, n_slots, b->row_cap, &poff, &pcnt))) return rc;

@@ -5,7 +5,8 @@
 #include "lrg_common.h"
 
 #ifndef LRG_MED48_BISECT
-#define LRG_MED48_BISECT 1      // regions above 16 Ki points (48 register keys per thread): bisection instead of the radix select
+#define LRG_MED48_BISECT 2      // regions above 16 Ki points (48 register keys per thread): 2 = two sampled pivots, then bisection among
+                                // the keys between them; 1 = bisection over all keys; 0 = radix select
 #endif
 
 __device__ __forceinline__ uint32_t lrg_f2key(float f) {
@@ -127,24 +128,18 @@ __device__ __forceinline__ float lrg_median_wave_r(const float *pts, const int32
 }
 
 
-// Larger regions: one BT-thread workgroup per (slot, channel), KT keys per thread in REGISTERS (two global round
-// trips in all), bisection with per-thread counters, a DPP wave sum and one LDS atomic + one barrier per step.
-template <int KT, int BT = 1024>
-__device__ __forceinline__ float lrg_median_block_regs(const float *pts, const int32_t *idx, int F, int nc, int *sh) {
+// Selection over KT register keys per thread of a BT-thread workgroup (key[r] = the key of position r * BT + tid, positions >= n
+// hold 0xFFFFFFFF): the key of rank k2 and, if need_lo, its mean with the key of rank k2 - 1 (numpy.median of an even count).
+// Bisection with per-thread counters, a DPP wave sum and one LDS atomic + one barrier per step.
+// sh[0] = min (caller: 0xFFFFFFFF), sh[1] = max, sh[2..49] = three counters per step, sh[50] = below-count, sh[51] = max below
+// (caller: 0), visible to the workgroup (a barrier after the initialisation).
+template <int KT, int BT>
+__device__ __forceinline__ float lrg_block_select_regs(const uint32_t (&key)[KT], int n, int k2, bool need_lo, int *sh) {
     const int tid = threadIdx.x, lane = lrg_lane();
-    uint32_t key[KT];
-    {
-        int id[KT];
-#pragma unroll
-        for (int r = 0; r < KT; ++r) id[r] = idx[min(r * BT + tid, nc - 1)];
-#pragma unroll
-        for (int r = 0; r < KT; ++r) key[r] = (r * BT + tid < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
-    }
-    // sh[0] = min, sh[1] = max, sh[2..49] = three counters per bisection step, sh[50] = below-count, sh[51] = max below
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
     for (int r = 0; r < KT; ++r)
-        if (r * BT + tid < nc) { kmin = min(kmin, key[r]); kmax = max(kmax, key[r]); }
+        if (r * BT + tid < n) { kmin = min(kmin, key[r]); kmax = max(kmax, key[r]); }
     kmin = lrg_wave_min_u32(kmin);
     kmax = lrg_wave_max_u32(kmax);
     if (lane == 0) { atomicMin(reinterpret_cast<unsigned *>(&sh[0]), kmin); atomicMax(reinterpret_cast<unsigned *>(&sh[1]), kmax); }
@@ -153,15 +148,13 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
     const uint32_t diff = kmin ^ kmax;
     const int hb = diff ? 32 - __clz((int)diff) : 0;
     const uint32_t common = hb >= 32 ? 0u : (kmin >> hb) << hb;
-    const int k2 = nc >> 1;
     uint32_t rb = common;
-    // two bits per step on aligned bit pairs (three thresholds; counts packed 16+16 | 32: a block holds at most 48 Ki keys).
+    // two bits per step on aligned bit pairs (three thresholds, three counters of up to 48 Ki each).
     // A pair that reaches into the common prefix needs no special case: a threshold that would flip a common bit counts
-    // either every key or the same keys as a lower threshold.  The step cost is the barrier, not the compares.
+    // either every key or the same keys as a lower threshold.
     int slot = 2;
     for (int bit = ((hb + 1) & ~1) - 2; bit >= 0; bit -= 2, slot += 3) {
         const uint32_t t1 = rb | (1u << bit), t2 = rb | (2u << bit), t3 = rb | (3u << bit);
-        // three counters, each up to 48 Ki: kept apart (packing two into 16 + 16 bits would overflow the low half)
         int c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
         for (int r = 0; r < KT; ++r) {
@@ -180,7 +173,8 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
         else if (s1 <= k2) rb = t1;
     }
     float hi = lrg_key2f(rb);
-    if (nc & 1) return hi;
+    if (!need_lo) return hi;
+    // the key of rank k2 - 1 is rb itself when fewer than k2 keys lie below rb (duplicates of rb span both ranks), else the largest below
     int below = 0;
     uint32_t mx = 0u;
 #pragma unroll
@@ -192,6 +186,117 @@ __device__ __forceinline__ float lrg_median_block_regs(const float *pts, const i
     __syncthreads();
     float lo = sh[50] >= k2 ? lrg_key2f((uint32_t)sh[51]) : hi;
     return __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+}
+
+// Larger regions: one BT-thread workgroup per (slot, channel), KT keys per thread in REGISTERS (two global round trips in all).
+template <int KT, int BT = 1024>
+__device__ __forceinline__ float lrg_median_block_regs(const float *pts, const int32_t *idx, int F, int nc, int *sh) {
+    const int tid = threadIdx.x;
+    uint32_t key[KT];
+    {
+        int id[KT];
+#pragma unroll
+        for (int r = 0; r < KT; ++r) id[r] = idx[min(r * BT + tid, nc - 1)];
+#pragma unroll
+        for (int r = 0; r < KT; ++r) key[r] = (r * BT + tid < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
+    }
+    return lrg_block_select_regs<KT, BT>(key, nc, nc >> 1, !(nc & 1), sh);
+}
+
+// The key of rank k among n <= 64 * R keys held R per lane by ONE wavefront (padding 0xFFFFFFFF): bisection, no LDS.
+template <int R>
+__device__ __forceinline__ uint32_t lrg_select_rank_wave(const uint32_t (&key)[R], int n, int k) {
+    const int lane = lrg_lane();
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (r * 64 + lane < n) { kmin = min(kmin, key[r]); kmax = max(kmax, key[r]); }
+    kmin = lrg_wave_min_u32(kmin);
+    kmax = lrg_wave_max_u32(kmax);
+    const uint32_t diff = kmin ^ kmax;
+    const int hb = diff ? 32 - __clz((int)diff) : 0;
+    uint32_t rb = hb >= 32 ? 0u : (kmin >> hb) << hb;
+    for (int bit = hb - 1; bit >= 0; --bit) {
+        const uint32_t cb = rb | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) cnt += key[r] < cb ? 1 : 0;
+        if (lrg_wave_sum_i32(cnt) <= k) rb = cb;
+    }
+    return rb;
+}
+
+// Regions of tens of thousands of points (KT = 48 keys per thread): a bisection step over all of them costs 48 x 3 compares per
+// thread -- ~5 k cycles for the 16 wavefronts of a CU -- and there are 10-16 of them (a 40 k-point ground region of a KITTI scene:
+// 53 us per channel).  Two pivots bracket the median first: the keys of ranks BT/2 -+ LRG_MED_SAMPLE_D of a systematic sample of
+// BT keys (one per thread, evenly spaced over the list; each rank found by one wavefront, 16 keys per lane), ONE counting pass
+// over all keys (how many lie below the bracket, how many inside), and the keys inside -- an eighth of them -- go to LDS, where
+// the ranks wanted are selected among KT2 <= 8 keys per thread.  Exact: when the bracket misses the ranks (the sample rank of the
+// true median is binomial, sigma = 16: beyond 4 sigma) or overflows its buffer, the full bisection runs.
+// sh: 64 ints as for lrg_block_select_regs, then BT sample keys, then LRG_MED_BRACKET_CAP bracket keys.
+#define LRG_MED_SAMPLE_D 64
+#define LRG_MED_BRACKET_CAP 8192
+#define LRG_SAMPLED_LDS_INTS(BT) (64 + (BT) + LRG_MED_BRACKET_CAP)
+template <int KT, int BT = 1024>
+__device__ __forceinline__ float lrg_median_block_sampled(const float *pts, const int32_t *idx, int F, int nc, int *sh) {
+    static_assert(BT == 1024, "the sample is selected 16 keys per lane");
+    const int tid = threadIdx.x, lane = lrg_lane(), wave = tid >> 6;
+    uint32_t *samp = reinterpret_cast<uint32_t *>(sh + 64), *brk = samp + BT;
+    uint32_t key[KT];
+    uint32_t skey;
+    {
+        int id[KT];
+        const int sid = idx[(int)(((long)tid * nc) / BT)];
+#pragma unroll
+        for (int r = 0; r < KT; ++r) id[r] = idx[min(r * BT + tid, nc - 1)];
+        skey = lrg_f2key(pts[(long)sid * F]);
+#pragma unroll
+        for (int r = 0; r < KT; ++r) key[r] = (r * BT + tid < nc) ? lrg_f2key(pts[(long)id[r] * F]) : 0xFFFFFFFFu;
+    }
+    samp[tid] = skey;
+    if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
+    __syncthreads();
+    if (wave < 2) {                                              // the two pivots, one wavefront each
+        uint32_t sk[BT / 64];
+#pragma unroll
+        for (int r = 0; r < BT / 64; ++r) sk[r] = samp[r * 64 + lane];
+        const uint32_t piv = lrg_select_rank_wave<BT / 64>(sk, BT, wave == 0 ? BT / 2 - LRG_MED_SAMPLE_D : BT / 2 + LRG_MED_SAMPLE_D);
+        if (lane == 0) sh[60 + wave] = (int)piv;
+    }
+    __syncthreads();
+    const uint32_t plo = (uint32_t)sh[60], phi = (uint32_t)sh[61];
+    int below = 0, inside = 0;
+#pragma unroll
+    for (int r = 0; r < KT; ++r) {
+        below += key[r] < plo ? 1 : 0;                           // (padding keys are above every pivot)
+        inside += (key[r] >= plo && key[r] <= phi && r * BT + tid < nc) ? 1 : 0;
+    }
+    // workgroup totals, and this thread's place in the bracket buffer (exclusive scan of `inside`: wavefront scan + wavefront offsets)
+    const int incl = lrg_wave_incl_scan_i32(inside);
+    const int wbelow = lrg_wave_sum_i32(below);
+    if (lane == 63) sh[32 + wave] = incl;
+    if (lane == 0 && wbelow) atomicAdd(&sh[62], wbelow);
+    __syncthreads();
+    int woff = 0, M = 0;
+#pragma unroll
+    for (int w = 0; w < BT / 64; ++w) { if (w < wave) woff += sh[32 + w]; M += sh[32 + w]; }
+    const int B = sh[62];
+    const int k2 = nc >> 1, k1 = (nc & 1) ? k2 : k2 - 1;
+    __syncthreads();                                             // (sh[32..] and sh[60..62] are read: the selects below start from a clean sh[0..63])
+    if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
+    __syncthreads();
+    if (!(B <= k1 && k2 < B + M && M <= LRG_MED_BRACKET_CAP))    // (workgroup-uniform)
+        return lrg_block_select_regs<KT, BT>(key, nc, k2, !(nc & 1), sh);
+    int pos = woff + incl - inside;
+#pragma unroll
+    for (int r = 0; r < KT; ++r)
+        if (key[r] >= plo && key[r] <= phi && r * BT + tid < nc) brk[pos++] = key[r];
+    __syncthreads();
+    constexpr int KT2 = LRG_MED_BRACKET_CAP / BT;
+    uint32_t k2v[KT2];
+#pragma unroll
+    for (int q = 0; q < KT2; ++q) k2v[q] = q * BT + tid < M ? brk[q * BT + tid] : 0xFFFFFFFFu;
+    return lrg_block_select_regs<KT2, BT>(k2v, M, k2 - B, !(nc & 1), sh);
 }
 
 

@@ -268,7 +268,7 @@ class RegionGrower:
         if self.params.scoring == 1 and not self.packed:
             raise ValueError("scoring='ml' needs the packed iteration (fused network, rooms of at most %d points)" % _lib.LRG_PACKED_MAX_POINTS)
         if self.packed:
-            cap_rows = (S * max(Ni, Nn) + 31) // 32 * 32
+            cap_rows = (S * ((max(Ni, Nn) + 15) // 16 * 16) + 31) // 32 * 32     # (a slot's rows are allocated in multiples of 8 or 16)
             self.row_cap = cap_rows
             self.p_xin = torch.zeros((cap_rows, F), dtype=torch.float32, device=dev)
             self.p_xnb = torch.zeros((cap_rows, F), dtype=torch.float32, device=dev)

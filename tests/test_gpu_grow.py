@@ -275,3 +275,54 @@ def test_room_fill_in(net, pattern):
     got = gr.d_filled[:n].cpu().numpy()
     want = grow_ref.fill_unlabeled(room['points'], lab.astype(np.int64)) if (lab != 0).any() else lab
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize('with_chan_major', [True, False])
+def test_medians_of_large_regions(net, monkeypatch, with_chan_major):
+    """numpy.median (:241) over regions of every size class of lrg_median -- one wavefront, the radix select with 4 / 16 keys per
+    thread, the sampled-pivot bisection above 16 Ki points, the LDS-cached selection above 48 Ki -- on channels that are smooth,
+    sorted along the list, two-valued, constant, or constant but for a few outliers; odd and even counts."""
+    import ctypes
+    import torch
+    from learn_region_grow_amd import _lib
+    from learn_region_grow_amd.grow import RegionGrower
+    from learn_region_grow_amd._lib import LrgSlot, LRG_ACTIVE
+    from learn_region_grow_amd.lrgnet import _ptr, _stream_ptr
+    if not with_chan_major:
+        monkeypatch.setenv('LRG_NO_CHAN_MAJOR', '1')
+    N = 70001
+    rs = np.random.RandomState(7)
+    pts = np.zeros((N, 13), dtype=np.float32)
+    grid = np.stack(np.meshgrid(np.arange(420), np.arange(170), indexing='ij'), -1).reshape(-1, 2)[:N]
+    pts[:, 0] = grid[:, 0] * 0.1 + 0.03
+    pts[:, 1] = grid[:, 1] * 0.1 + 0.04                    # one point per 0.1 m voxel (the loader insists)
+    pts[:, 2] = 0.05
+    pts[:, 6] = rs.rand(N)                                 # smooth
+    pts[:, 7] = np.sort(rs.randn(N)).astype(np.float32)    # sorted along the list
+    pts[:, 8] = (rs.rand(N) < 0.5)                         # two values
+    pts[:, 9] = 0.25                                       # constant
+    pts[:, 10] = np.where(rs.rand(N) < 0.001, rs.randn(N), 1.0)      # constant but for a few outliers
+    pts[:, 11] = -np.abs(rs.randn(N)) * 1e-3               # negative, clustered near zero
+    pts[:, 12] = rs.randint(0, 50, N) * 0.5                # heavy duplicates
+    room = dict(points=pts, obj_id=np.zeros(N, np.int32), order=np.arange(N, dtype=np.int32), room_id=0)
+    sizes = [200, 257, 1000, 1025, 4000, 4097, 16000, 16385, 30000, 40001, 49152, 49153, 70000]
+    gr = RegionGrower(net, rooms_in_flight=len(sizes), rng='counter', seed=1, policy='gt')
+    gr.load_rooms([room])
+    sz = ctypes.sizeof(LrgSlot)
+    lists = []
+    for s, nc in enumerate(sizes):
+        idx = np.sort(rs.permutation(N)[:nc]).astype(np.int32) if s % 2 else rs.permutation(N)[:nc].astype(np.int32)
+        lists.append(idx)
+        gr.d_curidx[s, :nc] = torch.from_numpy(idx).to(gr.dev)
+        sl = gr.h_slots[s]
+        sl.room, sl.status, sl.nc = 0, LRG_ACTIVE, nc
+    gr.d_slots.copy_(torch.from_numpy(np.frombuffer(bytes(gr.h_slots), dtype=np.uint8).copy()))
+    center = torch.full((len(sizes), 16), -7.0, dtype=torch.float32, device=gr.dev)
+    _lib.check(gr.lib.lrg_median(_ptr(gr.d_slots), _ptr(gr.d_rooms), len(sizes), ctypes.byref(gr.params), _ptr(center),
+                                 _stream_ptr(gr.dev)), 'lrg_median')
+    got = center.cpu().numpy()
+    for s, idx in enumerate(lists):
+        want = np.median(pts[idx], axis=0)
+        for ch in (0, 1, 6, 7, 8, 9, 10, 11, 12):
+            assert got[s, ch] == want[ch], 'region of %d points, channel %d: %r vs %r' % (len(idx), ch, got[s, ch], want[ch])
+        assert (got[s, 2:6] == 0).all()
