@@ -340,7 +340,9 @@ def main():
                    'frac_of_fp32_matrix_peak': loop_flops / (loop_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
                    'useful_tflops_over_the_steady_leg': inst_steps / world / elapsed * loop_flops / max(act, 1) / 1e12}
     traffic = None
-    tpath = os.path.join(REPO, 'profiles', 'r01_traffic_%s.json' % args.net_mode)
+    tpath = os.path.join(REPO, 'profiles', 'r02_traffic_%s.json' % args.net_mode)
+    if not os.path.exists(tpath):
+        tpath = os.path.join(REPO, 'profiles', 'r01_traffic_%s.json' % args.net_mode)
     if os.path.exists(tpath):
         traffic = json.load(open(tpath))['hbm_bytes_per_forward'] * S / 68.0
     sq = None
@@ -443,7 +445,7 @@ def main():
                                                    'batch (v_mfma_f32_32x32x2_f32, exact fp32)',
                          'achieved': tflops, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / FP32_MATRIX_PEAK_TFLOPS,
                          'traffic': traffic,
-                         'traffic_source': 'profiles/r01_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, S=68)' % args.net_mode,
+                         'traffic_source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of their own, S=68; tools/pmc_run.sh)' % os.path.basename(tpath),
                          'algorithmic_flops': flops, 'flops_per_instance': FLOPS_PER_INSTANCE_STEP,
                          'ms_per_launch': fwd_ms, 'instances_per_launch': S,
                          'hbm_accounting': {'note': 'SURVEY.md 8d layer-streamed accounting (what an unfused implementation would stream); the '
