@@ -413,6 +413,12 @@ typedef struct LrgPackedBuffers {
     int64_t *phase_ticks;   /* nullable: [n_slots,2] accumulators of wall_clock64() ticks the slot's workgroup spent in (0) mask
                                 update / stop decision / commit -- the reference's 'inlier' bucket, test_region_grow.py:260-306 --
                                 and (1) box query / median / sampling / gather -- its 'neighbor' bucket, :219-254            */
+    int32_t *med_queue;     /* nullable (and ignored unless the library was built with -DLRG_MED_POOL_KERNEL=1, an experiment):
+                                [16 + 9 * n_slots + med_pool] zero-filled ONCE and owned by these buffers: work queue of the
+                                med_pool median workgroups that then ride in the greedy front launch (regions above 256 points
+                                hand their nine channel medians to them) instead of a launch of their own                     */
+    int32_t med_pool;       /* number of those workgroups (0 with med_queue == NULL)                                        */
+    int32_t pad;
 } LrgPackedBuffers;
 
 /* One lock-step iteration, packed rows: lrg_front_kernel (mask update of the previous evaluation :262-288, stop decision

@@ -81,7 +81,8 @@ class LrgPackedBuffers(ctypes.Structure):
     _fields_ = [('center', _fp), ('sample_in', _fp), ('sample_nb', _fp), ('x_in', _fp), ('x_nb', _fp),
                 ('row_slot_in', _fp), ('row_slot_nb', _fp), ('upd_in', _fp), ('upd_nb', _fp), ('rmv_logits', _fp),
                 ('add_logits', _fp), ('slot_rows', _fp), ('counters', _fp), ('workspace', _fp),
-                ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('row_cap', ctypes.c_int32), ('rooms_have_pvox', ctypes.c_int32), ('slot_big', _fp), ('phase_ticks', _fp)]
+                ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('row_cap', ctypes.c_int32), ('rooms_have_pvox', ctypes.c_int32), ('slot_big', _fp), ('phase_ticks', _fp),
+                ('med_queue', _fp), ('med_pool', ctypes.c_int32), ('pad', ctypes.c_int32)]
 
 
 class LrgBeamGroup(ctypes.Structure):

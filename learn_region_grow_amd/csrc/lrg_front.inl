@@ -37,6 +37,8 @@ struct LrgFrontArgs {
     int pooled_stride;
     int64_t *stats;
     int64_t *phase_ticks;    // nullable: [n_slots,2] wall-clock ticks per slot: (0) update / stop / commit, (1) query / median / gather
+    int32_t *med_queue;      // nullable: work queue of the median workgroups that ride in the greedy front launch (LrgPackedBuffers.med_queue)
+    int med_pool;            // their number (the launch has n_slots + med_pool workgroups)
 };
 
 // ---- (1) mask update of the evaluation just finished + count / bounding box of the new mask + stop decision ----
@@ -596,6 +598,113 @@ __device__ __forceinline__ int lrg_voxel_index(const LrgVoxIndex &I, int vx, int
                                                         // limit of 32 Ki with 12 or 16 cells per trip gains nothing over the room-wide pass)
 #endif
 
+// The median of centred channel y of slot S's current points by one 1024-thread workgroup (the body of lrg_front_big_kernel; CAP =
+// bracket buffer of the sampled selection, so that `sh` fits where the caller has room).  Valid in thread 0.
+template <int CAP>
+__device__ __forceinline__ float lrg_big_median(const int32_t *cur_idx, const LrgRoom *R, int nc, int y, int ch, int F, int *sh) {
+    const int tid = threadIdx.x;
+    const LrgChanSrc cs = lrg_chan_src(R, y, ch, F);
+    if (nc <= 1024) {                                // one wavefront, keys in registers, no barrier
+        float mw = 0.f;
+        if (tid < 64) mw = nc <= 256 ? lrg_median_wave_r<4>(cs.base, cur_idx, cs.stride, nc) : lrg_median_wave_r<16>(cs.base, cur_idx, cs.stride, nc);
+        return mw;
+    }
+    float m;
+    const int chs[1] = {0};
+    float mm[1];
+    if (nc <= 4096) { lrg_median_block_radix<4, 1024, 1>(cs.base, chs, cur_idx, cs.stride, nc, sh, mm); m = mm[0]; }
+    else if (nc <= 16 * 1024) { lrg_median_block_radix<16, 1024, 1>(cs.base, chs, cur_idx, cs.stride, nc, sh, mm); m = mm[0]; }
+    else if (nc <= LRG_MED_REGS) m = lrg_median_block_sampled<48, 1024, CAP>(cs.base, cur_idx, cs.stride, nc, sh);
+    else {
+        if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
+        __syncthreads();
+        const int k2 = nc >> 1, k1r = (nc & 1) ? k2 : k2 - 1;
+        uint32_t ka, kb;
+        lrg_select2(nullptr, false, cs.base, cur_idx, cs.stride, 0, nc, k1r, k2, sh, &ka, &kb);
+        const float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
+        m = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+    }
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Median workgroups inside the greedy front launch.  The medians of regions above LRG_POOL_SMALL points used to be a launch of
+// their own between the front kernel and the branch stacks: ~9 us of a ~115 us chain of dependent launches (without it:
+// 117.5 -> 107.5 us per iteration, tools/r02_nobig.sh).  Now the launch carries `med_pool` extra workgroups behind the n_slots
+// front workgroups.  A front workgroup that has written the index lists of a large region publishes one item per centred channel
+// (release), every front workgroup counts itself as done when nothing more can come from it; a pool workgroup draws tickets,
+// waits for its item (acquire) or for the proof that none will come (all front workgroups done and fewer items reserved than its
+// ticket), computes the median and writes the centre, which nothing reads before the next launch.  The front workgroups never wait
+// for anybody, so nothing can deadlock whatever the order in which workgroups start; the last pool workgroup to leave resets the
+// counters for the next launch, consumers clear the items they take.
+// queue: [0] items reserved, [1] tickets drawn, [2] front workgroups done, [3] pool workgroups gone, [16 ...] items
+// (0x40000000 | slot << 4 | channel row), at least 9 * n_slots + med_pool of them.
+// ------------------------------------------------------------------------------------------------------------------------
+// EXPERIMENT, off by default (LRG_MED_POOL_KERNEL=1 compiles it in): as first built it lost -- 144 us per iteration with 64 pool
+// workgroups against 122 us with the launch of their own on the same box (32: 127 us, 128: 185 us) -- and was not exact yet (one
+// parity test and the determinism check failed).  What it costs, as far as seen: every poll was an acquire (an L2 invalidate per
+// spin), a spinning 1024-thread workgroup holds a whole CU, and with the 48-key selection inlined the kernel needs 128 VGPRs (one
+// workgroup per CU also for the front role: 5 % slower even with the pool switched off).  profiles/r02_median_pool_experiment.txt.
+#ifndef LRG_MED_POOL_KERNEL
+#define LRG_MED_POOL_KERNEL 0
+#endif
+#define LRG_POOL_ITEMS 16
+#ifndef LRG_POOL_SMALL
+#define LRG_POOL_SMALL 256      // regions up to this many points: medians by nine wavefronts of the slot's own workgroup
+#endif
+#if LRG_MED_POOL_KERNEL
+__device__ __noinline__ void lrg_median_pool_role(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams &prm,
+                                     const LrgFrontArgs &a, int *sh) {
+    __shared__ int sh_item;
+    const int tid = threadIdx.x;
+    int32_t *q = a.med_queue;
+    const int F = prm.feature_size;
+    for (;;) {
+        if (tid == 0) {
+            const int t = atomicAdd(&q[1], 1);
+            int item = 0;
+            for (int spin = 0; spin < (1 << 18); ++spin) {       // (bounded: a lost producer shows as a wrong centre, not as a hang)
+                item = __hip_atomic_load(&q[LRG_POOL_ITEMS + t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (item) break;
+                if (__hip_atomic_load(&q[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= n_slots &&
+                    t >= __hip_atomic_load(&q[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { item = -1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (item > 0) __hip_atomic_store(&q[LRG_POOL_ITEMS + t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_item = item > 0 ? item : -1;
+        }
+        __syncthreads();
+        const int item = sh_item;
+        __syncthreads();
+        if (item < 0) break;
+        const int s = (item & 0x3FFFFFFF) >> 4, y = item & 15;
+        const LrgSlot *S = &slots[s];
+        // (the slot was written by another workgroup of this launch: plain loads of its scalars could be served by the scalar cache)
+        const int nc = __hip_atomic_load(&S->nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int room = __hip_atomic_load(&S->room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ch = lrg_centred_channel(y, F);
+        if (ch >= 0 && room >= 0 && nc > 0) {
+            const float m = lrg_big_median<6144>(S->cur_idx, &rooms[room], nc, y, ch, F, sh);
+            if (tid == 0) a.center[s * 16 + ch] = m;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&q[3], 1) == a.med_pool - 1) {             // everybody else has left, every front workgroup is done
+            __hip_atomic_store(&q[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&q[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&q[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&q[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// a front workgroup counts itself as done (thread 0; after its items, if any, are out)
+#define LRG_POOL_LEAVE() do { if (a.med_queue && tid == 0) { __threadfence(); atomicAdd(&a.med_queue[2], 1); } } while (0)
+#else
+#define LRG_POOL_LEAVE() do { } while (0)
+#endif
+
 __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
                                                                               LrgGrowParams prm, LrgFrontArgs a, int32_t *big) {
     __shared__ uint8_t sh_flags[LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS];
@@ -606,6 +715,12 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     __shared__ int sh_i[8];                // 0 updated, 1 added count, 2 status, 3 seed-search minimum, 4 probe count, 5 add_acc, 6 remove_acc
     __shared__ int sh_list[32];
     __shared__ int wt_c[16], wt_e[16];   // (the grid query scans over all 16 wavefronts)
+#if LRG_MED_POOL_KERNEL
+    if ((int)blockIdx.x >= n_slots) {    // the median workgroups behind the front workgroups (a.med_pool of them)
+        lrg_median_pool_role(slots, rooms, n_slots, prm, a, reinterpret_cast<int *>(sh_flags));
+        return;
+    }
+#endif
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     LrgSlot *S = &slots[s];
     const int F = prm.feature_size, Ni = prm.n_inlier, Nn = prm.n_neighbor;
@@ -632,6 +747,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         for (int c = tid; c < a.pooled_stride; c += LRG_FRONT_THREADS) a.pooled[(long)s * a.pooled_stride + c] = 0.f;
     if (room < 0) {
         if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
+        LRG_POOL_LEAVE();
         return;
     }
     // ---- round trip 2: the room ----
@@ -857,6 +973,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
                     }
                     a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0;
                 }
+                LRG_POOL_LEAVE();
                 return;
             }
             const int sd = order[found];
@@ -898,6 +1015,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
                 S->seed = -1; S->status = LRG_WAIT; S->count = -1;
                 a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0;
             }
+            LRG_POOL_LEAVE();
             return;
         }
         // the slot's mask is all zero here (every region clears its members at commit; the host zeroes it when binding)
@@ -934,6 +1052,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 0] += tick1 - tick0;
     if (status != LRG_ACTIVE) {      // DONE / IDLE
         if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
+        LRG_POOL_LEAVE();
         return;
     }
 
@@ -1102,16 +1221,37 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         __syncthreads();
         if (sh_i[2] != LRG_ACTIVE) {
             if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
+            LRG_POOL_LEAVE();
             return;
         }
     }
     TRACE2(s, 3);
+    // The index lists are final (and visible to the workgroup: a full barrier lies behind both ways here).  With median workgroups in the
+    // launch: a region above LRG_POOL_SMALL points hands its medians to them -- one item per centred channel -- and in any case
+    // this workgroup has nothing more to publish.
+#if LRG_MED_POOL_KERNEL
+    const int small_max = a.med_queue ? LRG_POOL_SMALL : LRG_FRONT_SMALL;
+    if (a.med_queue && tid == 0) {
+        int32_t *q = a.med_queue;
+        if (q_nc > small_max) {
+            const int ncen = F <= 2 ? F : F <= 6 ? 2 : F - 4;
+            const int base = atomicAdd(&q[0], ncen);
+            __threadfence();                                     // the lists, S->nc: before the items
+            for (int y = 0; y < ncen; ++y)
+                __hip_atomic_store(&q[LRG_POOL_ITEMS + base + y], 0x40000000 | (s << 4) | y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+        atomicAdd(&q[2], 1);
+    }
+#else
+    const int small_max = LRG_FRONT_SMALL;
+#endif
 
     // =========================== (4) sampling (:237-252), centre (:241), gather (:242-254) ===========================
     __shared__ int sh_off[2];
     const int nc = q_nc, ne = q_ne;                      // (known to every thread: no trip through S->nc / S->ne)
     const int rin = min(nc, Ni), rnb = min(ne, Nn);
-    const bool is_big = nc > LRG_FRONT_SMALL;
+    const bool is_big = nc > small_max;
     int oi = 0, on = 0;
     if (tid == 0) {                                      // requested here, needed after the sampling arithmetic
         oi = atomicAdd(&a.counters[0], LRG_PAD_ROWS(rin));
@@ -1134,9 +1274,9 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     LRG_LDS_BARRIER();               // (the gather reads the source indices and the row offsets from LDS)
     TRACE2(s, 4);
     if (is_big) {
-        // the nine medians of a region above LRG_FRONT_SMALL points come from lrg_front_big_kernel (one workgroup per channel);
-        // nothing here waits for them: the rows go out uncentred
-        if (tid < 16) a.center[s * 16 + tid] = 0.f;
+        // the nine medians of such a region come from lrg_front_big_kernel (one workgroup per channel) or from the median
+        // workgroups of this launch; nothing here waits for them: the rows go out uncentred
+        if (tid < 16 && !(LRG_MED_POOL_KERNEL && a.med_queue && lrg_is_centred(tid, F))) a.center[s * 16 + tid] = 0.f;   // (theirs to write, maybe already)
         lrg_front_gather(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
         if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
         TRACE2(s, 5); TRACE2(s, 6); TRACE2(s, 7);

@@ -233,13 +233,14 @@ __device__ __forceinline__ uint32_t lrg_select_rank_wave(const uint32_t (&key)[R
 // over all keys (how many lie below the bracket, how many inside), and the keys inside -- an eighth of them -- go to LDS, where
 // the ranks wanted are selected among KT2 <= 8 keys per thread.  Exact: when the bracket misses the ranks (the sample rank of the
 // true median is binomial, sigma = 16: beyond 4 sigma) or overflows its buffer, the full bisection runs.
-// sh: 64 ints as for lrg_block_select_regs, then BT sample keys, then LRG_MED_BRACKET_CAP bracket keys.
+// sh: 64 ints as for lrg_block_select_regs, then BT sample keys, then CAP bracket keys.
 #define LRG_MED_SAMPLE_D 64
 #define LRG_MED_BRACKET_CAP 8192
 #define LRG_SAMPLED_LDS_INTS(BT) (64 + (BT) + LRG_MED_BRACKET_CAP)
-template <int KT, int BT = 1024>
+template <int KT, int BT = 1024, int CAP = LRG_MED_BRACKET_CAP>
 __device__ __forceinline__ float lrg_median_block_sampled(const float *pts, const int32_t *idx, int F, int nc, int *sh) {
     static_assert(BT == 1024, "the sample is selected 16 keys per lane");
+    static_assert(CAP % BT == 0, "whole keys per thread in the second stage");
     const int tid = threadIdx.x, lane = lrg_lane(), wave = tid >> 6;
     uint32_t *samp = reinterpret_cast<uint32_t *>(sh + 64), *brk = samp + BT;
     uint32_t key[KT];
@@ -285,14 +286,14 @@ __device__ __forceinline__ float lrg_median_block_sampled(const float *pts, cons
     __syncthreads();                                             // (sh[32..] and sh[60..62] are read: the selects below start from a clean sh[0..63])
     if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
     __syncthreads();
-    if (!(B <= k1 && k2 < B + M && M <= LRG_MED_BRACKET_CAP))    // (workgroup-uniform)
+    if (!(B <= k1 && k2 < B + M && M <= CAP))                    // (workgroup-uniform)
         return lrg_block_select_regs<KT, BT>(key, nc, k2, !(nc & 1), sh);
     int pos = woff + incl - inside;
 #pragma unroll
     for (int r = 0; r < KT; ++r)
         if (key[r] >= plo && key[r] <= phi && r * BT + tid < nc) brk[pos++] = key[r];
     __syncthreads();
-    constexpr int KT2 = LRG_MED_BRACKET_CAP / BT;
+    constexpr int KT2 = CAP / BT;
     uint32_t k2v[KT2];
 #pragma unroll
     for (int q = 0; q < KT2; ++q) k2v[q] = q * BT + tid < M ? brk[q * BT + tid] : 0xFFFFFFFFu;
@@ -302,6 +303,8 @@ __device__ __forceinline__ float lrg_median_block_sampled(const float *pts, cons
 
 // centred channel of grid row y: 0, 1, 6, 7, ... (:243-247); -1 past the feature count
 __device__ __forceinline__ int lrg_centred_channel(int y, int F) { const int ch = y < 2 ? y : y + 4; return ch < F ? ch : -1; }
+
+__device__ __forceinline__ bool lrg_is_centred(int ch, int F) { return (ch < 2 || ch >= 6) && ch < F; }
 
 // Where the keys of centred channel ch = lrg_centred_channel(y, F) of a room come from: value of point i = base[i * stride].
 // With the room's channel-major copy (LrgRoom::chan_major) a region -- mostly runs of consecutive indices, a room's points come

@@ -295,6 +295,12 @@ class RegionGrower:
             self.p_big = torch.zeros((S, 2), dtype=torch.int32, device=dev)
             pb.slot_big = self.p_big.data_ptr()
             pb.rooms_have_pvox = 1 if self.have_pvox else 0
+            # median workgroups inside the greedy front launch (one launch less per iteration): an experiment that is compiled in only with
+            # -DLRG_MED_POOL_KERNEL=1 and was slower as first built (csrc/lrg_front.inl); LRG_MED_POOL=<workgroups> asks for it
+            pool = int(os.environ.get('LRG_MED_POOL', '0'))
+            if pool > 0 and self.have_pvox and self.G == 1:
+                self.p_medq = torch.zeros(16 + 9 * S + pool, dtype=torch.int32, device=dev)
+                pb.med_queue, pb.med_pool = self.p_medq.data_ptr(), pool
             self.packed_buffers = pb
         self.h_stats = [torch.zeros(LRG_STATS_WORDS, dtype=torch.int64).pin_memory() for _ in range(self.depth)]
         self.ev = [torch.cuda.Event() for _ in range(self.depth)]

@@ -1,24 +1,20 @@
 #!/bin/bash
-# after moving the pool atomics / per-run bias loads off the passes: parity tests, pass stamps, bench by lane count, kernel stats
+# median workgroups inside the greedy front launch: a short smoke first (a hang must not cost the box), loop tests, determinism,
+# loop rate with the pool (default) and with the launch of their own (LRG_MED_POOL=0)
 mkdir -p gpurun_out
-R=$(pwd)
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
-timeout 1200 python -m pytest tests/test_gpu_net.py tests/test_gpu_grow.py -m gpu -q -x --tb=short -p no:cacheprovider 2>&1 | tail -5
-for L in 1 3; do
-  timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --p0-rooms 0 --lanes $L > gpurun_out/pool_bench_l$L.log 2>&1
-  echo "lanes $L: $(grep '^{' gpurun_out/pool_bench_l$L.log | tail -1 | cut -c80-330)"
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 || { echo "smoke failed / timed out"; exit 1; }
+timeout 900 python -m pytest tests/test_gpu_grow.py tests/test_gpu_configs.py tests/test_gpu_fullsize.py tests/test_gpu_cli.py -m gpu -q -x --tb=short -p no:cacheprovider > gpurun_out/pool_pytest.log 2>&1
+tail -3 gpurun_out/pool_pytest.log; grep -E "^(E |FAILED|ERROR)" gpurun_out/pool_pytest.log | head -10
+timeout 300 python tools/determinism_check.py 8 gt 2 4 2>&1 | grep -v amdgpu.ids | tail -4
+timeout 300 python tools/determinism_check.py 6 net 2 4 2>&1 | grep -v amdgpu.ids | tail -4
+line() { python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$1: %.0f %s, %.1f us/iteration, steady %.1f rooms/s' % (d['value'], d['unit'], 1e3 * d['ms_per_iteration'], d.get('rooms_per_sec_steady_cycling') or 0))"; }
+A="--steps 10 --warmup 5 --cpu-seconds 0 --p0-rooms 0 --fixed-rooms 0"
+for P in 64 0 32 128 64 0; do
+  LRG_MED_POOL=$P timeout 600 python bench.py $A 2> gpurun_out/pool_$P.err | line "pool $P"
 done
-cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/kt_l
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt_l -o kt --output-format csv -- python $R/bench.py --steps 6 --warmup 3 --cpu-seconds 0 --p0-rooms 0 --fixed-rooms 0 --lanes 1 > /tmp/kt_l.log 2>&1
-python - <<PY
-import csv,glob
-f=(glob.glob('/tmp/kt_l/*/*kernel_stats.csv')+glob.glob('/tmp/kt_l/*kernel_stats.csv'))[0]
-for r in csv.DictReader(open(f)):
-    if any(k in r['Name'] for k in ('fused_stack','front','gemm')) and int(r['Calls'])>1000:
-        print('   1 lane  %-70s calls %6s avg %8.1f us' % (r['Name'][:70], r['Calls'], float(r['AverageNs'])/1e3))
-PY
-cd $R
-rm -rf /tmp/trace_repo
-LRG_TRACE_LAYER=4 bash tools/trace_run.sh 2176 68 tools/trace_loop.py 2>&1 | tail -20 | tee gpurun_out/trace3_branch.txt
-rm -rf /tmp/trace_repo
-LRG_TRACE_LAYER=0 bash tools/trace_run.sh 8320 68 tools/trace_loop.py 2>&1 | tail -20 | tee gpurun_out/trace3_head_l0.txt
+LRG_MED_POOL=64 timeout 600 python bench.py $A --lanes 1 2> gpurun_out/pool_l1.err | line "pool 64, 1 lane"
+LRG_MED_POOL=0 timeout 600 python bench.py $A --lanes 1 2> gpurun_out/pool_l1n.err | line "pool 0, 1 lane"
