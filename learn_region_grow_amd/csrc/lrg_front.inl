@@ -37,6 +37,7 @@ struct LrgFrontArgs {
     int pooled_stride;
     int64_t *stats;
     int64_t *phase_ticks;    // nullable: [n_slots,2] wall-clock ticks per slot: (0) update / stop / commit, (1) query / median / gather
+    int own_medians;         // greedy front kernel: 1 = every slot's workgroup computes its nine medians itself (no launch of their own)
     int32_t *med_queue;      // nullable: work queue of the median workgroups that ride in the greedy front launch (LrgPackedBuffers.med_queue)
     int med_pool;            // their number (the launch has n_slots + med_pool workgroups)
 };
@@ -485,6 +486,14 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
 #ifndef LRG_FRONT_SMALL
 #define LRG_FRONT_SMALL 0
 #endif
+#ifndef LRG_FRONT_OWN_MEDIANS
+#define LRG_FRONT_OWN_MEDIANS 0 // 1: the greedy front kernel computes every region's medians in the slot's own workgroup (four launches per
+                                // iteration).  EXPERIMENT, measured slower: exact (48 loop tests, determinism check), but 135.0 us per
+                                // iteration against 111.4 us with the launch of the (slot, channel) medians on the same box (one lane: 142.1
+                                // against 116.3) -- nine channels of a 1-4 k-point region in ONE workgroup (36 LDS atomics per thread and
+                                // pass, 123 VGPRs + 176 bytes of scratch) take far longer than the 9 us the launch costs, and they sit on
+                                // the slowest slot of the front launch.  profiles/r02_median_pool_experiment.txt
+#endif
                                 // regions above this many points get their medians from lrg_front_big_kernel.  0 = all of them:
                                 // that launch runs in (almost) every iteration anyway -- with 68 slots some region is nearly
                                 // always large -- and its duration is set by the largest region, so the small ones ride along
@@ -598,6 +607,60 @@ __device__ __forceinline__ int lrg_voxel_index(const LrgVoxIndex &I, int vx, int
                                                         // limit of 32 Ki with 12 or 16 cells per trip gains nothing over the room-wide pass)
 #endif
 
+// All centred channels of a region by the slot's own 1024-thread workgroup, after its gather (sh: LRG_RADIX_LDS_INTS(9) ints):
+// the medians used to be a launch of their own between the front kernel and the branch stacks -- ~9 us of a chain of dependent,
+// latency-bound launches, 117.5 -> 107.5 us per iteration without it (tools/r02_nobig.sh) -- whose duration was the largest region's.
+// Up to 4 Ki points the nine channels go through ONE radix select together (one index load, the keys of all channels in flight at
+// once, shared barriers); up to 16 Ki in three groups of three; above, channel after channel by bisection over the list in memory
+// (slow, exact, and a region of that size in a room of at most 131 072 points is a rarity: rooms above 65 536 points run the
+// chunk-parallel lrg_grow_step by default).
+#if LRG_FRONT_OWN_MEDIANS
+__device__ __noinline__ void lrg_front_all_medians(const LrgRoom *R, const int32_t *cur_idx, int nc, int F, int *sh, float *sh_c) {
+    const int tid = threadIdx.x;
+    const float *cm = R->chan_major;
+    const float *base = cm ? cm : R->points;
+    const int stride = cm ? 1 : F;
+    if (nc <= 4096) {
+        int chs[9];
+        float m[9];
+#pragma unroll
+        for (int y = 0; y < 9; ++y) { const int ch = lrg_centred_channel(y, F); chs[y] = ch < 0 ? -1 : cm ? y * R->chan_stride : ch; }
+        lrg_median_block_radix<4, LRG_FRONT_THREADS, 9>(base, chs, cur_idx, stride, nc, sh, m);
+        if (tid == 0) {
+#pragma unroll
+            for (int y = 0; y < 9; ++y) { const int ch = lrg_centred_channel(y, F); if (ch >= 0) sh_c[ch] = m[y]; }
+        }
+    } else if (nc <= 16 * 1024) {
+        for (int g = 0; g < 3; ++g) {
+            int chs[3];
+            float m[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const int y = 3 * g + c, ch = lrg_centred_channel(y, F); chs[c] = ch < 0 ? -1 : cm ? y * R->chan_stride : ch; }
+            __syncthreads();
+            lrg_median_block_radix<16, LRG_FRONT_THREADS, 3>(base, chs, cur_idx, stride, nc, sh, m);
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const int ch = lrg_centred_channel(3 * g + c, F); if (ch >= 0) sh_c[ch] = m[c]; }
+            }
+        }
+    } else {
+        for (int y = 0; y < 9; ++y) {
+            const int ch = lrg_centred_channel(y, F);
+            if (ch < 0) continue;
+            __syncthreads();
+            if (tid < 64) sh[tid] = tid == 0 ? -1 : 0;
+            __syncthreads();
+            const LrgChanSrc cs = lrg_chan_src(R, y, ch, F);
+            const int k2 = nc >> 1, k1r = (nc & 1) ? k2 : k2 - 1;
+            uint32_t ka, kb;
+            lrg_select2(nullptr, false, cs.base, cur_idx, cs.stride, 0, nc, k1r, k2, sh, &ka, &kb);
+            const float lo = lrg_key2f(ka), hi = lrg_key2f(kb);
+            if (tid == 0) sh_c[ch] = (nc & 1) ? hi : __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+        }
+    }
+}
+#endif
+
 // The median of centred channel y of slot S's current points by one 1024-thread workgroup (the body of lrg_front_big_kernel; CAP =
 // bracket buffer of the sampled selection, so that `sh` fits where the caller has room).  Valid in thread 0.
 template <int CAP>
@@ -707,7 +770,9 @@ __device__ __noinline__ void lrg_median_pool_role(const LrgSlot *slots, const Lr
 
 __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
                                                                               LrgGrowParams prm, LrgFrontArgs a, int32_t *big) {
-    __shared__ uint8_t sh_flags[LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS];
+    // (flags of the room-wide pass / index bitmaps of the grid query / histograms of the nine-channel radix select)
+    __shared__ __attribute__((aligned(16))) uint8_t sh_flags[(!LRG_FRONT_OWN_MEDIANS || LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS > 4 * LRG_RADIX_LDS_INTS(9))
+                                                                 ? LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS : 4 * LRG_RADIX_LDS_INTS(9)];
     __shared__ int sh_tab[512], sh_tabc[512], sh_tabe[512];
     __shared__ int sh_src[2][512];         // during the update: [0] = indices switched on by this step
     __shared__ float sh_c[16];
@@ -1244,7 +1309,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         atomicAdd(&q[2], 1);
     }
 #else
-    const int small_max = LRG_FRONT_SMALL;
+    const int small_max = (LRG_FRONT_OWN_MEDIANS && a.own_medians) ? 256 : LRG_FRONT_SMALL;
 #endif
 
     // =========================== (4) sampling (:237-252), centre (:241), gather (:242-254) ===========================
@@ -1278,8 +1343,17 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
         // workgroups of this launch; nothing here waits for them: the rows go out uncentred
         if (tid < 16 && !(LRG_MED_POOL_KERNEL && a.med_queue && lrg_is_centred(tid, F))) a.center[s * 16 + tid] = 0.f;   // (theirs to write, maybe already)
         lrg_front_gather(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
+        TRACE2(s, 5);
+#if LRG_FRONT_OWN_MEDIANS
+        if (a.own_medians) {             // the region's medians by this workgroup (the launch of the (slot, channel) medians is gone)
+            __syncthreads();
+            lrg_front_all_medians(R, cur_idx, nc, F, reinterpret_cast<int *>(sh_flags), sh_c);
+            __syncthreads();
+            if (tid < 16) a.center[s * 16 + tid] = sh_c[tid];
+        }
+#endif
         if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
-        TRACE2(s, 5); TRACE2(s, 6); TRACE2(s, 7);
+        TRACE2(s, 6); TRACE2(s, 7);
 #if LRG_TRACE
         if (tid == 0 && g_lrg_trace2) { g_lrg_trace2[(long)s * 16 + 8] = nc; g_lrg_trace2[(long)s * 16 + 14] = lrg_is_stop(entry_status) || entry_status == LRG_WAIT || (entry_status == LRG_ACTIVE && S->step == 0); }
 #endif

@@ -1350,7 +1350,7 @@ static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_
     a.pooled = static_cast<float *>(b->workspace) + poff; a.pooled_stride = (int)(pcnt / (size_t)n_slots);
     a.stats = b->stats;
     a.phase_ticks = b->phase_ticks;
-    a.med_queue = nullptr; a.med_pool = 0;
+    a.med_queue = nullptr; a.med_pool = 0; a.own_medians = 0;
     hipStream_t st = (hipStream_t)stream;
     if (lrg_uses_greedy_front(params, b)) {
         const int ncentred = params->feature_size <= 2 ? params->feature_size : params->feature_size <= 6 ? 2 : params->feature_size - 4;
@@ -1358,13 +1358,16 @@ static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_
         // wants the medians elsewhere (launch_medians false: the branch launch computes them)
         const bool pooled = LRG_MED_POOL_KERNEL && launch_medians && b->med_queue && b->med_pool > 0;
         if (pooled) { a.med_queue = b->med_queue; a.med_pool = b->med_pool; }
+        // every slot's workgroup computes its medians itself (LRG_FRONT_OWN_MEDIANS, default): no launch of their own
+        const bool own = LRG_FRONT_OWN_MEDIANS && launch_medians && !pooled;
+        a.own_medians = own ? 1 : 0;
         hipLaunchKernelGGL(lrg_front_greedy_kernel, dim3(n_slots + a.med_pool), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots,
                            *params, a, b->slot_big);
         LRG_LAUNCH_CHECK();
 #ifdef LRG_EXP_NO_BIG_LAUNCH      // timing experiment only (centres stay zero): what the iteration would gain without this launch
         if (false) {
 #else
-        if (launch_medians && !pooled) {
+        if (launch_medians && !pooled && !own) {
 #endif
             hipLaunchKernelGGL(lrg_front_big_kernel, dim3(n_slots, ncentred), dim3(1024), 0, st, slots, rooms, *params, a, b->slot_big);
             LRG_LAUNCH_CHECK();

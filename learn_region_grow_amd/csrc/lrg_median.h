@@ -327,9 +327,10 @@ __device__ __forceinline__ LrgChanSrc lrg_chan_src(const LrgRoom *R, int y, int 
 // wavefront's scan of 256 bins, barrier) replace the 10-16 barrier-separated bisection steps: what a step costs is the barrier
 // and the reductions, not the compares.  Same result as lrg_median_block_regs: the key K with #(key < K) <= nc/2 < #(key <= K),
 // averaged with the largest key below it (or with itself, duplicates) when nc is even.
-// sh: 64 + NCH * 1024 ints of LDS.  out[c] valid in every thread.  Channels ch[c] < 0 are skipped.
+// sh: LRG_RADIX_LDS_INTS(NCH) ints of LDS.  out[c] valid in every thread.  Channels ch[c] < 0 are skipped.
 // ------------------------------------------------------------------------------------------------------------------------
-#define LRG_RADIX_LDS_INTS(NCH) (64 + (NCH) * 1024)
+#define LRG_RADIX_HDR(NCH) ((NCH) <= 3 ? 64 : 256)
+#define LRG_RADIX_LDS_INTS(NCH) (LRG_RADIX_HDR(NCH) + (NCH) * 1024)
 template <int KT, int BT, int NCH>
 __device__ __forceinline__ void lrg_median_block_radix(const float *points, const int (&ch)[NCH], const int32_t *idx, int F, int nc,
                                                        int *sh, float (&out)[NCH]) {
@@ -345,8 +346,11 @@ __device__ __forceinline__ void lrg_median_block_radix(const float *points, cons
             for (int r = 0; r < KT; ++r)
                 key[c][r] = (ch[c] >= 0 && r * BT + tid < nc) ? lrg_f2key(points[(long)id[r] * F + ch[c]]) : 0xFFFFFFFFu;
     }
-    for (int i = 64 + tid; i < LRG_RADIX_LDS_INTS(NCH); i += BT) sh[i] = 0;
-    if (tid < 64) sh[tid] = (tid < 2 * NCH && !(tid & 1)) ? -1 : 0;
+    // header: [0, 2 NCH) min / max per channel, [BIN0 ...) bin and rank of every (channel, pass), [LOW0 ...) count and maximum below
+    constexpr int HDR = LRG_RADIX_HDR(NCH), BIN0 = NCH <= 3 ? 16 : 32, LOW0 = NCH <= 3 ? 48 : 128;
+    static_assert(2 * NCH <= BIN0 && BIN0 + 8 * NCH <= LOW0 && LOW0 + 2 * NCH <= HDR, "header layout");
+    for (int i = HDR + tid; i < LRG_RADIX_LDS_INTS(NCH); i += BT) sh[i] = 0;
+    if (tid < HDR) sh[tid] = (tid < 2 * NCH && !(tid & 1)) ? -1 : 0;
     __syncthreads();
     static_assert(KT <= 64, "alive masks are 64 bits");
     unsigned long long alive[NCH];
@@ -383,7 +387,7 @@ __device__ __forceinline__ void lrg_median_block_radix(const float *points, cons
             if (top[c] <= 0) continue;
             const int shift = max(top[c] - 8, 0);
             const uint32_t mask = (1u << (top[c] - shift)) - 1u;
-            int *hist = sh + 64 + (c * 4 + pass) * 256;
+            int *hist = sh + HDR + (c * 4 + pass) * 256;
 #pragma unroll
             for (int r = 0; r < KT; ++r)
                 if (alive[c] >> r & 1ull) atomicAdd(&hist[(key[c][r] >> shift) & mask], 1);
@@ -393,7 +397,7 @@ __device__ __forceinline__ void lrg_median_block_radix(const float *points, cons
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 if (c != wave || top[c] <= 0) continue;
-                const int *hist = sh + 64 + (c * 4 + pass) * 256;
+                const int *hist = sh + HDR + (c * 4 + pass) * 256;
                 const int4 h = *reinterpret_cast<const int4 *>(hist + 4 * lane);
                 const int s4 = h.x + h.y + h.z + h.w;
                 const int incl = lrg_wave_incl_scan_i32(s4), excl = incl - s4;
@@ -402,8 +406,8 @@ __device__ __forceinline__ void lrg_median_block_radix(const float *points, cons
                     if (kk[c] >= before + h.x) { before += h.x; b = 1;
                         if (kk[c] >= before + h.y) { before += h.y; b = 2;
                             if (kk[c] >= before + h.z) { before += h.z; b = 3; } } }
-                    sh[16 + (c * 4 + pass) * 2] = 4 * lane + b;
-                    sh[16 + (c * 4 + pass) * 2 + 1] = before;
+                    sh[BIN0 + (c * 4 + pass) * 2] = 4 * lane + b;
+                    sh[BIN0 + (c * 4 + pass) * 2 + 1] = before;
                 }
             }
         }
@@ -413,7 +417,7 @@ __device__ __forceinline__ void lrg_median_block_radix(const float *points, cons
             if (top[c] <= 0) continue;
             const int shift = max(top[c] - 8, 0);
             const uint32_t mask = (1u << (top[c] - shift)) - 1u;
-            const int bin = sh[16 + (c * 4 + pass) * 2], before = sh[16 + (c * 4 + pass) * 2 + 1];
+            const int bin = sh[BIN0 + (c * 4 + pass) * 2], before = sh[BIN0 + (c * 4 + pass) * 2 + 1];
             prefix[c] |= (uint32_t)bin << shift;
             kk[c] -= before;
 #pragma unroll
@@ -433,7 +437,7 @@ __device__ __forceinline__ void lrg_median_block_radix(const float *points, cons
                 if (r * BT + tid < nc && key[c][r] < prefix[c]) { ++below; mx = max(mx, key[c][r]); }
             below = lrg_wave_sum_i32(below);
             mx = lrg_wave_max_u32(mx);
-            if (lane == 0) { if (below) atomicAdd(&sh[48 + 2 * c], below); atomicMax(reinterpret_cast<unsigned *>(&sh[48 + 2 * c + 1]), mx); }
+            if (lane == 0) { if (below) atomicAdd(&sh[LOW0 + 2 * c], below); atomicMax(reinterpret_cast<unsigned *>(&sh[LOW0 + 2 * c + 1]), mx); }
         }
         __syncthreads();
     }
@@ -442,7 +446,7 @@ __device__ __forceinline__ void lrg_median_block_radix(const float *points, cons
         const float hi = lrg_key2f(prefix[c]);
         if (nc & 1) out[c] = hi;
         else {
-            const float lo = sh[48 + 2 * c] >= (nc >> 1) ? lrg_key2f((uint32_t)sh[48 + 2 * c + 1]) : hi;
+            const float lo = sh[LOW0 + 2 * c] >= (nc >> 1) ? lrg_key2f((uint32_t)sh[LOW0 + 2 * c + 1]) : hi;
             out[c] = __fmul_rn(__fadd_rn(lo, hi), 0.5f);
         }
     }
