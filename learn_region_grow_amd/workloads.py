@@ -26,9 +26,12 @@ def area5_rooms(n_rooms=68, seed_base=1000, cache_dir=None, targets=None, scale=
         cache = os.path.join(cache_dir, 'lrg_area5_%d_%d_%g_%g_%d.npz' % (n_rooms, seed_base, scale, resolution,
                                                                             targets[0] if targets else 0))
         if os.path.exists(cache):
-            z = np.load(cache)
-            return [dict(points=z['p%d' % i], obj_id=z['o%d' % i], order=z['s%d' % i], room_id=int(z['ids'][i]))
-                    for i in range(n_rooms)]
+            try:
+                z = np.load(cache)
+                return [dict(points=z['p%d' % i], obj_id=z['o%d' % i], order=z['s%d' % i], room_id=int(z['ids'][i]))
+                        for i in range(n_rooms)]
+            except Exception:        # a truncated file left behind by a killed run: generate again
+                pass
     for i in range(n_rooms):
         t = max(300, int(targets[i % len(targets)] * scale))
         rooms.append(make_room(t, seed_base + i, seed_base + i, resolution=resolution))
@@ -36,7 +39,10 @@ def area5_rooms(n_rooms=68, seed_base=1000, cache_dir=None, targets=None, scale=
         d = {'ids': np.array([r['room_id'] for r in rooms])}
         for i, r in enumerate(rooms):
             d['p%d' % i], d['o%d' % i], d['s%d' % i] = r['points'], r['obj_id'], r['order']
-        np.savez(cache, **d)
+        # several ranks of one node may generate the same set at the same time: write aside, then rename (atomic)
+        tmp = '%s.%d.tmp.npz' % (cache, os.getpid())
+        np.savez(tmp, **d)
+        os.replace(tmp, cache)
     return rooms
 
 
