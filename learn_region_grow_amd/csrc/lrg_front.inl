@@ -716,9 +716,11 @@ __device__ __forceinline__ float lrg_big_median(const int32_t *cur_idx, const Lr
 #define LRG_POOL_SMALL 256      // regions up to this many points: medians by nine wavefronts of the slot's own workgroup
 #endif
 #if LRG_MED_POOL_KERNEL
-__device__ __noinline__ void lrg_median_pool_role(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams &prm,
-                                     const LrgFrontArgs &a, int *sh) {
-    __shared__ int sh_item;
+// (inlined, and its one LDS word handed in by the kernel: as a __noinline__ function with a __shared__ variable of its own the mere
+// presence of this role in the kernel changed the results of the FRONT role -- with the queue off, the role never entered -- while
+// the same code inlined is exact: tools/r02_pool2.sh, variants (g) / (h))
+__device__ __forceinline__ void lrg_median_pool_role(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams &prm,
+                                                     const LrgFrontArgs &a, int *sh, int &sh_item) {
     const int tid = threadIdx.x;
     int32_t *q = a.med_queue;
     const int F = prm.feature_size;
@@ -726,13 +728,17 @@ __device__ __noinline__ void lrg_median_pool_role(const LrgSlot *slots, const Lr
         if (tid == 0) {
             const int t = atomicAdd(&q[1], 1);
             int item = 0;
+            // relaxed polls (an acquire per poll is an L2 invalidate per poll), ONE acquire fence after the hit
             for (int spin = 0; spin < (1 << 18); ++spin) {       // (bounded: a lost producer shows as a wrong centre, not as a hang)
-                item = __hip_atomic_load(&q[LRG_POOL_ITEMS + t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                item = __hip_atomic_load(&q[LRG_POOL_ITEMS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (item) break;
-                if (__hip_atomic_load(&q[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= n_slots &&
-                    t >= __hip_atomic_load(&q[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { item = -1; break; }
-                __builtin_amdgcn_s_sleep(8);
+                if (__hip_atomic_load(&q[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_slots) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (the reservations of every front workgroup that is done)
+                    if (t >= __hip_atomic_load(&q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { item = -1; break; }
+                }
+                __builtin_amdgcn_s_sleep(16);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (item > 0) __hip_atomic_store(&q[LRG_POOL_ITEMS + t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sh_item = item > 0 ? item : -1;
         }
@@ -768,7 +774,18 @@ __device__ __noinline__ void lrg_median_pool_role(const LrgSlot *slots, const Lr
 #define LRG_POOL_LEAVE() do { } while (0)
 #endif
 
-__global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
+// The greedy front kernel is accounted 128 VGPRs (it needs 88): four of its waves then fill a SIMD's register file, so a slot's
+// workgroup has its CU to itself.  With two lanes the other lane's tile workgroups otherwise move in beside it (160 VGPRs are left
+// per SIMD), slow it down, and a launch lasts as long as its slowest slot: 566.6 k -> 586.2 k instance-steps/s (115.0 -> 111.2 us per
+// iteration; no change on one lane; tools/r02_excl.sh).
+#ifndef LRG_FRONT_EXCLUSIVE
+#define LRG_FRONT_EXCLUSIVE 1
+#endif
+#ifndef LRG_BIG_EXCLUSIVE
+#define LRG_BIG_EXCLUSIVE 0
+#endif
+#define LRG_FRONT_OCC
+__global__ __launch_bounds__(LRG_FRONT_THREADS) LRG_FRONT_OCC void lrg_front_greedy_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
                                                                               LrgGrowParams prm, LrgFrontArgs a, int32_t *big) {
     // (flags of the room-wide pass / index bitmaps of the grid query / histograms of the nine-channel radix select)
     __shared__ __attribute__((aligned(16))) uint8_t sh_flags[(!LRG_FRONT_OWN_MEDIANS || LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS > 4 * LRG_RADIX_LDS_INTS(9))
@@ -780,9 +797,12 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
     __shared__ int sh_i[8];                // 0 updated, 1 added count, 2 status, 3 seed-search minimum, 4 probe count, 5 add_acc, 6 remove_acc
     __shared__ int sh_list[32];
     __shared__ int wt_c[16], wt_e[16];   // (the grid query scans over all 16 wavefronts)
+#if LRG_FRONT_EXCLUSIVE
+    asm volatile("" ::: "v127");         // the kernel is accounted 128 VGPRs: four of its waves fill a SIMD's register file, a CU to itself
+#endif
 #if LRG_MED_POOL_KERNEL
     if ((int)blockIdx.x >= n_slots) {    // the median workgroups behind the front workgroups (a.med_pool of them)
-        lrg_median_pool_role(slots, rooms, n_slots, prm, a, reinterpret_cast<int *>(sh_flags));
+        lrg_median_pool_role(slots, rooms, n_slots, prm, a, reinterpret_cast<int *>(sh_flags), sh_i[7]);
         return;
     }
 #endif
@@ -1387,6 +1407,9 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
 __global__ __launch_bounds__(1024) void lrg_front_big_kernel(const LrgSlot *slots, const LrgRoom *rooms, LrgGrowParams prm,
                                                               LrgFrontArgs a, int32_t *big) {
     __shared__ __attribute__((aligned(16))) int sh[LRG_SAMPLED_LDS_INTS(1024)];      // (>= LRG_RADIX_LDS_INTS(1))
+#if LRG_BIG_EXCLUSIVE
+    asm volatile("" ::: "v127");
+#endif
     const int s = blockIdx.x, tid = threadIdx.x;
     if (big[2 * s] == 0) return;
     const long long tickb = a.phase_ticks ? wall_clock64() : 0;

@@ -1367,7 +1367,11 @@ static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_
 #ifdef LRG_EXP_NO_BIG_LAUNCH      // timing experiment only (centres stay zero): what the iteration would gain without this launch
         if (false) {
 #else
+#ifdef LRG_POOL_ALSO_BIG       // diagnosis of the pool experiment: the launch of the (slot, channel) medians runs as well and has the last word
+        if (launch_medians && !own) {
+#else
         if (launch_medians && !pooled && !own) {
+#endif
 #endif
             hipLaunchKernelGGL(lrg_front_big_kernel, dim3(n_slots, ncentred), dim3(1024), 0, st, slots, rooms, *params, a, b->slot_big);
             LRG_LAUNCH_CHECK();
