@@ -62,6 +62,7 @@ struct LrgFusedArgs {
     LrgFusedProb p[2];
     int nprob;           // set by the packed launchers: problems interleaved in a one-dimensional grid
     int nmed;            // median workgroups in front of the tiles (0: none)
+    int few;             // packed launches: 1 = few tiles (at most ~one per CU): they are accounted 256 VGPRs, two tiles per CU at most
     LrgFusedMedians med;
 };
 

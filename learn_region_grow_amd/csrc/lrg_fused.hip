@@ -177,10 +177,15 @@ __device__ __forceinline__ void lrg_fused_median_wg(const LrgFusedMedians &M, in
 // and on an in-place head layer; parity tests only) -- it costs ~25 VGPRs, which is the third wave per SIMD.
 // PACKED: the rows of all instances are stored back to back (only the distinct ones, lrg_front_kernel); a tile is 32
 // consecutive packed rows and may hold rows of several instances -- the runs of equal row_inst inside it.
-template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false, bool MED = false>
+template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false, bool MED = false, bool FEW = false>
 __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFusedArgs args) {
     constexpr int FM = 32 * RT;      // rows (points) per workgroup
     static_assert(!PACKED || RT == 1, "packed rows use 32-row tiles");
+    // FEW (the loop at a few dozen slots per lane: ~150 tiles per launch, a launch lasts as long as its slowest tile): accounted 256
+    // VGPRs, so that at most two workgroups share a CU -- with three allowed the other lane's tiles double and triple up on
+    // CUs while others idle.  585.7 k -> 596.6 k instance-steps/s at 68 rooms on two lanes (alternating runs, tools/r02_excl2.sh);
+    // with hundreds of slots in flight (several tiles per CU wanted) it costs 8 %, hence the switch; 512 (a CU per tile) loses 5 %.
+    if constexpr (PACKED && FEW) asm volatile("" ::: "v255");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #if LRG_TRACE
     __shared__ long long lrg_trace_sh[32];
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(FTHREADS, OCC) void lrg_fused_stack_kernel(LrgFused
 #endif
 }
 
-template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false, bool MED = false>
+template <int CAP0, int CAP1, int RT, int FD, int OCC, bool DIRECT, bool PACKED = false, bool MED = false, bool FEW = false>
 static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     constexpr int FM = 32 * RT;
     long maxrows = 0;
@@ -689,7 +694,7 @@ static int launch_stack(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     }
     if (maxrows == 0) return 0;
     const size_t lds = (size_t)(CAP0 + CAP1 + 512 + (PACKED ? 3 * FM + 8 : 0)) * sizeof(float);
-    auto kern = lrg_fused_stack_kernel<CAP0, CAP1, RT, FD, OCC, DIRECT, PACKED, MED>;
+    auto kern = lrg_fused_stack_kernel<CAP0, CAP1, RT, FD, OCC, DIRECT, PACKED, MED, FEW>;
     static bool attr_done[LRG_MAX_DEVICES] = {};      // per instantiation, per device
     const int dev = lrg_current_device();
     if (!attr_done[dev]) {
@@ -763,9 +768,11 @@ int lrg_fused_branches_packed(const LrgFusedArgs &a, int nprob, hipStream_t st) 
         return launch_stack<32 * 68, 32 * 132, 1, LRG_PACKED_FD, 2, false, true, true>(a, nprob, st);
     }
     if (needs_direct(a, nprob)) return launch_stack<32 * 68, 32 * 132, 1, 4, 2, true, true>(a, nprob, st);
+    if (a.few) return launch_stack<32 * 68, 32 * 132, 1, LRG_PACKED_FD, LRG_PACKED_OCC, false, true, false, true>(a, nprob, st);
     return launch_stack<32 * 68, 32 * 132, 1, LRG_PACKED_FD, LRG_PACKED_OCC, false, true>(a, nprob, st);
 }
 
 int lrg_fused_heads_packed(const LrgFusedArgs &a, int nprob, hipStream_t st) {
+    if (a.few && !needs_direct(a, nprob)) return launch_stack<32 * 260, 32 * 68, 1, LRG_PACKED_HEAD_FD, 3, false, true, false, true>(a, nprob, st);
     return launch_stack<32 * 260, 32 * 68, 1, LRG_PACKED_HEAD_FD, 3, false, true>(a, nprob, st);
 }

@@ -9,6 +9,9 @@
 //   lrg_head_final_kernel      [C] -> 2 logits
 #include "lrg_common.h"
 #include "lrg_fused.h"
+#ifndef LRG_FEW_TILES_SLOTS
+#define LRG_FEW_TILES_SLOTS 64       // packed launches over at most this many instances count as "few tiles" (LrgFusedArgs.few)
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -291,10 +294,16 @@ __global__ __launch_bounds__(64 * LRG_GEMV_WAVES) void lrg_head_gemv_kernel(LrgG
 // split K (each P/8 deep) and their partial tiles are summed through LDS in a fixed order.  The weights are then read once
 // per 32 instances instead of once per LRG_GEMV_TB (70 MB -> 6 MB of L2 traffic at 68 instances).
 typedef float gemm_f32x16 __attribute__((ext_vector_type(16)));
+#ifndef LRG_GEMM_EXCLUSIVE
+#define LRG_GEMM_EXCLUSIVE 0
+#endif
 #define LRG_GEMM_WAVES 8
 template <int NG>      // k-groups of 8 per wave: P = 64 * NG; fully unrolled so that every operand load is in flight at once
 __global__ __launch_bounds__(64 * LRG_GEMM_WAVES) void lrg_head_gemm_kernel(LrgGemvArgs a) {
     __shared__ float part[LRG_GEMM_WAVES][32][33];
+#if LRG_GEMM_EXCLUSIVE
+    asm volatile("" ::: "v255");          // accounted 256 VGPRs: the two waves per SIMD of a workgroup fill the register file, a CU to itself
+#endif
     const int z = blockIdx.z, c0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
     if (a.cnt_src && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 2) {
@@ -701,6 +710,7 @@ static int forward_packed(const LrgWeights *w, const float *x_in, const float *x
     }
     {
         LrgFusedArgs a = {};
+        a.few = n_inst <= LRG_FEW_TILES_SLOTS ? 1 : 0;      // few tiles per launch: two workgroups per CU at most (lrg_fused.hip)
         for (int br = 0; br < 2; ++br) {
             LrgFusedProb &P = a.p[br];
             P.x = br == 0 ? x_in : x_nb;
@@ -751,6 +761,7 @@ static int forward_packed(const LrgWeights *w, const float *x_in, const float *x
         const int hbr[2] = {1, 0};      // head 0 = add on the neighbour rows, head 1 = remove on the inlier rows
         const int32_t *cnt = nrows_heads ? nrows_heads : nrows;
         LrgFusedArgs a = {};
+        a.few = n_inst <= LRG_FEW_TILES_SLOTS ? 1 : 0;      // few tiles per launch: two workgroups per CU at most (lrg_fused.hip)
         for (int hd = 0; hd < 2; ++hd) {
             const int br = hbr[hd];
             LrgFusedProb &P = a.p[hd];
