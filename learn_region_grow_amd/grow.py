@@ -691,12 +691,15 @@ class RegionGrower:
 
 
 def auto_lanes(slots_in_flight):
-    """Two lanes from about 64 slots in flight.  At a fixed number of rooms in flight lanes buy little: the loop is a chain of
-    latency-bound launches whose durations hardly depend on the slot count, so halving a lane's slots halves its throughput;
-    what a second lane adds is its fill-in / rebinding in the shadow of the other's iteration (one MI355X, 68 rooms: 1 lane
-    507 k instance-steps/s and 347 rooms/s, 2 lanes 518 k and 357, 3 lanes 499 k and 345 -- two kernels at most run side by
-    side, profiles/r02_stream_overlap.txt)."""
-    return 2 if slots_in_flight >= 64 else 1
+    """Lanes by the number of slots in flight: 1 below 64, 3 up to 127, 2 from 128.  At a fixed number of rooms in flight lanes buy
+    little: the loop is a chain of latency-bound launches whose durations hardly depend on the slot count, so a lane with a third of
+    the slots has a third of the throughput; what more lanes add is one lane's launches in the shadow of another's.  One MI355X, 68
+    rooms, since a front workgroup has its CU to itself and the loop's tiles share a CU two at most (csrc/lrg_front.inl,
+    lrg_fused.hip): 1 lane 560.6 k instance-steps/s, 2 lanes 597.2 k, 3 lanes 607.9 k, 4 lanes 348 k (tools/r02_lanes3.sh; before:
+    531 / 557 / ~500 k).  Hundreds of slots in flight fill the chip from two lanes."""
+    if slots_in_flight < 64:
+        return 1
+    return 3 if slots_in_flight < 128 else 2
 
 
 _LANE_STREAMS = {}       # (device index, CU-masked lane count or 0) -> ([torch streams], [raw handles]), one set per process

@@ -1,5 +1,5 @@
 """GPU: BASELINE.json's named configurations, each checked on labels (not only timed):
-  configs[1]  the benchmark configuration itself -- 68 Area-5-shaped rooms in flight over two lanes;
+  configs[1]  the benchmark configuration itself -- 68 Area-5-shaped rooms in flight over the lanes bench.py chooses (three);
   configs[2]  ScanNet-shaped rooms, 8 in flight;
   configs[3]  test_random_restart.py --scoring np with 16 restarts per seed batched per launch (1088 slots for the 68-room set).
 Exact parity where the oracle finishes in seconds (ground-truth masks do not depend on the logits; small rooms under the
@@ -102,13 +102,15 @@ def test_scannet_shaped_rooms(net):
 
 # ---- configs[1]: the benchmark configuration --------------------------------------------------------------------------------
 def test_benchmark_configuration_labels(net):
-    """68 Area-5-shaped rooms in flight over two lanes with HIP-graph replays (what bench.py times): every room passes the
+    """68 Area-5-shaped rooms in flight over the automatic number of lanes with HIP-graph replays (what bench.py times): every room passes the
     invariants; the labels of eight rooms -- the 45 k-point one, the smallest, the median and five more -- equal single-room
     oracle runs."""
     import torch
     from learn_region_grow_amd.grow import LanedRegionGrower
     rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir=CACHE)
-    lg = LanedRegionGrower(net, rooms_in_flight=68, lanes=2, rng='counter', seed=0, policy='gt', graph_iterations=4)
+    from learn_region_grow_amd.grow import auto_lanes
+    lg = LanedRegionGrower(net, rooms_in_flight=68, lanes=None, rng='counter', seed=0, policy='gt', graph_iterations=4)
+    assert len(lg.growers) == auto_lanes(68) == 3
     got = lg.run(rooms)
     assert all(g.packed and g._graph is not None for g in lg.growers)
     for room, res in zip(rooms, got):
@@ -153,7 +155,7 @@ def test_benchmark_configuration_with_a_busy_chip(net):
     """Slots must not depend on when their workgroups start.  The front kernel allocates the packed rows of an iteration from
     row 0 again, so a slot whose workgroup starts late -- here: while a second stream keeps every CU busy with dense LrgNet
     evaluations -- would find last iteration's rows overwritten if it still looked for them there (it did, up to ABI 3: with two
-    lanes 13 of 68 rooms gave more than one outcome over eight runs, tools/determinism_check.py).  Two lanes + the hog, twice,
+    lanes 13 of 68 rooms gave more than one outcome over eight runs, tools/determinism_check.py).  The default lanes + the hog, twice,
     against a quiet single-lane run: same regions and labels for all 68 rooms."""
     import threading
     import torch
@@ -181,7 +183,7 @@ def test_benchmark_configuration_with_a_busy_chip(net):
         th = threading.Thread(target=hog)
         th.start()
         try:
-            busy = LanedRegionGrower(net, lanes=2, graph_iterations=4, **kw).run(rooms)
+            busy = LanedRegionGrower(net, lanes=None, graph_iterations=4, **kw).run(rooms)     # (three lanes: what bench.py runs)
         finally:
             stop.set()
             th.join()
