@@ -691,15 +691,16 @@ class RegionGrower:
 
 
 def auto_lanes(slots_in_flight):
-    """Lanes by the number of slots in flight: 1 below 64, 3 up to 127, 2 from 128.  At a fixed number of rooms in flight lanes buy
+    """Lanes by the number of slots in flight: 1 below 24, 2 below 64, 3 from there.  At a fixed number of rooms in flight lanes buy
     little: the loop is a chain of latency-bound launches whose durations hardly depend on the slot count, so a lane with a third of
-    the slots has a third of the throughput; what more lanes add is one lane's launches in the shadow of another's.  One MI355X, 68
-    rooms, since a front workgroup has its CU to itself and the loop's tiles share a CU two at most (csrc/lrg_front.inl,
-    lrg_fused.hip): 1 lane 560.6 k instance-steps/s, 2 lanes 597.2 k, 3 lanes 607.9 k, 4 lanes 348 k (tools/r02_lanes3.sh; before:
-    531 / 557 / ~500 k).  Hundreds of slots in flight fill the chip from two lanes."""
-    if slots_in_flight < 64:
+    the slots has a third of the throughput; what more lanes add is one lane's launches in the shadow of another's.  One MI355X,
+    since a front workgroup has its CU to itself and the loop's tiles share a CU two at most (csrc/lrg_front.inl, lrg_fused.hip) --
+    68 rooms: 1 / 2 / 3 / 4 lanes 560.6 / 597.2 / 607.9 / 348 k instance-steps/s (before: 531 / 557 / ~500 k); 39 ScanNet-shaped rooms:
+    385 / 397 / 396 k; 32 rooms: 322 / 335 k; 272 rooms: 2 / 3 lanes 1.147 / 1.166 M; 16 restarts per seed (1088 slots): 1.132 / 1.192 M
+    (tools/r02_lanes3.sh, r02_lanes4.sh)."""
+    if slots_in_flight < 24:
         return 1
-    return 3 if slots_in_flight < 128 else 2
+    return 2 if slots_in_flight < 64 else 3
 
 
 _LANE_STREAMS = {}       # (device index, CU-masked lane count or 0) -> ([torch streams], [raw handles]), one set per process
