@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define LRG_ABI_VERSION 4
+#define LRG_ABI_VERSION 5
 #define LRG_EINVAL (-1000)
 
 #define LRG_MAX_CONV 5 /* branch layers: lite=0 -> 5, lite=1 -> 2, lite=2 -> 3  (learn_region_grow_util.py:77-85) */
@@ -30,7 +30,7 @@ extern "C" {
 int lrg_abi_version(void);
 /* Name of the code object's target ("gfx950"); a build sanity hook for the loader. */
 const char *lrg_target_arch(void);
-/* sizeof() of the ABI structs as compiled (0 LrgWeights, 1 LrgRoom, 2 LrgSlot, 3 LrgGrowParams, 4 LrgStepBuffers, 5 LrgPackedBuffers, 6 LrgBeamGroup), so that a
+/* sizeof() of the ABI structs as compiled (0 LrgWeights, 1 LrgRoom, 2 LrgSlot, 3 LrgGrowParams, 4 LrgStepBuffers, 5 LrgPackedBuffers, 6 LrgBeamGroup, 7 LrgAsyncBuffers), so that a
  * foreign-language binding can verify its mirror of the layout at load time. */
 size_t lrg_struct_size(int which);
 
@@ -339,7 +339,7 @@ typedef struct LrgStepBuffers {
     int32_t *rows_nb;
 } LrgStepBuffers;
 
-/* stats layout: [0] committed seeds, [1] rooms finished, [2] instance-steps taken, [3] reserved,
+/* stats layout: [0] committed seeds, [1] rooms finished, [2] instance-steps taken, [3] hand-overs given up by lrg_grow_async (0 unless something is broken),
  * [4 + k % LRG_DONE_RING] = first slot of the k-th finished group (ring written by lrg_advance). */
 #define LRG_DONE_RING 1020
 #define LRG_STATS_WORDS (4 + LRG_DONE_RING)
@@ -413,12 +413,6 @@ typedef struct LrgPackedBuffers {
     int64_t *phase_ticks;   /* nullable: [n_slots,2] accumulators of wall_clock64() ticks the slot's workgroup spent in (0) mask
                                 update / stop decision / commit -- the reference's 'inlier' bucket, test_region_grow.py:260-306 --
                                 and (1) box query / median / sampling / gather -- its 'neighbor' bucket, :219-254            */
-    int32_t *med_queue;     /* nullable (and ignored unless the library was built with -DLRG_MED_POOL_KERNEL=1, an experiment):
-                                [16 + 9 * n_slots + med_pool] zero-filled ONCE and owned by these buffers: work queue of the
-                                med_pool median workgroups that then ride in the greedy front launch (regions above 256 points
-                                hand their nine channel medians to them) instead of a launch of their own                     */
-    int32_t med_pool;       /* number of those workgroups (0 with med_queue == NULL)                                        */
-    int32_t pad;
 } LrgPackedBuffers;
 
 /* One lock-step iteration, packed rows: lrg_front_kernel (mask update of the previous evaluation :262-288, stop decision
@@ -445,6 +439,38 @@ int lrg_step_graph_create(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_p
                           void **graph_out);
 int lrg_step_graph_launch(void *graph, void *stream);
 int lrg_step_graph_destroy(void *graph);
+
+/* ------------------------------------------------------------------------------------------------
+ * Free-running iterations: the same loop (test_region_grow.py:208-306), every slot at its own pace inside ONE launch.
+ * lrg_grow_step_packed is five launches over all slots, each as long as its slowest slot or tile; rooms are independent
+ * (:110-183), so here a slot's stages -- front (mask update :262-288, stop decision :291-306, commit / next seed :186-217, box
+ * query :221-235, medians :241, sampling :237-252, gather :242-254), branch stacks, pooled product, head stacks
+ * (learn_region_grow_util.py:106-162) -- are ordered by that slot's own arrival counters: front workgroups serve the slots,
+ * the other CUs run tile tasks from a queue (csrc/lrg_async.inl).  Greedy growing (restarts = group_size = 1) on rooms with
+ * packed voxel words, n_inlier / n_neighbor <= 512, lite 0 / 2 -- LRG_EINVAL otherwise (use lrg_grow_step_packed).
+ * State between calls is exactly that of lrg_grow_step_packed (a call ends every slot between two evaluations, logits in
+ * place), so the two may alternate on the same buffers; results are identical bit for bit.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct LrgAsyncBuffers {
+    int32_t *queue;             /* lrg_grow_async_queue_bytes(n_slots) bytes, 256-byte aligned: task ring + control words (cleared by every call) */
+    size_t queue_bytes;
+    int32_t *sync;              /* [n_slots, 16] arrival counters of the slots (cleared by every call)                     */
+    int32_t front_workgroups;   /* workgroups serving the slots (each up to 8 of them), 0 = default                       */
+    int32_t teams;              /* tile teams (four wavefronts) per worker workgroup: 1 .. 3, 0 = default                 */
+    int32_t compute_units;      /* workgroups of the launch in all (front + worker), at most one per CU of the device; 0 = all CUs */
+    int32_t pad;
+} LrgAsyncBuffers;
+
+size_t lrg_grow_async_queue_bytes(int n_slots);
+
+/* One free-running launch: every slot takes up to max_steps evaluations (grow steps), and starts no new one once budget_us
+ * microseconds have passed since the launch began (0 = no time limit); slots whose room is finished or that are not bound
+ * leave at once.  `buffers` are those of lrg_grow_step_packed with row_cap >= n_slots * 32 * ceil(max(n_inlier, n_neighbor) / 32)
+ * (slot s owns that many rows from s * that number on).  A hand-over that was given up (no progress for seconds) is counted in
+ * stats[3]; the caller must treat a non-zero count as a failed call. */
+int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
+                   const LrgWeights *weights, const LrgPackedBuffers *buffers, const LrgAsyncBuffers *async_buffers,
+                   int max_steps, int budget_us, void *stream);
 
 /* A stream whose kernels run only on the compute units set in `mask` (bit i of word i / 32; hipExtStreamCreateWithCUMask).
  * Meant for lanes (slot groups iterating independently on their own streams, the batched scheduler of north_star) on disjoint CU

@@ -81,8 +81,12 @@ class LrgPackedBuffers(ctypes.Structure):
     _fields_ = [('center', _fp), ('sample_in', _fp), ('sample_nb', _fp), ('x_in', _fp), ('x_nb', _fp),
                 ('row_slot_in', _fp), ('row_slot_nb', _fp), ('upd_in', _fp), ('upd_nb', _fp), ('rmv_logits', _fp),
                 ('add_logits', _fp), ('slot_rows', _fp), ('counters', _fp), ('workspace', _fp),
-                ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('row_cap', ctypes.c_int32), ('rooms_have_pvox', ctypes.c_int32), ('slot_big', _fp), ('phase_ticks', _fp),
-                ('med_queue', _fp), ('med_pool', ctypes.c_int32), ('pad', ctypes.c_int32)]
+                ('workspace_bytes', ctypes.c_size_t), ('stats', _fp), ('row_cap', ctypes.c_int32), ('rooms_have_pvox', ctypes.c_int32), ('slot_big', _fp), ('phase_ticks', _fp)]
+
+
+class LrgAsyncBuffers(ctypes.Structure):
+    _fields_ = [('queue', _fp), ('queue_bytes', ctypes.c_size_t), ('sync', _fp), ('front_workgroups', ctypes.c_int32), ('teams', ctypes.c_int32),
+                ('compute_units', ctypes.c_int32), ('pad', ctypes.c_int32)]
 
 
 class LrgBeamGroup(ctypes.Structure):
@@ -110,19 +114,41 @@ class LrgHipError(RuntimeError):
 
 
 def build(verbose=False):
-    """hipcc --offload-arch=gfx950 -> learn_region_grow_amd/liblrg_hip.so (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ('lrg_common.h', 'lrg_rng.h', 'lrg_fused.h', 'lrg_front.inl', 'lrg_beam.inl')] + \
+    """hipcc --offload-arch=gfx950 -> learn_region_grow_amd/liblrg_hip.so (cross-compiles without a GPU).
+    One object per translation unit (csrc/build/, compiled side by side, only the stale ones), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    import glob
+    headers = sorted(glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inl'))) + \
         [os.path.join(os.path.dirname(HERE), 'include', 'lrg_hip.h')]
-    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    hnew = max(os.path.getmtime(h) for h in headers)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     # -ffp-contract=off: no implicit FMA fusion, so the kernels that restate NumPy float32 arithmetic (voxel keys,
     # fill-in distances, ball query) round exactly like the reference; hot loops use explicit fmaf / MFMA.
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-o', LIB_PATH] + srcs
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC'] + os.environ.get('LRG_HIPCC_FLAGS', '').split()
+    bdir = os.path.join(CSRC, 'build')
+    os.makedirs(bdir, exist_ok=True)
+    stamp = os.path.join(bdir, 'flags.txt')
+    if not os.path.exists(stamp) or open(stamp).read() != ' '.join(flags):
+        for o in glob.glob(os.path.join(bdir, '*.o')):
+            os.remove(o)
+        with open(stamp, 'w') as f:
+            f.write(' '.join(flags))
+    objs, jobs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(bdir, s.replace('.hip', '.o'))
+        objs.append(obj)
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(hnew, os.path.getmtime(src)):
+            jobs.append([hipcc] + flags + ['-c', '-o', obj, src])
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd, stderr=None if verbose else subprocess.DEVNULL)
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB_PATH] + objs)
     return LIB_PATH
 
 
@@ -171,6 +197,9 @@ _SIGS = {
     'lrg_packed_rows_center': (ctypes.c_void_p, [ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgPackedBuffers)]),
     'lrg_grow_step_packed': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
                                             ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgPackedBuffers), _fp]),
+    'lrg_grow_async_queue_bytes': (ctypes.c_size_t, [ctypes.c_int]),
+    'lrg_grow_async': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgWeights),
+                                      ctypes.POINTER(LrgPackedBuffers), ctypes.POINTER(LrgAsyncBuffers), ctypes.c_int, ctypes.c_int, _fp]),
     'lrg_front_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
                                       ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgPackedBuffers), _fp]),
     'lrg_step_graph_create': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
@@ -227,9 +256,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lrg_abi_version() != 4:
+    if lib.lrg_abi_version() != 5:
         raise LrgHipError('ABI version mismatch')
-    for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LrgBeamGroup)):
+    for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LrgBeamGroup, LrgAsyncBuffers)):
         if lib.lrg_struct_size(which) != ctypes.sizeof(st):
             raise LrgHipError('struct layout mismatch for %s: C %d vs ctypes %d' %
                               (st.__name__, lib.lrg_struct_size(which), ctypes.sizeof(st)))

@@ -389,6 +389,24 @@ def lrgnet_variable_shapes(feature_size=13, lite=0):
     return shapes
 
 
+def lrgnet_checkpoint_tensors(weights, adam_m=None, adam_v=None, step=0, beta1=0.9, beta2=0.999):
+    """Everything ``tf.compat.v1.train.Saver().save`` writes for an LrgNet graph -- which is what ``Saver().restore``
+    (test_region_grow.py:92-93) then asks for: the trainable variables, their Adam slots ``<name>/Adam`` (first moment) and
+    ``<name>/Adam_1`` (second moment), ``beta1_power`` / ``beta2_power`` (learn_region_grow_util.py:188: AdamOptimizer) and
+    ``Variable`` (the global step ``batch``, :187, int32) -- 99 entries for lite 0, the key set of models/lrgnet_model5.ckpt.index.
+    weights / adam_m / adam_v: name -> array in the TF shapes (missing slots: zeros, a freshly built optimizer)."""
+    out = {}
+    for k, w in weights.items():
+        w = np.asarray(w, dtype=np.float32)
+        out[k] = w
+        out[k + '/Adam'] = np.asarray(adam_m[k], dtype=np.float32).reshape(w.shape) if adam_m is not None else np.zeros_like(w)
+        out[k + '/Adam_1'] = np.asarray(adam_v[k], dtype=np.float32).reshape(w.shape) if adam_v is not None else np.zeros_like(w)
+    out['beta1_power'] = np.float32(float(beta1) ** int(step))
+    out['beta2_power'] = np.float32(float(beta2) ** int(step))
+    out['Variable'] = np.int32(step)
+    return out
+
+
 def load_lrgnet_weights(prefix, feature_size=13, lite=0, verify=True):
     """The trainable variables of an LrgNet checkpoint (optimizer slots ignored), shapes checked against the
     architecture ``LrgNet(..., feature_size, lite)`` builds -- what ``saver.restore`` would have assigned."""

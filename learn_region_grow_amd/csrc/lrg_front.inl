@@ -38,8 +38,7 @@ struct LrgFrontArgs {
     int64_t *stats;
     int64_t *phase_ticks;    // nullable: [n_slots,2] wall-clock ticks per slot: (0) update / stop / commit, (1) query / median / gather
     int own_medians;         // greedy front kernel: 1 = every slot's workgroup computes its nine medians itself (no launch of their own)
-    int32_t *med_queue;      // nullable: work queue of the median workgroups that ride in the greedy front launch (LrgPackedBuffers.med_queue)
-    int med_pool;            // their number (the launch has n_slots + med_pool workgroups)
+    int row_stride;          // free-running kernel: slot s owns the rows [s * row_stride, (s + 1) * row_stride) of the row arrays
 };
 
 // ---- (1) mask update of the evaluation just finished + count / bounding box of the new mask + stop decision ----
@@ -441,8 +440,8 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
     }
     LrgRoom *R = &rooms[room];
     TRACE2(s, 0);
-    if constexpr (MODE == 1) {
-        if (prm.scoring == 1 && S->status == LRG_ACTIVE) lrg_front_ml_score(S, R, s, prm, a);
+    if constexpr ((MODE & 1) != 0) {
+        if (prm.scoring == 1 && S->status == LRG_ACTIVE) lrg_front_ml_score(S, R, s, prm, a);      // (also restarts with one slot per group, MODE 7)
     }
     if ((MODE & 1) && S->status == LRG_ACTIVE) lrg_front_update(S, R, s, prm, a, &sh_src[0][0], red);
     TRACE2(s, 1);
@@ -486,14 +485,6 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_kernel(LrgSlot *s
 #ifndef LRG_FRONT_SMALL
 #define LRG_FRONT_SMALL 0
 #endif
-#ifndef LRG_FRONT_OWN_MEDIANS
-#define LRG_FRONT_OWN_MEDIANS 0 // 1: the greedy front kernel computes every region's medians in the slot's own workgroup (four launches per
-                                // iteration).  EXPERIMENT, measured slower: exact (48 loop tests, determinism check), but 135.0 us per
-                                // iteration against 111.4 us with the launch of the (slot, channel) medians on the same box (one lane: 142.1
-                                // against 116.3) -- nine channels of a 1-4 k-point region in ONE workgroup (36 LDS atomics per thread and
-                                // pass, 123 VGPRs + 176 bytes of scratch) take far longer than the 9 us the launch costs, and they sit on
-                                // the slowest slot of the front launch.  profiles/r02_median_pool_experiment.txt
-#endif
                                 // regions above this many points get their medians from lrg_front_big_kernel.  0 = all of them:
                                 // that launch runs in (almost) every iteration anyway -- with 68 slots some region is nearly
                                 // always large -- and its duration is set by the largest region, so the small ones ride along
@@ -525,7 +516,8 @@ __device__ __forceinline__ int lrg_div_small(int v, int d, float rcp) {
 #ifndef LRG_ROW_PAD
 #define LRG_ROW_PAD 8
 #endif
-#define LRG_PAD_ROWS(r) (((r) + LRG_ROW_PAD - 1) / LRG_ROW_PAD * LRG_ROW_PAD)
+#define LRG_PAD_ROWS_TO(r, p) (((r) + (p) - 1) / (p) * (p))
+#define LRG_PAD_ROWS(r) LRG_PAD_ROWS_TO(r, LRG_ROW_PAD)
 
 // Workgroup barrier for hand-overs through LDS only: waits for this wavefront's LDS operations, not for the acknowledgement of
 // its global stores (__syncthreads() does, ~1.5 k cycles after a burst of stores that nobody in the workgroup reads back).
@@ -535,11 +527,11 @@ __device__ __forceinline__ int lrg_div_small(int v, int d, float rcp) {
 // ground-truth flags input_remove / input_add (:230-231,:248,:254) ride along (element 0 of each row).  Besides the packed rows,
 // every row leaves x, y, z (as stored: uncentred) and its flag in the slot's own upd_* arrays for the next mask update.
 // U = loads in flight per thread: two full sets (2 x 512 rows x 13 floats = 13 k elements) still go in one trip with 13.
-template <int U>
+template <int U, int PAD, bool COH>
 __device__ __forceinline__ void lrg_front_gather_rows(int target, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
                                                       const LrgFrontArgs &a, const int (*sh_src)[512], int rin, int rnb, int offi, int offn,
                                                       int tid, int bd) {
-    const int rin_p = LRG_PAD_ROWS(rin), rnb_p = LRG_PAD_ROWS(rnb);      // (rows past the set: copies of its last row)
+    const int rin_p = LRG_PAD_ROWS_TO(rin, PAD), rnb_p = LRG_PAD_ROWS_TO(rnb, PAD);      // (rows past the set: copies of its last row)
     const int nel_in = rin_p * F, nel = nel_in + rnb_p * F;
     const float rF = 1.0f / (float)F;
     float *out_in = a.x_in + (long)offi * F, *out_nb = a.x_nb + (long)offn * F;
@@ -562,7 +554,7 @@ __device__ __forceinline__ void lrg_front_gather_rows(int target, const float *p
             if (e < nel) {
                 const int side = e >= nel_in ? 1 : 0, l = e - (side ? nel_in : 0);
                 const int j = lrg_div_small(l, F, rF), f = l - j * F;
-                (side ? out_nb : out_in)[l] = v[u];
+                if constexpr (COH) lrg_st_coh((side ? out_nb : out_in) + l, v[u]); else (side ? out_nb : out_in)[l] = v[u];
                 if (j < (side ? rnb : rin)) {
                     float *upd = (side ? upd_nb : upd_in) + 4 * j;
                     if (f < 3) upd[f] = v[u];
@@ -573,17 +565,20 @@ __device__ __forceinline__ void lrg_front_gather_rows(int target, const float *p
     }
 }
 
+template <int PAD, bool COH>
 __device__ __forceinline__ void lrg_front_gather(int target, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
                                                  const LrgFrontArgs &a, const int (*sh_src)[512], int rin,
                                                  int rnb, int offi, int offn, int first, int nthreads) {
     const int tid = (int)threadIdx.x - first, bd = nthreads;
     if (tid < 0 || tid >= nthreads) return;
-    for (int j = tid; j < LRG_PAD_ROWS(rin); j += bd) a.row_slot_in[offi + j] = s;
-    for (int j = tid; j < LRG_PAD_ROWS(rnb); j += bd) a.row_slot_nb[offn + j] = s;
-    const int nel = (LRG_PAD_ROWS(rin) + LRG_PAD_ROWS(rnb)) * F;
-    if (nel <= 2 * bd) lrg_front_gather_rows<2>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
-    else if (nel <= 6 * bd) lrg_front_gather_rows<6>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
-    else lrg_front_gather_rows<13>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);   // 2 x 512 rows x 13 floats
+    if constexpr (!COH) {         // (the free-running kernel: a slot's rows have a fixed place, the tags were written once)
+        for (int j = tid; j < LRG_PAD_ROWS_TO(rin, PAD); j += bd) a.row_slot_in[offi + j] = s;
+        for (int j = tid; j < LRG_PAD_ROWS_TO(rnb, PAD); j += bd) a.row_slot_nb[offn + j] = s;
+    }
+    const int nel = (LRG_PAD_ROWS_TO(rin, PAD) + LRG_PAD_ROWS_TO(rnb, PAD)) * F;
+    if (nel <= 2 * bd) lrg_front_gather_rows<2, PAD, COH>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
+    else if (nel <= 6 * bd) lrg_front_gather_rows<6, PAD, COH>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
+    else lrg_front_gather_rows<13, PAD, COH>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);   // 2 x 512 rows x 13 floats
 }
 
 // voxel -> point index: one load from the room's dense grid when it has one, else the probe chain of the hash table
@@ -614,7 +609,6 @@ __device__ __forceinline__ int lrg_voxel_index(const LrgVoxIndex &I, int vx, int
 // once, shared barriers); up to 16 Ki in three groups of three; above, channel after channel by bisection over the list in memory
 // (slow, exact, and a region of that size in a room of at most 131 072 points is a rarity: rooms above 65 536 points run the
 // chunk-parallel lrg_grow_step by default).
-#if LRG_FRONT_OWN_MEDIANS
 __device__ __noinline__ void lrg_front_all_medians(const LrgRoom *R, const int32_t *cur_idx, int nc, int F, int *sh, float *sh_c) {
     const int tid = threadIdx.x;
     const float *cm = R->chan_major;
@@ -659,7 +653,6 @@ __device__ __noinline__ void lrg_front_all_medians(const LrgRoom *R, const int32
         }
     }
 }
-#endif
 
 // The median of centred channel y of slot S's current points by one 1024-thread workgroup (the body of lrg_front_big_kernel; CAP =
 // bracket buffer of the sampled selection, so that `sh` fits where the caller has room).  Valid in thread 0.
@@ -690,90 +683,6 @@ __device__ __forceinline__ float lrg_big_median(const int32_t *cur_idx, const Lr
     return m;
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// Median workgroups inside the greedy front launch.  The medians of regions above LRG_POOL_SMALL points used to be a launch of
-// their own between the front kernel and the branch stacks: ~9 us of a ~115 us chain of dependent launches (without it:
-// 117.5 -> 107.5 us per iteration, tools/r02_nobig.sh).  Now the launch carries `med_pool` extra workgroups behind the n_slots
-// front workgroups.  A front workgroup that has written the index lists of a large region publishes one item per centred channel
-// (release), every front workgroup counts itself as done when nothing more can come from it; a pool workgroup draws tickets,
-// waits for its item (acquire) or for the proof that none will come (all front workgroups done and fewer items reserved than its
-// ticket), computes the median and writes the centre, which nothing reads before the next launch.  The front workgroups never wait
-// for anybody, so nothing can deadlock whatever the order in which workgroups start; the last pool workgroup to leave resets the
-// counters for the next launch, consumers clear the items they take.
-// queue: [0] items reserved, [1] tickets drawn, [2] front workgroups done, [3] pool workgroups gone, [16 ...] items
-// (0x40000000 | slot << 4 | channel row), at least 9 * n_slots + med_pool of them.
-// ------------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT, off by default (LRG_MED_POOL_KERNEL=1 compiles it in): as first built it lost -- 144 us per iteration with 64 pool
-// workgroups against 122 us with the launch of their own on the same box (32: 127 us, 128: 185 us) -- and was not exact yet (one
-// parity test and the determinism check failed).  What it costs, as far as seen: every poll was an acquire (an L2 invalidate per
-// spin), a spinning 1024-thread workgroup holds a whole CU, and with the 48-key selection inlined the kernel needs 128 VGPRs (one
-// workgroup per CU also for the front role: 5 % slower even with the pool switched off).  profiles/r02_median_pool_experiment.txt.
-#ifndef LRG_MED_POOL_KERNEL
-#define LRG_MED_POOL_KERNEL 0
-#endif
-#define LRG_POOL_ITEMS 16
-#ifndef LRG_POOL_SMALL
-#define LRG_POOL_SMALL 256      // regions up to this many points: medians by nine wavefronts of the slot's own workgroup
-#endif
-#if LRG_MED_POOL_KERNEL
-// (inlined, and its one LDS word handed in by the kernel: as a __noinline__ function with a __shared__ variable of its own the mere
-// presence of this role in the kernel changed the results of the FRONT role -- with the queue off, the role never entered -- while
-// the same code inlined is exact: tools/r02_pool2.sh, variants (g) / (h))
-__device__ __forceinline__ void lrg_median_pool_role(const LrgSlot *slots, const LrgRoom *rooms, int n_slots, const LrgGrowParams &prm,
-                                                     const LrgFrontArgs &a, int *sh, int &sh_item) {
-    const int tid = threadIdx.x;
-    int32_t *q = a.med_queue;
-    const int F = prm.feature_size;
-    for (;;) {
-        if (tid == 0) {
-            const int t = atomicAdd(&q[1], 1);
-            int item = 0;
-            // relaxed polls (an acquire per poll is an L2 invalidate per poll), ONE acquire fence after the hit
-            for (int spin = 0; spin < (1 << 18); ++spin) {       // (bounded: a lost producer shows as a wrong centre, not as a hang)
-                item = __hip_atomic_load(&q[LRG_POOL_ITEMS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (item) break;
-                if (__hip_atomic_load(&q[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_slots) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (the reservations of every front workgroup that is done)
-                    if (t >= __hip_atomic_load(&q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { item = -1; break; }
-                }
-                __builtin_amdgcn_s_sleep(16);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (item > 0) __hip_atomic_store(&q[LRG_POOL_ITEMS + t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh_item = item > 0 ? item : -1;
-        }
-        __syncthreads();
-        const int item = sh_item;
-        __syncthreads();
-        if (item < 0) break;
-        const int s = (item & 0x3FFFFFFF) >> 4, y = item & 15;
-        const LrgSlot *S = &slots[s];
-        // (the slot was written by another workgroup of this launch: plain loads of its scalars could be served by the scalar cache)
-        const int nc = __hip_atomic_load(&S->nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int room = __hip_atomic_load(&S->room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int ch = lrg_centred_channel(y, F);
-        if (ch >= 0 && room >= 0 && nc > 0) {
-            const float m = lrg_big_median<6144>(S->cur_idx, &rooms[room], nc, y, ch, F, sh);
-            if (tid == 0) a.center[s * 16 + ch] = m;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(&q[3], 1) == a.med_pool - 1) {             // everybody else has left, every front workgroup is done
-            __hip_atomic_store(&q[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&q[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&q[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&q[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-// a front workgroup counts itself as done (thread 0; after its items, if any, are out)
-#define LRG_POOL_LEAVE() do { if (a.med_queue && tid == 0) { __threadfence(); atomicAdd(&a.med_queue[2], 1); } } while (0)
-#else
-#define LRG_POOL_LEAVE() do { } while (0)
-#endif
-
 // The greedy front kernel is accounted 128 VGPRs (it needs 88): four of its waves then fill a SIMD's register file, so a slot's
 // workgroup has its CU to itself.  With two lanes the other lane's tile workgroups otherwise move in beside it (160 VGPRs are left
 // per SIMD), slow it down, and a launch lasts as long as its slowest slot: 566.6 k -> 586.2 k instance-steps/s (115.0 -> 111.2 us per
@@ -784,29 +693,37 @@ __device__ __forceinline__ void lrg_median_pool_role(const LrgSlot *slots, const
 #ifndef LRG_BIG_EXCLUSIVE
 #define LRG_BIG_EXCLUSIVE 0
 #endif
-#define LRG_FRONT_OCC
-__global__ __launch_bounds__(LRG_FRONT_THREADS) LRG_FRONT_OCC void lrg_front_greedy_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots,
-                                                                              LrgGrowParams prm, LrgFrontArgs a, int32_t *big) {
-    // (flags of the room-wide pass / index bitmaps of the grid query / histograms of the nine-channel radix select)
-    __shared__ __attribute__((aligned(16))) uint8_t sh_flags[(!LRG_FRONT_OWN_MEDIANS || LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS > 4 * LRG_RADIX_LDS_INTS(9))
-                                                                 ? LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS : 4 * LRG_RADIX_LDS_INTS(9)];
-    __shared__ int sh_tab[512], sh_tabc[512], sh_tabe[512];
-    __shared__ int sh_src[2][512];         // during the update: [0] = indices switched on by this step
-    __shared__ float sh_c[16];
-    __shared__ int red[16 * 8];
-    __shared__ int sh_i[8];                // 0 updated, 1 added count, 2 status, 3 seed-search minimum, 4 probe count, 5 add_acc, 6 remove_acc
-    __shared__ int sh_list[32];
-    __shared__ int wt_c[16], wt_e[16];   // (the grid query scans over all 16 wavefronts)
-#if LRG_FRONT_EXCLUSIVE
-    asm volatile("" ::: "v127");         // the kernel is accounted 128 VGPRs: four of its waves fill a SIMD's register file, a CU to itself
-#endif
-#if LRG_MED_POOL_KERNEL
-    if ((int)blockIdx.x >= n_slots) {    // the median workgroups behind the front workgroups (a.med_pool of them)
-        lrg_median_pool_role(slots, rooms, n_slots, prm, a, reinterpret_cast<int *>(sh_flags), sh_i[7]);
-        return;
-    }
-#endif
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// LDS of the greedy front (a struct, so that the free-running kernel can lay it over the same bytes its tile teams use)
+#define LRG_FRONT_FLAG_BYTES (LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS > 4 * LRG_RADIX_LDS_INTS(9) ? LRG_FRONT_MAXCHUNK * LRG_FRONT_THREADS : 4 * LRG_RADIX_LDS_INTS(9))
+struct LrgFrontShared {
+    // flags of the room-wide pass / index bitmaps of the grid query / histograms of the nine-channel radix select
+    __attribute__((aligned(16))) uint8_t flags[LRG_FRONT_FLAG_BYTES];
+    int tab[512], tabc[512], tabe[512];
+    int src[2][512];         // during the update: [0] = indices switched on by this step
+    float c[16];
+    int red[16 * 8];
+    int i[8];                // 0 updated, 1 added count, 2 status, 3 seed-search minimum, 4 probe count, 5 add_acc, 6 remove_acc
+    int list[32];
+    int wt_c[16], wt_e[16];  // (the grid query scans over all 16 wavefronts)
+    int box[8];              // bounding box of the mask (S->mn, S->mx) for the box query, [6] count, [7] target
+    int off[2];
+};
+
+// One slot's front: returns 0 when no evaluation was prepared (slot idle / room finished / seed search to be continued), else
+// (distinct inlier rows << 16) | distinct neighbour rows.
+// ASYNC (the free-running kernel, lrg_async.inl): the slot's rows live at the fixed offset s * a.row_stride of the row arrays,
+// padded to whole 32-row tiles; what other workgroups of the same launch read (rows, centre, the zeroed pooled feature) goes out
+// write-through, what they wrote (the logits) is read past the L1 (lrg_fused_tile.inl, COH).
+template <bool ASYNC>
+__device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams &prm,
+                                                     const LrgFrontArgs &a, int32_t *big, const int s) {
+    uint8_t *sh_flags = SH.flags;
+    int *sh_tab = SH.tab, *sh_tabc = SH.tabc, *sh_tabe = SH.tabe;
+    int (*sh_src)[512] = SH.src;
+    float *sh_c = SH.c;
+    int *red = SH.red, *sh_i = SH.i, *sh_list = SH.list, *wt_c = SH.wt_c, *wt_e = SH.wt_e, *sh_box = SH.box, *sh_off = SH.off;
+    constexpr int PAD = ASYNC ? 32 : LRG_ROW_PAD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     LrgSlot *S = &slots[s];
     const int F = prm.feature_size, Ni = prm.n_inlier, Nn = prm.n_neighbor;
     // ---- round trip 1: everything addressed by the slot number alone ----
@@ -819,21 +736,22 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) LRG_FRONT_OCC void lrg_front_gre
     const int sq0 = S->seq_mn[0], sq1 = S->seq_mn[1], sq2 = S->seq_mn[2], sq3 = S->seq_mx[0], sq4 = S->seq_mx[1], sq5 = S->seq_mx[2];
     int cur_seed = seed0, cur_restart = restart0, cur_step = step0, cur_target = S->target;
     bool lists_ready = false;            // a fresh seed: its index lists come from the seed search, no box query
-    __shared__ int sh_box[8];            // bounding box of the mask (S->mn, S->mx) for the box query
     uint8_t *cur = S->cur;
     int32_t *cur_idx = S->cur_idx, *cand_idx = S->cand_idx;
     const int rows_off_in = a.slot_rows[4 * s + 2], rows_off_nb = a.slot_rows[4 * s + 3];
-    const float c0 = a.center[s * 16 + 0], c1 = a.center[s * 16 + 1];
+    // (free-running: the centre went out write-through -- read it the way other workgroups do, not through a line of this CU's L1)
+    const float c0 = ASYNC ? lrg_ld_coh(a.center + s * 16 + 0) : a.center[s * 16 + 0], c1 = ASYNC ? lrg_ld_coh(a.center + s * 16 + 1) : a.center[s * 16 + 1];
     const int half = tid >> 9, j = tid & 511;                    // first half: add slot j, second half: remove slot j
     const bool mine = j < (half ? Ni : Nn);
     int sj = 0;
     if (mine) sj = (half ? a.sample_in : a.sample_nb)[(long)s * (half ? Ni : Nn) + j];
     if (a.pooled)                    // the last evaluation's pooled feature has been consumed: zero for the next one
-        for (int c = tid; c < a.pooled_stride; c += LRG_FRONT_THREADS) a.pooled[(long)s * a.pooled_stride + c] = 0.f;
+        for (int c = tid; c < a.pooled_stride; c += LRG_FRONT_THREADS) {
+            if constexpr (ASYNC) lrg_st_coh(a.pooled + (long)s * a.pooled_stride + c, 0.f); else a.pooled[(long)s * a.pooled_stride + c] = 0.f;
+        }
     if (room < 0) {
         if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
-        LRG_POOL_LEAVE();
-        return;
+        return 0;
     }
     // ---- round trip 2: the room ----
     LrgRoom *R = &rooms[room];
@@ -869,7 +787,10 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) LRG_FRONT_OCC void lrg_front_gre
         if (mine) {
             const float4 u = (half ? a.upd_in : a.upd_nb)[(long)s * Nside + srow];
             const float px = u.x, py = u.y, pz = u.z;
-            const float *lg = (half ? a.rmv_logits : a.add_logits) + 2 * row;
+            const float *lgp = (half ? a.rmv_logits : a.add_logits) + 2 * row;
+            float lg[2];
+            if constexpr (ASYNC) { const float2 t = lrg_ld_coh2(lgp); lg[0] = t.x; lg[1] = t.y; }      // (written by a tile team of this launch)
+            else { lg[0] = lgp[0]; lg[1] = lgp[1]; }
             const int gtf = u.w != 0.f;
             correct = (lg[1] > lg[0] ? 1 : 0) == gtf;                                        // add_acc / remove_acc (util:174-180)
             bool take;
@@ -1058,8 +979,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) LRG_FRONT_OCC void lrg_front_gre
                     }
                     a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0;
                 }
-                LRG_POOL_LEAVE();
-                return;
+                        return 0;
             }
             const int sd = order[found];
             cursor = found + 1;
@@ -1100,8 +1020,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) LRG_FRONT_OCC void lrg_front_gre
                 S->seed = -1; S->status = LRG_WAIT; S->count = -1;
                 a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0;
             }
-            LRG_POOL_LEAVE();
-            return;
+                return 0;
         }
         // the slot's mask is all zero here (every region clears its members at commit; the host zeroes it when binding)
         if ((int)tid < n_cand) cand_idx[tid] = sh_list[tid];
@@ -1137,8 +1056,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) LRG_FRONT_OCC void lrg_front_gre
     if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 0] += tick1 - tick0;
     if (status != LRG_ACTIVE) {      // DONE / IDLE
         if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
-        LRG_POOL_LEAVE();
-        return;
+        return 0;
     }
 
     // =========================== (3) dilated voxel-box query with ordered compaction (:221-235) ===========================
@@ -1306,41 +1224,23 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) LRG_FRONT_OCC void lrg_front_gre
         __syncthreads();
         if (sh_i[2] != LRG_ACTIVE) {
             if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
-            LRG_POOL_LEAVE();
-            return;
+                return 0;
         }
     }
     TRACE2(s, 3);
-    // The index lists are final (and visible to the workgroup: a full barrier lies behind both ways here).  With median workgroups in the
-    // launch: a region above LRG_POOL_SMALL points hands its medians to them -- one item per centred channel -- and in any case
-    // this workgroup has nothing more to publish.
-#if LRG_MED_POOL_KERNEL
-    const int small_max = a.med_queue ? LRG_POOL_SMALL : LRG_FRONT_SMALL;
-    if (a.med_queue && tid == 0) {
-        int32_t *q = a.med_queue;
-        if (q_nc > small_max) {
-            const int ncen = F <= 2 ? F : F <= 6 ? 2 : F - 4;
-            const int base = atomicAdd(&q[0], ncen);
-            __threadfence();                                     // the lists, S->nc: before the items
-            for (int y = 0; y < ncen; ++y)
-                __hip_atomic_store(&q[LRG_POOL_ITEMS + base + y], 0x40000000 | (s << 4) | y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __threadfence();
-        atomicAdd(&q[2], 1);
-    }
-#else
-    const int small_max = (LRG_FRONT_OWN_MEDIANS && a.own_medians) ? 256 : LRG_FRONT_SMALL;
-#endif
+    const int small_max = (ASYNC && a.own_medians) ? 256 : LRG_FRONT_SMALL;
 
     // =========================== (4) sampling (:237-252), centre (:241), gather (:242-254) ===========================
-    __shared__ int sh_off[2];
     const int nc = q_nc, ne = q_ne;                      // (known to every thread: no trip through S->nc / S->ne)
     const int rin = min(nc, Ni), rnb = min(ne, Nn);
     const bool is_big = nc > small_max;
     int oi = 0, on = 0;
     if (tid == 0) {                                      // requested here, needed after the sampling arithmetic
-        oi = atomicAdd(&a.counters[0], LRG_PAD_ROWS(rin));
-        on = atomicAdd(&a.counters[1], LRG_PAD_ROWS(rnb));
+        if constexpr (ASYNC) { oi = s * a.row_stride; on = s * a.row_stride; }
+        else {
+            oi = atomicAdd(&a.counters[0], LRG_PAD_ROWS(rin));
+            on = atomicAdd(&a.counters[1], LRG_PAD_ROWS(rnb));
+        }
     }
     if (mine) {
         const int nn = half ? nc : ne, kk = half ? Ni : Nn;      // (here the first half samples the neighbours, the second the inliers)
@@ -1361,23 +1261,21 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) LRG_FRONT_OCC void lrg_front_gre
     if (is_big) {
         // the nine medians of such a region come from lrg_front_big_kernel (one workgroup per channel) or from the median
         // workgroups of this launch; nothing here waits for them: the rows go out uncentred
-        if (tid < 16 && !(LRG_MED_POOL_KERNEL && a.med_queue && lrg_is_centred(tid, F))) a.center[s * 16 + tid] = 0.f;   // (theirs to write, maybe already)
-        lrg_front_gather(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
+        if (tid < 16 && !(ASYNC && a.own_medians)) a.center[s * 16 + tid] = 0.f;
+        lrg_front_gather<PAD, ASYNC>(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
         TRACE2(s, 5);
-#if LRG_FRONT_OWN_MEDIANS
-        if (a.own_medians) {             // the region's medians by this workgroup (the launch of the (slot, channel) medians is gone)
+        if constexpr (ASYNC) if (a.own_medians) {   // the region's medians by this workgroup (no launch of the (slot, channel) medians)
             __syncthreads();
             lrg_front_all_medians(R, cur_idx, nc, F, reinterpret_cast<int *>(sh_flags), sh_c);
             __syncthreads();
-            if (tid < 16) a.center[s * 16 + tid] = sh_c[tid];
+            if (tid < 16) { if constexpr (ASYNC) lrg_st_coh(a.center + s * 16 + tid, sh_c[tid]); else a.center[s * 16 + tid] = sh_c[tid]; }
         }
-#endif
         if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
         TRACE2(s, 6); TRACE2(s, 7);
 #if LRG_TRACE
         if (tid == 0 && g_lrg_trace2) { g_lrg_trace2[(long)s * 16 + 8] = nc; g_lrg_trace2[(long)s * 16 + 14] = lrg_is_stop(entry_status) || entry_status == LRG_WAIT || (entry_status == LRG_ACTIVE && S->step == 0); }
 #endif
-        return;
+        return (rin << 16) | rnb;
     }
     if (wave < 9) {                                              // one wavefront per centred channel, keys in registers
         const int ch = lrg_centred_channel(wave, F);
@@ -1389,17 +1287,30 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) LRG_FRONT_OCC void lrg_front_gre
             if (lane == 0) sh_c[ch] = m;
         }
     } else {
-        lrg_front_gather(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
+        lrg_front_gather<PAD, ASYNC>(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
     }
     __syncthreads();
     TRACE2(s, 5);
-    if (tid < 16) a.center[s * 16 + tid] = sh_c[tid];           // the branch kernels and the next update centre with it (:243-247,:271,:275)
+    if (tid < 16) {                                              // the branch kernels and the next update centre with it (:243-247,:271,:275)
+        if constexpr (ASYNC) lrg_st_coh(a.center + s * 16 + tid, sh_c[tid]); else a.center[s * 16 + tid] = sh_c[tid];
+    }
     TRACE2(s, 6);
     if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
     TRACE2(s, 7);
 #if LRG_TRACE
     if (tid == 0 && g_lrg_trace2) { g_lrg_trace2[(long)s * 16 + 8] = nc; g_lrg_trace2[(long)s * 16 + 14] = lrg_is_stop(entry_status) || entry_status == LRG_WAIT || (entry_status == LRG_ACTIVE && S->step == 0); }
 #endif
+    return (rin << 16) | rnb;
+}
+
+// The greedy front as a launch of its own (lrg_grow_step_packed): one workgroup per slot.
+__global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(LrgSlot *slots, LrgRoom *rooms, int n_slots, LrgGrowParams prm,
+                                                                             LrgFrontArgs a, int32_t *big) {
+    __shared__ LrgFrontShared SH;
+#if LRG_FRONT_EXCLUSIVE
+    asm volatile("" ::: "v127");         // the kernel is accounted 128 VGPRs: four of its waves fill a SIMD's register file, a CU to itself
+#endif
+    (void)lrg_front_greedy_slot<false>(SH, slots, rooms, n_slots, prm, a, big, (int)blockIdx.x);
 }
 
 // Medians of regions above LRG_FRONT_SMALL points: one workgroup per (slot, centred channel), keys in registers (two

@@ -34,36 +34,15 @@ struct LrgFusedProb {
     const int *row_inst; // [capacity] instance of each packed row
     const float *center; // nullable (packed): [instances,16] per-instance centre; the staged value of row r, column c is
                          // x[r,c] - center[row_inst[r]*16 + c]  (the rows are stored uncentred, test_region_grow.py:243-247 applied here)
-    // medians riding in the same launch (LrgFusedArgs.nmed > 0): the centre of instance i, channel c arrives as the tagged word
-    // ctag[i*16 + c] = (tags[2*i + 1] << 32) | float bits, written by this launch's median workgroups; channels outside cmask
-    // are not centred
-    const unsigned long long *ctag;
-    const int32_t *tags;
-    unsigned cmask;
     long rows;
     int ldx, Kin, rows_per_inst, pool_stride, nlayers, zero_count;
     LrgFusedLayer L[LRG_FUSED_MAXL];
 };
 
-// The nine channel medians of every slot's region (test_region_grow.py:241) computed by the FIRST workgroups (a few per slot,
-// lrg_fused_median_workgroups) of the packed branch launch instead of a launch of their own: they never wait, the tile workgroups behind them (dispatched
-// in order, so every median workgroup is already running or done) pick each centre up as one tagged 64-bit word.
-struct LrgFusedMedians {
-    const LrgSlot *slots;
-    const LrgRoom *rooms;
-    const int32_t *big;          // [n_slots,2]: (rows prepared this iteration, tag) written by lrg_front_greedy_kernel
-    float *center;               // [n_slots,16] plain copy for the next launches (mask update, :271,:275)
-    unsigned long long *ctag;    // [n_slots,16]
-    int64_t *phase_ticks;        // nullable
-    int n_slots, ncentred, F;
-};
-
 struct LrgFusedArgs {
     LrgFusedProb p[2];
     int nprob;           // set by the packed launchers: problems interleaved in a one-dimensional grid
-    int nmed;            // median workgroups in front of the tiles (0: none)
     int few;             // packed launches: 1 = few tiles (at most ~one per CU): they are accounted 256 VGPRs, two tiles per CU at most
-    LrgFusedMedians med;
 };
 
 int lrg_fused_branches(const LrgFusedArgs &a, int nprob, hipStream_t st);
@@ -72,10 +51,20 @@ int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st);
 int lrg_fused_branches_packed(const LrgFusedArgs &a, int nprob, hipStream_t st);
 int lrg_fused_heads_packed(const LrgFusedArgs &a, int nprob, hipStream_t st);
 
-int lrg_fused_median_workgroups(int n_slots);       // median workgroups in front of the tiles of a packed branch launch
+// hoisted pooled-feature product of the heads' first layer: hb[b,c] = bias[c] + sum_k pooled[b,k] w[k,c]  (lrg_net.hip)
+struct LrgGemvArgs {
+    const float *pooled;
+    const float *w[2];
+    const float *bias[2];
+    float *hb[2];
+    int ldw, B, P, C;
+    int *cnt_src, *cnt_dst;   // nullable pair (packed rows): block (0,0,0) copies cnt_src[0..1] to cnt_dst[0..1] and zeroes cnt_src --
+                              // the branch kernels are done with the row counts, the heads read the copy, the next front kernel
+                              // allocates from zero again
+};
 
-// lrg_forward_packed with the medians in the branch launch (lrg_net.hip; called by lrg_grow_step_packed)
-int lrg_forward_packed_medians(const LrgWeights *w, const float *x_in, const float *x_nb, const int32_t *row_inst_in,
-                               const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
-                               float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes,
-                               const LrgFusedMedians *med, hipStream_t st);
+// The descriptors of a packed evaluation (two branch stacks, pooled product, two head stacks) without launching anything: for the
+// free-running region-grow kernel, whose tile teams run them task by task (lrg_async.inl).  Needs w->packed.
+int lrg_packed_problems(const LrgWeights *w, const float *x_in, const float *x_nb, const float *center, const int32_t *row_inst_in,
+                        const int32_t *row_inst_nb, int32_t *nrows, int n_inst, int row_cap, float *add_logits, float *rmv_logits,
+                        void *workspace, size_t workspace_bytes, LrgFusedArgs *branches, LrgGemvArgs *gemv, LrgFusedArgs *heads);

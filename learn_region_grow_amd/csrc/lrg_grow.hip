@@ -7,6 +7,7 @@
 #include "lrg_rng.h"
 #include "lrg_median.h"
 #include "lrg_fused.h"
+#include "lrg_fused_tile.inl"
 
 #define LRG_SCAN_THREADS 1024
 
@@ -1066,6 +1067,7 @@ __global__ void lrg_nn1_write_kernel(const int32_t *label_in, int n, const unsig
 }
 
 #include "lrg_front.inl"
+#include "lrg_async.inl"
 #include "lrg_beam.inl"
 
 // ------------------------------------------------------------------------------------------------
@@ -1317,14 +1319,6 @@ const float *lrg_packed_rows_center(const LrgGrowParams *params, const LrgPacked
     return (params && b && lrg_uses_greedy_front(params, b)) ? b->center : nullptr;
 }
 
-// Medians of the greedy front in the packed branch launch (LrgFusedMedians) instead of lrg_front_big_kernel: one launch less, but
-// the tiles of the large regions -- the last to start -- then wait for medians computed by 256-thread workgroups with three
-// channels each: branch launch 57.6 us against 41.2 + 8.5 for the two launches (profiles/r02_fused_medians_experiment.txt).
-// Off; build-time switch for A/B measurements.
-#ifndef LRG_FUSE_MEDIANS
-#define LRG_FUSE_MEDIANS 0
-#endif
-
 static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                            const LrgWeights *weights, const LrgPackedBuffers *b, void *stream, bool launch_medians) {
     int rc = check_params(params);
@@ -1350,29 +1344,13 @@ static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_
     a.pooled = static_cast<float *>(b->workspace) + poff; a.pooled_stride = (int)(pcnt / (size_t)n_slots);
     a.stats = b->stats;
     a.phase_ticks = b->phase_ticks;
-    a.med_queue = nullptr; a.med_pool = 0; a.own_medians = 0;
+    a.own_medians = 0; a.row_stride = 0;
     hipStream_t st = (hipStream_t)stream;
     if (lrg_uses_greedy_front(params, b)) {
         const int ncentred = params->feature_size <= 2 ? params->feature_size : params->feature_size <= 6 ? 2 : params->feature_size - 4;
-        // median workgroups in this launch (LrgPackedBuffers.med_queue) instead of a launch of their own -- not when the caller
-        // wants the medians elsewhere (launch_medians false: the branch launch computes them)
-        const bool pooled = LRG_MED_POOL_KERNEL && launch_medians && b->med_queue && b->med_pool > 0;
-        if (pooled) { a.med_queue = b->med_queue; a.med_pool = b->med_pool; }
-        // every slot's workgroup computes its medians itself (LRG_FRONT_OWN_MEDIANS, default): no launch of their own
-        const bool own = LRG_FRONT_OWN_MEDIANS && launch_medians && !pooled;
-        a.own_medians = own ? 1 : 0;
-        hipLaunchKernelGGL(lrg_front_greedy_kernel, dim3(n_slots + a.med_pool), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots,
-                           *params, a, b->slot_big);
+        hipLaunchKernelGGL(lrg_front_greedy_kernel, dim3(n_slots), dim3(LRG_FRONT_THREADS), 0, st, slots, rooms, n_slots, *params, a, b->slot_big);
         LRG_LAUNCH_CHECK();
-#ifdef LRG_EXP_NO_BIG_LAUNCH      // timing experiment only (centres stay zero): what the iteration would gain without this launch
-        if (false) {
-#else
-#ifdef LRG_POOL_ALSO_BIG       // diagnosis of the pool experiment: the launch of the (slot, channel) medians runs as well and has the last word
-        if (launch_medians && !own) {
-#else
-        if (launch_medians && !pooled && !own) {
-#endif
-#endif
+        if (launch_medians) {
             hipLaunchKernelGGL(lrg_front_big_kernel, dim3(n_slots, ncentred), dim3(1024), 0, st, slots, rooms, *params, a, b->slot_big);
             LRG_LAUNCH_CHECK();
         }
@@ -1399,25 +1377,98 @@ int lrg_front_step(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
 int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                          const LrgWeights *weights, const LrgPackedBuffers *b, void *stream) {
     if (!params || !b) return LRG_EINVAL - 1;
-    const bool fuse = LRG_FUSE_MEDIANS && lrg_uses_greedy_front(params, b);
-    int rc = front_step_impl(slots, rooms, n_slots, max_points, params, weights, b, stream, !fuse);
+    int rc = front_step_impl(slots, rooms, n_slots, max_points, params, weights, b, stream, true);
     if (rc) return rc;
-    if (fuse) {
-        LrgFusedMedians med;
-        med.slots = slots; med.rooms = rooms; med.big = b->slot_big; med.center = b->center; med.ctag = nullptr;
-        med.phase_ticks = b->phase_ticks;
-        med.n_slots = n_slots;
-        med.ncentred = params->feature_size <= 2 ? params->feature_size : params->feature_size <= 6 ? 2 : params->feature_size - 4;
-        med.F = params->feature_size;
-        return lrg_forward_packed_medians(weights, b->x_in, b->x_nb, b->row_slot_in, b->row_slot_nb, b->counters, b->counters + 2, n_slots,
-                                          b->row_cap, b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes, &med,
-                                          (hipStream_t)stream);
-    }
     return lrg_forward_packed(weights, b->x_in, b->x_nb, lrg_packed_rows_center(params, b), b->row_slot_in, b->row_slot_nb, b->counters,
                               b->counters + 2, n_slots, b->row_cap, b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes,
                               LRG_FWD_POOL_ZEROED, stream);
 }
 
+
+size_t lrg_grow_async_queue_bytes(int n_slots) {
+    if (n_slots <= 0) return 0;
+    size_t ring = 1 << 14;                                   // entries: far more than the tasks that can be outstanding (~80 per slot)
+    while (ring < (size_t)n_slots * 512) ring <<= 1;
+    return (LRG_AQ_RING + ring) * sizeof(int32_t);
+}
+
+int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params, const LrgWeights *weights,
+                   const LrgPackedBuffers *b, const LrgAsyncBuffers *ab, int max_steps, int budget_us, void *stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!slots || !rooms || !weights || !b || !ab || n_slots <= 0 || max_points <= 0 || max_steps < 1 || budget_us < 0) return LRG_EINVAL - 1;
+    if (weights->feature_size != params->feature_size) return LRG_EINVAL - 2;
+    if (!lrg_uses_greedy_front(params, b) || max_points > LRG_FRONT_MAXCHUNK * LRG_SCAN_CHUNK) return LRG_EINVAL - 3;
+    if (!b->center || !b->sample_in || !b->sample_nb || !b->x_in || !b->x_nb || !b->row_slot_in || !b->row_slot_nb || !b->upd_in ||
+        !b->upd_nb || !b->rmv_logits || !b->add_logits || !b->slot_rows || !b->counters || !b->workspace || !ab->queue || !ab->sync)
+        return LRG_EINVAL - 4;
+    const int row_stride = (max(params->n_inlier, params->n_neighbor) + 31) / 32 * 32;
+    if (b->row_cap % LRG_ROW_TILE != 0 || (long)b->row_cap < (long)n_slots * row_stride) return LRG_EINVAL - 5;
+    const size_t qbytes = lrg_grow_async_queue_bytes(n_slots);
+    if (ab->queue_bytes < qbytes || ((uintptr_t)ab->queue & 255) || n_slots >= (1 << 20)) return LRG_EINVAL - 6;
+    size_t poff = 0, pcnt = 0;
+    if ((rc = lrg_forward_packed_pooled_view(weights, n_slots, b->row_cap, &poff, &pcnt))) return rc;
+
+    LrgAsyncArgs A;
+    LrgFusedArgs branches, heads;
+    if ((rc = lrg_packed_problems(weights, b->x_in, b->x_nb, b->center, b->row_slot_in, b->row_slot_nb, b->counters, n_slots, b->row_cap,
+                                  b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes, &branches, &A.gemv, &heads)))
+        return rc;
+    A.prob[0] = branches.p[0]; A.prob[1] = branches.p[1]; A.prob[2] = heads.p[0]; A.prob[3] = heads.p[1];
+    for (int i = 0; i < 4; ++i) {
+        const LrgFusedProb &P = A.prob[i];
+        // the shapes the team tiles are instantiated for: lite 0 / 2 (lite 1 stores conv[1] from the accumulators: lrg_grow_step_packed)
+        const int Kp = (P.Kin + 7) & ~7;
+        if (32 * (Kp + 4) > (i < 2 ? 32 * 132 : 32 * 68)) return LRG_EINVAL - 7;
+        for (int l = 0; l < P.nlayers; ++l) {
+            const LrgFusedLayer &L = P.L[l];
+            const bool inplace = (L.flags & LRG_FL_INPLACE) != 0, to_buf1 = ((l & 1) != 0) == !inplace;
+            if (L.gout && (!(L.flags & LRG_FL_KEEP) || inplace)) return LRG_EINVAL - 7;
+            if ((L.flags & LRG_FL_KEEP) && 32 * (L.N + 4) > (to_buf1 ? (i < 2 ? 32 * 132 : 32 * 68) : (i < 2 ? 32 * 68 : 32 * 260))) return LRG_EINVAL - 7;
+        }
+    }
+    if (A.gemv.P + 512 > LRG_ASYNC_TILE_FLOATS || (A.gemv.P & 1)) return LRG_EINVAL - 7;
+    LrgFrontArgs &a = A.front;
+    a.center = b->center; a.sample_in = b->sample_in; a.sample_nb = b->sample_nb;
+    a.x_in = b->x_in; a.x_nb = b->x_nb; a.row_slot_in = b->row_slot_in; a.row_slot_nb = b->row_slot_nb;
+    a.upd_in = reinterpret_cast<float4 *>(b->upd_in); a.upd_nb = reinterpret_cast<float4 *>(b->upd_nb); a.rmv_logits = b->rmv_logits; a.add_logits = b->add_logits;
+    a.slot_rows = b->slot_rows; a.counters = b->counters;
+    a.pooled = static_cast<float *>(b->workspace) + poff; a.pooled_stride = (int)(pcnt / (size_t)n_slots);
+    a.stats = b->stats;
+    a.phase_ticks = nullptr;
+    a.own_medians = 1; a.row_stride = row_stride;
+
+    hipDeviceProp_t prop;
+    LRG_HIP_CHECK(hipGetDeviceProperties(&prop, lrg_current_device()));
+    int wgs = prop.multiProcessorCount;
+    if (ab->compute_units > 0 && ab->compute_units < wgs) wgs = ab->compute_units;
+    int n_front = ab->front_workgroups > 0 ? ab->front_workgroups : (n_slots + 1) / 2;
+    n_front = min(n_front, n_slots);
+    n_front = max(n_front, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED);
+    if (n_front >= wgs) return LRG_EINVAL - 8;               // no CU left for the tile teams
+    const int teams = ab->teams > 0 ? min(ab->teams, 3) : 3;
+    A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big;
+    A.qmask = (int)(qbytes / sizeof(int32_t)) - LRG_AQ_RING - 1;
+    A.n_slots = n_slots; A.n_front = n_front; A.teams = teams;
+    A.max_steps = max_steps;
+    A.budget_ticks = budget_us > 0 ? (long long)budget_us * 100 : (1LL << 60);      // wall_clock64: 100 MHz
+    A.abort_ticks = (budget_us > 0 ? (long long)budget_us * 100 : 0) + 400000000LL;  // ... + 4 s without an end: something is broken
+    hipStream_t st = (hipStream_t)stream;
+    LRG_HIP_CHECK(hipMemsetAsync(ab->queue, 0, qbytes, st));
+    LRG_HIP_CHECK(hipMemsetAsync(ab->sync, 0, (size_t)n_slots * LRG_ASYNC_SYNC_WORDS * sizeof(int32_t), st));
+    const size_t front_lds = ((sizeof(LrgFrontShared) + 15) & ~(size_t)15) + sizeof(LrgAsyncFrontCtl);
+    const size_t team_lds = (size_t)teams * LRG_ASYNC_TEAM_FLOATS * sizeof(float);
+    const size_t lds = (max(front_lds, team_lds) + 15) & ~(size_t)15;
+    static bool attr_done[LRG_MAX_DEVICES] = {};
+    const int dev = lrg_current_device();
+    if (!attr_done[dev]) {
+        LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_grow_async_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(lrg_grow_async_kernel, dim3(wgs), dim3(LRG_FRONT_THREADS), lds, st, slots, rooms, *params, A);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
 
 int lrg_beam_advance(LrgBeamGroup *groups, LrgSlot *slots, LrgRoom *rooms, int n_groups, int beam_width, int search_width,
                      const LrgGrowParams *params, int64_t *stats, void *stream) {

@@ -231,16 +231,6 @@ __global__ __launch_bounds__(256) void lrg_segmax_kernel(LrgSegmaxArgs a) {
 // hoisted pooled-feature product: hb[b,c] = bias[c] + sum_k pooled[b,k] w[k,c]
 // ------------------------------------------------------------------------------------------------
 #define LRG_GEMV_TB 2
-struct LrgGemvArgs {
-    const float *pooled;
-    const float *w[2];
-    const float *bias[2];
-    float *hb[2];
-    int ldw, B, P, C;
-    int *cnt_src, *cnt_dst;   // nullable pair (packed rows): block (0,0,0) copies cnt_src[0..1] to cnt_dst[0..1] and zeroes cnt_src --
-                              // the branch kernels are done with the row counts, the heads read the copy, the next front kernel
-                              // allocates from zero again
-};
 
 // 64 output columns x TB instances per 512-thread block; the 8 waves split K and their partial sums are
 // combined through LDS in a fixed order (deterministic, no atomics).
@@ -656,7 +646,6 @@ struct LrgPackedLayout {
     size_t pooled;       // [n_inst, 2*C_last]
     size_t hb[2];        // [n_inst, head_ch[0]] hoisted pooled product of the add / remove head
     size_t packed;       // lrg_pack_weights image when the caller supplies none
-    size_t ctag;         // [n_inst,16] 64-bit tagged centres (LrgFusedMedians), 2 floats each
     size_t total;
     int P;
 };
@@ -676,8 +665,6 @@ static int packed_layout(const LrgWeights *w, int n_inst, int row_cap, LrgPacked
     if (rc) return rc;
     L->packed = off;
     off = lrg_align_up(off + PL.total, 64);
-    L->ctag = off;
-    off = lrg_align_up(off + (size_t)n_inst * 32, 64);
     L->total = off;
     return 0;
 }
@@ -693,21 +680,14 @@ static int packed_shapes(const LrgWeights *w) {
     return 0;
 }
 
-static int forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const float *center, const int32_t *row_inst_in,
-                          const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
-                          float *add_logits, float *rmv_logits, float *ws, const LrgPackedLayout &L, bool pool_zeroed,
-                          hipStream_t st, const LrgFusedMedians *med = nullptr) {
+// The problems of a packed evaluation: the two branch stacks, the pooled GEMM and the two head stacks, as the launchers (and the
+// free-running kernel, lrg_async.inl) take them.  `pk` = the packed weight image in use.
+static int packed_problems(const LrgWeights *w, const float *pk, const LrgPackLayout &PL, const float *x_in, const float *x_nb, const float *center,
+                           const int32_t *row_inst_in, const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
+                           float *add_logits, float *rmv_logits, float *ws, const LrgPackedLayout &L, LrgFusedArgs *branches, LrgGemvArgs *gemv,
+                           LrgFusedArgs *heads) {
     const int nc = w->n_conv, nh = w->n_head;
     const int Clast = w->conv_ch[nc - 1];
-    if (!pool_zeroed) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)n_inst * L.P * sizeof(float), st));
-    LrgPackLayout PL;
-    int prc = pack_layout(w, &PL);
-    if (prc) return prc;
-    const float *pk = static_cast<const float *>(w->packed);
-    if (!pk) {
-        if ((prc = pack_weights(w, ws + L.packed, st))) return prc;
-        pk = ws + L.packed;
-    }
     {
         LrgFusedArgs a = {};
         a.few = n_inst <= LRG_FEW_TILES_SLOTS ? 1 : 0;      // few tiles per launch: two workgroups per CU at most (lrg_fused.hip)
@@ -717,14 +697,7 @@ static int forward_packed(const LrgWeights *w, const float *x_in, const float *x
             P.ldx = w->feature_size; P.Kin = w->feature_size;
             P.rows = row_cap; P.rows_per_inst = row_cap;
             P.nrows = nrows + br; P.row_inst = br == 0 ? row_inst_in : row_inst_nb;
-            P.center = med ? nullptr : center;
-            if (med) {
-                P.ctag = reinterpret_cast<const unsigned long long *>(ws + L.ctag);
-                P.tags = med->big;
-                unsigned cm = 0;
-                for (int y = 0; y < med->ncentred; ++y) { const int ch = y < 2 ? y : y + 4; if (ch < w->feature_size) cm |= 1u << ch; }
-                P.cmask = cm;
-            }
+            P.center = center;
             P.pool = ws + L.pooled + (br == 0 ? 0 : Clast); P.pool_stride = L.P;
             P.nlayers = nc;
             for (int i = 0; i < nc; ++i) {
@@ -737,13 +710,7 @@ static int forward_packed(const LrgWeights *w, const float *x_in, const float *x
                 F.gout = i == 1 ? ws + L.conv1[br] : nullptr;
             }
         }
-        if (med) {
-            a.med = *med;
-            a.med.ctag = reinterpret_cast<unsigned long long *>(ws + L.ctag);
-            a.nmed = lrg_fused_median_workgroups(med->n_slots);
-        }
-        int rc = lrg_fused_branches_packed(a, 2, st);
-        if (rc) return rc;
+        *branches = a;
     }
     const int C0 = w->head_ch[0];
     {
@@ -754,8 +721,7 @@ static int forward_packed(const LrgWeights *w, const float *x_in, const float *x
         g.hb[0] = ws + L.hb[0]; g.hb[1] = ws + L.hb[1];
         g.ldw = C0; g.B = n_inst; g.P = L.P; g.C = C0;
         if (nrows_heads) { g.cnt_src = nrows; g.cnt_dst = nrows_heads; }
-        int grc = launch_head_gemv(g, 2, st);
-        if (grc) return grc;
+        *gemv = g;
     }
     {
         const int hbr[2] = {1, 0};      // head 0 = add on the neighbour rows, head 1 = remove on the inlier rows
@@ -790,8 +756,47 @@ static int forward_packed(const LrgWeights *w, const float *x_in, const float *x
             P.fb = hd == 0 ? w->add_b[nh - 1] : w->rmv_b[nh - 1];
             P.fout = hd == 0 ? add_logits : rmv_logits;
         }
-        return lrg_fused_heads_packed(a, 2, st);
+        *heads = a;
     }
+    return 0;
+}
+
+static int forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb, const float *center, const int32_t *row_inst_in,
+                          const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
+                          float *add_logits, float *rmv_logits, float *ws, const LrgPackedLayout &L, bool pool_zeroed,
+                          hipStream_t st) {
+    if (!pool_zeroed) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)n_inst * L.P * sizeof(float), st));
+    LrgPackLayout PL;
+    int prc = pack_layout(w, &PL);
+    if (prc) return prc;
+    const float *pk = static_cast<const float *>(w->packed);
+    if (!pk) {
+        if ((prc = pack_weights(w, ws + L.packed, st))) return prc;
+        pk = ws + L.packed;
+    }
+    LrgFusedArgs branches, heads;
+    LrgGemvArgs gemv;
+    packed_problems(w, pk, PL, x_in, x_nb, center, row_inst_in, row_inst_nb, nrows, nrows_heads, n_inst, row_cap, add_logits, rmv_logits, ws, L,
+                    &branches, &gemv, &heads);
+    int rc = lrg_fused_branches_packed(branches, 2, st);
+    if (rc) return rc;
+    if ((rc = launch_head_gemv(gemv, 2, st))) return rc;
+    return lrg_fused_heads_packed(heads, 2, st);
+}
+
+// (lrg_fused.h) the same descriptors for a caller that runs the tiles itself; needs w->packed
+int lrg_packed_problems(const LrgWeights *w, const float *x_in, const float *x_nb, const float *center, const int32_t *row_inst_in,
+                        const int32_t *row_inst_nb, int32_t *nrows, int n_inst, int row_cap, float *add_logits, float *rmv_logits,
+                        void *workspace, size_t workspace_bytes, LrgFusedArgs *branches, LrgGemvArgs *gemv, LrgFusedArgs *heads) {
+    LrgPackedLayout L;
+    int rc = packed_layout(w, n_inst, row_cap, &L);
+    if (rc) return rc;
+    if (!w->packed || !workspace || workspace_bytes < L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return LRG_EINVAL - 6;
+    if ((rc = packed_shapes(w))) return rc;
+    LrgPackLayout PL;
+    if ((rc = pack_layout(w, &PL))) return rc;
+    return packed_problems(w, static_cast<const float *>(w->packed), PL, x_in, x_nb, center, row_inst_in, row_inst_nb, nrows, nullptr, n_inst,
+                           row_cap, add_logits, rmv_logits, static_cast<float *>(workspace), L, branches, gemv, heads);
 }
 
 extern "C" {
@@ -828,21 +833,6 @@ int lrg_forward_packed(const LrgWeights *w, const float *x_in, const float *x_nb
 
 }  // extern "C"
 
-int lrg_forward_packed_medians(const LrgWeights *w, const float *x_in, const float *x_nb, const int32_t *row_inst_in,
-                               const int32_t *row_inst_nb, int32_t *nrows, int32_t *nrows_heads, int n_inst, int row_cap,
-                               float *add_logits, float *rmv_logits, void *workspace, size_t workspace_bytes,
-                               const LrgFusedMedians *med, hipStream_t st) {
-    LrgPackedLayout L;
-    int rc = packed_layout(w, n_inst, row_cap, &L);
-    if (rc) return rc;
-    if (!med || !med->slots || !med->rooms || !med->big || !med->center || med->n_slots != n_inst) return LRG_EINVAL - 5;
-    if (workspace_bytes < L.total * sizeof(float) || ((uintptr_t)workspace & 255)) return LRG_EINVAL - 6;
-    if ((rc = packed_shapes(w))) return rc;
-    return forward_packed(w, x_in, x_nb, nullptr, row_inst_in, row_inst_nb, nrows, nrows_heads, n_inst, row_cap, add_logits, rmv_logits,
-                          static_cast<float *>(workspace), L, true, st, med);
-}
-
-
 extern "C" {
 
 int lrg_abi_version(void) { return LRG_ABI_VERSION; }
@@ -856,6 +846,7 @@ size_t lrg_struct_size(int which) {
     case 4: return sizeof(LrgStepBuffers);
     case 5: return sizeof(LrgPackedBuffers);
     case 6: return sizeof(LrgBeamGroup);
+    case 7: return sizeof(LrgAsyncBuffers);
     }
     return 0;
 }

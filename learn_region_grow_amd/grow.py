@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LRG_ACTIVE, LRG_DONE, LRG_WAIT, LRG_IDLE,
+from ._lib import (LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LrgAsyncBuffers, LRG_ACTIVE, LRG_DONE, LRG_WAIT, LRG_IDLE,
                    LRG_STATS_WORDS, LRG_DONE_RING, REASON_NAMES)
 from .lrgnet import _ptr, _stream_ptr
 
@@ -50,10 +50,14 @@ class RoomResult:
 class RegionGrower:
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
-                 skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np'):
+                 skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np', free_run=False,
+                 free_run_steps=64, free_run_budget_us=0, free_run_fronts=0, free_run_teams=0):
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
-        graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*)."""
+        graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*).
+        free_run: True / None (= whenever it applies: packed greedy growing, lite 0 / 2) / False: one host call = ONE launch in
+        which every slot takes up to free_run_steps grow steps at its own pace (lrg_grow_async), starting none after
+        free_run_budget_us microseconds (0 = no time limit); same results as the lock-step iterations."""
         self.lib = _lib.load()
         self.net = net
         self.dev = net.device
@@ -95,6 +99,12 @@ class RegionGrower:
         self.graph_iterations = int(graph_iterations)
         self.packed = False
         self._graph = None
+        self.want_free_run = free_run
+        self.free_run = False
+        self.free_run_steps = int(free_run_steps)
+        self.free_run_budget_us = int(free_run_budget_us)
+        self.free_run_fronts = int(free_run_fronts)
+        self.free_run_teams = int(free_run_teams)
         self.debug_hook = None      # tests: called once per active slot per legacy iteration with the step's data
         self._rooms_loaded = False
 
@@ -261,6 +271,9 @@ class RegionGrower:
         can_pack = (self.rng == 'counter' and self.net.mode == 'fused' and max(ns) <= _lib.LRG_PACKED_MAX_POINTS and
                     max(Ni, Nn) <= 1024 and self.skip_duplicate_rows and
                     self.lib.lrg_forward_packed_workspace_bytes(ctypes.byref(self.net._w), S, 32) > 0)
+        self.free_run = False
+        if self.want_free_run and not can_pack:
+            raise ValueError('free-running launches need packed iterations')
         if self.want_packed and not can_pack:
             raise ValueError('packed iterations need the counter stream, the fused network and rooms of at most %d points'
                              % _lib.LRG_PACKED_MAX_POINTS)
@@ -268,7 +281,8 @@ class RegionGrower:
         if self.params.scoring == 1 and not self.packed:
             raise ValueError("scoring='ml' needs the packed iteration (fused network, rooms of at most %d points)" % _lib.LRG_PACKED_MAX_POINTS)
         if self.packed:
-            cap_rows = (S * ((max(Ni, Nn) + 15) // 16 * 16) + 31) // 32 * 32     # (a slot's rows are allocated in multiples of 8 or 16)
+            cap_rows = S * ((max(Ni, Nn) + 31) // 32 * 32)     # (a slot's rows are allocated in multiples of 8 -- or, free-running, have
+                                                                 #  a place of their own of whole 32-row tiles)
             self.row_cap = cap_rows
             self.p_xin = torch.zeros((cap_rows, F), dtype=torch.float32, device=dev)
             self.p_xnb = torch.zeros((cap_rows, F), dtype=torch.float32, device=dev)
@@ -295,13 +309,27 @@ class RegionGrower:
             self.p_big = torch.zeros((S, 2), dtype=torch.int32, device=dev)
             pb.slot_big = self.p_big.data_ptr()
             pb.rooms_have_pvox = 1 if self.have_pvox else 0
-            # median workgroups inside the greedy front launch (one launch less per iteration): an experiment that is compiled in only with
-            # -DLRG_MED_POOL_KERNEL=1 and was slower as first built (csrc/lrg_front.inl); LRG_MED_POOL=<workgroups> asks for it
-            pool = int(os.environ.get('LRG_MED_POOL', '0'))
-            if pool > 0 and self.have_pvox and self.G == 1:
-                self.p_medq = torch.zeros(16 + 9 * S + pool, dtype=torch.int32, device=dev)
-                pb.med_queue, pb.med_pool = self.p_medq.data_ptr(), pool
             self.packed_buffers = pb
+            # free-running launches (lrg_grow_async): greedy growing through the single-launch front, lite 0 / 2
+            can_free = (self.G == 1 and self.params.restarts == 1 and self.have_pvox and max(Ni, Nn) <= 512 and
+                        getattr(self.net, 'lite', 0) != 1)
+            if self.want_free_run and not can_free:
+                raise ValueError('free-running launches need greedy growing (restarts = group_size = 1), rooms with packed voxel words, '
+                                 'at most 512 + 512 points per set and lite 0 or 2')
+            if self.want_free_run is None:
+                self.free_run = can_free and os.environ.get('LRG_FREE_RUN', '1') != '0'
+            else:
+                self.free_run = bool(self.want_free_run)
+            if self.free_run:
+                qbytes = self.lib.lrg_grow_async_queue_bytes(S)
+                self.a_queue = torch.zeros(qbytes // 4, dtype=torch.int32, device=dev)
+                self.a_sync = torch.zeros((S, 16), dtype=torch.int32, device=dev)
+                ab = LrgAsyncBuffers()
+                ab.queue, ab.queue_bytes, ab.sync = self.a_queue.data_ptr(), qbytes, self.a_sync.data_ptr()
+                ab.front_workgroups = self.free_run_fronts or int(os.environ.get('LRG_FREE_RUN_FRONTS', '0'))
+                ab.teams = self.free_run_teams or int(os.environ.get('LRG_FREE_RUN_TEAMS', '0'))
+                ab.compute_units = int(os.environ.get('LRG_FREE_RUN_CUS', '0'))
+                self.async_buffers = ab
         self.h_stats = [torch.zeros(LRG_STATS_WORDS, dtype=torch.int64).pin_memory() for _ in range(self.depth)]
         self.ev = [torch.cuda.Event() for _ in range(self.depth)]
         self.group_room = [-1] * self.n_groups
@@ -428,9 +456,23 @@ class RegionGrower:
         self.iterations += self.graph_iterations
         self._record_poll()
 
+    def enqueue_free_run(self, steps=None, budget_us=None):
+        """One free-running launch: every slot up to `steps` grow steps at its own pace (lrg_grow_async)."""
+        steps = self.free_run_steps if steps is None else int(steps)
+        budget = self.free_run_budget_us if budget_us is None else int(budget_us)
+        rc = self.lib.lrg_grow_async(_ptr(self.d_slots), _ptr(self.d_rooms), self.S, self.cap, ctypes.byref(self.params),
+                                     ctypes.byref(self.net._w), ctypes.byref(self.packed_buffers), ctypes.byref(self.async_buffers),
+                                     steps, budget, _stream_ptr(self.dev))
+        _lib.check(rc, 'lrg_grow_async')
+        self.iterations += steps
+        self._record_poll()
+
     def enqueue(self):
-        """The next batch of iterations by the cheapest route: a graph replay when one is configured, else one iteration."""
-        if self.packed and self.graph_iterations > 0 and torch.cuda.current_stream(self.dev).cuda_stream != 0:
+        """The next batch of iterations by the cheapest route: a free-running launch, a graph replay when one is configured, else
+        one iteration."""
+        if self.free_run:
+            self.enqueue_free_run()
+        elif self.packed and self.graph_iterations > 0 and torch.cuda.current_stream(self.dev).cuda_stream != 0:
             self.enqueue_graph()
         else:
             self.enqueue_iteration()
@@ -456,6 +498,8 @@ class RegionGrower:
             out.append(int(st[4 + (j % LRG_DONE_RING)]) // self.G)
         self._seen_done = done_total
         self.last_stats = (int(st[0]), int(st[1]), int(st[2]))
+        if int(st[3]):
+            raise _lib.LrgHipError('lrg_grow_async gave up on a hand-over between workgroups (%d): results are invalid' % int(st[3]))
         return out
 
     # ------------------------------------------------------------------------------------------

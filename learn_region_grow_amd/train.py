@@ -88,6 +88,20 @@ class LrgNetTrainer:
         shapes = self.net.variable_shapes()
         return {k: self.views[k].cpu().numpy().reshape(shapes[k]) for k in self.names}
 
+    def checkpoint_numpy(self):
+        """name -> array of everything the reference's ``Saver`` stores for this graph: variables, Adam slots, beta powers and the
+        global step (checkpoint.lrgnet_checkpoint_tensors), so that ``Saver().restore`` (test_region_grow.py:92-93) finds every key."""
+        from . import checkpoint
+        shapes = self.net.variable_shapes()
+        m = {k: self.m[o:o + self.views[k].numel()].cpu().numpy().reshape(shapes[k]) for k, o in zip(self.names, self.offs[:-1])}
+        v = {k: self.v[o:o + self.views[k].numel()].cpu().numpy().reshape(shapes[k]) for k, o in zip(self.names, self.offs[:-1])}
+        return checkpoint.lrgnet_checkpoint_tensors(self.weights_numpy(), m, v, self.t, self.b1, self.b2)
+
+    def evaluate(self, inlier, neighbor, add_mask, rmv_mask):
+        """Loss, precision and recall of a batch without the backward pass (the validation loop, train_region_grow.py:186-219, runs
+        only ``net.loss`` and the four ratios): forward + the loss kernel, no dW / dX products."""
+        return self.backward(inlier, neighbor, add_mask, rmv_mask, loss_only=True)
+
     # ---- kernels ----
     def _gemm(self, M, N, K, A, lda, tA, B, ldb, tB, C, ldc, addend=None, mask=None, split=1):
         _lib.check(self.lib.lrg_gemm_f32(M, N, K, _ptr(A), lda, tA, _ptr(B), ldb, tB, _ptr(C), ldc, _ptr(addend), _ptr(mask), split,
@@ -108,7 +122,7 @@ class LrgNetTrainer:
         _lib.check(self.lib.lrg_segment_colsum(_ptr(part), 1, nseg, N, _ptr(out), st), 'lrg_segment_colsum')
 
     # ---- one step ----
-    def backward(self, inlier, neighbor, add_mask, rmv_mask):
+    def backward(self, inlier, neighbor, add_mask, rmv_mask, loss_only=False):
         """Forward + losses + gradients into self.gviews; returns the scalars the reference fetches."""
         net, B, Ni, Nn, F = self.net, self.B, self.Ni, self.Nn, self.F
         cc, c2 = net.conv_channels, net.conv2_channels
@@ -134,6 +148,8 @@ class LrgNetTrainer:
                                             _ptr(self._stats[0]), st), 'lrg_ce_grad')
             _lib.check(self.lib.lrg_ce_grad(_ptr(rmv), _ptr(rm), B * Ni, 1.0 / n_pos if n_pos else 0.0, 1.0 / n_neg if n_neg else 0.0,
                                             _ptr(self._dlog['rmv']), _ptr(self._stats[1]), st), 'lrg_ce_grad')
+            if loss_only:
+                return self._scalars(self._stats.cpu().numpy())
             # ---- heads (:138-162), down to the gradient of their first layer's pre-activation ----
             P, C1 = 2 * cc[-1], cc[1]
             dz0 = {}
@@ -179,6 +195,10 @@ class LrgNetTrainer:
                         self._gemm(R, K, cc[i], cur, cc[i], 0, self.views[pre + 'kernel%d' % i], cc[i], 1, nxt, K, addend=extra, mask=A[i])
                         cur, nxt = nxt, cur
             s = self._stats.cpu().numpy()
+        return self._scalars(s)
+
+    @staticmethod
+    def _scalars(s):
         loss = float(s[0, 0] + s[1, 0])
         return dict(loss=loss, add_loss=float(s[0, 0]), remove_loss=float(s[1, 0]),
                     add_acc=s[0, 1] / s[0, 5], remove_acc=s[1, 1] / s[1, 5],

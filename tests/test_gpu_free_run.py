@@ -1,0 +1,84 @@
+"""GPU: free-running launches (lrg_grow_async: every slot at its own pace inside one launch, csrc/lrg_async.inl) against the
+lock-step iterations (lrg_grow_step_packed) and the oracle.  Same front code, same tile code on the same rows, so regions and
+labels must agree exactly -- whatever the number of front workgroups, tile teams, steps per launch or the order in which the
+slots happen to be served (test_region_grow.py:208-306 per slot; rooms are independent, :110-183)."""
+import numpy as np
+import pytest
+
+from conftest import seed_without_near_tie
+from learn_region_grow_amd import synthetic
+from oracle import grow_ref, rng_ref
+from test_gpu_grow import WEIGHT_KW, SAME_LOGITS_MARGIN, gpu_net_fn, small_room, same_regions
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def net(cuda_device):
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    return LrgNetHIP(1, 1, 512, 512, 13, 0, device=cuda_device).load_weights(synthetic.make_synthetic_weights(**WEIGHT_KW))
+
+
+def _rooms():
+    return [small_room(400 + i, 600 + 200 * i, room_id=10 + i) for i in range(3)] + \
+           [small_room(300, 1500, furniture=4, room_id=13), small_room(301, 2500, furniture=6, room_id=14)]
+
+
+@pytest.mark.parametrize('steps,fronts,teams,in_flight', [(1, 0, 0, 5), (7, 0, 0, 5), (64, 1, 1, 3), (64, 5, 3, 5), (16, 2, 2, 2)])
+def test_free_run_equals_lock_step(net, steps, fronts, teams, in_flight):
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = _rooms()
+    kw = dict(rooms_in_flight=in_flight, rng='counter', seed=123, policy='net')
+    want = RegionGrower(net, free_run=False, **kw).run(rooms)
+    gr = RegionGrower(net, free_run=True, free_run_steps=steps, free_run_fronts=fronts, free_run_teams=teams, **kw)
+    got = gr.run(rooms)
+    assert gr.free_run
+    for g, w in zip(got, want):
+        same_regions(g.regions, w.regions)
+        np.testing.assert_array_equal(g.cluster_label, w.cluster_label)
+        np.testing.assert_array_equal(g.filled_label, w.filled_label)
+
+
+def test_free_run_matches_oracle(net):
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = _rooms()[:4]
+
+    def oracle(seed):
+        return [grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.CounterStream(seed, room['room_id']),
+                                   net_fn=gpu_net_fn(net)) for room in rooms]
+    seed, wants = seed_without_near_tie(oracle, range(123, 131), SAME_LOGITS_MARGIN)
+    res = RegionGrower(net, rooms_in_flight=4, rng='counter', seed=seed, free_run=True, free_run_steps=32).run(rooms)
+    for i, want in enumerate(wants):
+        same_regions(res[i].regions, want.regions)
+        np.testing.assert_array_equal(res[i].cluster_label, want.cluster_label)
+        np.testing.assert_array_equal(res[i].filled_label, want.filled_label)
+
+
+def test_free_run_alternates_with_lock_step(net):
+    """A launch ends every slot between two evaluations, logits in place: free-running launches and lock-step iterations may
+    alternate on the same buffers."""
+    import torch
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = _rooms()[:3]
+    kw = dict(rooms_in_flight=3, rng='counter', seed=7, policy='net')
+    want = RegionGrower(net, free_run=False, **kw).run(rooms)
+    gr = RegionGrower(net, free_run=True, free_run_steps=5, **kw)
+    gr.load_rooms(rooms)
+    for g in range(3):
+        gr.bind(g, g)
+    for k in range(100000):
+        if k % 2:
+            gr.enqueue_free_run()
+        else:
+            for _ in range(3):
+                gr.enqueue_iteration()
+        if k % 8 == 7:
+            torch.cuda.synchronize()
+            if int(gr.d_stats[1].item()) >= 3:
+                break
+    for r in range(3):
+        gr.fill(r)
+    got = gr.collect()
+    for g, w in zip(got, want):
+        same_regions(g.regions, w.regions)
+        np.testing.assert_array_equal(g.filled_label, w.filled_label)

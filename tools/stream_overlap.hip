@@ -40,10 +40,11 @@ int main(int argc, char **argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     const int K = 400;
     const int m0 = argc > 1 ? atoi(argv[1]) : 0;
+    const int smax = argc > 2 ? atoi(argv[2]) : 4;        // streams 1 .. smax
     for (int masked = m0; masked <= m0; ++masked)
         for (int G : {64, 248})
             for (int us : {5, 20})
-                for (int S : {1, 2, 3, 4}) {
+                for (int S = 1; S <= smax; ++S) {
                     const double dt = run(S, K, G, us, masked);
                     printf("%s streams %d  grid %3d  spin %2d us: %7.1f us per round of %d launches (%.2f x one stream's kernel time)\n",
                            masked ? "CU-masked" : "plain    ", S, G, us, dt / K * 1e6, S, dt / K * 1e6 / us);

@@ -28,7 +28,7 @@ def parse(argv=None):
     ap.add_argument('--model-dir', default='models')
     ap.add_argument('--ckpt', default=None, help='output checkpoint prefix (default: the reference naming scheme)')
     ap.add_argument('--cross-domain', action='store_true')
-    ap.add_argument('--multiseed', type=int, default=0)
+    ap.add_argument('--multiseed', type=int, default=8, help='seeds cycled per epoch, data/multiseed/seed<k>_area<a>.h5 (reference default 8; 0 = data/staged_area<a>.h5)')
     ap.add_argument('--lite', type=int, default=None)
     ap.add_argument('--feature-size', type=int, default=13, choices=[6, 9, 12, 13])
     ap.add_argument('--batch-size', type=int, default=100)
@@ -76,7 +76,7 @@ def run_epoch(trainer, data, rs, batch_size, train=True, shuffle=True):
         if train:
             rows.append(trainer.train_step(xi, xn, ia, ir))
         else:
-            sc = trainer.backward(xi, xn, ia, ir)
+            sc = trainer.evaluate(xi, xn, ia, ir)              # forward + loss only (no dW / dX products)
             rows.append((sc['loss'], sc['add_prc'], sc['add_rcl'], sc['remove_prc'], sc['remove_rcl']))
     return np.mean(np.array(rows, dtype=np.float64), axis=0) if rows else np.zeros(5)
 
@@ -127,7 +127,7 @@ def main(argv=None):
         print('Avg Epoch Time: %.3f' % np.mean(epoch_time))
     out = model_path(args)
     os.makedirs(os.path.dirname(out) or '.', exist_ok=True)
-    checkpoint.write_bundle(out, trainer.weights_numpy())
+    checkpoint.write_bundle(out, trainer.checkpoint_numpy())      # variables + Adam slots + beta powers + global step (99 entries)
     print('Saved %s' % out)
     return 0
 
