@@ -458,7 +458,9 @@ typedef struct LrgAsyncBuffers {
     int32_t front_workgroups;   /* workgroups serving the slots (each up to 8 of them), 0 = default                       */
     int32_t teams;              /* tile teams (four wavefronts) per worker workgroup: 1 .. 3, 0 = default                 */
     int32_t compute_units;      /* workgroups of the launch in all (front + worker), at most one per CU of the device; 0 = all CUs */
-    int32_t pad;
+    int32_t poll_sleep;         /* idle tile teams poll the queue every poll_sleep x ~0.25 us; 0 = default                  */
+    uint64_t *debug_ticks;      /* nullable: [64] accumulators (never cleared by the library) of wall-clock ticks by stage of the
+                                   launch, for tools/free_run_perf.py (layout: csrc/lrg_async.inl, LrgAsyncArgs.dbg)            */
 } LrgAsyncBuffers;
 
 size_t lrg_grow_async_queue_bytes(int n_slots);

@@ -13,7 +13,7 @@
 //     its head tiles has arrived.
 //   worker workgroups (the rest of the CUs, one each): teams of four wavefronts (one per SIMD) that pull tasks from one queue:
 //       branch tile (slot, side, tile)   lrg_fused_tile on 32 of the slot's rows; the last tile of the slot to arrive publishes ...
-//       pooled product (slot, head, 64 columns)  the arithmetic of lrg_head_gemv_kernel; the last block to arrive publishes ...
+//       pooled product (slot, head, 128 columns)  the arithmetic of lrg_head_gemv_kernel; the last block to arrive publishes ...
 //       head tile (slot, head, tile)     lrg_fused_tile -> logits; the last one is what the slot's front workgroup waits for.
 //
 // Nothing waits for a workgroup that could still be waiting to be dispatched: the grid is one workgroup per CU (1024 threads each,
@@ -30,6 +30,9 @@
 // padded to whole tiles with copies of its last row, which neither the max-pool nor anybody's logits notice), the pooled product
 // in the summation order of lrg_head_gemv_kernel.
 
+#ifndef LRG_ASYNC_FD
+#define LRG_ASYNC_FD 4              // depth of the tile teams' weight ring (k-groups in flight)
+#endif
 #define LRG_AQ_TAIL 0            // control words of the queue (ints), one 64-byte line each
 #define LRG_AQ_HEAD 16
 #define LRG_AQ_FRONTS_DONE 32
@@ -45,7 +48,7 @@
 
 // LDS of a tile team: the head stack's tile is the larger one
 #define LRG_ASYNC_TILE_FLOATS LRG_TILE_LDS_FLOATS(32 * 260, 32 * 68, 1, true)
-#define LRG_ASYNC_TEAM_FLOATS (LRG_ASYNC_TILE_FLOATS + 24)      // + task word, barrier counter (16-byte multiples)
+#define LRG_ASYNC_TEAM_FLOATS (LRG_ASYNC_TILE_FLOATS + 24 + (LRG_TRACE ? 64 : 0))      // + task word, barrier counter (16-byte multiples) (+ the cycle stamps of an LRG_TRACE build)
 
 struct LrgAsyncArgs {
     LrgFusedProb prob[4];        // 0 inlier branch, 1 neighbour branch, 2 add head (neighbour rows), 3 remove head (inlier rows)
@@ -56,10 +59,18 @@ struct LrgAsyncArgs {
     int32_t *big;
     int qmask;                   // ring entries - 1 (power of two)
     int n_slots, n_front, teams;
+    int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
     int max_steps;               // evaluations per slot in this launch
     long long budget_ticks;      // wall_clock64 ticks (100 MHz) after which no new evaluation is started
     long long abort_ticks;       // ... after which a waiting workgroup gives up
+    unsigned long long *dbg;     // nullable: [32] accumulators of wall-clock ticks (10 ns) for tools/free_run_perf.py --
+                                 // 0 front busy, 1 front steps; per evaluation, since its tasks were published: 2 last branch tile in,
+                                 // 3 last pooled-product block in, 4 last head tile in, 5 seen by the front workgroup, 6 evaluations;
+                                 // 8 + 2 t busy ticks of task type t, 9 + 2 t their number; 16 ticks teams waited for a task, 17 waits
 };
+__device__ __forceinline__ void lrg_dbg_add(const LrgAsyncArgs &A, int i, long long v) {
+    if (A.dbg) atomicAdd(&A.dbg[i], (unsigned long long)v);
+}
 
 __device__ __forceinline__ void lrg_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -72,48 +83,214 @@ __device__ __forceinline__ void lrg_async_push(const LrgAsyncArgs &A, int n, int
     if (lane < n) lrg_st_coh(&A.queue[LRG_AQ_RING + ((base + lane) & A.qmask)], code_of(lane));
 }
 
-// ---- pooled product of a head's first layer for ONE slot and 64 columns (lrg_head_gemv_kernel's arithmetic: eight K ranges summed
-//      one after the other, then their partial sums in order, then the bias) by a team of four wavefronts ----
+// ---- pooled product of a head's first layer for ONE slot and 128 columns by a team of four wavefronts, in the summation order of
+//      lrg_head_gemv_kernel (eight K ranges, each summed k after k; then the eight partial sums in order; then the bias) ----
+// What it costs is the trip of 1024 x 128 weights (512 KB) from L2, not the arithmetic: every lane owns FOUR consecutive columns
+// (one 16-byte load per row of the kernel) and ONE of the eight K ranges -- 16 lanes per range and column half, the four lane
+// groups of a wavefront on four ranges -- with sixteen rows in flight per lane.  (With one column per lane and the loop left to the
+// compiler two loads were in flight: 34 us per block of 64 columns, profiles/r03_free3_perf.log.)
+#define LRG_GEMV_TASK_COLS 128
 template <class TEAM>
 __device__ __forceinline__ void lrg_async_gemv(const LrgGemvArgs &g, int slot, int z, int cb, float *sm, const TEAM &team) {
     const int tid = team.tid(), lane = tid & 63, wave = tid >> 6;
-    float *pl = sm, *part = sm + g.P;          // [P] pooled row, [8][64] partial sums
+    float *pl = sm, *part = sm + g.P;          // [P] pooled row, [8][128] partial sums
     for (int i = 2 * tid; i < g.P; i += 2 * FTHREADS) {
         const float2 v = lrg_ld_coh2(g.pooled + (long)slot * g.P + i);
         pl[i] = v.x; pl[i + 1] = v.y;
     }
     team.sync();
-    const int c = cb * 64 + lane;
-    const int kq = (g.P + 7) / 8;
+    const int kq = g.P >> 3;                   // (a multiple of 16: checked by lrg_grow_async)
+    const int half = wave >> 1, r = 4 * (wave & 1) + (lane >> 4), cl = half * 64 + 4 * (lane & 15);
+    const int c = cb * LRG_GEMV_TASK_COLS + cl;
     if (c < g.C) {
-        const float *w = g.w[z] + c;
+        const float *w = g.w[z] + c + (long)(r * kq) * g.ldw;
+        const float *p = pl + r * kq;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int kb = 0; kb < kq; kb += 16) {
+            float4 wv[16];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = wave + 4 * h;
-            const int k0 = r * kq, k1 = min(g.P, k0 + kq);
-            float acc = 0.f;
-#pragma unroll 16
-            for (int k = k0; k < k1; ++k) acc = fmaf(pl[k], w[(long)k * g.ldw], acc);
-            part[r * 64 + lane] = acc;
+            for (int u = 0; u < 16; ++u) wv[u] = *reinterpret_cast<const float4 *>(w + (long)(kb + u) * g.ldw);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float pk = p[kb + u];
+                acc.x = fmaf(pk, wv[u].x, acc.x); acc.y = fmaf(pk, wv[u].y, acc.y);
+                acc.z = fmaf(pk, wv[u].z, acc.z); acc.w = fmaf(pk, wv[u].w, acc.w);
+            }
         }
+        *reinterpret_cast<float4 *>(part + r * LRG_GEMV_TASK_COLS + cl) = acc;
     }
     team.sync();
-    if (wave == 0 && c < g.C) {
-        float s = part[lane];
+    if (tid < LRG_GEMV_TASK_COLS && cb * LRG_GEMV_TASK_COLS + tid < g.C) {
+        const int col = cb * LRG_GEMV_TASK_COLS + tid;
+        float s = part[tid];
 #pragma unroll
-        for (int r = 1; r < 8; ++r) s += part[r * 64 + lane];
-        lrg_st_coh(g.hb[z] + (long)slot * g.C + c, s + (g.bias[z] ? g.bias[z][c] : 0.f));
+        for (int q = 1; q < 8; ++q) s += part[q * LRG_GEMV_TASK_COLS + tid];
+        lrg_st_coh(g.hb[z] + (long)slot * g.C + col, s + (g.bias[z] ? g.bias[z][col] : 0.f));
     }
 }
 
-// ---- a worker team: tasks until every front workgroup is done ----
-__device__ __forceinline__ void lrg_async_worker(const LrgAsyncArgs &A, float *sm, const LrgLdsTeam &team, long long t_launch) {
+// ---- the launch's arguments ----
+// ONE kernel parameter, so that every role below can be a function of its own (own register allocation: the tile code needs 112
+// VGPRs, a 1024-thread workgroup has 128 per lane -- inlined into one kernel body, the three task types and the front spilled
+// ~150 dwords per lane, some of them inside the tiles' passes) and still reads the arguments the way a kernel does: scalar loads
+// from the kernarg segment, nothing passed on, nothing copied to the stack.
+struct LrgAsyncKArgs {
+    LrgSlot *slots;
+    LrgRoom *rooms;
+    LrgGrowParams prm;
+    LrgAsyncArgs A;
+};
+// (inside a non-kernel function __builtin_amdgcn_kernarg_segment_ptr() folds to null: the kernel takes the pointer and hands it on,
+//  typed as constant address space, so that the roles' loads of the arguments stay scalar loads)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) void *lrg_kargs_ptr;
+#else
+typedef const void *lrg_kargs_ptr;
+#endif
+#define LRG_ASYNC_KARGS() (*(const LrgAsyncKArgs *)kp)
+// Arguments of a non-kernel function arrive in vector registers; what is wave-uniform goes back to scalar registers first, so that
+// the loads of the launch's arguments are scalar loads and the addresses derived from them scalar arithmetic.
+__device__ __forceinline__ lrg_kargs_ptr lrg_uniform(lrg_kargs_ptr p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (lrg_kargs_ptr)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int lrg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// the launch's dynamic LDS: roles get OFFSETS into it (a float * parameter would be a generic pointer, and every LDS access of a
+// tile a flat instruction)
+extern __shared__ __attribute__((aligned(16))) float lrg_async_smem[];
+#define LRG_ASYNC_ROLE __device__ __noinline__
+
+__device__ __forceinline__ LrgLdsTeam lrg_async_team(const LrgAsyncArgs &A, float *sm, int target) {      // sm: the team's part of the LDS
+    int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
+    LrgLdsTeam team;
+    team.cnt = &word[4];
+    team.target = target;
+    team.base = (int)(threadIdx.x & ~255u);
+    team.gave_up = &A.queue[LRG_AQ_ABORT];
+    return team;
+}
+
+// ---- the three task types (each returns the team's barrier count, to be handed to the next one) ----
+LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    float *sm = lrg_async_smem + sm_off;
+    const LrgLdsTeam team = lrg_async_team(A, sm, target);
     const int tid = team.tid(), lane = tid & 63;
+    const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
+    int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
+    int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
+    const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
+    long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;      // (LRG_TRACE build: cycle stamps of the tile's phases)
+    lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps);
+#if LRG_TRACE == 2176
+    if (tid == 0 && A.dbg) {      // cycles since the tile began, at every stamp (tools/free_run_perf.py prints their means)
+        for (int i = 1; i < 21; ++i) if (stamps[i] > stamps[0]) lrg_dbg_add(A, 32 + i, stamps[i] - stamps[0]);
+        lrg_dbg_add(A, 32, 1);
+    }
+#endif
+    lrg_drain_stores();                              // conv[1] rows and the pooled maxima are out before the arrival
+    team.sync();
+    if (tid < 64) {
+        int last = 0;
+        if (lane == 0) {
+            const int done = __hip_atomic_fetch_add(&sy[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            last = done == lrg_ld_coh(&sy[1]);
+            if (A.dbg) {
+                const long long now = wall_clock64();
+                lrg_dbg_add(A, 8 + 2 * LRG_TASK_BRANCH, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_BRANCH, 1);
+                if (last) lrg_dbg_add(A, 2, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+            }
+        }
+        if (__shfl(last, 0)) {                       // the slot's pooled feature is complete: its product with the heads' first layers
+            const int nb = (A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS;
+            lrg_async_push(A, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
+        }
+    }
+    return team.target;
+}
+
+LRG_ASYNC_ROLE int lrg_async_task_gemv(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    float *sm = lrg_async_smem + sm_off;
+    const LrgLdsTeam team = lrg_async_team(A, sm, target);
+    const int tid = team.tid(), lane = tid & 63;
+    const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
+    int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
+    lrg_async_gemv(A.gemv, slot, side, idx, sm, team);
+    lrg_drain_stores();
+    team.sync();
+    if (tid < 64) {
+        int last = 0, nt_in = 0, nt_nb = 0;
+        if (lane == 0) {
+            const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            last = done == lrg_ld_coh(&sy[3]);
+            if (last) { nt_in = lrg_ld_coh(&sy[6]); nt_nb = lrg_ld_coh(&sy[7]); }
+            if (A.dbg) {
+                const long long now = wall_clock64();
+                lrg_dbg_add(A, 8 + 2 * LRG_TASK_GEMV, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_GEMV, 1);
+                if (last) lrg_dbg_add(A, 3, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+            }
+        }
+        if (__shfl(last, 0)) {                       // head 0 = add on the neighbour rows, head 1 = remove on the inlier rows
+            nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
+            lrg_async_push(A, nt_nb + nt_in, lane, [&](int i) {
+                return i < nt_nb ? LRG_TASK(LRG_TASK_HEAD, slot, 0, i) : LRG_TASK(LRG_TASK_HEAD, slot, 1, i - nt_nb);
+            });
+        }
+    }
+    return team.target;
+}
+
+LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    float *sm = lrg_async_smem + sm_off;
+    const LrgLdsTeam team = lrg_async_team(A, sm, target);
+    const int tid = team.tid();
+    const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
+    int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
+    int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
+    const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
+    long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;
+    lrg_fused_tile<32 * 260, 32 * 68, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[2 + side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps);
+#if LRG_TRACE == 8320
+    if (tid == 0 && A.dbg) {
+        for (int i = 1; i < 21; ++i) if (stamps[i] > stamps[0]) lrg_dbg_add(A, 32 + i, stamps[i] - stamps[0]);
+        lrg_dbg_add(A, 32, 1);
+    }
+#endif
+    lrg_drain_stores();                              // the logits are out before the arrival the front workgroup polls
+    team.sync();
+    if (tid == 0) {
+        const int done = __hip_atomic_fetch_add(&sy[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        if (A.dbg) {
+            const long long now = wall_clock64();
+            lrg_dbg_add(A, 8 + 2 * LRG_TASK_HEAD, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_HEAD, 1);
+            if (done == lrg_ld_coh(&sy[5])) lrg_dbg_add(A, 4, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+        }
+    }
+    return team.target;
+}
+
+// ---- a worker team: tasks until every front workgroup is done ----
+LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t_launch) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int sm_off = lrg_uniform(sm_off_);
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    float *sm = lrg_async_smem + sm_off;
+    LrgLdsTeam team = lrg_async_team(A, sm, 0);
+    const int tid = team.tid();
     int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);       // [0] task of this round
-    const int row_stride = A.front.row_stride;
-    const int n_gemv_blocks = (A.gemv.C + 63) / 64;
     for (;;) {
+        long long t_task = 0;
         if (tid == 0) {
+            const long long t_wait = A.dbg ? wall_clock64() : 0;
             const int t = __hip_atomic_fetch_add(&A.queue[LRG_AQ_HEAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int *slot = &A.queue[LRG_AQ_RING + (t & A.qmask)];
             int code = 0;
@@ -128,58 +305,20 @@ __device__ __forceinline__ void lrg_async_worker(const LrgAsyncArgs &A, float *s
                         break;
                     }
                 }
-                __builtin_amdgcn_s_sleep(8);
+                for (int q = 0; q < A.poll_sleep; ++q) __builtin_amdgcn_s_sleep(8);
             }
             if (code > 0) lrg_st_coh(slot, 0);
             word[0] = code;
+            if (A.dbg) { t_task = wall_clock64(); lrg_dbg_add(A, 16, t_task - t_wait); lrg_dbg_add(A, 17, 1); }
         }
         team.sync();
         const int code = word[0];
         team.sync();                                         // (read by everybody before thread 0 writes the next one)
         if (code < 0) return;
-        const int type = (code >> 28) & 7, slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
-        int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
-        if (type == LRG_TASK_BRANCH) {
-            const LrgFusedProb &P = A.prob[side];
-            const long r0 = (long)slot * row_stride + (long)idx * 32;
-            lrg_fused_tile<32 * 68, 32 * 132, 1, 4, false, true, true>(P, r0, 0, idx, 0x7fffffff, 0x7fffffff, sm, team, nullptr);
-            lrg_drain_stores();                              // conv[1] rows and the pooled maxima are out before the arrival
-            team.sync();
-            if (tid < 64) {
-                int last = 0;
-                if (lane == 0) {
-                    const int done = __hip_atomic_fetch_add(&sy[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-                    last = done == lrg_ld_coh(&sy[1]);
-                }
-                if (__shfl(last, 0))                         // the slot's pooled feature is complete: its product with the heads' first layers
-                    lrg_async_push(A, 2 * n_gemv_blocks, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / n_gemv_blocks, i % n_gemv_blocks); });
-            }
-        } else if (type == LRG_TASK_GEMV) {
-            lrg_async_gemv(A.gemv, slot, side, idx, sm, team);
-            lrg_drain_stores();
-            team.sync();
-            if (tid < 64) {
-                int last = 0, nt_in = 0, nt_nb = 0;
-                if (lane == 0) {
-                    const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-                    last = done == lrg_ld_coh(&sy[3]);
-                    if (last) { nt_in = lrg_ld_coh(&sy[6]); nt_nb = lrg_ld_coh(&sy[7]); }
-                }
-                if (__shfl(last, 0)) {                       // head 0 = add on the neighbour rows, head 1 = remove on the inlier rows
-                    nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
-                    lrg_async_push(A, nt_nb + nt_in, lane, [&](int i) {
-                        return i < nt_nb ? LRG_TASK(LRG_TASK_HEAD, slot, 0, i) : LRG_TASK(LRG_TASK_HEAD, slot, 1, i - nt_nb);
-                    });
-                }
-            }
-        } else {
-            const LrgFusedProb &P = A.prob[2 + side];
-            const long r0 = (long)slot * row_stride + (long)idx * 32;
-            lrg_fused_tile<32 * 260, 32 * 68, 1, 4, false, true, true>(P, r0, 0, idx, 0x7fffffff, 0x7fffffff, sm, team, nullptr);
-            lrg_drain_stores();                              // the logits are out before the arrival the front workgroup polls
-            team.sync();
-            if (tid == 0) __hip_atomic_fetch_add(&sy[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const int type = (code >> 28) & 7;
+        if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task);
+        else if (type == LRG_TASK_GEMV) team.target = lrg_async_task_gemv(kp, code, sm_off, team.target, t_task);
+        else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task);
     }
 }
 
@@ -190,37 +329,20 @@ struct LrgAsyncFrontCtl {
     int bc[4];                           // broadcasts of thread 0
 };
 
-__global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgSlot *slots, LrgRoom *rooms, LrgGrowParams prm, LrgAsyncArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// ---- a front workgroup: serves the slots f, f + n_front, ... ----
+__device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_launch) {      // (the kernel's own body: no call, no saved registers)
+    const LrgAsyncKArgs &K = LRG_ASYNC_KARGS();
+    float *smem = lrg_async_smem;
+    const LrgAsyncArgs &A = K.A;
+    LrgSlot *slots = K.slots;
+    LrgRoom *rooms = K.rooms;
     const int tid = threadIdx.x, lane = tid & 63;
-    const long long t_launch = wall_clock64();
-    if ((int)blockIdx.x >= A.n_front) {
-        // ---------------------------------------------- worker workgroup ----------------------------------------------
-        const int t = tid >> 8;                              // team = four consecutive wavefronts (one per SIMD)
-        if (t >= A.teams) return;
-        float *sm = smem + (long)t * LRG_ASYNC_TEAM_FLOATS;
-        int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
-        if ((tid & 255) == 0) word[4] = 0;                   // the team's barrier counter (its first sync() follows thread 0's own LDS store)
-        LrgLdsTeam team;
-        team.cnt = &word[4];
-        team.target = 0;
-        team.base = t * 256;
-        team.gave_up = &A.queue[LRG_AQ_ABORT];
-        team.deadline = t_launch + A.abort_ticks + 100000000LL;      // (a second after everybody else has given up)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // (a wavefront of the team that runs ahead adds to the counter only after thread 0's wavefront zeroed it if it waits for that
-        //  store: wavefronts of one workgroup start together, but not in lock step -- so the first meeting is a plain one)
-        __builtin_amdgcn_s_barrier();                        // the only workgroup-wide barrier of a worker: before any team has started
-        lrg_async_worker(A, sm, team, t_launch);
-        return;
-    }
-    // ------------------------------------------------- front workgroup -------------------------------------------------
     LrgFrontShared &SH = *reinterpret_cast<LrgFrontShared *>(smem);
     LrgAsyncFrontCtl &C = *reinterpret_cast<LrgAsyncFrontCtl *>(reinterpret_cast<char *>(smem) + ((sizeof(LrgFrontShared) + 15) & ~(size_t)15));
     const int f = blockIdx.x;
     const int n_served = (A.n_slots - f + A.n_front - 1) / A.n_front;          // slots f, f + n_front, ...
     const int row_stride = A.front.row_stride;
-    const int n_gemv = 2 * ((A.gemv.C + 63) / 64);
+    const int n_gemv = 2 * ((A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS);
     if (tid < LRG_ASYNC_MAX_SERVED) { C.state[tid] = tid < n_served ? 0 : 2; C.steps[tid] = 0; C.tgt[tid][0] = C.tgt[tid][1] = C.tgt[tid][2] = 0; }
     // a slot's rows have a fixed place in the row arrays: their tags are written once per launch
     for (int i = 0; i < n_served; ++i) {
@@ -259,6 +381,10 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgSl
                 __syncthreads();
                 if (!ready) continue;
                 st = 0;
+                if (A.dbg && tid == 0) {
+                    lrg_dbg_add(A, 5, (int)((unsigned)wall_clock64() - (unsigned)lrg_ld_coh(&A.sync[(long)s * LRG_ASYNC_SYNC_WORDS + 8])));
+                    lrg_dbg_add(A, 6, 1);
+                }
             }
             // a new evaluation only within the budget of this launch
             if (tid == 0) {
@@ -269,7 +395,8 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgSl
             const int stop = C.bc[1];
             __syncthreads();
             if (stop) { if (tid == 0) C.state[i] = 2; continue; }
-            const int r = lrg_front_greedy_slot<true>(SH, slots, rooms, A.n_slots, prm, A.front, A.big, s);
+            const long long t_front = A.dbg ? wall_clock64() : 0;
+            const int r = lrg_front_greedy_slot<true>(SH, slots, rooms, A.n_slots, K.prm, A.front, A.big, s);
             if (r == 0) {
                 // no evaluation: the slot is idle / its room finished (-> finished for this launch), or it stopped a region / goes on
                 // looking for a seed (-> served again at once)
@@ -291,6 +418,11 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgSl
                     C.tgt[i][0] += nt_in + nt_nb; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb;
                     lrg_st_coh(&sy[1], C.tgt[i][0]); lrg_st_coh(&sy[3], C.tgt[i][1]); lrg_st_coh(&sy[5], C.tgt[i][2]);
                     lrg_st_coh(&sy[6], nt_in); lrg_st_coh(&sy[7], nt_nb);
+                    if (A.dbg) {
+                        const long long now = wall_clock64();
+                        lrg_st_coh(&sy[8], (int)(unsigned)now);
+                        lrg_dbg_add(A, 0, now - t_front); lrg_dbg_add(A, 1, 1);
+                    }
                     C.state[i] = 1;
                     C.steps[i] += 1;
                 }
@@ -307,4 +439,27 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgSl
     lrg_drain_stores();
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(&A.queue[LRG_AQ_FRONTS_DONE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgAsyncKArgs K) {
+    const int tid = threadIdx.x;
+    const long long t_launch = wall_clock64();
+#if defined(__HIP_DEVICE_COMPILE__)
+    lrg_kargs_ptr kp = (lrg_kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    lrg_kargs_ptr kp = nullptr;
+#endif
+    if ((int)blockIdx.x >= K.A.n_front) {
+        // worker workgroup: teams of four consecutive wavefronts (one per SIMD), each on its own part of the LDS
+        const int t = tid >> 8;
+        if (t >= K.A.teams) return;
+        const int sm_off = t * LRG_ASYNC_TEAM_FLOATS;
+        int *word = reinterpret_cast<int *>(lrg_async_smem + sm_off + LRG_ASYNC_TILE_FLOATS);
+        if ((tid & 255) == 0) word[4] = 0;                   // the team's barrier counter
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // the only workgroup-wide barrier of a worker: before any team has started
+        lrg_async_worker(kp, sm_off, t_launch);
+        return;
+    }
+    lrg_async_front(kp, t_launch);
 }

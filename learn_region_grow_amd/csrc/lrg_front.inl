@@ -38,6 +38,7 @@ struct LrgFrontArgs {
     int64_t *stats;
     int64_t *phase_ticks;    // nullable: [n_slots,2] wall-clock ticks per slot: (0) update / stop / commit, (1) query / median / gather
     int own_medians;         // greedy front kernel: 1 = every slot's workgroup computes its nine medians itself (no launch of their own)
+    unsigned long long *phase_dbg;   // nullable (free-running kernel): [8] accumulated wall-clock ticks of the front's phases
     int row_stride;          // free-running kernel: slot s owns the rows [s * row_stride, (s + 1) * row_stride) of the row arrays
 };
 
@@ -768,6 +769,10 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
     const int entry_status = status;
     TRACE2(s, 0);
+    long long t_phase = (ASYNC && a.phase_dbg) ? wall_clock64() : 0;
+    auto phase = [&](int i) {      // ticks since the last stamp -> accumulator i (thread 0)
+        if constexpr (ASYNC) if (a.phase_dbg && tid == 0) { const long long now = wall_clock64(); atomicAdd(&a.phase_dbg[i], (unsigned long long)(now - t_phase)); t_phase = now; }
+    };
     const long long tick0 = a.phase_ticks ? wall_clock64() : 0;
 
     int q_nc = nc0, q_ne = ne0;        // sizes of the lists the sampling below draws from (set by the seed path / the box query)
@@ -906,7 +911,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         LRG_LDS_BARRIER();           // (status, box and count go through LDS; nobody reads thread 0's stores to the slot before the next full barrier)
         status = sh_i[2];
     }
-    TRACE2(s, 1);
+    TRACE2(s, 1); phase(1);
 
     // =========================== (2) commit (:210-217), next seed (:186-188), reset (:197-204) ===========================
     if (lrg_is_stop(status)) {
@@ -1051,7 +1056,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         status = LRG_ACTIVE;
         cur_target = sh_box[7];
     }
-    TRACE2(s, 2);
+    TRACE2(s, 2); phase(2);
     const long long tick1 = a.phase_ticks ? wall_clock64() : 0;
     if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 0] += tick1 - tick0;
     if (status != LRG_ACTIVE) {      // DONE / IDLE
@@ -1227,7 +1232,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
                 return 0;
         }
     }
-    TRACE2(s, 3);
+    TRACE2(s, 3); phase(3);
     const int small_max = (ASYNC && a.own_medians) ? 256 : LRG_FRONT_SMALL;
 
     // =========================== (4) sampling (:237-252), centre (:241), gather (:242-254) ===========================
@@ -1257,19 +1262,20 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     }
     if (tid < 16) sh_c[tid] = 0.f;
     LRG_LDS_BARRIER();               // (the gather reads the source indices and the row offsets from LDS)
-    TRACE2(s, 4);
+    TRACE2(s, 4); phase(4);
     if (is_big) {
         // the nine medians of such a region come from lrg_front_big_kernel (one workgroup per channel) or from the median
         // workgroups of this launch; nothing here waits for them: the rows go out uncentred
         if (tid < 16 && !(ASYNC && a.own_medians)) a.center[s * 16 + tid] = 0.f;
         lrg_front_gather<PAD, ASYNC>(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
-        TRACE2(s, 5);
+        TRACE2(s, 5); phase(5);
         if constexpr (ASYNC) if (a.own_medians) {   // the region's medians by this workgroup (no launch of the (slot, channel) medians)
             __syncthreads();
             lrg_front_all_medians(R, cur_idx, nc, F, reinterpret_cast<int *>(sh_flags), sh_c);
             __syncthreads();
             if (tid < 16) { if constexpr (ASYNC) lrg_st_coh(a.center + s * 16 + tid, sh_c[tid]); else a.center[s * 16 + tid] = sh_c[tid]; }
         }
+        phase(6);
         if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
         TRACE2(s, 6); TRACE2(s, 7);
 #if LRG_TRACE
@@ -1290,7 +1296,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         lrg_front_gather<PAD, ASYNC>(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
     }
     __syncthreads();
-    TRACE2(s, 5);
+    TRACE2(s, 5); phase(5);
     if (tid < 16) {                                              // the branch kernels and the next update centre with it (:243-247,:271,:275)
         if constexpr (ASYNC) lrg_st_coh(a.center + s * 16 + tid, sh_c[tid]); else a.center[s * 16 + tid] = sh_c[tid];
     }

@@ -31,20 +31,26 @@ struct LrgLdsTeam {
     int *cnt;
     mutable int target;
     int base;            // first thread of the team within the workgroup
-    int *gave_up;        // nullable: global word that is set when a meeting was given up ...
-    long long deadline;  // ... which happens when wall_clock64() has passed this
+    int *gave_up;        // nullable: global word that is set when a meeting was given up (after ~5 s without the others)
     __device__ __forceinline__ int tid() const { return (int)threadIdx.x - base; }
     __device__ __forceinline__ void sync() const {
         target += 4;
-        // this wavefront's LDS traffic and global stores are done before it arrives (what __syncthreads() also waits for)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // this wavefront's LDS traffic is done before it arrives.  NOT its global traffic: inside a tile nothing goes from wavefront to
+        // wavefront through global memory, and the weight ring's loads for the NEXT pass are meant to stay in flight across the layer
+        // boundary (__syncthreads() waits for vmcnt(0) too and drains them); who needs stores to be out drains explicitly.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if ((threadIdx.x & 63) == 0) {
             __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // (bounded: a team that lost a wavefront shows as wrong results and a raised abort word, not as a hung GPU)
+            long long t_long = 0;
             for (unsigned spin = 1; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spin) {
-                if ((spin & 4095u) == 0 && (long long)wall_clock64() > deadline) {
-                    if (gave_up) __hip_atomic_store(gave_up, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                if ((spin & 4095u) == 0) {
+                    const long long now = (long long)wall_clock64();
+                    if (!t_long) t_long = now;
+                    else if (now - t_long > 500000000LL) {      // 100 MHz: five seconds
+                        if (gave_up) __hip_atomic_store(gave_up, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -175,7 +181,10 @@ __device__ __forceinline__ void tile_mfma_first(f32x16 (&acc)[RT], const float *
 //   r0 = first row of the tile in P.x; inst = the tile's instance (not PACKED); nvalid = rows of the instance that are not copies
 //   (not PACKED; INT_MAX: all); nrows_packed = packed rows in all (PACKED); trace_sh: LDS stamps of an LRG_TRACE build (or null).
 // Returns the number of runs (1 unless PACKED), 0 for a tile that was skipped.
-template <int CAP0, int CAP1, int RT, int FD, bool DIRECT, bool PACKED, bool COH, class TEAM>
+// ONE (with PACKED): all rows of the tile belong to ONE instance, `inst`, and all of them are live (the free-running kernel: a slot's
+// rows have a place of their own, padded to whole tiles with copies of its last row) -- no run detection, the centre and the
+// per-instance bias addressed by `inst` directly (no trip through row_inst first).
+template <int CAP0, int CAP1, int RT, int FD, bool DIRECT, bool PACKED, bool COH, class TEAM, bool ONE = false>
 __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, int inst, int tile, int nvalid, int nrows_packed,
                                               float *smem, const TEAM &team, long long *trace_sh) {
     constexpr int FM = 32 * RT;      // rows (points) per tile
@@ -190,6 +199,9 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
     const int tid = team.tid();
     const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+#if LRG_TRACE
+    if (CAP0 == LRG_TRACE && tid < 32 && trace_sh) trace_sh[tid] = 0;
+#endif
     TRACE(0);
 
     // A 64-wide layer of a 64-row tile is laid out 2x2 (each wave one 32x32 tile) instead of 1x4 strips of which only
@@ -243,7 +255,7 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             int row = idx / Kp, c = idx - row * Kp;
             float v = 0.f;
             if (c < Kin) {
-                const int ins = (r0 + row < nrows_packed) ? (COH ? lrg_ld_coh(P.row_inst + r0 + row) : P.row_inst[r0 + row]) : -1;
+                const int ins = ONE ? inst : (r0 + row < nrows_packed) ? (COH ? lrg_ld_coh(P.row_inst + r0 + row) : P.row_inst[r0 + row]) : -1;
                 if constexpr (COH) {
                     const float xv = lrg_ld_coh(P.x + (r0 + row) * P.ldx + c);
                     v = ins >= 0 ? __fsub_rn(xv, lrg_ld_coh(P.center + ins * 16 + c)) : 0.f;
@@ -264,7 +276,9 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
     if (P.fw) { for (int i = tid; i < 2 * P.L[P.nlayers - 1].N; i += FTHREADS) poolbuf[i] = P.fw[i]; }
     else { for (int i = tid; i < 512; i += FTHREADS) poolbuf[i] = 0.f; }      // (PACKED keeps its maxima elsewhere)
     if (tile * FM >= nvalid) return 0;             // uniform over the tile's threads
-    if (PACKED && tid < 64) {
+    if (PACKED && ONE) {
+        if (tid == 0) { run_start[0] = 0; run_start[1] = FM; run_inst[0] = inst; *run_count = 1; }
+    } else if (PACKED && tid < 64) {
         // runs of equal instance among the tile's rows (rows past *nrows: instance -1), found by wave 0 with one ballot
         const int row = tid & 31;
         const int mine = (r0 + row < nrows_packed) ? (COH ? lrg_ld_coh(P.row_inst + r0 + row) : P.row_inst[r0 + row]) : -1;
@@ -280,7 +294,7 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
     }
     team.sync();
     TRACE(1);
-    const int nruns = PACKED ? *run_count : 1;
+    const int nruns = (PACKED && !ONE) ? *run_count : 1;
 
     const int nlayers = P.nlayers;
     int prevN = Kp;
@@ -323,8 +337,8 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             if constexpr (PACKED) {
                 if (wave_on && (L.flags & LRG_FL_INST_BIAS) && L.bias) {
 #pragma unroll
-                    for (int k = 0; k < RB; ++k) {
-                        const int ins = k < nruns ? run_inst[k] : -1;
+                    for (int k = 0; k < (ONE ? 1 : RB); ++k) {
+                        const int ins = ONE ? inst : k < nruns ? run_inst[k] : -1;
                         if (ins >= 0) bk[k] = COH ? lrg_ld_coh(L.bias + (long)ins * L.N + col0 + li) : L.bias[(long)ins * L.N + col0 + li];
                     }
                 }
@@ -426,7 +440,7 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
                             if (lh == 0) {
                                 if (k < runcap) parked[k * L.N + col] = m;
                                 else {
-                                    const int ins = run_inst[k];
+                                    const int ins = ONE ? inst : run_inst[k];
                                     if (ins >= 0 && m > 0) atomicMax(reinterpret_cast<int *>(P.pool + (long)ins * P.pool_stride + col), m);
                                 }
                             }
@@ -480,7 +494,7 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
                 const int runcap = (act_out == buf1 ? CAP1 : CAP0) / L.N;
                 const int nk = nruns < runcap ? nruns : runcap;
                 for (int k = 0; k < nk; ++k) {
-                    const int ins = run_inst[k];
+                    const int ins = ONE ? inst : run_inst[k];
                     if (ins < 0) continue;
                     int *dst = reinterpret_cast<int *>(P.pool + (long)ins * P.pool_stride);
                     for (int c = tid; c < L.N; c += FTHREADS) {

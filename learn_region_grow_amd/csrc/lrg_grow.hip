@@ -1344,7 +1344,7 @@ static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_
     a.pooled = static_cast<float *>(b->workspace) + poff; a.pooled_stride = (int)(pcnt / (size_t)n_slots);
     a.stats = b->stats;
     a.phase_ticks = b->phase_ticks;
-    a.own_medians = 0; a.row_stride = 0;
+    a.own_medians = 0; a.row_stride = 0; a.phase_dbg = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (lrg_uses_greedy_front(params, b)) {
         const int ncentred = params->feature_size <= 2 ? params->feature_size : params->feature_size <= 6 ? 2 : params->feature_size - 4;
@@ -1409,7 +1409,9 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     size_t poff = 0, pcnt = 0;
     if ((rc = lrg_forward_packed_pooled_view(weights, n_slots, b->row_cap, &poff, &pcnt))) return rc;
 
-    LrgAsyncArgs A;
+    LrgAsyncKArgs K;
+    K.slots = slots; K.rooms = rooms; K.prm = *params;
+    LrgAsyncArgs &A = K.A;
     LrgFusedArgs branches, heads;
     if ((rc = lrg_packed_problems(weights, b->x_in, b->x_nb, b->center, b->row_slot_in, b->row_slot_nb, b->counters, n_slots, b->row_cap,
                                   b->add_logits, b->rmv_logits, b->workspace, b->workspace_bytes, &branches, &A.gemv, &heads)))
@@ -1427,7 +1429,9 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
             if ((L.flags & LRG_FL_KEEP) && 32 * (L.N + 4) > (to_buf1 ? (i < 2 ? 32 * 132 : 32 * 68) : (i < 2 ? 32 * 68 : 32 * 260))) return LRG_EINVAL - 7;
         }
     }
-    if (A.gemv.P + 512 > LRG_ASYNC_TILE_FLOATS || (A.gemv.P & 1)) return LRG_EINVAL - 7;
+    if (A.gemv.P + 8 * LRG_GEMV_TASK_COLS > LRG_ASYNC_TILE_FLOATS || (A.gemv.P & 127) || (A.gemv.ldw & 3) || (A.gemv.C & 3) ||
+        (((uintptr_t)A.gemv.w[0] | (uintptr_t)A.gemv.w[1]) & 15))
+        return LRG_EINVAL - 7;                              // (pooled product: sixteen 16-byte rows in flight per lane, K ranges of P / 8)
     LrgFrontArgs &a = A.front;
     a.center = b->center; a.sample_in = b->sample_in; a.sample_nb = b->sample_nb;
     a.x_in = b->x_in; a.x_nb = b->x_nb; a.row_slot_in = b->row_slot_in; a.row_slot_nb = b->row_slot_nb;
@@ -1437,6 +1441,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     a.stats = b->stats;
     a.phase_ticks = nullptr;
     a.own_medians = 1; a.row_stride = row_stride;
+    a.phase_dbg = ab->debug_ticks ? reinterpret_cast<unsigned long long *>(ab->debug_ticks) + 20 : nullptr;
 
     hipDeviceProp_t prop;
     LRG_HIP_CHECK(hipGetDeviceProperties(&prop, lrg_current_device()));
@@ -1447,12 +1452,14 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     n_front = max(n_front, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED);
     if (n_front >= wgs) return LRG_EINVAL - 8;               // no CU left for the tile teams
     const int teams = ab->teams > 0 ? min(ab->teams, 3) : 3;
-    A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big;
+    A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
     A.qmask = (int)(qbytes / sizeof(int32_t)) - LRG_AQ_RING - 1;
     A.n_slots = n_slots; A.n_front = n_front; A.teams = teams;
+    A.poll_sleep = ab->poll_sleep > 0 ? ab->poll_sleep : 1;
     A.max_steps = max_steps;
     A.budget_ticks = budget_us > 0 ? (long long)budget_us * 100 : (1LL << 60);      // wall_clock64: 100 MHz
     A.abort_ticks = (budget_us > 0 ? (long long)budget_us * 100 : 0) + 400000000LL;  // ... + 4 s without an end: something is broken
+    static_assert(sizeof(LrgAsyncKArgs) <= 4096, "kernel arguments");
     hipStream_t st = (hipStream_t)stream;
     LRG_HIP_CHECK(hipMemsetAsync(ab->queue, 0, qbytes, st));
     LRG_HIP_CHECK(hipMemsetAsync(ab->sync, 0, (size_t)n_slots * LRG_ASYNC_SYNC_WORDS * sizeof(int32_t), st));
@@ -1465,7 +1472,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_grow_async_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(lrg_grow_async_kernel, dim3(wgs), dim3(LRG_FRONT_THREADS), lds, st, slots, rooms, *params, A);
+    hipLaunchKernelGGL(lrg_grow_async_kernel, dim3(wgs), dim3(LRG_FRONT_THREADS), lds, st, K);
     LRG_LAUNCH_CHECK();
     return 0;
 }

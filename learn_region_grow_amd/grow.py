@@ -329,6 +329,10 @@ class RegionGrower:
                 ab.front_workgroups = self.free_run_fronts or int(os.environ.get('LRG_FREE_RUN_FRONTS', '0'))
                 ab.teams = self.free_run_teams or int(os.environ.get('LRG_FREE_RUN_TEAMS', '0'))
                 ab.compute_units = int(os.environ.get('LRG_FREE_RUN_CUS', '0'))
+                ab.poll_sleep = int(os.environ.get('LRG_FREE_RUN_POLL', '0'))
+                if os.environ.get('LRG_FREE_RUN_DEBUG') == '1':          # stage-by-stage tick accumulators (tools/free_run_perf.py)
+                    self.a_dbg = torch.zeros(64, dtype=torch.int64, device=dev)
+                    ab.debug_ticks = self.a_dbg.data_ptr()
                 self.async_buffers = ab
         self.h_stats = [torch.zeros(LRG_STATS_WORDS, dtype=torch.int64).pin_memory() for _ in range(self.depth)]
         self.ev = [torch.cuda.Event() for _ in range(self.depth)]

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Steady-state rate of the free-running launches (lrg_grow_async) on the 68-room Area-5-shaped set, by front workgroups, tile teams
+and steps per launch -- next to the lock-step iterations in the same process.
+    python tools/free_run_perf.py [--rooms 68] [--seconds 1.5] [--configs fronts:teams:steps[:budget_us],...]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rooms', type=int, default=68)
+    ap.add_argument('--seconds', type=float, default=1.5)
+    ap.add_argument('--workload', default='area5')
+    ap.add_argument('--configs', default='0:0:64,68:3:64,34:3:64,17:3:64,34:2:64,34:1:64,34:3:16,34:3:256')
+    ap.add_argument('--lockstep', type=int, default=1)
+    ap.add_argument('--out', default=None)
+    args = ap.parse_args()
+    import torch
+    from learn_region_grow_amd import synthetic, workloads
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    from learn_region_grow_amd.grow import RegionGrower, LanedRegionGrower
+    dev = torch.device('cuda:0')
+    weights = synthetic.load_trained_weights()
+    if args.workload == 'scannet':
+        rooms = workloads.scannet_rooms(min(args.rooms, 39), seed_base=7000, cache_dir='/tmp/lrg_cache')
+    else:
+        rooms = workloads.area5_rooms(args.rooms, seed_base=1000, cache_dir='/tmp/lrg_cache')
+    net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, mode='fused').load_weights(weights)
+    stream = torch.cuda.Stream(device=dev)
+    results = []
+
+    def run(gr, label):
+        with torch.cuda.stream(stream):
+            gr.load_rooms(rooms)
+            for g in range(gr.n_groups):
+                gr.bind(g, g)
+
+            def cycle(seconds):
+                t_end = time.perf_counter() + seconds
+                while time.perf_counter() < t_end:
+                    gr.enqueue()
+                    for g in gr.poll_done():
+                        r = gr.group_room[g]
+                        gr.fill(r)
+                        gr.reset_room(r)
+                        gr.bind(g, r)
+            cycle(0.7)
+            torch.cuda.synchronize()
+            s0 = gr.d_stats[:4].cpu().numpy().astype(np.float64)
+            t0 = time.perf_counter()
+            cycle(args.seconds)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            s1 = gr.d_stats[:4].cpu().numpy().astype(np.float64)
+        row = dict(config=label, steps_per_sec=(s1[2] - s0[2]) / (t1 - t0), rooms_per_sec=(s1[1] - s0[1]) / (t1 - t0), given_up=int(s1[3]))
+        if getattr(gr, 'a_dbg', None) is not None:      # LRG_FREE_RUN_DEBUG=1: ticks of 10 ns -> microseconds
+            d = gr.a_dbg.cpu().numpy().astype(np.float64)
+            ev = max(d[6], 1.0)
+            row['us'] = dict(front_busy_per_step=d[0] / max(d[1], 1) / 100, last_branch_tile_in=d[2] / ev / 100, last_pooled_block_in=d[3] / ev / 100,
+                             last_head_tile_in=d[4] / ev / 100, seen_by_front=d[5] / ev / 100,
+                             branch_tile=d[10] / max(d[11], 1) / 100, pooled_block=d[12] / max(d[13], 1) / 100, head_tile=d[14] / max(d[15], 1) / 100,
+                             team_wait_per_task=d[16] / max(d[17], 1) / 100)
+            row['front_phase_us'] = dict(zip(['update', 'commit_seed', 'query', 'sampling', 'gather(+small medians)', 'big medians'],
+                                             [float(x) / max(d[1], 1) / 100 for x in d[21:27]]))
+            if d[32] > 0:      # LRG_TRACE build: mean cycles since the tile began at each stamp
+                names = ['staged'] + [x for l in range(5) for x in ('L%d start' % l, 'L%d end' % l)] + \
+                        [x for c in range(4) for x in ('pass%d mfma' % c, 'pass%d epilogue' % c)] + ['end']
+                row['tile_cycles'] = {n: int(d[33 + i] / d[32]) for i, n in enumerate(names) if d[33 + i] > 0}
+            row['tasks_per_evaluation'] = dict(branch=d[11] / ev, pooled=d[13] / ev, head=d[15] / ev)
+        print(json.dumps(row), flush=True)
+        results.append(row)
+
+    kw = dict(rooms_in_flight=len(rooms), rng='counter', policy='net', seed=0)
+    if args.lockstep:
+        run(RegionGrower(net, free_run=False, graph_iterations=4, **kw), 'lock-step, one lane, graph x4')
+    for c in args.configs.split(','):
+        p = [int(x) for x in c.split(':')]
+        fronts, teams, steps = p[0], p[1], p[2]
+        budget = p[3] if len(p) > 3 else 0
+        run(RegionGrower(net, free_run=True, free_run_fronts=fronts, free_run_teams=teams, free_run_steps=steps, free_run_budget_us=budget, **kw),
+            'free-run fronts=%d teams=%d steps=%d budget_us=%d' % (fronts, teams, steps, budget))
+    if args.out:
+        json.dump(results, open(args.out, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
