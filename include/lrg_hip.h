@@ -340,7 +340,8 @@ typedef struct LrgStepBuffers {
 } LrgStepBuffers;
 
 /* stats layout: [0] committed seeds, [1] rooms finished, [2] instance-steps taken, [3] hand-overs given up by lrg_grow_async (0 unless something is broken),
- * [4 + k % LRG_DONE_RING] = first slot of the k-th finished group (ring written by lrg_advance). */
+ * [4 + k % LRG_DONE_RING] = first slot of the k-th finished group (ring written by lrg_advance; the greedy front kernels add the
+ * room index: slot | room << 32). */
 #define LRG_DONE_RING 1020
 #define LRG_STATS_WORDS (4 + LRG_DONE_RING)
 
@@ -459,6 +460,13 @@ typedef struct LrgAsyncBuffers {
     int32_t teams;              /* tile teams (four wavefronts) per worker workgroup: 1 .. 3, 0 = default                 */
     int32_t compute_units;      /* workgroups of the launch in all (front + worker), at most one per CU of the device; 0 = all CUs */
     int32_t poll_sleep;         /* idle tile teams poll the queue every poll_sleep x ~0.25 us; 0 = default                  */
+    int32_t *room_queue;        /* nullable: rooms waiting for a slot -- [0] rooms handed out so far (the caller zeroes it when it refills
+                                   the queue), [1] rooms queued, [2 + k] = room index | reset << 30 (reset: clear visited / labels /
+                                   cursor first, as lrg_bind_group does).  A slot whose room is finished (or that has none) takes the
+                                   next one inside the launch; finished rooms appear in the stats ring as slot | room << 32      */
+    uint64_t *work;             /* nullable: [4] running totals (never cleared by the library) of what the launches evaluated: LrgNet
+                                   evaluations, distinct inlier rows, distinct neighbour rows, 32-row tiles per stack (branch = head) --
+                                   the algorithmic FLOPs of the launches follow from these                                        */
     uint64_t *debug_ticks;      /* nullable: [64] accumulators (never cleared by the library) of wall-clock ticks by stage of the
                                    launch, for tools/free_run_perf.py (layout: csrc/lrg_async.inl, LrgAsyncArgs.dbg)            */
 } LrgAsyncBuffers;

@@ -86,7 +86,7 @@ class LrgPackedBuffers(ctypes.Structure):
 
 class LrgAsyncBuffers(ctypes.Structure):
     _fields_ = [('queue', _fp), ('queue_bytes', ctypes.c_size_t), ('sync', _fp), ('front_workgroups', ctypes.c_int32), ('teams', ctypes.c_int32),
-                ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('debug_ticks', _fp)]
+                ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('room_queue', _fp), ('work', _fp), ('debug_ticks', _fp)]
 
 
 class LrgBeamGroup(ctypes.Structure):

@@ -33,11 +33,12 @@
 #ifndef LRG_ASYNC_FD
 #define LRG_ASYNC_FD 4              // depth of the tile teams' weight ring (k-groups in flight)
 #endif
-#define LRG_AQ_TAIL 0            // control words of the queue (ints), one 64-byte line each
-#define LRG_AQ_HEAD 16
+#define LRG_AQ_TAIL 0            // control words of the queue (ints), one 64-byte line each; ring 1 (pooled blocks and head tiles when
+#define LRG_AQ_HEAD 16           // the workgroups run more than one team): + LRG_AQ_SECOND
 #define LRG_AQ_FRONTS_DONE 32
 #define LRG_AQ_ABORT 48
-#define LRG_AQ_RING 64
+#define LRG_AQ_SECOND 64
+#define LRG_AQ_RING 128          // ring 0, then ring 1 (qmask + 1 entries each)
 #define LRG_ASYNC_SYNC_WORDS 16  // per slot: 0 branch tiles done, 1 their target, 2 pooled-product blocks done, 3 target, 4 head tiles done, 5 target,
                                  //           6 inlier tiles, 7 neighbour tiles of the evaluation in flight
 #define LRG_ASYNC_MAX_SERVED 8   // slots per front workgroup
@@ -57,12 +58,14 @@ struct LrgAsyncArgs {
     int32_t *queue;              // control words + ring
     int32_t *sync;               // [n_slots, LRG_ASYNC_SYNC_WORDS]
     int32_t *big;
+    int32_t *room_queue;         // nullable: [0] rooms handed out so far, [1] rooms queued, [2 + k] = room index | reset << 30
     int qmask;                   // ring entries - 1 (power of two)
     int n_slots, n_front, teams;
     int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
     int max_steps;               // evaluations per slot in this launch
     long long budget_ticks;      // wall_clock64 ticks (100 MHz) after which no new evaluation is started
     long long abort_ticks;       // ... after which a waiting workgroup gives up
+    unsigned long long *work;    // nullable: [4] evaluations, distinct inlier rows, distinct neighbour rows, 32-row tiles (x 2 stacks) of this buffer's launches
     unsigned long long *dbg;     // nullable: [32] accumulators of wall-clock ticks (10 ns) for tools/free_run_perf.py --
                                  // 0 front busy, 1 front steps; per evaluation, since its tasks were published: 2 last branch tile in,
                                  // 3 last pooled-product block in, 4 last head tile in, 5 seen by the front workgroup, 6 evaluations;
@@ -76,11 +79,11 @@ __device__ __forceinline__ void lrg_drain_stores() { asm volatile("s_waitcnt vmc
 
 // ---- publishing `n` tasks: one reservation, then the entries (lanes 0 .. n-1 of the calling wavefront; n <= 64) ----
 template <class F>
-__device__ __forceinline__ void lrg_async_push(const LrgAsyncArgs &A, int n, int lane, F code_of) {
+__device__ __forceinline__ void lrg_async_push(const LrgAsyncArgs &A, int ring, int n, int lane, F code_of) {
     int base = 0;
-    if (lane == 0) base = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) base = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL + ring * LRG_AQ_SECOND], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     base = __shfl(base, 0);
-    if (lane < n) lrg_st_coh(&A.queue[LRG_AQ_RING + ((base + lane) & A.qmask)], code_of(lane));
+    if (lane < n) lrg_st_coh(&A.queue[LRG_AQ_RING + ring * (A.qmask + 1) + ((base + lane) & A.qmask)], code_of(lane));
 }
 
 // ---- pooled product of a head's first layer for ONE slot and 128 columns by a team of four wavefronts, in the summation order of
@@ -206,7 +209,7 @@ LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
         }
         if (__shfl(last, 0)) {                       // the slot's pooled feature is complete: its product with the heads' first layers
             const int nb = (A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS;
-            lrg_async_push(A, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
+            lrg_async_push(A, A.teams > 1 ? 1 : 0, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
         }
     }
     return team.target;
@@ -238,7 +241,7 @@ LRG_ASYNC_ROLE int lrg_async_task_gemv(lrg_kargs_ptr kp_, int code_, int sm_off_
         }
         if (__shfl(last, 0)) {                       // head 0 = add on the neighbour rows, head 1 = remove on the inlier rows
             nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
-            lrg_async_push(A, nt_nb + nt_in, lane, [&](int i) {
+            lrg_async_push(A, A.teams > 1 ? 1 : 0, nt_nb + nt_in, lane, [&](int i) {
                 return i < nt_nb ? LRG_TASK(LRG_TASK_HEAD, slot, 0, i) : LRG_TASK(LRG_TASK_HEAD, slot, 1, i - nt_nb);
             });
         }
@@ -287,12 +290,17 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
     LrgLdsTeam team = lrg_async_team(A, sm, 0);
     const int tid = team.tid();
     int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);       // [0] task of this round
+    const bool secondary = sm_off != 0;
     for (;;) {
         long long t_task = 0;
         if (tid == 0) {
             const long long t_wait = A.dbg ? wall_clock64() : 0;
-            const int t = __hip_atomic_fetch_add(&A.queue[LRG_AQ_HEAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int *slot = &A.queue[LRG_AQ_RING + (t & A.qmask)];
+            const bool leave = false;
+            if (leave) { word[0] = -1; }
+            else {
+            const int ring = secondary ? 1 : 0;      // (more than one team per workgroup: the first teams run the branch tiles, the others the rest)
+            const int t = __hip_atomic_fetch_add(&A.queue[LRG_AQ_HEAD + ring * LRG_AQ_SECOND], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int *slot = &A.queue[LRG_AQ_RING + ring * (A.qmask + 1) + (t & A.qmask)];
             int code = 0;
             for (unsigned spin = 0;; ++spin) {
                 code = lrg_ld_coh(slot);
@@ -309,7 +317,9 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
             }
             if (code > 0) lrg_st_coh(slot, 0);
             word[0] = code;
-            if (A.dbg) { t_task = wall_clock64(); lrg_dbg_add(A, 16, t_task - t_wait); lrg_dbg_add(A, 17, 1); }
+            t_task = wall_clock64();
+            if (A.dbg) { lrg_dbg_add(A, 16, t_task - t_wait); lrg_dbg_add(A, 17, 1); }
+            }
         }
         team.sync();
         const int code = word[0];
@@ -403,33 +413,53 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 __syncthreads();
                 if (tid == 0) {
                     const int status = slots[s].status;
-                    C.state[i] = (slots[s].room < 0 || status == LRG_DONE || status == LRG_IDLE) ? 2 : 0;
+                    const bool idle = slots[s].room < 0 || status == LRG_DONE || status == LRG_IDLE;
+                    int next = -1;
+                    if (idle && A.room_queue) {      // the slot's room is finished (or it has none): the next room of the queue, if any is left
+                        if (lrg_ld_coh(&A.room_queue[0]) < A.room_queue[1]) {
+                            const int k = __hip_atomic_fetch_add(&A.room_queue[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (k < A.room_queue[1]) next = A.room_queue[2 + k];
+                        }
+                    }
+                    C.bc[3] = next;
+                    C.state[i] = (idle && next < 0) ? 2 : 0;
                 }
+                __syncthreads();
+                const int next = C.bc[3];
+                if (next >= 0) lrg_bind_group_device(slots, rooms, s, 1, next & 0x3FFFFFFF, next >> 30, 1);
                 __syncthreads();
                 continue;
             }
-            // rows, centre and the zeroed pooled feature are out (write-through) once every wavefront has drained
+            // The evaluation's targets and the reservation of its queue entries go out with the rows (one trip, not three in a row);
+            // rows, centre, the zeroed pooled feature and the targets are out (write-through) once every wavefront has drained; only
+            // then the entries are written -- a consumer waits for its entry, not for the reservation.
+            const int nt_in = ((r >> 16) + 31) >> 5, nt_nb = ((r & 0xFFFF) + 31) >> 5;
+            int base = 0;
+            if (tid == 0) {
+                int32_t *sy = A.sync + (long)s * LRG_ASYNC_SYNC_WORDS;
+                C.tgt[i][0] += nt_in + nt_nb; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb;
+                lrg_st_coh(&sy[1], C.tgt[i][0]); lrg_st_coh(&sy[3], C.tgt[i][1]); lrg_st_coh(&sy[5], C.tgt[i][2]);
+                lrg_st_coh(&sy[6], nt_in); lrg_st_coh(&sy[7], nt_nb);
+                if (A.dbg) {
+                    const long long now = wall_clock64();
+                    lrg_st_coh(&sy[8], (int)(unsigned)now);
+                    lrg_dbg_add(A, 0, now - t_front); lrg_dbg_add(A, 1, 1);
+                }
+                if (A.work) {
+                    atomicAdd(&A.work[0], 1ULL); atomicAdd(&A.work[1], (unsigned long long)(r >> 16));
+                    atomicAdd(&A.work[2], (unsigned long long)(r & 0xFFFF)); atomicAdd(&A.work[3], (unsigned long long)(nt_in + nt_nb));
+                }
+                C.state[i] = 1;
+                C.steps[i] += 1;
+                base = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL], nt_in + nt_nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             lrg_drain_stores();
             __syncthreads();
-            const int nt_in = ((r >> 16) + 31) >> 5, nt_nb = ((r & 0xFFFF) + 31) >> 5;
             if (tid < 64) {
-                if (lane == 0) {
-                    int32_t *sy = A.sync + (long)s * LRG_ASYNC_SYNC_WORDS;
-                    C.tgt[i][0] += nt_in + nt_nb; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb;
-                    lrg_st_coh(&sy[1], C.tgt[i][0]); lrg_st_coh(&sy[3], C.tgt[i][1]); lrg_st_coh(&sy[5], C.tgt[i][2]);
-                    lrg_st_coh(&sy[6], nt_in); lrg_st_coh(&sy[7], nt_nb);
-                    if (A.dbg) {
-                        const long long now = wall_clock64();
-                        lrg_st_coh(&sy[8], (int)(unsigned)now);
-                        lrg_dbg_add(A, 0, now - t_front); lrg_dbg_add(A, 1, 1);
-                    }
-                    C.state[i] = 1;
-                    C.steps[i] += 1;
-                }
-                lrg_drain_stores();
-                lrg_async_push(A, nt_in + nt_nb, lane, [&](int k) {
-                    return k < nt_in ? LRG_TASK(LRG_TASK_BRANCH, s, 0, k) : LRG_TASK(LRG_TASK_BRANCH, s, 1, k - nt_in);
-                });
+                base = __shfl(base, 0);
+                if (lane < nt_in + nt_nb)
+                    lrg_st_coh(&A.queue[LRG_AQ_RING + ((base + lane) & A.qmask)],      // (ring 0)
+                               lane < nt_in ? LRG_TASK(LRG_TASK_BRANCH, s, 0, lane) : LRG_TASK(LRG_TASK_BRANCH, s, 1, lane - nt_in));
             }
             __syncthreads();
         }
@@ -455,7 +485,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgAs
         if (t >= K.A.teams) return;
         const int sm_off = t * LRG_ASYNC_TEAM_FLOATS;
         int *word = reinterpret_cast<int *>(lrg_async_smem + sm_off + LRG_ASYNC_TILE_FLOATS);
-        if ((tid & 255) == 0) word[4] = 0;                   // the team's barrier counter
+        if ((tid & 255) == 0) { word[4] = 0; word[5] = 0; }  // the team's barrier counter, its 'at work' flag
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // the only workgroup-wide barrier of a worker: before any team has started
         lrg_async_worker(kp, sm_off, t_launch);

@@ -744,8 +744,10 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     const float c0 = ASYNC ? lrg_ld_coh(a.center + s * 16 + 0) : a.center[s * 16 + 0], c1 = ASYNC ? lrg_ld_coh(a.center + s * 16 + 1) : a.center[s * 16 + 1];
     const int half = tid >> 9, j = tid & 511;                    // first half: add slot j, second half: remove slot j
     const bool mine = j < (half ? Ni : Nn);
+    // which row of its set sample slot j of the LAST evaluation stands for (:240,:252): not stored by that step's sampling but worked out
+    // again where it is needed -- a pure function of the slot's state, one Philox block for a padded set, and the update below waits
+    // for memory, not for arithmetic
     int sj = 0;
-    if (mine) sj = (half ? a.sample_in : a.sample_nb)[(long)s * (half ? Ni : Nn) + j];
     if (a.pooled)                    // the last evaluation's pooled feature has been consumed: zero for the next one
         for (int c = tid; c < a.pooled_stride; c += LRG_FRONT_THREADS) {
             if constexpr (ASYNC) lrg_st_coh(a.pooled + (long)s * a.pooled_stride + c, 0.f); else a.pooled[(long)s * a.pooled_stride + c] = 0.f;
@@ -785,6 +787,9 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
 #pragma unroll
         for (int k = 0; k < 4; ++k) id0[k] = cur_idx[min(tid + k * LRG_FRONT_THREADS, nc0 - 1)];
         const int nside = half ? nc0 : ne0, Nside = half ? Ni : Nn;
+        if (mine && nside < Nside)
+            sj = (int)lrg_sample_position((uint32_t)j, (uint32_t)nside, (uint32_t)Nside, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
+                                          (uint32_t)seed0, (uint32_t)restart0, (uint32_t)step0, k0, k1);
         const int srow = nside < Nside ? sj : j;                                              // a padded slot reads its source row
         const long row = (half ? rows_off_in : rows_off_nb) + srow;
         int idx = -1;
@@ -980,7 +985,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
                     S->status = LRG_DONE;
                     if (a.stats) {
                         unsigned long long k = atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[1]), 1ULL);
-                        a.stats[4 + (k % LRG_DONE_RING)] = s;
+                        a.stats[4 + (k % LRG_DONE_RING)] = (int64_t)s | ((int64_t)room << 32);      // (slot, room: a free-running launch may have rebound the slot by the time the host looks)
                     }
                     a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0;
                 }
@@ -1233,7 +1238,9 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         }
     }
     TRACE2(s, 3); phase(3);
-    const int small_max = (ASYNC && a.own_medians) ? 256 : LRG_FRONT_SMALL;
+    // (free-running: up to 1024 points one wavefront per channel with the keys in registers, beside the gather; above, the radix select
+    //  of all nine channels by the whole workgroup after it)
+    const int small_max = (ASYNC && a.own_medians) ? 1024 : LRG_FRONT_SMALL;
 
     // =========================== (4) sampling (:237-252), centre (:241), gather (:242-254) ===========================
     const int nc = q_nc, ne = q_ne;                      // (known to every thread: no trip through S->nc / S->ne)
@@ -1249,10 +1256,13 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     }
     if (mine) {
         const int nn = half ? nc : ne, kk = half ? Ni : Nn;      // (here the first half samples the neighbours, the second the inliers)
-        const int pos = (int)lrg_sample_position((uint32_t)j, (uint32_t)nn, (uint32_t)kk, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
-                                                 (uint32_t)cur_seed, (uint32_t)cur_restart, (uint32_t)cur_step, k0, k1);
-        (half ? a.sample_in : a.sample_nb)[(long)s * kk + j] = pos;
-        if (j < min(nn, kk)) sh_src[half ? 0 : 1][j] = (half ? cur_idx : cand_idx)[pos];
+        // only the distinct rows are gathered: a padded set's are its members in order (:240,:252), a full set's the prefix of the
+        // permutation (:238,:250); the positions of the copies are the next update's business
+        if (j < min(nn, kk)) {
+            const int pos = nn < kk ? j : (int)lrg_sample_position((uint32_t)j, (uint32_t)nn, (uint32_t)kk, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
+                                                                   (uint32_t)cur_seed, (uint32_t)cur_restart, (uint32_t)cur_step, k0, k1);
+            sh_src[half ? 0 : 1][j] = (half ? cur_idx : cand_idx)[pos];
+        }
     }
     if (tid == 0) {
         sh_off[0] = oi; sh_off[1] = on;

@@ -184,9 +184,12 @@ __device__ __forceinline__ void tile_mfma_first(f32x16 (&acc)[RT], const float *
 // ONE (with PACKED): all rows of the tile belong to ONE instance, `inst`, and all of them are live (the free-running kernel: a slot's
 // rows have a place of their own, padded to whole tiles with copies of its last row) -- no run detection, the centre and the
 // per-instance bias addressed by `inst` directly (no trip through row_inst first).
-template <int CAP0, int CAP1, int RT, int FD, bool DIRECT, bool PACKED, bool COH, class TEAM, bool ONE = false>
+struct LrgNoWait { __device__ __forceinline__ void operator()() const {} };
+// before_inst_bias: called by every thread right before the first per-instance bias (the hoisted pooled product of a head) is read --
+// the free-running kernel's head tiles wait there for the pooled blocks of their slot.
+template <int CAP0, int CAP1, int RT, int FD, bool DIRECT, bool PACKED, bool COH, class TEAM, bool ONE = false, class WAIT = LrgNoWait>
 __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, int inst, int tile, int nvalid, int nrows_packed,
-                                              float *smem, const TEAM &team, long long *trace_sh) {
+                                              float *smem, const TEAM &team, long long *trace_sh, const WAIT &before_inst_bias = WAIT()) {
     constexpr int FM = 32 * RT;      // rows (points) per tile
     static_assert(!PACKED || RT == 1, "packed rows use 32-row tiles");
     float *buf0 = smem;                       // outputs of even layers
@@ -335,6 +338,7 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             constexpr int RB = 4;
             float bk[RB] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (PACKED) {
+                if ((L.flags & LRG_FL_INST_BIAS) && L.bias && cb == 0) before_inst_bias();
                 if (wave_on && (L.flags & LRG_FL_INST_BIAS) && L.bias) {
 #pragma unroll
                     for (int k = 0; k < (ONE ? 1 : RB); ++k) {

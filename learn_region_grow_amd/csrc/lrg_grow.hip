@@ -70,8 +70,9 @@ __global__ void lrg_hash_build_kernel(const int32_t *vox, int n, uint64_t *keys,
 // (re)binding a slot group to a room on the device: what a host-side struct upload would do, without the upload (a
 // pageable host-to-device copy blocks the host until the stream has drained, which starves the other lanes)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void lrg_bind_group_kernel(LrgSlot *slots, LrgRoom *rooms, int first_slot, int group_size, int room,
-                                                              int reset_room, int clear_masks) {
+// (a device function: the free-running kernel rebinds a slot whose room is finished to the next room of its queue itself)
+__device__ __forceinline__ void lrg_bind_group_device(LrgSlot *slots, LrgRoom *rooms, int first_slot, int group_size, int room, int reset_room,
+                                                      int clear_masks) {
     const int tid = threadIdx.x;
     if (room >= 0 && reset_room) {                                            // test_region_grow.py:176-178 for a fresh pass
         LrgRoom *R = &rooms[room];
@@ -99,6 +100,12 @@ __global__ __launch_bounds__(1024) void lrg_bind_group_kernel(LrgSlot *slots, Lr
             S->scan_cnt = 0; S->query = 0;
             for (int d = 0; d < 3; ++d) { S->scan_mn[d] = INT_MAX; S->scan_mx[d] = INT_MIN; }
         }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void lrg_bind_group_kernel(LrgSlot *slots, LrgRoom *rooms, int first_slot, int group_size, int room,
+                                                              int reset_room, int clear_masks) {
+    lrg_bind_group_device(slots, rooms, first_slot, group_size, room, reset_room, clear_masks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1389,7 +1396,7 @@ size_t lrg_grow_async_queue_bytes(int n_slots) {
     if (n_slots <= 0) return 0;
     size_t ring = 1 << 14;                                   // entries: far more than the tasks that can be outstanding (~80 per slot)
     while (ring < (size_t)n_slots * 512) ring <<= 1;
-    return (LRG_AQ_RING + ring) * sizeof(int32_t);
+    return (LRG_AQ_RING + 2 * ring) * sizeof(int32_t);      // (two rings: branch tiles | pooled blocks and head tiles)
 }
 
 int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params, const LrgWeights *weights,
@@ -1447,13 +1454,18 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     LRG_HIP_CHECK(hipGetDeviceProperties(&prop, lrg_current_device()));
     int wgs = prop.multiProcessorCount;
     if (ab->compute_units > 0 && ab->compute_units < wgs) wgs = ab->compute_units;
+    // Front workgroups: one per two slots (68 slots on one MI355X: 34 x 1 team 612 k instance-steps/s, 68 x 2 teams 579 k, 68 x 3 teams
+    // 548 k, profiles/r03_free11_perf.log -- a front workgroup is busy a third of the time, and a CU it holds is a CU without tile teams)
     int n_front = ab->front_workgroups > 0 ? ab->front_workgroups : (n_slots + 1) / 2;
     n_front = min(n_front, n_slots);
     n_front = max(n_front, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED);
-    if (n_front >= wgs) return LRG_EINVAL - 8;               // no CU left for the tile teams
-    const int teams = ab->teams > 0 ? min(ab->teams, 3) : 3;
-    A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
-    A.qmask = (int)(qbytes / sizeof(int32_t)) - LRG_AQ_RING - 1;
+    n_front = min(n_front, wgs / 2);                         // (at least half of the CUs for the tile teams)
+    if (n_front < (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED) return LRG_EINVAL - 8;      // more slots than the front workgroups can serve
+    // one team per worker CU while the slots are few (a tile beside another takes 1.2-1.4x as long, and at 68 slots a step is a chain
+    // of latencies); three where the teams are the bottleneck
+    const int teams = ab->teams > 0 ? min(ab->teams, 3) : (n_slots <= 96 ? 1 : 3);
+    A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.room_queue = ab->room_queue; A.work = reinterpret_cast<unsigned long long *>(ab->work); A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
+    A.qmask = ((int)(qbytes / sizeof(int32_t)) - LRG_AQ_RING) / 2 - 1;
     A.n_slots = n_slots; A.n_front = n_front; A.teams = teams;
     A.poll_sleep = ab->poll_sleep > 0 ? ab->poll_sleep : 1;
     A.max_steps = max_steps;

@@ -50,14 +50,14 @@ class RoomResult:
 class RegionGrower:
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
-                 skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np', free_run=False,
-                 free_run_steps=64, free_run_budget_us=0, free_run_fronts=0, free_run_teams=0):
+                 skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np', free_run=None,
+                 free_run_steps=1 << 20, free_run_budget_us=5000, free_run_fronts=0, free_run_teams=0):
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
         graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*).
-        free_run: True / None (= whenever it applies: packed greedy growing, lite 0 / 2) / False: one host call = ONE launch in
-        which every slot takes up to free_run_steps grow steps at its own pace (lrg_grow_async), starting none after
-        free_run_budget_us microseconds (0 = no time limit); same results as the lock-step iterations."""
+        free_run: True / None (= where it applies and is the faster formulation: packed greedy growing, lite 0 / 2, at most 96 slots) /
+        False: one host call = ONE launch in which every slot takes up to free_run_steps grow steps at its own pace (lrg_grow_async),
+        starting none after free_run_budget_us microseconds (0 = no time limit); same results as the lock-step iterations."""
         self.lib = _lib.load()
         self.net = net
         self.dev = net.device
@@ -317,7 +317,9 @@ class RegionGrower:
                 raise ValueError('free-running launches need greedy growing (restarts = group_size = 1), rooms with packed voxel words, '
                                  'at most 512 + 512 points per set and lite 0 or 2')
             if self.want_free_run is None:
-                self.free_run = can_free and os.environ.get('LRG_FREE_RUN', '1') != '0'
+                # (auto: where a step is a chain of latencies -- up to ~100 slots; with hundreds of slots in flight the lock-step
+                #  launches, whose tiles pack the rows of all slots, get more out of the chip: 272 rooms 1.17 M against 0.82 M)
+                self.free_run = can_free and S <= 96 and os.environ.get('LRG_FREE_RUN', '1') != '0'
             else:
                 self.free_run = bool(self.want_free_run)
             if self.free_run:
@@ -330,6 +332,8 @@ class RegionGrower:
                 ab.teams = self.free_run_teams or int(os.environ.get('LRG_FREE_RUN_TEAMS', '0'))
                 ab.compute_units = int(os.environ.get('LRG_FREE_RUN_CUS', '0'))
                 ab.poll_sleep = int(os.environ.get('LRG_FREE_RUN_POLL', '0'))
+                self.a_work = torch.zeros(4, dtype=torch.int64, device=dev)      # evaluations, inlier rows, neighbour rows, tiles
+                ab.work = self.a_work.data_ptr()
                 if os.environ.get('LRG_FREE_RUN_DEBUG') == '1':          # stage-by-stage tick accumulators (tools/free_run_perf.py)
                     self.a_dbg = torch.zeros(64, dtype=torch.int64, device=dev)
                     ab.debug_ticks = self.a_dbg.data_ptr()
@@ -483,6 +487,7 @@ class RegionGrower:
 
     def poll_done(self, wait=False):
         """Groups whose room finished, as seen `depth-1` read-backs ago (or at the latest one, if wait)."""
+        self.done_rooms = []          # room of each finished group as the device saw it (greedy front kernels: slot | room << 32)
         if self._polls == 0:
             return []
         if wait:
@@ -499,7 +504,9 @@ class RegionGrower:
         if done_total - self._seen_done > LRG_DONE_RING:
             raise _lib.LrgHipError('done ring overflow')
         for j in range(self._seen_done, done_total):
-            out.append(int(st[4 + (j % LRG_DONE_RING)]) // self.G)
+            e = int(st[4 + (j % LRG_DONE_RING)])
+            out.append((e & 0xFFFFFFFF) // self.G)
+            self.done_rooms.append(e >> 32)
         self._seen_done = done_total
         self.last_stats = (int(st[0]), int(st[1]), int(st[2]))
         if int(st[3]):
@@ -515,9 +522,40 @@ class RegionGrower:
         self._polls = 0
         self._polls_seen = -1
 
+    def set_room_queue(self, rooms, reset=False):
+        """Free-running launches: the rooms (indices) that wait for a slot.  A slot whose room is finished takes the next one inside
+        the launch (LrgAsyncBuffers.room_queue); the host only learns of finished rooms (poll_done: done_rooms) and fills them in."""
+        q = np.zeros(2 + max(1, len(rooms)), dtype=np.int32)
+        q[1] = len(rooms)
+        q[2:2 + len(rooms)] = np.asarray(rooms, dtype=np.int64) | ((1 << 30) if reset else 0)
+        self.a_roomq = torch.from_numpy(q).to(self.dev)
+        self.async_buffers.room_queue = self.a_roomq.data_ptr()
+
+    def _grow_loaded_free_run(self, fill=True):
+        """The first S rooms bound by the host, the rest handed out on the device; fill-ins as finished rooms are reported."""
+        self.reset_state()
+        first = min(self.n_groups, self.n_rooms)
+        for g in range(self.n_groups):
+            self.bind(g, g if g < first else -1)
+        self.set_room_queue(list(range(first, self.n_rooms)))
+        finished = 0
+        while finished < self.n_rooms:
+            self.enqueue_free_run()
+            self.poll_done()
+            for r in self.done_rooms:
+                if fill:
+                    self.fill(r)
+                finished += 1
+            self.done_rooms = []
+        torch.cuda.current_stream(self.dev).synchronize()
+        self.async_buffers.room_queue = None
+        return self.n_rooms
+
     def grow_loaded(self, fill=True):
         """Counter stream: grow (and fill in) every loaded room from its current state; labels final on the device on return."""
         assert self.rng == 'counter'
+        if self.free_run:
+            return self._grow_loaded_free_run(fill)
         self.reset_state()
         queue = list(range(self.n_rooms))
         for g in range(self.n_groups):
@@ -698,6 +736,8 @@ class RegionGrower:
                         self.bind(g, queue.pop(0) if queue else -1)
                 if max_iterations and self.iterations >= max_iterations:
                     break
+        elif self.free_run and not max_iterations:
+            self._grow_loaded_free_run(fill)
         else:
             while finished < self.n_rooms:
                 self.enqueue()
@@ -801,6 +841,10 @@ class LanedRegionGrower:
         self.net = net
         if lanes is None or int(lanes) <= 0:
             lanes = auto_lanes(int(rooms_in_flight) * int(kw.get('restarts', 1)))
+            # free-running launches (RegionGrower's choice up to 96 greedy slots) fill the chip by themselves: one lane
+            if (kw.get('free_run', None) is not False and int(kw.get('restarts', 1)) == 1 and int(rooms_in_flight) <= 96 and
+                    kw.get('packed', None) is not False and os.environ.get('LRG_FREE_RUN', '1') != '0'):
+                lanes = 1
         lanes = max(1, min(int(lanes), int(rooms_in_flight)))
         share = [rooms_in_flight // lanes + (1 if k < rooms_in_flight % lanes else 0) for k in range(lanes)]
         self.streams = lane_streams(net.device, lanes, cu_partition)

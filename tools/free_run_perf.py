@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--configs', default='0:0:64,68:3:64,34:3:64,17:3:64,34:2:64,34:1:64,34:3:16,34:3:256')
     ap.add_argument('--lockstep', type=int, default=1)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--in-flight', type=int, default=0, help='rooms in flight (default: --rooms)')
+    ap.add_argument('--jobs', type=int, default=0, help='> 0: that many room jobs (the geometries x random-stream keys) through the slots, reset -> labels')
     args = ap.parse_args()
     import torch
     from learn_region_grow_amd import synthetic, workloads
@@ -35,6 +37,22 @@ def main():
     net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, mode='fused').load_weights(weights)
     stream = torch.cuda.Stream(device=dev)
     results = []
+
+    def breakdown(gr, row):
+        if getattr(gr, 'a_dbg', None) is not None:      # LRG_FREE_RUN_DEBUG=1: ticks of 10 ns -> microseconds
+            d = gr.a_dbg.cpu().numpy().astype(np.float64)
+            ev = max(d[6], 1.0)
+            row['us'] = dict(front_busy_per_step=d[0] / max(d[1], 1) / 100, last_branch_tile_in=d[2] / ev / 100, last_pooled_block_in=d[3] / ev / 100,
+                             last_head_tile_in=d[4] / ev / 100, seen_by_front=d[5] / ev / 100,
+                             branch_tile=d[10] / max(d[11], 1) / 100, pooled_block=d[12] / max(d[13], 1) / 100, head_tile=d[14] / max(d[15], 1) / 100,
+                             team_wait_per_task=d[16] / max(d[17], 1) / 100)
+            row['front_phase_us'] = dict(zip(['update', 'commit_seed', 'query', 'sampling', 'gather(+small medians)', 'big medians'],
+                                             [float(x) / max(d[1], 1) / 100 for x in d[21:27]]))
+            if d[32] > 0:      # LRG_TRACE build: mean cycles since the tile began at each stamp
+                names = ['staged'] + [x for l in range(5) for x in ('L%d start' % l, 'L%d end' % l)] + \
+                        [x for c in range(4) for x in ('pass%d mfma' % c, 'pass%d epilogue' % c)] + ['end']
+                row['tile_cycles'] = {n: int(d[33 + i] / d[32]) for i, n in enumerate(names) if d[33 + i] > 0}
+            row['tasks_per_evaluation'] = dict(branch=d[11] / ev, pooled=d[13] / ev, head=d[15] / ev)
 
     def run(gr, label):
         with torch.cuda.stream(stream):
@@ -60,24 +78,47 @@ def main():
             t1 = time.perf_counter()
             s1 = gr.d_stats[:4].cpu().numpy().astype(np.float64)
         row = dict(config=label, steps_per_sec=(s1[2] - s0[2]) / (t1 - t0), rooms_per_sec=(s1[1] - s0[1]) / (t1 - t0), given_up=int(s1[3]))
-        if getattr(gr, 'a_dbg', None) is not None:      # LRG_FREE_RUN_DEBUG=1: ticks of 10 ns -> microseconds
-            d = gr.a_dbg.cpu().numpy().astype(np.float64)
-            ev = max(d[6], 1.0)
-            row['us'] = dict(front_busy_per_step=d[0] / max(d[1], 1) / 100, last_branch_tile_in=d[2] / ev / 100, last_pooled_block_in=d[3] / ev / 100,
-                             last_head_tile_in=d[4] / ev / 100, seen_by_front=d[5] / ev / 100,
-                             branch_tile=d[10] / max(d[11], 1) / 100, pooled_block=d[12] / max(d[13], 1) / 100, head_tile=d[14] / max(d[15], 1) / 100,
-                             team_wait_per_task=d[16] / max(d[17], 1) / 100)
-            row['front_phase_us'] = dict(zip(['update', 'commit_seed', 'query', 'sampling', 'gather(+small medians)', 'big medians'],
-                                             [float(x) / max(d[1], 1) / 100 for x in d[21:27]]))
-            if d[32] > 0:      # LRG_TRACE build: mean cycles since the tile began at each stamp
-                names = ['staged'] + [x for l in range(5) for x in ('L%d start' % l, 'L%d end' % l)] + \
-                        [x for c in range(4) for x in ('pass%d mfma' % c, 'pass%d epilogue' % c)] + ['end']
-                row['tile_cycles'] = {n: int(d[33 + i] / d[32]) for i, n in enumerate(names) if d[33 + i] > 0}
-            row['tasks_per_evaluation'] = dict(branch=d[11] / ev, pooled=d[13] / ev, head=d[15] / ev)
+        breakdown(gr, row)
         print(json.dumps(row), flush=True)
         results.append(row)
 
-    kw = dict(rooms_in_flight=len(rooms), rng='counter', policy='net', seed=0)
+    def run_jobs(gr, label):
+        jobs = [dict(rooms[j % len(rooms)], room_id=100000 + j) for j in range(args.jobs)]
+        with torch.cuda.stream(stream):
+            gr.load_rooms(jobs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gr.grow_loaded(fill=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            st = gr.d_stats[:4].cpu().numpy().astype(np.float64)
+            ok = bool((gr.d_filled[:int(gr.room_off[gr.n_rooms - 1]) + gr.room_n[-1]] >= 0).all())
+            lab = int(sum(int((gr.d_filled[int(gr.room_off[k]):int(gr.room_off[k]) + gr.room_n[k]] > 0).all()) for k in range(gr.n_rooms)))
+        row = dict(config=label, jobs=args.jobs, seconds=t1 - t0, rooms_per_sec=args.jobs / (t1 - t0), steps_per_sec=st[2] / (t1 - t0),
+                   rooms_fully_labeled=lab, given_up=int(st[3]))
+        breakdown(gr, row)
+        print(json.dumps(row), flush=True)
+        results.append(row)
+
+    kw = dict(rooms_in_flight=args.in_flight or len(rooms), rng='counter', policy='net', seed=0)
+    if args.jobs:
+        if args.lockstep:
+            from learn_region_grow_amd.grow import LanedRegionGrower
+            lg = LanedRegionGrower(net, free_run=False, graph_iterations=4, **kw)
+            jobs = [dict(rooms[j % len(rooms)], room_id=100000 + j) for j in range(args.jobs)]
+            lg.load_rooms(jobs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lg.grow_loaded(fill=True)
+            torch.cuda.synchronize()
+            print(json.dumps(dict(config='lock-step, lanes auto', jobs=args.jobs, rooms_per_sec=args.jobs / (time.perf_counter() - t0))), flush=True)
+        for c in args.configs.split(','):
+            p = [int(x) for x in c.split(':')]
+            run_jobs(RegionGrower(net, free_run=True, free_run_fronts=p[0], free_run_teams=p[1], free_run_steps=p[2],
+                                  free_run_budget_us=p[3] if len(p) > 3 else 0, **kw), 'free-run jobs fronts=%d teams=%d steps=%d budget_us=%d' % (p[0], p[1], p[2], p[3] if len(p) > 3 else 0))
+        if args.out:
+            json.dump(results, open(args.out, 'w'), indent=1)
+        return
     if args.lockstep:
         run(RegionGrower(net, free_run=False, graph_iterations=4, **kw), 'lock-step, one lane, graph x4')
     for c in args.configs.split(','):
