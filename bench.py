@@ -3,18 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Two legs, both with inputs (13-D room features, weights) resident in HBM before the clock starts:
+With N > 1 and no torch.distributed environment the script starts its N ranks itself (torch.distributed.run, 127.0.0.1); a
+WORLD_SIZE that contradicts --gpus is an error.  Inputs (13-D room features, weights) are resident in HBM before any clock starts.
 
-  steady leg (``value``, instance-steps/s).  A *step* is a macro-step of ``--iters-per-step`` (512) lock-step iterations of
-      the batched grow loop over the 68-room Area-5-shaped set (BASELINE.json configs[1]) with all rooms in flight: in every
-      iteration each in-flight room takes one region-grow step (box query, median, sampling, one LrgNet evaluation on its
-      512+512-point sets, mask update).  A room that finishes gets its 1-NN fill-in and restarts at once, so the batch
-      stays full.  W warm-up steps roll the rooms into their steady phase, then EXACTLY K steps are timed (20 steps =
-      10 240 iterations, about a second).  For N > 1 every rank runs its own 68-room set (weak scaling; no collective
-      inside the loop) and the device step counters are summed with one all-reduce after the clock stops.
-  fixed-work leg (``rooms_per_sec``).  R = 544 room jobs (the 68 geometries x 8 random-stream keys) are sharded over the N
-      ranks by point count (longest first), pushed through 68 slots per GPU from reset to final labels (grow + fill-in),
-      and the per-room labels are gathered over RCCL -- the only collective of the path.  Same R for every N (strong scaling).
+  steady leg (``value``, instance-steps/s).  The rooms of the Area-5-shaped set (BASELINE.json configs[1]), `--rooms` = 68 of them
+      in flight; every in-flight room takes region-grow steps (box query, medians, sampling, one LrgNet evaluation on its 512 + 512
+      point sets, mask update; test_region_grow.py:208-306), a room that finishes gets its 1-NN fill-in and the slot goes on with
+      the next room job (the 68 geometries under fresh random-stream keys), so the batch stays full.
+        free-running launches (default up to 96 slots): a *step* is ONE launch of lrg_grow_async with a budget of --step-ms
+            (25 ms) in which every slot takes as many grow steps as it can, then the fill-ins of the rooms that finished;
+        lock-step iterations (--mode lockstep, and above 96 slots): a *step* is --iters-per-step (512) iterations of
+            lrg_grow_step_packed over all slots, on the automatic number of lanes.
+      W warm-up steps, then EXACTLY K steps timed between barriers.  N > 1: every rank its own set (weak scaling, no collective in
+      the loop); the device counters are summed with one all-reduce after the clock stops.
+      An instance-step is counted per slot and iteration of the loop, whatever the number of rows its LrgNet evaluation needed: the
+      distinct rows of a 512 + 512 set are evaluated, the copies that pad it are not (``rows_evaluated_fraction``), so the unit is a
+      PADDED-EQUIVALENT one -- the roofline object prices the rows that were evaluated, not 271.7 MFLOP per instance-step.
+  fixed-work leg (``rooms_per_sec``).  R = 544 room jobs (the 68 geometries x 8 random-stream keys) sharded over the N ranks by point
+      count (longest first), pushed through `--rooms` slots per GPU from reset to final labels (grow + fill-in), the labels gathered
+      over RCCL -- the only collective of the path.  Same R for every N (strong scaling).  ``fixed_work_best``: the same R jobs with
+      the number of slots per GPU chosen by a short sweep (rooms/s is not a property of 68 slots).
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,6 +32,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -45,7 +54,11 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--mode', default='auto', choices=['auto', 'free', 'lockstep'],
+                    help='auto: free-running launches (lrg_grow_async) up to 96 greedy slots per GPU, lock-step iterations above')
+    ap.add_argument('--step-ms', type=float, default=25.0, help='free-running launches: budget of one launch = one step')
     ap.add_argument('--iters-per-step', type=int, default=512, help='lock-step iterations per (macro-)step')
+    ap.add_argument('--best-slots', default='68,136,272', help='slot counts of the fixed_work_best sweep (empty = skip)')
     ap.add_argument('--rooms', type=int, default=68, help='rooms in flight per GPU (the Area-5 set has 68)')
     ap.add_argument('--restarts', type=int, default=1)
     ap.add_argument('--workload', default='area5', choices=['area5', 'kitti', 'scannet'],
@@ -179,17 +192,104 @@ def p0_rates(n_rooms, dev):
     return out
 
 
+def _respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks (one per GPU) and become their launcher."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+class _Leg:
+    """One grower configuration over a list of room jobs: free-running launches on one stream, or lock-step lanes."""
+
+    def __init__(self, net, jobs, slots, mode, args, grow_kw, seed, dev, step_budget_us):
+        import torch
+        from learn_region_grow_amd.grow import LanedRegionGrower, RegionGrower
+        self.torch, self.dev, self.jobs, self.fill = torch, dev, jobs, bool(args.fill)
+        greedy = args.restarts == 1
+        self.free = greedy and (mode == 'free' or (mode == 'auto' and slots <= 96)) and bool(grow_kw.get('packed'))
+        self.slots = slots
+        if self.free:
+            self.stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(self.stream):
+                self.gr = RegionGrower(net, rooms_in_flight=slots, seed=seed, free_run=True, free_run_budget_us=int(step_budget_us),
+                                       **{k: v for k, v in grow_kw.items() if k != 'graph_iterations'})
+                self.gr.load_rooms(jobs)
+            self.growers = [self.gr]
+            self.lanes = 1
+        else:
+            self.lg = LanedRegionGrower(net, rooms_in_flight=slots, lanes=args.lanes if args.lanes > 0 else None, cu_partition=args.cu_partition > 0,
+                                        seed=seed, free_run=False, **grow_kw)
+            self.lg.load_rooms(jobs)
+            self.growers = [g for g in self.lg.growers if g.n_rooms]
+            self.lanes = len(self.lg.growers)
+        torch.cuda.synchronize()
+
+    def stats(self):
+        return sum(g.d_stats[:4].cpu().numpy().astype(np.float64) for g in self.growers)
+
+    def work(self):
+        """(evaluations, distinct inlier rows, distinct neighbour rows, 32-row tiles per stack) of the free-running launches so far."""
+        return self.gr.a_work.cpu().numpy().astype(np.float64) if self.free else None
+
+    def grow_all(self):
+        """Every job from reset to final labels (grow + fill-in) on the device."""
+        if self.free:
+            with self.torch.cuda.stream(self.stream):
+                self.gr.grow_loaded(fill=self.fill)
+        else:
+            self.lg.grow_loaded(fill=self.fill)
+        self.torch.cuda.synchronize()
+
+    def labels(self):
+        """-> (flat int32 labels of this leg's rooms in grower order, job index of each room, its length)."""
+        torch = self.torch
+        flat = torch.cat([g.d_filled[int(g.room_off[k]):int(g.room_off[k]) + g.room_n[k]] for g in self.growers for k in range(g.n_rooms)]) \
+            if self.jobs else torch.zeros(0, dtype=torch.int32, device=self.dev)
+        if self.free:
+            order = list(range(self.gr.n_rooms))
+        else:
+            order = [i for g in self.growers for i in g.room_index]
+        lens = [n for g in self.growers for n in g.room_n]
+        return flat, order, lens
+
+    def room_steps(self):
+        """job index -> instance-steps of its pass (region log)."""
+        out = {}
+        k0 = 0
+        for g in self.growers:
+            rl = g.d_rlog.cpu().numpy()
+            rr = g._read_rooms()
+            idx = list(range(g.n_rooms)) if self.free else g.room_index
+            for k in range(g.n_rooms):
+                o = int(g.room_off[k])
+                out[idx[k]] = int(rl[o:o + rr[k].n_regions, 1].sum())
+        return out
+
+    def close(self):
+        for g in self.growers:
+            g._release_graph()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        _respawn_under_torchrun(args)
     import torch
     import torch.distributed as dist
     from learn_region_grow_amd import _lib, synthetic, workloads, dist as lrg_dist
     from learn_region_grow_amd.lrgnet import LrgNetHIP, _ptr
-    from learn_region_grow_amd.grow import LanedRegionGrower, RegionGrower, auto_lanes, lane_streams
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a torch.distributed environment)'
+                         % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     # LRG_BENCH_ONE_DEVICE=1 (testing on a 1-GPU box): every rank uses cuda:0 and the collectives go over gloo
@@ -213,109 +313,156 @@ def main():
     resolution = 0.1
     if args.workload == 'kitti':
         resolution = 0.3
-        rooms = workloads.kitti_scenes(min(args.rooms, 8), seed_base=5000 + 100 * rank, cache_dir=args.cache)
-        base = workloads.kitti_scenes(min(args.rooms, 8), seed_base=5000, cache_dir=args.cache) if rank else rooms
+        base = workloads.kitti_scenes(min(args.rooms, 8), seed_base=5000, cache_dir=args.cache)
     elif args.workload == 'scannet':
-        rooms = workloads.scannet_rooms(min(args.rooms, 39), seed_base=7000 + 100 * rank, cache_dir=args.cache)
-        base = workloads.scannet_rooms(min(args.rooms, 39), seed_base=7000, cache_dir=args.cache) if rank else rooms
+        base = workloads.scannet_rooms(min(args.rooms, 39), seed_base=7000, cache_dir=args.cache)
     else:
-        rooms = workloads.area5_rooms(args.rooms, seed_base=1000 + 100 * rank, cache_dir=args.cache)
-        base = workloads.area5_rooms(args.rooms, seed_base=1000, cache_dir=args.cache) if rank else rooms
+        base = workloads.area5_rooms(min(args.rooms, 68), seed_base=1000, cache_dir=args.cache)
+    slots = min(args.rooms, 8) if args.workload == 'kitti' else args.rooms
     net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, mode=args.net_mode).load_weights(weights)
-    packed = bool(args.packed) and args.net_mode == 'fused' and max(len(r['points']) for r in rooms) <= (
+    packed = bool(args.packed) and args.net_mode == 'fused' and max(len(r['points']) for r in base) <= (
         _lib.LRG_PACKED_MAX_POINTS if args.packed > 1 else _lib.LRG_PACKED_AUTO_POINTS)      # --packed 2 forces it up to 131072 points
     graph = args.graph if packed else 0
     if graph and args.iters_per_step % graph:
         raise SystemExit('--iters-per-step must be a multiple of --graph')
-    grow_kw = dict(restarts=args.restarts, rng='counter', policy=args.policy, resolution=resolution, packed=packed,
-                   graph_iterations=graph)
-
-    # ------------------------------------------------------------------------------------------------------------------
-    # steady leg: the rooms in flight dealt over `lanes` growers, each on its own stream (largest rooms first, round the lanes)
-    # ------------------------------------------------------------------------------------------------------------------
-    n_lanes = max(1, min(args.lanes, len(rooms))) if args.lanes > 0 else auto_lanes(len(rooms) * args.restarts)
-    by_size = sorted(range(len(rooms)), key=lambda i: -len(rooms[i]['points']))
-    parts = [[i for i in by_size[k::n_lanes]] for k in range(n_lanes)]
-    cu_part = args.cu_partition > 0
-    lane_streams_ = lane_streams(dev, n_lanes, cu_part)
-    growers = []
-    for k in range(n_lanes):
-        with torch.cuda.stream(lane_streams_[k]):
-            g_ = RegionGrower(net, rooms_in_flight=len(parts[k]), seed=rank, **grow_kw)
-            g_.load_rooms([rooms[i] for i in parts[k]])
-            for g in range(g_.n_groups):
-                g_.bind(g, g)
-            growers.append(g_)
-    torch.cuda.synchronize()
-    room_steps = {}          # room index -> instance-steps of its last completed pass (from the device's region log)
-
-    def iterate(iters):
-        per_call = graph if graph else 1
-        for _ in range(0, iters, per_call):
-            for lane, g_ in enumerate(growers):
-                with torch.cuda.stream(lane_streams_[lane]):
-                    g_.enqueue()
-                    for g in g_.poll_done():          # finished rooms get their fill-in (:308-316) and restart at once
-                        r = g_.group_room[g]
-                        if args.fill:
-                            g_.fill(r)
-                        g_.reset_room(r)
-                        g_.bind(g, r)
-
-    def read_stats():
-        return sum(g_.d_stats[:3].cpu().numpy().astype(np.float64) for g_ in growers)
+    grow_kw = dict(restarts=args.restarts, rng='counter', policy=args.policy, resolution=resolution, packed=packed, graph_iterations=graph)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    iterate(args.warmup * args.iters_per_step)
-    barrier()
-    s0 = read_stats()
-    t0 = time.perf_counter()
-    iterate(args.steps * args.iters_per_step)
-    barrier()
-    t1 = time.perf_counter()
-    s1 = read_stats()
-    elapsed = lrg_dist.allreduce_max(t1 - t0, device=coll_dev)
-    inst_steps, rooms_cycled, seeds = lrg_dist.allreduce_sum([float(s1[2] - s0[2]), float(s1[1] - s0[1]), float(s1[0] - s0[0])],
-                                                             device=coll_dev)
-    iterations = args.steps * args.iters_per_step
+    def jobs_of(n, key0):
+        """n room jobs: the geometries of the set, job j under the random-stream key key0 + j."""
+        return [dict(base[j % len(base)], room_id=key0 + j) for j in range(n)]
 
     # ------------------------------------------------------------------------------------------------------------------
-    # roofline of the LrgNet evaluation (the dominant kernels), HIP events on the launch stream
+    # steady leg
     # ------------------------------------------------------------------------------------------------------------------
-    S = sum(g_.S for g_ in growers)
-    reps = 20
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    rs = np.random.RandomState(0)
-    d_inl = torch.from_numpy((rs.randn(S, 512, 13) * 0.5).astype(np.float32)).to(dev)
-    d_nbr = torch.from_numpy((rs.randn(S, 512, 13) * 0.5).astype(np.float32)).to(dev)
-    # (a) dense: all 512 + 512 rows of every instance in flight (the formulation SURVEY.md 8d prices)
-    net.forward(d_inl, d_nbr)
-    torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(reps):
-        net.forward(d_inl, d_nbr)
-    ev1.record()
-    torch.cuda.synchronize()
-    fwd_ms = ev0.elapsed_time(ev1) / reps
-    flops = S * FLOPS_PER_INSTANCE_STEP
-    tflops = flops / (fwd_ms * 1e-3) / 1e12
-    hbm_accounting = S * BYTES_PER_INSTANCE_STEP / (fwd_ms * 1e-3) / 1e9
-    # (b) as the loop issues it: the packed distinct rows of the lanes' last iteration
-    in_loop = None
-    if packed:
+    step_us = args.step_ms * 1e3
+    free_steady = args.restarts == 1 and packed and (args.mode == 'free' or (args.mode == 'auto' and slots <= 96))
+    ev_pairs = []
+    if free_steady:
+        # enough jobs for the warm-up and the timed steps at twice the rate seen so far (~650 rooms/s per GPU), at least two per slot
+        n_jobs = max(2 * slots, int((args.warmup + args.steps) * args.step_ms * 1e-3 * 1500) + slots)
+        leg = _Leg(net, jobs_of(n_jobs, 1000000 * (rank + 1)), slots, 'free', args, grow_kw, rank, dev, step_us)
+        gr = leg.gr
+        with torch.cuda.stream(leg.stream):
+            gr.free_run_begin()
+
+        def iterate(steps, timed):
+            with torch.cuda.stream(leg.stream):
+                for _ in range(steps):
+                    if timed:      # HIP events round the launch, on the stream it is launched on
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(leg.stream)
+                        gr.enqueue_free_run()
+                        e1.record(leg.stream)
+                        ev_pairs.append((e0, e1))
+                        gr.poll_done()
+                        for r in gr.done_rooms:
+                            if args.fill:
+                                gr.fill(r)
+                        gr.rooms_finished += len(gr.done_rooms)
+                        gr.done_rooms = []
+                    else:
+                        gr.free_run_step(fill=bool(args.fill))
+        step_what = 'one free-running launch of lrg_grow_async with a budget of %.0f ms (every in-flight room takes as many region-grow steps ' \
+                    'as it can), then the fill-ins of the rooms that finished' % args.step_ms
+        iterations = None
+    else:
+        from learn_region_grow_amd.grow import RegionGrower, auto_lanes, lane_streams
+        rooms = base if rank == 0 else ({'kitti': workloads.kitti_scenes, 'scannet': workloads.scannet_rooms}.get(args.workload, workloads.area5_rooms)(
+            len(base), seed_base={'kitti': 5000, 'scannet': 7000}.get(args.workload, 1000) + 100 * rank, cache_dir=args.cache))
+        rooms = [rooms[i % len(rooms)] if i < len(rooms) else dict(rooms[i % len(rooms)], room_id=50000 + i) for i in range(slots)]
+        n_lanes = max(1, min(args.lanes, len(rooms))) if args.lanes > 0 else auto_lanes(len(rooms) * args.restarts)
+        by_size = sorted(range(len(rooms)), key=lambda i: -len(rooms[i]['points']))
+        parts = [[i for i in by_size[k::n_lanes]] for k in range(n_lanes)]
+        lane_streams_ = lane_streams(dev, n_lanes, args.cu_partition > 0)
+        growers = []
+        for k in range(n_lanes):
+            with torch.cuda.stream(lane_streams_[k]):
+                g_ = RegionGrower(net, rooms_in_flight=len(parts[k]), seed=rank, free_run=False, **grow_kw)
+                g_.load_rooms([rooms[i] for i in parts[k]])
+                for g in range(g_.n_groups):
+                    g_.bind(g, g)
+                growers.append(g_)
+        torch.cuda.synchronize()
+
+        class _L:
+            pass
+        leg = _L()
+        leg.growers, leg.free, leg.lanes, leg.slots = growers, False, n_lanes, slots
+        leg.stats = lambda: sum(g_.d_stats[:4].cpu().numpy().astype(np.float64) for g_ in growers)
+        leg.close = lambda: [g_._release_graph() for g_ in growers]
+
+        def iterate(steps, timed):
+            per_call = graph if graph else 1
+            for _ in range(0, steps * args.iters_per_step, per_call):
+                for lane, g_ in enumerate(growers):
+                    with torch.cuda.stream(lane_streams_[lane]):
+                        g_.enqueue()
+                        for g in g_.poll_done():          # finished rooms get their fill-in (:308-316) and restart at once
+                            r = g_.group_room[g]
+                            if args.fill:
+                                g_.fill(r)
+                            g_.reset_room(r)
+                            g_.bind(g, r)
+        step_what = '%d lock-step iterations of lrg_grow_step_packed (every in-flight room takes one region-grow step per iteration)' % args.iters_per_step
+        iterations = args.steps * args.iters_per_step
+
+    iterate(args.warmup, False)
+    barrier()
+    s0 = leg.stats()
+    w0 = leg.work() if leg.free else None
+    t0 = time.perf_counter()
+    iterate(args.steps, True)
+    barrier()
+    t1 = time.perf_counter()
+    s1 = leg.stats()
+    w1 = leg.work() if leg.free else None
+    elapsed = lrg_dist.allreduce_max(t1 - t0, device=coll_dev)
+    inst_steps, rooms_cycled, seeds = lrg_dist.allreduce_sum([float(s1[2] - s0[2]), float(s1[1] - s0[1]), float(s1[0] - s0[0])], device=coll_dev)
+    if int(s1[3]):
+        raise SystemExit('bench.py: lrg_grow_async gave up on a hand-over (%d): the numbers would be invalid' % int(s1[3]))
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # roofline of the kernel the timed loop runs.  Free-running: lrg_grow_async_kernel IS the loop -- its launches were timed with HIP
+    # events on their stream, its algorithmic FLOPs follow from the rows its tile teams evaluated (device counters: distinct rows of
+    # the 512 + 512 sets, pooled products).  Lock-step: the packed branch stack (the longest of the five launches), timed here with
+    # HIP events on the rows of the lanes' last iteration.
+    # ------------------------------------------------------------------------------------------------------------------
+    S = slots
+    roof = {'bound': 'mfma', 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s'}
+    if leg.free:
+        dw = w1 - w0
+        launch_ms = [a.elapsed_time(b) for a, b in ev_pairs]
+        flops = (dw[1] + dw[2]) * (FLOPS_PER_BRANCH_ROW + FLOPS_PER_HEAD_ROW) + dw[0] * FLOPS_POOLED_GEMM
+        t_kernel = sum(launch_ms) * 1e-3
+        ach = flops / t_kernel / 1e12
+        roof.update({'kernel': 'lrg_grow_async_kernel: the whole timed loop in one launch per step (front workgroups + tile teams: branch stacks, '
+                               'pooled products, head stacks on fp32 MFMA, v_mfma_f32_32x32x2_f32)',
+                     'achieved': ach, 'frac': ach / FP32_MATRIX_PEAK_TFLOPS,
+                     'algorithmic_flops_in_loop': flops, 'flops_per_launch': flops / max(len(launch_ms), 1), 'launches': len(launch_ms),
+                     'avg_us': 1e3 * float(np.mean(launch_ms)), 'kernel_seconds': t_kernel,
+                     'flops_definition': 'distinct rows evaluated x (165 504 branch + 98 816 head FLOP per row) + evaluations x 1 048 576 (pooled products); '
+                                         'copies that pad a set to 512 rows and the copies that pad a slot\'s rows to whole 32-row tiles are NOT counted',
+                     'evaluations': dw[0], 'rows_evaluated': [dw[1], dw[2]], 'rows_evaluated_fraction': (dw[1] + dw[2]) / max(dw[0] * 1024.0, 1.0),
+                     'tiles_run_per_stack': dw[3], 'rows_in_tiles_fraction': (dw[1] + dw[2]) / max(dw[3] * 32.0, 1.0),
+                     'reproduce': 'rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps %d --warmup %d  (profiles/r03_bench_kernel_stats.csv)'
+                                  % (args.steps, args.warmup)})
+    else:
+        reps = 20
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         rows = np.zeros(2)
         act = 0
-        loop_ms = 0.0
-        for g_ in growers:
+        loop_ms = branch_ms = 0.0
+        for g_ in leg.growers:
+            if not g_.packed:
+                continue
             sr = g_.p_slot_rows.cpu().numpy()
             rows += sr[:, :2].sum(axis=0)
             act += int((sr[:, 0] > 0).sum())
-            # rows as the loop's last evaluation saw them: the hand-over copy of the allocation counters (a slot's rows are
-            # allocated in multiples of 8, the padding being copies of its last row)
             nr = g_.p_counters[2:4].clone()
             pb = g_.packed_buffers
 
@@ -333,131 +480,150 @@ def main():
             ev1.record()
             torch.cuda.synchronize()
             loop_ms += ev0.elapsed_time(ev1) / reps
-        loop_flops = rows[0] * (FLOPS_PER_BRANCH_ROW + FLOPS_PER_HEAD_ROW) + rows[1] * (FLOPS_PER_BRANCH_ROW + FLOPS_PER_HEAD_ROW) + \
-            act * FLOPS_POOLED_GEMM
-        in_loop = {'rows_evaluated_fraction': float(rows.sum()) / (S * 1024.0), 'packed_rows': [int(rows[0]), int(rows[1])],
-                   'ms_per_evaluation_all_lanes': loop_ms, 'tflops': loop_flops / (loop_ms * 1e-3) / 1e12,
-                   'frac_of_fp32_matrix_peak': loop_flops / (loop_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
-                   'useful_tflops_over_the_steady_leg': inst_steps / world / elapsed * loop_flops / max(act, 1) / 1e12}
-    traffic = None
-    tpath = os.path.join(REPO, 'profiles', 'r02_traffic_%s.json' % args.net_mode)
-    if not os.path.exists(tpath):
-        tpath = os.path.join(REPO, 'profiles', 'r01_traffic_%s.json' % args.net_mode)
+        flops = rows.sum() * (FLOPS_PER_BRANCH_ROW + FLOPS_PER_HEAD_ROW) + act * FLOPS_POOLED_GEMM
+        ach = flops / (loop_ms * 1e-3) / 1e12 if loop_ms else 0.0
+        roof.update({'kernel': 'lrg_forward_packed as the loop issues it (branch stacks + pooled GEMM + head stacks on the packed distinct rows of the '
+                               'lanes\' last iteration), HIP events on the launch stream',
+                     'achieved': ach, 'frac': ach / FP32_MATRIX_PEAK_TFLOPS, 'algorithmic_flops_in_loop': flops,
+                     'flops_per_launch': flops, 'avg_us': 1e3 * loop_ms, 'packed_rows': [int(rows[0]), int(rows[1])],
+                     'rows_evaluated_fraction': float(rows.sum()) / (S * 1024.0),
+                     'flops_definition': 'distinct rows evaluated x (165 504 + 98 816 FLOP per row) + active slots x 1 048 576'})
+    # the dense evaluation (all 512 + 512 rows of S instances): the formulation SURVEY.md 8d prices, a side launch outside the timed loop
+    reps = 10
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    rs = np.random.RandomState(0)
+    d_inl = torch.from_numpy((rs.randn(S, 512, 13) * 0.5).astype(np.float32)).to(dev)
+    d_nbr = torch.from_numpy((rs.randn(S, 512, 13) * 0.5).astype(np.float32)).to(dev)
+    net.forward(d_inl, d_nbr)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        net.forward(d_inl, d_nbr)
+    ev1.record()
+    torch.cuda.synchronize()
+    fwd_ms = ev0.elapsed_time(ev1) / reps
+    dflops = S * FLOPS_PER_INSTANCE_STEP
+    roof['dense'] = {'note': 'side launch, NOT in the timed loop: lrg_forward on all 512 + 512 rows of %d instances' % S,
+                     'achieved': dflops / (fwd_ms * 1e-3) / 1e12, 'frac': dflops / (fwd_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+                     'ms_per_launch': fwd_ms, 'algorithmic_flops': dflops,
+                     'hbm_accounting': {'note': 'SURVEY.md 8d layer-streamed accounting (what an unfused implementation would stream); the fused kernels '
+                                                'keep activations in LDS, so this is NOT traffic', 'bytes_per_instance': BYTES_PER_INSTANCE_STEP,
+                                        'GBps': S * BYTES_PER_INSTANCE_STEP / (fwd_ms * 1e-3) / 1e9,
+                                        'frac_of_hbm_peak': S * BYTES_PER_INSTANCE_STEP / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    # HBM traffic / matrix-pipe occupancy of the loop's kernel: PMC passes of their own (tools/pmc_free_run.sh), quoted from the committed
+    # file only when it was measured on this ABI and formulation
+    roof['traffic'] = None
+    tpath = os.path.join(REPO, 'profiles', 'r03_pmc_free_run.json' if leg.free else 'r02_traffic_loop.json')
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath))['hbm_bytes_per_forward'] * S / 68.0
-    sq = None
-    spath = os.path.join(REPO, 'profiles', 'r02_pmc_sq_loop.json')
-    if os.path.exists(spath):
-        sq = json.load(open(spath))
-        if in_loop is not None:      # chip-wide matrix-pipe utilisation over the loop's kernels, from the committed SQ counter pass
-            in_loop['mfma_util_chipwide'] = sq.get('mfma_util_chipwide')
-            in_loop['mfma_util_chipwide_source'] = 'profiles/r02_pmc_sq_loop.json (tools/pmc_sq_loop.sh; round 1 by the same definition: %.3f)' % \
-                sq.get('round_1_same_definition', {}).get('mfma_util_chipwide', float('nan'))
-
-    lpath = os.path.join(REPO, 'profiles', 'r02_traffic_loop.json')
-    if os.path.exists(lpath) and in_loop is not None:      # HBM bytes of the loop's five launches, from the committed PMC passes
-        lt = json.load(open(lpath))
-        in_loop['hbm_bytes_per_iteration'] = lt.get('hbm_bytes_per_iteration')
-        in_loop['hbm_bytes_source'] = 'profiles/r02_traffic_loop.json (tools/pmc_traffic_loop.sh: FETCH_SIZE / WRITE_SIZE passes, 68 rooms in flight)'
+        tj = json.load(open(tpath))
+        if leg.free and tj.get('abi') == _lib.load().lrg_abi_version():
+            per_launch = tj.get('hbm_bytes_per_launch')
+            roof['traffic'] = per_launch
+            roof['traffic_quoted_from'] = {'file': 'profiles/' + os.path.basename(tpath), 'measured_at_commit': tj.get('commit'), 'abi': tj.get('abi'),
+                                           'launch_ms': tj.get('launch_ms'), 'hbm_GBps': tj.get('hbm_GBps'), 'frac_of_hbm_peak': tj.get('frac_of_hbm_peak'),
+                                           'mfma_util_chipwide': tj.get('mfma_util_chipwide'),
+                                           'note': 'rocprofv3 --pmc passes of their own over the same command; bytes per launch of %.0f ms' % args.step_ms}
+        elif not leg.free:
+            roof['traffic'] = tj.get('hbm_bytes_per_iteration')
+            roof['traffic_quoted_from'] = {'file': 'profiles/' + os.path.basename(tpath), 'note': 'round-2 measurement of the five lock-step launches, per iteration'}
+    leg.close()
+    del leg
+    torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------------------------------------------------------
-    # fixed-work leg: R room jobs over all ranks, reset -> final labels (grow + fill-in) -> RCCL gather
+    # fixed-work leg(s): R room jobs over all ranks, reset -> final labels (grow + fill-in) -> RCCL gather
     # ------------------------------------------------------------------------------------------------------------------
-    fixed = None
-    if args.fixed_rooms < 0:
-        args.fixed_rooms = 8 * len(base)
-    if args.fixed_rooms > 0 and args.restarts == 1:
-        for g_ in growers:
-            g_._release_graph()
-        del growers
-        torch.cuda.empty_cache()
-        R = args.fixed_rooms
-        jobs = [(j % len(base), j) for j in range(R)]                   # (geometry, random-stream key): 8 keys per geometry at R = 544
-        sizes = [len(base[b]['points']) for b, _ in jobs]
+    room_steps = {}
+
+    def fixed_work(R, n_slots):
+        jobs = jobs_of(R, 100000)
+        sizes = [len(j['points']) for j in jobs]
         mine = lrg_dist.shard_rooms_lpt(sizes, world)[rank]
-        job_rooms = [dict(base[jobs[j][0]], room_id=100000 + jobs[j][1]) for j in mine]
-        slots = min(args.rooms, max(1, len(job_rooms)))
-        lg = LanedRegionGrower(net, rooms_in_flight=slots, lanes=args.lanes if args.lanes > 0 else None, cu_partition=cu_part, seed=0, **grow_kw)
-        lg.load_rooms(job_rooms)
+        my_jobs = [jobs[j] for j in mine]
+        fl = _Leg(net, my_jobs, min(n_slots, max(1, len(my_jobs))), args.mode, args, grow_kw, 0, dev, step_us)
         barrier()
         tf0 = time.perf_counter()
-        lg.grow_loaded(fill=bool(args.fill))
+        fl.grow_all()
         tf_grow = time.perf_counter() - tf0
-        # the final gather: every rank ends up with every room's labels (one table + one flat int32 buffer, all_gather)
-        # (rooms start at multiples of 16 points in a lane's arena: take each room's own span)
-        flat = torch.cat([gr.d_filled[int(gr.room_off[k]):int(gr.room_off[k]) + gr.room_n[k]] for gr in lg.growers for k in range(gr.n_rooms)]) \
-            if job_rooms else torch.zeros(0, dtype=torch.int32, device=dev)
-        ids = [mine[i] for gr in lg.growers if gr.n_rooms for i in gr.room_index]
-        lens = [n for gr in lg.growers if gr.n_rooms for n in gr.room_n]
+        flat, order, lens = fl.labels()
+        ids = [mine[i] for i in order]
         tg0 = time.perf_counter()
         gathered = lrg_dist.gather_flat_labels(ids, lens, flat, R, device=coll_dev)
         barrier()
         tf1 = time.perf_counter()
-        fixed_elapsed = lrg_dist.allreduce_max(tf1 - tf0, device=coll_dev)
-        st = sum(gr.d_stats[:3].cpu().numpy().astype(np.float64) for gr in lg.growers if gr.n_rooms)
-        f_steps, f_rooms = lrg_dist.allreduce_sum([float(st[2]), float(len(job_rooms))], device=coll_dev)
+        el = lrg_dist.allreduce_max(tf1 - tf0, device=coll_dev)
+        st = fl.stats()
+        f_steps, f_rooms = lrg_dist.allreduce_sum([float(st[2]), float(len(my_jobs))], device=coll_dev)
         ok = all(gathered[j] is not None and len(gathered[j]) == sizes[j] and int(gathered[j].min()) > 0 for j in range(R))
-        for res_lane in [gr for gr in lg.growers if gr.n_rooms]:
-            rl = res_lane.d_rlog.cpu().numpy()
-            rr = res_lane._read_rooms()
-            for k in range(res_lane.n_rooms):
-                o = int(res_lane.room_off[k])
-                room_steps.setdefault(jobs[mine[res_lane.room_index[k]]][0], int(rl[o:o + rr[k].n_regions, 1].sum()))
-        fixed = {'rooms': int(f_rooms), 'seconds': fixed_elapsed, 'rooms_per_sec': f_rooms / fixed_elapsed,
-                 'instance_steps': f_steps, 'instance_steps_per_sec': f_steps / fixed_elapsed, 'scaling': 'strong',
-                 'slots_per_gpu': slots, 'lanes': len(lg.growers), 'grow_seconds_rank0': tf_grow, 'gather_seconds_rank0': tf1 - tg0,
-                 'rccl_ranks': world, 'collective_backend': backend, 'all_rooms_labeled_after_gather': bool(ok),
-                 'what': '%d room jobs = the %d geometries x %d random-stream keys, LPT-sharded by point count over %d rank(s), '
-                         'reset -> grow -> 1-NN fill-in -> all_gather of the labels' % (R, len(base), (R + len(base) - 1) // len(base), world)}
+        crc = 0
+        for j in range(R):                                  # one checksum over every room's final labels, in job order
+            crc = zlib.crc32(np.ascontiguousarray(gathered[j], dtype=np.int32).tobytes(), crc) if gathered[j] is not None else crc
+        for k, v in fl.room_steps().items():
+            room_steps.setdefault(mine[k] % len(base), v)
+        out = {'rooms': int(f_rooms), 'seconds': el, 'rooms_per_sec': f_rooms / el, 'instance_steps': f_steps, 'instance_steps_per_sec': f_steps / el,
+               'scaling': 'strong', 'slots_per_gpu': fl.slots, 'formulation': 'free-running launches' if fl.free else 'lock-step iterations',
+               'lanes': fl.lanes, 'grow_seconds_rank0': tf_grow, 'gather_seconds_rank0': tf1 - tg0, 'rccl_ranks': world,
+               'collective_backend': backend, 'all_rooms_labeled_after_gather': bool(ok), 'labels_crc32': int(crc), 'given_up': int(st[3]),
+               'what': '%d room jobs = the %d geometries x %d random-stream keys, LPT-sharded by point count over %d rank(s), reset -> grow -> '
+                       '1-NN fill-in -> all_gather of the labels' % (R, len(base), (R + len(base) - 1) // len(base), world)}
+        fl.close()
+        del fl
+        torch.cuda.empty_cache()
+        return out
+
+    fixed = best = None
+    if args.fixed_rooms < 0:
+        args.fixed_rooms = 8 * len(base)
+    if args.fixed_rooms > 0 and args.restarts == 1:
+        fixed = fixed_work(args.fixed_rooms, slots)
+        sweep = [int(x) for x in args.best_slots.split(',') if x.strip()] if args.workload != 'kitti' else []
+        tried = {slots: fixed}
+        for n_slots in sweep:
+            if n_slots not in tried and n_slots * world <= args.fixed_rooms:
+                tried[n_slots] = fixed_work(args.fixed_rooms, n_slots)
+        if len(tried) > 1:
+            pick = max(tried, key=lambda k: tried[k]['rooms_per_sec'] if tried[k]['all_rooms_labeled_after_gather'] else -1.0)
+            best = dict(tried[pick])
+            best['sweep'] = {str(k): {'rooms_per_sec': tried[k]['rooms_per_sec'], 'instance_steps_per_sec': tried[k]['instance_steps_per_sec'],
+                                      'formulation': tried[k]['formulation'], 'lanes': tried[k]['lanes']} for k in sorted(tried)}
 
     if rank == 0:
         out = {
-            'metric': 'region-grow steps/sec (rooms/sec alongside), %s shape' % {'area5': 'S3DIS Area-5', 'scannet': 'ScanNet',
-                                                                                 'kitti': 'KITTI'}[args.workload],
+            'metric': 'region-grow steps/sec (rooms/sec alongside), %s shape' % {'area5': 'S3DIS Area-5', 'scannet': 'ScanNet', 'kitti': 'KITTI'}[args.workload],
             'value': inst_steps / elapsed,
             'unit': 'instance-steps/s',
+            'value_note': 'an instance-step = one slot taking one region-grow step, whatever the number of distinct rows its LrgNet evaluation had '
+                          '(a padded-equivalent unit: see roofline.rows_evaluated_fraction)',
             'rooms_per_sec': fixed['rooms_per_sec'] if fixed else rooms_cycled / elapsed,
-            'rooms_per_sec_steady_cycling': rooms_cycled / elapsed,
+            'rooms_per_sec_steady': rooms_cycled / elapsed,
             'regions_per_sec': seeds / elapsed,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
-            'ms_per_iteration': 1e3 * elapsed / iterations,
+            'us_per_instance_step_per_slot': 1e6 * elapsed * S * world / max(inst_steps, 1.0),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('Semantic-KITTI-shaped synthetic scenes (~100 k points at 0.3 m), %d in flight' % len(rooms)
-                                    if args.workload == 'kitti' else
-                                    'ScanNet-shaped synthetic rooms (%d-room set per GPU, all in flight, cycled)' % len(rooms)
+            'config': {'workload': ('Semantic-KITTI-shaped synthetic scenes (~100 k points at 0.3 m), %d in flight' % S if args.workload == 'kitti' else
+                                    'ScanNet-shaped synthetic rooms (%d-room set per GPU, %d in flight, recycled under fresh random-stream keys)' % (len(base), S)
                                     if args.workload == 'scannet' else
-                                    'S3DIS Area-5-shaped synthetic rooms (68-room set per GPU, all in flight, cycled)') +
+                                    'S3DIS Area-5-shaped synthetic rooms (68-room set per GPU, %d in flight, recycled under fresh random-stream keys)' % S) +
                                    (', greedy test_region_grow.py loop' if args.restarts == 1 else
                                     ', test_random_restart.py loop with %d restarts per seed batched per launch' % args.restarts),
-                       'step': '%d lock-step iterations (every in-flight room takes one region-grow step per iteration)' % args.iters_per_step,
-                       'iterations_per_step': args.iters_per_step, 'timed_iterations': iterations,
-                       'rooms_in_flight_per_gpu': len(rooms), 'slots_per_gpu': S, 'lanes': n_lanes, 'policy': args.policy,
-                       'restarts': args.restarts, 'points': '512 inlier + 512 neighbour x 13 features',
-                       'rng': 'counter (Philox) stream',
+                       'step': step_what, 'formulation': 'free-running launches (lrg_grow_async)' if free_steady else 'lock-step iterations (lrg_grow_step_packed)' if packed else 'lrg_grow_step',
+                       'rooms_in_flight_per_gpu': S, 'slots_per_gpu': S * args.restarts, 'lanes': 1 if free_steady else n_lanes, 'policy': args.policy,
+                       'restarts': args.restarts, 'points': '512 inlier + 512 neighbour x 13 features', 'rng': 'counter (Philox) stream',
                        'weights': ('trained on synthetic Area-5-shaped rooms by train_region_grow.py (learn_region_grow_amd/weights)'
                                    if args.weights == 'trained' else 'random, seed 0'), 'net_mode': args.net_mode,
-                       'iteration': 'lrg_grow_step_packed (front kernel + branch / GEMM / head on packed rows)' if packed else 'lrg_grow_step',
-                       'hip_graph_iterations': graph,
-                       'active_fraction': inst_steps / (iterations * S * world)},
-            'roofline': {'bound': 'mfma', 'kernel': 'lrg_forward: fused branch stacks + pooled GEMM + head stacks of one dense LrgNet evaluation '
-                                                   'batch (v_mfma_f32_32x32x2_f32, exact fp32)',
-                         'achieved': tflops, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / FP32_MATRIX_PEAK_TFLOPS,
-                         'traffic': traffic,
-                         'traffic_source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of their own, S=68; tools/pmc_run.sh)' % os.path.basename(tpath),
-                         'algorithmic_flops': flops, 'flops_per_instance': FLOPS_PER_INSTANCE_STEP,
-                         'ms_per_launch': fwd_ms, 'instances_per_launch': S,
-                         'hbm_accounting': {'note': 'SURVEY.md 8d layer-streamed accounting (what an unfused implementation would stream); the '
-                                                    'fused kernels keep activations in LDS, so this is NOT traffic',
-                                            'algorithmic_bytes': S * BYTES_PER_INSTANCE_STEP, 'bytes_per_instance': BYTES_PER_INSTANCE_STEP,
-                                            'GBps': hbm_accounting, 'frac_of_hbm_peak': hbm_accounting / HBM_PEAK_GBS},
-                         'traffic_ratio': (traffic / (S * BYTES_PER_INSTANCE_STEP)) if traffic else None,
-                         'note': 'dense launch: all 512+512 rows of every instance evaluated',
-                         'in_loop': in_loop, 'in_loop_sq_counters': sq},
+                       'hip_graph_iterations': 0 if free_steady else graph},
+            'roofline': roof,
         }
+        if iterations:
+            out['ms_per_iteration'] = 1e3 * elapsed / iterations
+            out['config']['iterations_per_step'] = args.iters_per_step
+            out['config']['active_fraction'] = inst_steps / (iterations * S * args.restarts * world)
         if fixed:
             out['fixed_work'] = fixed
+        if best:
+            out['fixed_work_best'] = best
         if world == 1 and args.cpu_seconds > 0:
             out['cpu_baseline'] = cpu_baseline(base, weights, args.cpu_seconds, args.policy, room_steps)
         if world == 1 and args.p0_rooms > 0:

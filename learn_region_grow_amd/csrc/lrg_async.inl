@@ -28,7 +28,7 @@
 //
 // Results are those of lrg_grow_step_packed bit for bit: the same front code, the same tile code on the same rows (a slot's rows
 // padded to whole tiles with copies of its last row, which neither the max-pool nor anybody's logits notice), the pooled product
-// in the summation order of lrg_head_gemv_kernel.
+// in the one summation order all formulations share (lrg_head_gemv_kernel, lrg_net.hip).
 
 #ifndef LRG_ASYNC_FD
 #define LRG_ASYNC_FD 4              // depth of the tile teams' weight ring (k-groups in flight)
@@ -87,7 +87,8 @@ __device__ __forceinline__ void lrg_async_push(const LrgAsyncArgs &A, int ring, 
 }
 
 // ---- pooled product of a head's first layer for ONE slot and 128 columns by a team of four wavefronts, in the summation order of
-//      lrg_head_gemv_kernel (eight K ranges, each summed k after k; then the eight partial sums in order; then the bias) ----
+//      lrg_head_gemv_kernel / lrg_head_gemm_kernel (eight K ranges, each a chain of FMAs over k = 8g + 0, 4, 1, 5, 2, 6, 3, 7 -- what
+//      v_mfma_f32_32x32x2_f32 does with its lane halves --; then the eight partial sums in order; then the bias) ----
 // What it costs is the trip of 1024 x 128 weights (512 KB) from L2, not the arithmetic: every lane owns FOUR consecutive columns
 // (one 16-byte load per row of the kernel) and ONE of the eight K ranges -- 16 lanes per range and column half, the four lane
 // groups of a wavefront on four ranges -- with sixteen rows in flight per lane.  (With one column per lane and the loop left to the
@@ -114,7 +115,8 @@ __device__ __forceinline__ void lrg_async_gemv(const LrgGemvArgs &g, int slot, i
 #pragma unroll
             for (int u = 0; u < 16; ++u) wv[u] = *reinterpret_cast<const float4 *>(w + (long)(kb + u) * g.ldw);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int uu = 0; uu < 16; ++uu) {
+                const int u = (uu & 8) | ((uu & 1) << 2) | ((uu >> 1) & 3);      // k = 8g + 0, 4, 1, 5, 2, 6, 3, 7: the order of the MFMA formulation
                 const float pk = p[kb + u];
                 acc.x = fmaf(pk, wv[u].x, acc.x); acc.y = fmaf(pk, wv[u].y, acc.y);
                 acc.z = fmaf(pk, wv[u].z, acc.z); acc.w = fmaf(pk, wv[u].w, acc.w);

@@ -531,22 +531,32 @@ class RegionGrower:
         self.a_roomq = torch.from_numpy(q).to(self.dev)
         self.async_buffers.room_queue = self.a_roomq.data_ptr()
 
-    def _grow_loaded_free_run(self, fill=True):
-        """The first S rooms bound by the host, the rest handed out on the device; fill-ins as finished rooms are reported."""
+    def free_run_begin(self):
+        """Free-running launches over ALL loaded rooms: the first S rooms bound by the host, the rest handed out on the device."""
         self.reset_state()
         first = min(self.n_groups, self.n_rooms)
         for g in range(self.n_groups):
             self.bind(g, g if g < first else -1)
         self.set_room_queue(list(range(first, self.n_rooms)))
-        finished = 0
-        while finished < self.n_rooms:
-            self.enqueue_free_run()
-            self.poll_done()
-            for r in self.done_rooms:
-                if fill:
-                    self.fill(r)
-                finished += 1
-            self.done_rooms = []
+        self.rooms_finished = 0
+
+    def free_run_step(self, fill=True, steps=None, budget_us=None, wait=False):
+        """One launch, then the fill-in (test_region_grow.py:308-316) of the rooms reported finished since the last call; returns
+        how many those were."""
+        self.enqueue_free_run(steps, budget_us)
+        self.poll_done(wait=wait)
+        n = len(self.done_rooms)
+        for r in self.done_rooms:
+            if fill:
+                self.fill(r)
+        self.rooms_finished += n
+        self.done_rooms = []
+        return n
+
+    def _grow_loaded_free_run(self, fill=True):
+        self.free_run_begin()
+        while self.rooms_finished < self.n_rooms:
+            self.free_run_step(fill)
         torch.cuda.current_stream(self.dev).synchronize()
         self.async_buffers.room_queue = None
         return self.n_rooms

@@ -1,43 +1,90 @@
-"""GPU: bench.py end to end on a tiny configuration -- the one JSON line the driver parses, with its roofline and
-cpu_baseline objects."""
+"""GPU: bench.py end to end on tiny configurations -- the one JSON line the driver parses, with its roofline and cpu_baseline
+objects, for both formulations of the loop; `--gpus 2` started WITHOUT a torch.distributed environment (the script spawns its
+ranks itself); a WORLD_SIZE that contradicts --gpus is refused."""
 import json
 import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+            'config', 'roofline', 'rooms_per_sec', 'fixed_work')
 
 
-@pytest.mark.parametrize('lanes,graph', [(1, 0), (2, 4)])
-def test_bench_line(cuda_device, tmp_path, lanes, graph):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '2', '--iters-per-step', '16',
-                        '--rooms', '6', '--fixed-rooms', '12', '--cpu-seconds', '3', '--p0-rooms', '1', '--lanes', str(lanes),
-                        '--graph', str(graph), '--cache', str(tmp_path / 'cache')],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+def run_bench(argv, env=None, timeout=1200):
+    e = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=e)
+    return r, [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+
+
+@pytest.mark.parametrize('mode,lanes,graph', [('free', 0, 0), ('lockstep', 1, 0), ('lockstep', 2, 4)])
+def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
+    r, lines = run_bench(['--gpus', '1', '--steps', '3', '--warmup', '2', '--iters-per-step', '16', '--step-ms', '2', '--rooms', '6', '--fixed-rooms', '12',
+                          '--best-slots', '3,6', '--cpu-seconds', '3', '--p0-rooms', '1', '--mode', mode, '--lanes', str(lanes), '--graph', str(graph),
+                          '--cache', str(tmp_path / 'cache')])
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
-              'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'rooms_per_sec', 'fixed_work'):
+    for k in CONTRACT + ('cpu_baseline',):
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 2 and d['higher_is_better'] is True
     assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32' and d['data'] == 'synthetic'
-    assert d['value'] > 0 and d['unit'] == 'instance-steps/s' and 'workload' in d['config'] and d['config']['lanes'] == lanes
-    assert d['config']['iterations_per_step'] == 16 and d['config']['timed_iterations'] == 48 and d['config']['hip_graph_iterations'] == graph
+    assert d['value'] > 0 and d['unit'] == 'instance-steps/s' and 'workload' in d['config']
+    if mode == 'free':
+        assert 'free-running' in d['config']['formulation'] and d['config']['lanes'] == 1
+    else:
+        assert d['config']['lanes'] == lanes and d['config']['iterations_per_step'] == 16 and d['config']['hip_graph_iterations'] == graph
     rf = d['roofline']
-    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'hbm_accounting', 'in_loop'):
+    for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_flops_in_loop', 'flops_per_launch', 'avg_us',
+              'rows_evaluated_fraction', 'dense'):
         assert k in rf, k
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
-    assert rf['instances_per_launch'] == 6 and rf['in_loop']['rows_evaluated_fraction'] > 0
+    assert 0 < rf['rows_evaluated_fraction'] <= 1 and rf['dense']['frac'] > 0
+    if mode == 'free':
+        # the roofline headline can be recomputed from the line alone: algorithmic FLOPs of the timed launches / their time / the peak
+        assert abs(rf['algorithmic_flops_in_loop'] / rf['kernel_seconds'] / 1e12 / rf['peak'] - rf['frac']) < 1e-9
+        assert rf['launches'] == 3 and 'lrg_grow_async_kernel' in rf['kernel']
     fw = d['fixed_work']
-    assert fw['rooms'] == 12 and fw['rooms_per_sec'] > 0 and fw['all_rooms_labeled_after_gather'] and fw['rccl_ranks'] == 1
+    assert fw['rooms'] == 12 and fw['rooms_per_sec'] > 0 and fw['all_rooms_labeled_after_gather'] and fw['rccl_ranks'] == 1 and fw['given_up'] == 0
     assert d['rooms_per_sec'] == fw['rooms_per_sec']
+    fb = d['fixed_work_best']
+    assert fb['all_rooms_labeled_after_gather'] and fb['rooms_per_sec'] >= fw['rooms_per_sec'] and set(fb['sweep']) == {'3', '6'}
     cb = d['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample', 'rooms_per_sec'):
         assert k in cb, k
     assert cb['kind'] == 'port' and cb['value'] > 0 and cb['strong']['value'] > 0 and cb['rooms_per_sec'] > 0
     assert d['preprocessing_p0']['gpu_rooms_per_sec'] > 0
+
+
+def test_bench_two_ranks_started_by_the_script_itself(cuda_device, tmp_path):
+    """`python bench.py --gpus 2` with no torch.distributed environment: the script starts its two ranks (here both on cuda:0,
+    collectives over gloo: LRG_BENCH_ONE_DEVICE=1), shards the fixed work over them and gathers every room's labels."""
+    common = ['--steps', '2', '--warmup', '1', '--step-ms', '2', '--rooms', '4', '--fixed-rooms', '8', '--best-slots', '', '--cpu-seconds', '0',
+              '--p0-rooms', '0', '--cache', str(tmp_path / 'cache')]
+    r2, l2 = run_bench(['--gpus', '2'] + common, env={'LRG_BENCH_ONE_DEVICE': '1'})
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert len(l2) == 1
+    d2 = json.loads(l2[0])
+    for k in CONTRACT:
+        assert k in d2, k
+    assert d2['n_gpus'] == 2 and d2['fixed_work']['rccl_ranks'] == 2 and d2['fixed_work']['rooms'] == 8
+    assert d2['fixed_work']['all_rooms_labeled_after_gather'] and d2['fixed_work']['collective_backend'] == 'gloo'
+    # the same fixed work on one rank: the same labels (checksum over all rooms) and the same number of instance-steps
+    r1, l1 = run_bench(['--gpus', '1'] + common)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    d1 = json.loads(l1[0])
+    assert d1['n_gpus'] == 1 and d1['fixed_work']['instance_steps'] == d2['fixed_work']['instance_steps']
+    assert d1['fixed_work']['labels_crc32'] == d2['fixed_work']['labels_crc32']      # the gathered labels of all rooms equal the one-rank run's
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus(cuda_device, tmp_path):
+    r, lines = run_bench(['--gpus', '4', '--steps', '1', '--warmup', '0', '--cache', str(tmp_path / 'cache')],
+                         env={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'}, timeout=300)
+    assert r.returncode != 0 and not lines and '--gpus 4' in (r.stderr + r.stdout)

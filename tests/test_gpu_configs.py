@@ -101,18 +101,25 @@ def test_scannet_shaped_rooms(net):
 
 
 # ---- configs[1]: the benchmark configuration --------------------------------------------------------------------------------
-def test_benchmark_configuration_labels(net):
-    """68 Area-5-shaped rooms in flight over the automatic number of lanes with HIP-graph replays (what bench.py times): every room passes the
-    invariants; the labels of eight rooms -- the 45 k-point one, the smallest, the median and five more -- equal single-room
-    oracle runs."""
+@pytest.mark.parametrize('mode', ['free-run', 'lock-step'])
+def test_benchmark_configuration_labels(net, mode):
+    """68 Area-5-shaped rooms in flight, as bench.py runs them -- free-running launches (one lane), or lock-step iterations over the
+    automatic number of lanes with HIP-graph replays: every room passes the invariants; the labels of eight rooms -- the 45 k-point
+    one, the smallest, the median and five more -- equal single-room oracle runs."""
     import torch
     from learn_region_grow_amd.grow import LanedRegionGrower
     rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir=CACHE)
     from learn_region_grow_amd.grow import auto_lanes
-    lg = LanedRegionGrower(net, rooms_in_flight=68, lanes=None, rng='counter', seed=0, policy='gt', graph_iterations=4)
-    assert len(lg.growers) == auto_lanes(68) == 3
-    got = lg.run(rooms)
-    assert all(g.packed and g._graph is not None for g in lg.growers)
+    if mode == 'free-run':
+        lg = LanedRegionGrower(net, rooms_in_flight=68, lanes=None, rng='counter', seed=0, policy='gt')
+        assert len(lg.growers) == 1
+        got = lg.run(rooms)
+        assert lg.growers[0].free_run
+    else:
+        lg = LanedRegionGrower(net, rooms_in_flight=68, lanes=None, rng='counter', seed=0, policy='gt', graph_iterations=4, free_run=False)
+        assert len(lg.growers) == auto_lanes(68) == 3
+        got = lg.run(rooms)
+        assert all(g.packed and g._graph is not None for g in lg.growers)
     for room, res in zip(rooms, got):
         check_invariants(room, res)
     by_size = [int(i) for i in np.argsort([len(r['points']) for r in rooms])]
@@ -151,18 +158,21 @@ def test_restarts_scoring_ml_matches_the_oracle(net):
     assert differs, "'ml' and 'np' scoring picked the same restart everywhere: the test rooms do not exercise the score"
 
 
-def test_benchmark_configuration_with_a_busy_chip(net):
+@pytest.mark.parametrize('mode,policy', [('lock-step', 'gt'), ('lock-step', 'net'), ('free-run', 'net')])
+def test_benchmark_configuration_with_a_busy_chip(net, mode, policy):
     """Slots must not depend on when their workgroups start.  The front kernel allocates the packed rows of an iteration from
     row 0 again, so a slot whose workgroup starts late -- here: while a second stream keeps every CU busy with dense LrgNet
     evaluations -- would find last iteration's rows overwritten if it still looked for them there (it did, up to ABI 3: with two
     lanes 13 of 68 rooms gave more than one outcome over eight runs, tools/determinism_check.py).  The default lanes + the hog, twice,
-    against a quiet single-lane run: same regions and labels for all 68 rooms."""
+    against a quiet single-lane run: same regions and labels for all 68 rooms -- under ground-truth masks and under the Bernoulli
+    policy that bench.py times, for the lock-step lanes and for the free-running launches (whose workgroups then are not all resident
+    from the start: the hog's tiles hold CUs)."""
     import threading
     import torch
     from learn_region_grow_amd.grow import LanedRegionGrower
     rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir=CACHE)
-    kw = dict(rooms_in_flight=68, rng='counter', seed=0, policy='gt')
-    quiet = LanedRegionGrower(net, lanes=1, **kw).run(rooms)
+    kw = dict(rooms_in_flight=68, rng='counter', seed=0, policy=policy)
+    quiet = LanedRegionGrower(net, lanes=1, free_run=False, **kw).run(rooms)      # (lock-step, one lane: every formulation gives the same bits)
     dev = net.device
     rs = np.random.RandomState(0)
     xi = torch.from_numpy((rs.randn(68, 512, 13) * 0.5).astype(np.float32)).to(dev)
@@ -183,7 +193,10 @@ def test_benchmark_configuration_with_a_busy_chip(net):
         th = threading.Thread(target=hog)
         th.start()
         try:
-            busy = LanedRegionGrower(net, lanes=None, graph_iterations=4, **kw).run(rooms)     # (three lanes: what bench.py runs)
+            if mode == 'lock-step':
+                busy = LanedRegionGrower(net, lanes=None, graph_iterations=4, free_run=False, **kw).run(rooms)     # (three lanes)
+            else:
+                busy = LanedRegionGrower(net, lanes=None, **kw).run(rooms)                                          # (free-running, one lane)
         finally:
             stop.set()
             th.join()
@@ -215,3 +228,49 @@ def test_voxel_grid_and_channel_major_copy_change_nothing(net, monkeypatch):
         assert regions_of(x) == regions_of(y) == regions_of(z)
         np.testing.assert_array_equal(x.filled_label, y.filled_label)
         np.testing.assert_array_equal(x.filled_label, z.filled_label)
+
+
+# ---- configs[1] exactly as bench.py builds it, against the oracle ------------------------------------------------------------
+@pytest.mark.parametrize('mode', ['free-run', 'lock-step'])
+def test_benchmark_configuration_as_benchmarked_matches_the_oracle(cuda_device, mode):
+    """What bench.py times -- the weights trained by this repository (synthetic.load_trained_weights), the reference's Bernoulli
+    policy (test_region_grow.py:266-267), 68 rooms in flight, free-running launches (default) or three lock-step lanes with graph
+    replays of four iterations -- against single-room oracle runs evaluating the same GPU network: the 45 k-point room, the
+    median, the smallest and three more.  The oracle's one-instance evaluation and the loop's give the same logits bit for bit
+    (one summation order in every formulation: vector kernel, matrix-core GEMM, free-running pooled blocks); the lock-step case
+    evaluates the oracle's network as eight copies all the same, i.e. through the GEMM, to prove that."""
+    import torch
+    from learn_region_grow_amd.grow import LanedRegionGrower
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    weights = synthetic.load_trained_weights()
+    net1 = LrgNetHIP(1, 1, 512, 512, 13, 0, device=cuda_device).load_weights(weights)
+    net8 = LrgNetHIP(8, 1, 512, 512, 13, 0, device=cuda_device).load_weights(weights)
+    rooms = workloads.area5_rooms(68, seed_base=1000, cache_dir=CACHE)
+    by_size = [int(i) for i in np.argsort([len(r['points']) for r in rooms])]
+    assert len(rooms[by_size[-1]]['points']) > 40000
+    picks = [by_size[-1], by_size[len(by_size) // 2], by_size[0]] + by_size[9:60:20]
+    assert len(picks) >= 6
+
+    def net_fn(xi, xn):
+        if mode == 'free-run':
+            _, add, _, rmv, _ = net1.run(xi, xn)
+            return add, rmv
+        _, add, _, rmv, _ = net8.run(np.repeat(xi, 8, axis=0), np.repeat(xn, 8, axis=0))
+        return add[:1], rmv[:1]
+
+    def oracle(seed):
+        return [grow_ref.grow_room(rooms[i]['points'], rooms[i]['obj_id'], rooms[i]['order'], None,
+                                   rng_ref.CounterStream(seed, rooms[i]['room_id']), net_fn=net_fn, policy='net', faithful=False) for i in picks]
+    seed, wants = seed_without_near_tie(oracle, range(0, 6), 5e-7)
+    if mode == 'free-run':
+        lg = LanedRegionGrower(net1, rooms_in_flight=68, lanes=None, rng='counter', seed=seed, policy='net')
+    else:
+        lg = LanedRegionGrower(net1, rooms_in_flight=68, lanes=None, rng='counter', seed=seed, policy='net', graph_iterations=4, free_run=False)
+    got = lg.run(rooms)
+    assert (len(lg.growers) == 1 and lg.growers[0].free_run) if mode == 'free-run' else (len(lg.growers) == 3 and all(g._graph is not None for g in lg.growers))
+    for i, want in zip(picks, wants):
+        assert regions_of(got[i]) == regions_of(want), 'room %d (%d points)' % (i, len(rooms[i]['points']))
+        np.testing.assert_array_equal(got[i].cluster_label, want.cluster_label)
+        np.testing.assert_array_equal(got[i].filled_label, want.filled_label)
+    for room, res in zip(rooms, got):                      # (no partition invariant here: a region the network empties leaves its seed to the fill-in)
+        assert res.filled_label.min() >= 1 and len(res.regions) > 0

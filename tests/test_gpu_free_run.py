@@ -1,7 +1,8 @@
 """GPU: free-running launches (lrg_grow_async: every slot at its own pace inside one launch, csrc/lrg_async.inl) against the
 lock-step iterations (lrg_grow_step_packed) and the oracle.  Same front code, same tile code on the same rows, so regions and
 labels must agree exactly -- whatever the number of front workgroups, tile teams, steps per launch or the order in which the
-slots happen to be served (test_region_grow.py:208-306 per slot; rooms are independent, :110-183)."""
+slots happen to be served (test_region_grow.py:208-306 per slot; rooms are independent, :110-183).  (With nine slots the lock-step
+launches sum the heads' pooled product on the matrix cores, the free-running kernel with vector FMAs in the same order.)"""
 import numpy as np
 import pytest
 
@@ -24,7 +25,7 @@ def _rooms():
            [small_room(300, 1500, furniture=4, room_id=13), small_room(301, 2500, furniture=6, room_id=14)]
 
 
-@pytest.mark.parametrize('steps,fronts,teams,in_flight', [(1, 0, 0, 5), (7, 0, 0, 5), (64, 1, 1, 3), (64, 5, 3, 5), (16, 2, 2, 2)])
+@pytest.mark.parametrize('steps,fronts,teams,in_flight', [(1, 0, 0, 5), (7, 0, 0, 5), (64, 1, 1, 3), (64, 5, 3, 5), (16, 2, 2, 2), (64, 0, 0, 9)])
 def test_free_run_equals_lock_step(net, steps, fronts, teams, in_flight):
     from learn_region_grow_amd.grow import RegionGrower
     rooms = _rooms()

@@ -100,11 +100,11 @@ def test_legacy_matches_reference_script_output(net, name, restarts):
     res = RegionGrower(net, rooms_in_flight=1, rng='legacy', restarts=restarts).run([room])[0]
     same_regions(res.regions, want.regions)
     np.testing.assert_array_equal(res.filled_label, want.filled_label)
-    if not np.array_equal(res.filled_label, g['filled_label']):
-        # the oracle itself (NumPy network) reproduces the golden exactly (tests/test_oracle_golden.py); a
-        # difference here can only come from a draw within fp32 noise of its confidence
-        assert want.min_rel_margin < OTHER_NETWORK_MARGIN, 'labels differ from the reference output without a near-tie'
-        pytest.xfail('near-tie Bernoulli draw (margin %.2e) flipped by fp32 rounding of the logits' % want.min_margin)
+    # against the reference script's own output (tests/golden: test_region_grow.py / test_random_restart.py run unmodified): the inputs are
+    # fixed, so this either holds or it does not -- the closest Bernoulli draw of these two runs keeps a relative distance of
+    # > 1e-5 from its confidence (the oracle's min_rel_margin), far above what float32 rounding of the logits can move
+    assert want.min_rel_margin > OTHER_NETWORK_MARGIN / 100
+    np.testing.assert_array_equal(res.filled_label, g['filled_label'])
 
 
 def test_legacy_many_rooms_in_flight(net):
@@ -176,8 +176,9 @@ def test_lanes_do_not_change_results(net, lanes, in_flight):
 @pytest.mark.parametrize('restarts', [1, 3])
 def test_packed_iterations_equal_the_nine_launch_step(net, restarts):
     """lrg_grow_step_packed (one fused front kernel per slot + the network on packed distinct rows) against lrg_grow_step (the
-    nine-launch chain on padded per-slot tiles), and a HIP-graph replay of four packed iterations per host call: same
-    regions, same labels.  Rooms from 0.5 k to 6 k points, so regions above 512 / 1024 / 4096 points occur."""
+    nine-launch chain on padded per-slot tiles), a HIP-graph replay of four packed iterations per host call, and (greedy growing)
+    the free-running launches of lrg_grow_async: same regions, same labels.  Rooms from 0.5 k to 6 k points, so regions above
+    512 / 1024 / 4096 points occur."""
     import torch
     from learn_region_grow_amd.grow import RegionGrower
     rooms = [small_room(620 + i, n, furniture=f, room_id=50 + i) for i, (n, f) in enumerate([(500, 0), (900, 2), (2500, 3), (6000, 4)])]
@@ -185,21 +186,26 @@ def test_packed_iterations_equal_the_nine_launch_step(net, restarts):
     for policy in ('gt', 'net'):
         a = RegionGrower(net, packed=False, policy=policy, **kw)
         ra = a.run(rooms)
-        b = RegionGrower(net, packed=True, policy=policy, **kw)
+        b = RegionGrower(net, packed=True, free_run=False, policy=policy, **kw)
         rb = b.run(rooms)
-        assert not a.packed and b.packed
+        assert not a.packed and b.packed and not b.free_run
         st = torch.cuda.Stream()
         with torch.cuda.stream(st):
-            c = RegionGrower(net, packed=True, graph_iterations=4, policy=policy, **kw)
+            c = RegionGrower(net, packed=True, free_run=False, graph_iterations=4, policy=policy, **kw)
             rc = c.run(rooms)
         assert c._graph is not None
-        for x, y, z in zip(ra, rb, rc):
+        d = RegionGrower(net, packed=True, policy=policy, **kw)          # free-running launches where they apply (greedy growing)
+        rd = d.run(rooms)
+        assert d.free_run == (restarts == 1)
+        for x, y, z, w in zip(ra, rb, rc, rd):
             same_regions(y.regions, x.regions)
             same_regions(z.regions, x.regions)
+            same_regions(w.regions, x.regions)
             np.testing.assert_array_equal(x.cluster_label, y.cluster_label)
             np.testing.assert_array_equal(x.filled_label, y.filled_label)
             np.testing.assert_array_equal(x.filled_label, z.filled_label)
-            assert x.total_steps == y.total_steps == z.total_steps
+            np.testing.assert_array_equal(x.filled_label, w.filled_label)
+            assert x.total_steps == y.total_steps == z.total_steps == w.total_steps
 
 
 def test_unequalised_room_is_rejected(net):
