@@ -538,7 +538,7 @@ def main():
     def fixed_work(R, n_slots):
         jobs = jobs_of(R, 100000)
         sizes = [len(j['points']) for j in jobs]
-        mine = lrg_dist.shard_rooms_lpt(sizes, world)[rank]
+        mine = sorted(lrg_dist.shard_rooms_lpt(sizes, world)[rank], key=lambda j: -sizes[j])      # largest first: the small rooms fill the tail
         my_jobs = [jobs[j] for j in mine]
         fl = _Leg(net, my_jobs, min(n_slots, max(1, len(my_jobs))), args.mode, args, grow_kw, 0, dev, step_us)
         barrier()
