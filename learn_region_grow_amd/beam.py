@@ -24,6 +24,7 @@ class BeamSearchGrower(RegionGrower):
     """A room in flight = one group of beam_width * search_width slots; a level of every room in flight = one call of
     lrg_beam_level (queue logic, child set-up, the loop's kernels) with no host decision in between.  The host only watches the
     stats ring for finished rooms (as in greedy growing), fills them in and binds the next room."""
+    device_bind = False      # (groups of beam x search slots with a queue of their own: bound on the host, bind_group; reset_room eager)
 
     def __init__(self, net, rooms_in_flight=16, beam_width=3, search_width=3, seed=0, policy='net', resolution=0.1,
                  cluster_threshold=10):

@@ -75,6 +75,24 @@ __device__ __forceinline__ void lrg_st_coh(float *p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void lrg_st_coh(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16 bytes at once (one fabric transaction instead of two or four: a narrow sc1 store is a write of its own, 452 KB of write traffic
+// for an 8 KB tile of conv[1] rows as 8-byte stores, profiles/r03_pmc_free_run.json): through a buffer descriptor on `base` (wave-uniform)
+typedef unsigned int lrg_u32x4v __attribute__((ext_vector_type(4)));
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void lrg_st_coh4(float *base, unsigned byte_off, float4 v) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+    const lrg_u32x4v u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 16);       // aux 16 = sc1
+}
+__device__ __forceinline__ float4 lrg_ld_coh4(const float *base, unsigned byte_off) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+    const lrg_u32x4v u = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+#else
+__device__ __forceinline__ void lrg_st_coh4(float *, unsigned, float4) {}
+__device__ __forceinline__ float4 lrg_ld_coh4(const float *, unsigned) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+#endif
 __device__ __forceinline__ void lrg_st_coh2(float *p, float a, float b) {      // 8-byte aligned
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -245,10 +263,8 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             int row = idx / q, c4 = idx - row * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (4 * c4 < Kin) {
-                if constexpr (COH) {
-                    const float2 a = lrg_ld_coh2(P.x + (r0 + row) * P.ldx + 4 * c4), b = lrg_ld_coh2(P.x + (r0 + row) * P.ldx + 4 * c4 + 2);
-                    v = make_float4(a.x, a.y, b.x, b.y);
-                } else v = *reinterpret_cast<const float4 *>(P.x + (r0 + row) * P.ldx + 4 * c4);
+                if constexpr (COH) v = lrg_ld_coh4(P.x + r0 * P.ldx, (unsigned)(row * P.ldx + 4 * c4) * 4u);
+                else v = *reinterpret_cast<const float4 *>(P.x + (r0 + row) * P.ldx + 4 * c4);
             }
             *reinterpret_cast<float4 *>(&buf1[row * ld_x + 4 * c4]) = v;
         }
@@ -515,10 +531,8 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             for (int idx = tid; idx < FM * q; idx += FTHREADS) {
                 const int row = idx / q, c4 = idx - row * q;
                 const float4 v = *reinterpret_cast<const float4 *>(act_out + row * ld_out + 4 * c4);
-                if constexpr (COH) {
-                    lrg_st_coh2(gb + (unsigned)(row * L.N + 4 * c4), v.x, v.y);
-                    lrg_st_coh2(gb + (unsigned)(row * L.N + 4 * c4 + 2), v.z, v.w);
-                } else *reinterpret_cast<float4 *>(gb + (unsigned)(row * L.N + 4 * c4)) = v;
+                if constexpr (COH) lrg_st_coh4(gb, (unsigned)(row * L.N + 4 * c4) * 4u, v);
+                else *reinterpret_cast<float4 *>(gb + (unsigned)(row * L.N + 4 * c4)) = v;
             }
         }
         TRACE(2 + 2 * l + 1);

@@ -48,6 +48,8 @@ class RoomResult:
 
 
 class RegionGrower:
+    device_bind = True       # slots are (re)bound by a kernel (lrg_bind_group); a subclass with slot state of its own binds on the host
+
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
                  skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np', free_run=None,
@@ -352,7 +354,7 @@ class RegionGrower:
     # ------------------------------------------------------------------------------------------
     def reset_room(self, r):
         """Return room r to its pristine state (visited / labels cleared, cursor at 0)."""
-        if self.rng == 'counter':
+        if self.rng == 'counter' and self.device_bind:
             self._reset_pending.add(r)          # folded into the device-side bind that follows (one launch, no upload)
             return
         o, n = int(self.room_off[r]), self.room_n[r]
@@ -367,7 +369,7 @@ class RegionGrower:
     def bind(self, group, r):
         """Bind slot group `group` to room r: every slot waits with seed -1, so the next lrg_advance
         picks the room's first seed (:186-188)."""
-        if self.rng == 'counter' and type(self).__name__ == 'RegionGrower':
+        if self.rng == 'counter' and self.device_bind:
             # on the device (lrg_bind_group): a pageable host-to-device copy would block the host until this lane's stream has
             # drained, and the other lanes would starve meanwhile
             reset = 1 if r in self._reset_pending else 0

@@ -138,6 +138,7 @@ def main():
         golden_lrgnet(0, 13, 64, 128, 2, seed=16)       # 64-row multiples: the fused kernels' tile size
         golden_lrgnet(1, 13, 64, 64, 1, seed=17)
         golden_lrgnet(2, 12, 64, 64, 1, seed=18)
+        golden_lrgnet(None, 13, 64, 128, 2, seed=19)    # LITE=None wiring at a shape the fused kernels take (64-row multiples), Ni != Nn
     if 'greedy' in which:
         room = synthetic.generate_room_points(1500, seed=100).astype(np.float32)
         run_reference_script('test_region_grow.py', ['--area', '5'], room, 'greedy_room100')

@@ -54,6 +54,31 @@ def test_real_lrgnet_checkpoint_index(tmp_path):
         ck.load_lrgnet_weights(str(tmp_path / 'm.ckpt'), feature_size=12)
 
 
+def test_written_checkpoint_has_the_key_set_of_the_reference_bundle(tmp_path):
+    """What train_region_grow.py saves (LrgNetTrainer.checkpoint_numpy -> checkpoint.lrgnet_checkpoint_tensors): the variables, their
+    Adam slots, the beta powers and the global step -- the 99 keys, shapes and dtypes of models/lrgnet_model5.ckpt.index, i.e. what the
+    reference's ``Saver().restore`` (test_region_grow.py:92-93) asks a bundle for."""
+    shutil.copy(os.path.join(GOLDEN, 'lrgnet_model5.ckpt.index'), tmp_path / 'm.ckpt.index')
+    _, ref = ck.read_bundle_index(str(tmp_path / 'm.ckpt'))
+    w = synthetic.make_synthetic_weights(seed=3)
+    rs = np.random.RandomState(0)
+    m = {k: rs.randn(*np.shape(x)).astype(np.float32) for k, x in w.items()}
+    v = {k: np.abs(rs.randn(*np.shape(x))).astype(np.float32) for k, x in w.items()}
+    tensors = ck.lrgnet_checkpoint_tensors(w, m, v, step=123, beta1=0.9, beta2=0.999)
+    prefix = str(tmp_path / 'out.ckpt')
+    ck.write_bundle(prefix, tensors)
+    _, got = ck.read_bundle_index(prefix)
+    assert sorted(got) == sorted(ref) and len(got) == 99
+    for k in ref:
+        assert tuple(got[k].shape) == tuple(ref[k].shape) and got[k].dtype == ref[k].dtype, k
+    back = ck.load_bundle(prefix)
+    assert int(back['Variable']) == 123 and back['Variable'].dtype == np.int32
+    np.testing.assert_allclose(back['beta1_power'], 0.9 ** 123, rtol=1e-6)
+    np.testing.assert_array_equal(back['lrg_kernel0/Adam'], m['lrg_kernel0'])
+    np.testing.assert_array_equal(back['lrg_add_kernel0/Adam_1'], v['lrg_add_kernel0'])
+    assert set(ck.load_lrgnet_weights(prefix)) == set(w)
+
+
 def test_real_checkpoint_bytes_pass_their_crc(tmp_path):
     """Bytes TensorFlow wrote (MCPNet checkpoint of the reference, variables <= 4 KiB): masked CRC-32C of the raw
     tensor bytes equals the index entry; entries re-encode to the very bytes TensorFlow serialized."""

@@ -2,8 +2,11 @@
 """tf_ops/grouping replacements at the reference's own harness shapes:
     query_ball_point.cpp:88   b=32 n=512  m=128 nsample=64 c=64      G1 ball query, G3 group point, G4 its gradient
     selection_sort.cu:55      b=32 n=2048 m=512 k=128                 G2 selection sort, knn_point fused / unfused
-GPU: HIP events round `reps` launches.  CPU: the reference's OWN functions (tf_ops/grouping/test/*.cpp compiled into oracle/_ref by
-oracle/Makefile) on a bounded share of the batch, scaled.  Bytes: the algorithmic HBM bytes of SURVEY.md 8d, against 8 TB/s.
+GPU: HIP events round `reps` (>= 100) back-to-back launches.  CPU: the reference's OWN functions (tf_ops/grouping/test/*.cpp compiled
+into oracle/_ref by oracle/Makefile) on a bounded share of the batch, scaled.
+Rooflines: bytes that can reach HBM -- outputs + each input ONCE (a gather reads its 4 MB source 16 times over, from cache: pricing the
+gathered volume as HBM traffic gave 1.18 of the HBM peak in round 2) -- against 8 TB/s; the selection (G2, knn) is defined by its
+k x n compares per row and priced against the vector unit: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T compares/s.
 Prints one JSON object (also importable: grouping_rates())."""
 import json
 import os
@@ -30,7 +33,7 @@ class _quiet_stdout:
         os.close(self.saved)
 
 
-def _time_gpu(fn, reps=20):
+def _time_gpu(fn, reps=100):
     import torch
     fn()
     torch.cuda.synchronize()
@@ -43,7 +46,10 @@ def _time_gpu(fn, reps=20):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def grouping_rates(device='cuda:0', cpu=True, reps=20):
+VALU_COMPARES = 256 * 4 * 16 * 2.4e9
+
+
+def grouping_rates(device='cuda:0', cpu=True, reps=100):
     import torch
     from learn_region_grow_amd import grouping
     from oracle import grouping_ref as G         # CPU side: the reference's compiled functions (oracle/_ref)
@@ -61,9 +67,10 @@ def grouping_rates(device='cuda:0', cpu=True, reps=20):
     rows.append(('G1 query_ball_point', _time_gpu(lambda: grouping.query_ball_point(radius, ns, d1, d2), reps),
                  b * (n + m) * 12 + b * m * (ns + 1) * 4, lambda k: G.query_ball_point(radius, ns, x1[:k], x2[:k], use_reference=True)))
     rows.append(('G3 group_point', _time_gpu(lambda: grouping.group_point(dp, idx), reps),
-                 2 * b * m * ns * c * 4 + b * m * ns * 4, lambda k: G.group_point(pts[:k], idx.cpu().numpy()[:k], use_reference=True)))
+                 b * m * ns * c * 4 + b * n * c * 4 + b * m * ns * 4,      # output + the source once + the indices
+                 lambda k: G.group_point(pts[:k], idx.cpu().numpy()[:k], use_reference=True)))
     rows.append(('G4 group_point_grad', _time_gpu(lambda: grouping.group_point_grad(dp, idx, go), reps),
-                 2 * b * m * ns * c * 4 + b * m * ns * 4 + b * n * c * 4,
+                 b * m * ns * c * 4 + b * m * ns * 4 + b * n * c * 4,      # grad_out + the indices + grad_points once
                  lambda k: G.group_point_grad(go.cpu().numpy()[:k], idx.cpu().numpy()[:k], n, use_reference=True)))
     shape1 = dict(b=b, n=n, m=m, nsample=ns, c=c, radius=radius)
     for name, t, nbytes, cpu_fn in rows:
@@ -88,16 +95,19 @@ def grouping_rates(device='cuda:0', cpu=True, reps=20):
         _lib.check(lib.lrg_pairwise_sqdist(b, n, m, 3, _ptr(d1), _ptr(d2), _ptr(dist), _stream_ptr()), 'pairwise')
     shape2 = dict(b=b, n=n, m=m, k=k, c=3)
     t_pair = _time_gpu(pair, reps)
-    t_sel = _time_gpu(lambda: grouping.select_top_k(k, dist), 5)
-    t_fused = _time_gpu(lambda: grouping.knn_point(k, d1, d2, fused=True), 5)
-    t_unf = _time_gpu(lambda: grouping.knn_point(k, d1, d2, fused=False), 5)
+    t_sel = _time_gpu(lambda: grouping.select_top_k(k, dist), 100)
+    t_fused = _time_gpu(lambda: grouping.knn_point(k, d1, d2, fused=True), 100)
+    t_unf = _time_gpu(lambda: grouping.knn_point(k, d1, d2, fused=False), 100)
     bytes_sel = 3 * b * m * n * 4 + b * m * n * 4            # read dist, write out + outi (full size, the op's contract)
     bytes_fused = b * (n + m) * 12 + b * m * k * 8            # coordinates in, k (value, index) pairs out
     out['G2 select_top_k (full-size outputs)'] = dict(gpu_us=t_sel * 1e6, algorithmic_bytes=bytes_sel, GBps=bytes_sel / t_sel / 1e9,
-                                                      frac_of_hbm_peak=bytes_sel / t_sel / HBM, shape=shape2)
+                                                      frac_of_hbm_peak=bytes_sel / t_sel / HBM, shape=shape2, bound='valu compares',
+                                                      selection_compares=b * m * k * n, compares_per_sec=b * m * k * n / t_sel,
+                                                      frac_of_valu_compare_peak=b * m * k * n / t_sel / VALU_COMPARES)
     out['knn_point fused (lrg_knn_topk)'] = dict(gpu_us=t_fused * 1e6, algorithmic_bytes=bytes_fused, GBps=bytes_fused / t_fused / 1e9,
                                                  frac_of_hbm_peak=bytes_fused / t_fused / HBM, shape=shape2,
-                                                 selection_compares=b * m * k * n,
+                                                 selection_compares=b * m * k * n, bound='valu compares', compares_per_sec=b * m * k * n / t_fused,
+                                                 frac_of_valu_compare_peak=b * m * k * n / t_fused / VALU_COMPARES,
                                                  note='bound by the k x n compares of the selection the op is defined by, not by its bytes')
     out['knn_point unfused (distance matrix + select_top_k + slice)'] = dict(
         gpu_us=t_unf * 1e6, pairwise_us=t_pair * 1e6, algorithmic_bytes=bytes_sel + b * m * n * 4 + b * (n + m) * 12, shape=shape2)
