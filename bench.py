@@ -211,7 +211,8 @@ class _Leg:
         from learn_region_grow_amd.grow import LanedRegionGrower, RegionGrower
         self.torch, self.dev, self.jobs, self.fill = torch, dev, jobs, bool(args.fill)
         greedy = args.restarts == 1
-        self.free = greedy and (mode == 'free' or (mode == 'auto' and slots <= 96)) and bool(grow_kw.get('packed'))
+        small = max(len(j['points']) for j in jobs) <= 65536 if jobs else True      # (_lib.LRG_FREE_RUN_AUTO_POINTS: one front workgroup walks a room)
+        self.free = greedy and (mode == 'free' or (mode == 'auto' and slots <= 96 and small)) and bool(grow_kw.get('packed'))
         self.slots = slots
         if self.free:
             self.stream = torch.cuda.Stream(device=dev)
@@ -340,7 +341,8 @@ def main():
     # steady leg
     # ------------------------------------------------------------------------------------------------------------------
     step_us = args.step_ms * 1e3
-    free_steady = args.restarts == 1 and packed and (args.mode == 'free' or (args.mode == 'auto' and slots <= 96))
+    free_steady = args.restarts == 1 and packed and (args.mode == 'free' or (args.mode == 'auto' and slots <= 96 and
+                                                                         max(len(r['points']) for r in base) <= _lib.LRG_FREE_RUN_AUTO_POINTS))
     ev_pairs = []
     if free_steady:
         # enough jobs for the warm-up and the timed steps at twice the rate seen so far (~650 rooms/s per GPU), at least two per slot

@@ -460,6 +460,9 @@ typedef struct LrgAsyncBuffers {
     int32_t teams;              /* tile teams (four wavefronts) per worker workgroup: 1 .. 3, 0 = default                 */
     int32_t compute_units;      /* workgroups of the launch in all (front + worker), at most one per CU of the device; 0 = all CUs */
     int32_t poll_sleep;         /* idle tile teams poll the queue every poll_sleep x ~0.25 us; 0 = default                  */
+    int32_t branch_parts;       /* tasks per branch tile (1, 2 or 4: they share the four column blocks of its pooled layer and each run the
+                                   layers before it again); 0 = by the number of slots (2 up to 12 slots, else 1)                    */
+    int32_t pad;
     int32_t *room_queue;        /* nullable: rooms waiting for a slot -- [0] rooms handed out so far (the caller zeroes it when it refills
                                    the queue), [1] rooms queued, [2 + k] = room index | reset << 30 (reset: clear visited / labels /
                                    cursor first, as lrg_bind_group does).  A slot whose room is finished (or that has none) takes the

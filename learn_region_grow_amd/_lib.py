@@ -86,7 +86,7 @@ class LrgPackedBuffers(ctypes.Structure):
 
 class LrgAsyncBuffers(ctypes.Structure):
     _fields_ = [('queue', _fp), ('queue_bytes', ctypes.c_size_t), ('sync', _fp), ('front_workgroups', ctypes.c_int32), ('teams', ctypes.c_int32),
-                ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('room_queue', _fp), ('work', _fp), ('debug_ticks', _fp)]
+                ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('branch_parts', ctypes.c_int32), ('pad', ctypes.c_int32), ('room_queue', _fp), ('work', _fp), ('debug_ticks', _fp)]
 
 
 class LrgBeamGroup(ctypes.Structure):
@@ -100,9 +100,11 @@ class LrgBeamGroup(ctypes.Structure):
 LRG_ROW_TILE = 32
 LRG_LOG_WORDS = 8
 LRG_PACKED_MAX_POINTS = 32 * 4096      # lrg_grow_step_packed: rooms up to 131072 points
-LRG_PACKED_AUTO_POINTS = 65536         # ... chosen by default up to this size: its front kernel walks a room with ONE workgroup per
-                                       # slot, which loses to the chunk-parallel scans of lrg_grow_step on 100 k-point scenes (KITTI shape:
-                                       # 41 k vs 57 k instance-steps/s, profiles/r02_kitti_*)
+LRG_PACKED_AUTO_POINTS = 32 * 4096     # ... chosen by default up to its limit (round 2 stopped at 65536: the chunk-parallel scans of lrg_grow_step
+                                       # won on 100 k-point scenes then; eight KITTI-shaped scenes under the trained weights and the Bernoulli
+                                       # policy now: packed 88 k against 69 k instance-steps/s, profiles/r03_kitti_*.json)
+LRG_FREE_RUN_AUTO_POINTS = 65536       # free-running launches by default up to this room size: one front workgroup walks a room, and on 100 k-point
+                                       # scenes the lock-step launches do better (88 k against 78 k)
 LRG_VGRID_MAX_CELLS = 1 << 26          # dense voxel grid of a room (LrgRoom.vgrid): at most 64 M cells (256 MB) per room ...
 LRG_VGRID_TOTAL_CELLS = 1 << 31        # ... and 8 GB for the rooms of one grower
 LRG_DONE_RING = 1020

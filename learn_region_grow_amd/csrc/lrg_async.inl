@@ -62,6 +62,7 @@ struct LrgAsyncArgs {
     int qmask;                   // ring entries - 1 (power of two)
     int n_slots, n_front, teams;
     int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
+    int branch_parts;            // tasks per branch tile (1, 2, 4): they share the column blocks of the pooled layer (lrg_fused_tile)
     int max_steps;               // evaluations per slot in this launch
     long long budget_ticks;      // wall_clock64 ticks (100 MHz) after which no new evaluation is started
     long long abort_ticks;       // ... after which a waiting workgroup gives up
@@ -184,12 +185,13 @@ LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
     float *sm = lrg_async_smem + sm_off;
     const LrgLdsTeam team = lrg_async_team(A, sm, target);
     const int tid = team.tid(), lane = tid & 63;
-    const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
+    const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 31, part = (code >> 5) & 3;      // (tile, part of its pooled layer)
     int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
     int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
     const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
     long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;      // (LRG_TRACE build: cycle stamps of the tile's phases)
-    lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps);
+    lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps,
+                                                                                            LrgNoWait(), part, A.branch_parts);
 #if LRG_TRACE == 2176
     if (tid == 0 && A.dbg) {      // cycles since the tile began, at every stamp (tools/free_run_perf.py prints their means)
         for (int i = 1; i < 21; ++i) if (stamps[i] > stamps[0]) lrg_dbg_add(A, 32 + i, stamps[i] - stamps[0]);
@@ -436,10 +438,9 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
             // rows, centre, the zeroed pooled feature and the targets are out (write-through) once every wavefront has drained; only
             // then the entries are written -- a consumer waits for its entry, not for the reservation.
             const int nt_in = ((r >> 16) + 31) >> 5, nt_nb = ((r & 0xFFFF) + 31) >> 5;
-            int base = 0;
             if (tid == 0) {
                 int32_t *sy = A.sync + (long)s * LRG_ASYNC_SYNC_WORDS;
-                C.tgt[i][0] += nt_in + nt_nb; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb;
+                C.tgt[i][0] += (nt_in + nt_nb) * A.branch_parts; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb;
                 lrg_st_coh(&sy[1], C.tgt[i][0]); lrg_st_coh(&sy[3], C.tgt[i][1]); lrg_st_coh(&sy[5], C.tgt[i][2]);
                 lrg_st_coh(&sy[6], nt_in); lrg_st_coh(&sy[7], nt_nb);
                 if (A.dbg) {
@@ -453,15 +454,15 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 }
                 C.state[i] = 1;
                 C.steps[i] += 1;
-                base = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL], nt_in + nt_nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                C.bc[3] = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL], (nt_in + nt_nb) * A.branch_parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             lrg_drain_stores();
             __syncthreads();
-            if (tid < 64) {
-                base = __shfl(base, 0);
-                if (lane < nt_in + nt_nb)
-                    lrg_st_coh(&A.queue[LRG_AQ_RING + ((base + lane) & A.qmask)],      // (ring 0)
-                               lane < nt_in ? LRG_TASK(LRG_TASK_BRANCH, s, 0, lane) : LRG_TASK(LRG_TASK_BRANCH, s, 1, lane - nt_in));
+            if (tid < 128) {                                     // (up to 32 tiles x 4 parts)
+                const int nt = nt_in + nt_nb, t = tid / A.branch_parts, part = tid - t * A.branch_parts;
+                if (tid < nt * A.branch_parts)
+                    lrg_st_coh(&A.queue[LRG_AQ_RING + ((C.bc[3] + tid) & A.qmask)],      // (ring 0)
+                               (t < nt_in ? LRG_TASK(LRG_TASK_BRANCH, s, 0, t) : LRG_TASK(LRG_TASK_BRANCH, s, 1, t - nt_in)) | (part << 5));
             }
             __syncthreads();
         }

@@ -205,9 +205,13 @@ __device__ __forceinline__ void tile_mfma_first(f32x16 (&acc)[RT], const float *
 struct LrgNoWait { __device__ __forceinline__ void operator()() const {} };
 // before_inst_bias: called by every thread right before the first per-instance bias (the hoisted pooled product of a head) is read --
 // the free-running kernel's head tiles wait there for the pooled blocks of their slot.
+// part / nparts (ONE only, nparts 1, 2 or 4): the column blocks of the POOLED layer -- 128 -> 512: four passes, more than half of a branch
+// tile's time -- are shared among nparts tasks that each run the layers before it again (a quarter of the FLOPs); the column maxima
+// are independent of each other, part 0 alone stores conv[1].  A tile's latency for its work, where teams are idle anyway.
 template <int CAP0, int CAP1, int RT, int FD, bool DIRECT, bool PACKED, bool COH, class TEAM, bool ONE = false, class WAIT = LrgNoWait>
 __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, int inst, int tile, int nvalid, int nrows_packed,
-                                              float *smem, const TEAM &team, long long *trace_sh, const WAIT &before_inst_bias = WAIT()) {
+                                              float *smem, const TEAM &team, long long *trace_sh, const WAIT &before_inst_bias = WAIT(),
+                                              int part = 0, int nparts = 1) {
     constexpr int FM = 32 * RT;      // rows (points) per tile
     static_assert(!PACKED || RT == 1, "packed rows use 32-row tiles");
     float *buf0 = smem;                       // outputs of even layers
@@ -330,14 +334,20 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
         const int ntile = m22 ? 1 : RT;
         const float *ap = act_in + (rbase + li) * ld_in + 4 * lh;
         const int ncb = m22 ? 1 : (L.N + FBN - 1) / FBN;
+        // (this task's share of the pooled layer's column blocks; every other layer whole)
+        const bool shared = ONE && nparts > 1 && (L.flags & LRG_FL_POOL) && !(L.flags & LRG_FL_KEEP);
+        const int cb_lo = shared ? part * ncb / nparts : 0, cb_hi = shared ? (part + 1) * ncb / nparts : ncb;
         TRACE(2 + 2 * l);
-        for (int cb = 0; cb < ncb; ++cb) {
+        for (int cb = cb_lo; cb < cb_hi; ++cb) {
             const int col0 = col_of(L, l, cb);
             const bool wave_on = col0 < L.N;         // a 64-wide layer outside the 2x2 layout keeps two of the four waves busy
             // the pass after this one: next column block, else the next layer's first
-            const bool same = cb + 1 < ncb;
+            const bool same = cb + 1 < cb_hi;
             const LrgFusedLayer &Lx = same ? L : Lnext;
-            int coln = col_of(Lx, same ? l : l + 1, same ? cb + 1 : 0);
+            // (the first pass of the next layer: this task's first column block of it, if that is the shared pooled layer)
+            const bool next_shared = !same && ONE && nparts > 1 && (Lx.flags & LRG_FL_POOL) && !(Lx.flags & LRG_FL_KEEP) && l + 1 < nlayers;
+            const int cb_next = same ? cb + 1 : next_shared ? part * ((Lx.N + FBN - 1) / FBN) / nparts : 0;
+            int coln = col_of(Lx, same ? l : l + 1, cb_next);
             if (coln >= Lx.N) coln = 0;
             const float4 *wpn = wptr(Lx, coln);
 
@@ -354,7 +364,7 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             constexpr int RB = 4;
             float bk[RB] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (PACKED) {
-                if ((L.flags & LRG_FL_INST_BIAS) && L.bias && cb == 0) before_inst_bias();
+                if ((L.flags & LRG_FL_INST_BIAS) && L.bias && cb == cb_lo) before_inst_bias();
                 if (wave_on && (L.flags & LRG_FL_INST_BIAS) && L.bias) {
 #pragma unroll
                     for (int k = 0; k < (ONE ? 1 : RB); ++k) {
@@ -370,14 +380,14 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
                         if (L.K == 64) tile_mfma<8, RT, 1, FD>(acc, ap, ld_in, wp, wpn, bq);
                         else {
                             prefetch_b<FD>(bq, wpn);
-                            tile_mfma_first<RT, 1>(acc, ap, ld_in, wp, L.ng, bf, cb == 0);
+                            tile_mfma_first<RT, 1>(acc, ap, ld_in, wp, L.ng, bf, cb == cb_lo);
                         }
                     } else if (L.K == 128) tile_mfma<16, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
                     else if (L.K == 64) tile_mfma<8, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
                     else if (L.K == 256) tile_mfma<32, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
                     else {
                         prefetch_b<FD>(bq, wpn);
-                        tile_mfma_first<RT, RT>(acc, ap, ld_in, wp, L.ng, bf, cb == 0);
+                        tile_mfma_first<RT, RT>(acc, ap, ld_in, wp, L.ng, bf, cb == cb_lo);
                     }
                 } else {
                     if (L.K == 128) tile_mfma<16, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
@@ -385,7 +395,7 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
                     else if (L.K == 256) tile_mfma<32, RT, RT, FD>(acc, ap, ld_in, wp, wpn, bq);
                     else {
                         prefetch_b<FD>(bq, wpn);
-                        tile_mfma_first<RT, RT>(acc, ap, ld_in, wp, L.ng, bf, cb == 0);
+                        tile_mfma_first<RT, RT>(acc, ap, ld_in, wp, L.ng, bf, cb == cb_lo);
                     }
                 }
             } else {
@@ -517,14 +527,14 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
                     const int ins = ONE ? inst : run_inst[k];
                     if (ins < 0) continue;
                     int *dst = reinterpret_cast<int *>(P.pool + (long)ins * P.pool_stride);
-                    for (int c = tid; c < L.N; c += FTHREADS) {
+                    for (int c = cb_lo * FBN + tid; c < min(L.N, cb_hi * FBN); c += FTHREADS) {      // (the columns this task ran)
                         const int m = reinterpret_cast<const int *>(act_out)[k * L.N + c];
                         if (m > 0) atomicMax(dst + c, m);
                     }
                 }
             }
         }
-        if (L.gout && (L.flags & LRG_FL_KEEP) && !inplace) {
+        if (L.gout && (L.flags & LRG_FL_KEEP) && !inplace && part == 0) {
             // HBM copy of a layer the next one reads from LDS (conv[1] for the heads, :130,:134): whole rows, float4
             const int q = L.N >> 2;
             float *gb = L.gout + r0 * L.N;

@@ -321,7 +321,7 @@ class RegionGrower:
             if self.want_free_run is None:
                 # (auto: where a step is a chain of latencies -- up to ~100 slots; with hundreds of slots in flight the lock-step
                 #  launches, whose tiles pack the rows of all slots, get more out of the chip: 272 rooms 1.17 M against 0.82 M)
-                self.free_run = can_free and S <= 96 and os.environ.get('LRG_FREE_RUN', '1') != '0'
+                self.free_run = can_free and S <= 96 and max(ns) <= _lib.LRG_FREE_RUN_AUTO_POINTS and os.environ.get('LRG_FREE_RUN', '1') != '0'
             else:
                 self.free_run = bool(self.want_free_run)
             if self.free_run:
@@ -334,6 +334,7 @@ class RegionGrower:
                 ab.teams = self.free_run_teams or int(os.environ.get('LRG_FREE_RUN_TEAMS', '0'))
                 ab.compute_units = int(os.environ.get('LRG_FREE_RUN_CUS', '0'))
                 ab.poll_sleep = int(os.environ.get('LRG_FREE_RUN_POLL', '0'))
+                ab.branch_parts = int(os.environ.get('LRG_FREE_RUN_PARTS', '0'))
                 self.a_work = torch.zeros(4, dtype=torch.int64, device=dev)      # evaluations, inlier rows, neighbour rows, tiles
                 ab.work = self.a_work.data_ptr()
                 if os.environ.get('LRG_FREE_RUN_DEBUG') == '1':          # stage-by-stage tick accumulators (tools/free_run_perf.py)

@@ -30,7 +30,11 @@ def main():
     from learn_region_grow_amd.grow import RegionGrower, LanedRegionGrower
     dev = torch.device('cuda:0')
     weights = synthetic.load_trained_weights()
-    if args.workload == 'scannet':
+    extra = {}
+    if args.workload == 'kitti':
+        rooms = workloads.kitti_scenes(min(args.rooms, 8), seed_base=5000, cache_dir='/tmp/lrg_cache')
+        extra = dict(resolution=0.3, packed=True)
+    elif args.workload == 'scannet':
         rooms = workloads.scannet_rooms(min(args.rooms, 39), seed_base=7000, cache_dir='/tmp/lrg_cache')
     else:
         rooms = workloads.area5_rooms(args.rooms, seed_base=1000, cache_dir='/tmp/lrg_cache')
@@ -100,7 +104,7 @@ def main():
         print(json.dumps(row), flush=True)
         results.append(row)
 
-    kw = dict(rooms_in_flight=args.in_flight or len(rooms), rng='counter', policy='net', seed=0)
+    kw = dict(rooms_in_flight=args.in_flight or len(rooms), rng='counter', policy='net', seed=0, **extra)
     if args.jobs:
         if args.lockstep:
             from learn_region_grow_amd.grow import LanedRegionGrower
