@@ -1293,6 +1293,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
 #endif
         return (rin << 16) | rnb;
     }
+    const long long t_small = (ASYNC && a.phase_dbg) ? wall_clock64() : 0;
     if (wave < 9) {                                              // one wavefront per centred channel, keys in registers
         const int ch = lrg_centred_channel(wave, F);
         if (ch >= 0) {
@@ -1302,8 +1303,10 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
                                        : lrg_median_wave_r64(cs.base, cur_idx, cs.stride, nc);
             if (lane == 0) sh_c[ch] = m;
         }
+        if constexpr (ASYNC) if (a.phase_dbg && tid == 0) atomicAdd(&a.phase_dbg[0], (unsigned long long)(wall_clock64() - t_small));      // (one median)
     } else {
         lrg_front_gather<PAD, ASYNC>(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
+        if constexpr (ASYNC) if (a.phase_dbg && tid == 9 * 64) atomicAdd(&a.phase_dbg[7], (unsigned long long)(wall_clock64() - t_small));  // (the gather)
     }
     __syncthreads();
     TRACE2(s, 5); phase(5);

@@ -513,7 +513,10 @@ class RegionGrower:
         self._seen_done = done_total
         self.last_stats = (int(st[0]), int(st[1]), int(st[2]))
         if int(st[3]):
-            raise _lib.LrgHipError('lrg_grow_async gave up on a hand-over between workgroups (%d): results are invalid' % int(st[3]))
+            code = int(self.a_queue[48].item()) if getattr(self, 'a_queue', None) is not None else -1
+            raise _lib.LrgHipError('lrg_grow_async gave up on a hand-over between workgroups (%d front workgroups; reason %d: 1 launch past its '
+                                   'time limit, 2 a team waited too long for a task, 3 a team lost a wavefront at a barrier): results are invalid'
+                                   % (int(st[3]), code))
         return out
 
     # ------------------------------------------------------------------------------------------

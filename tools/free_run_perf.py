@@ -50,8 +50,8 @@ def main():
                              last_head_tile_in=d[4] / ev / 100, seen_by_front=d[5] / ev / 100,
                              branch_tile=d[10] / max(d[11], 1) / 100, pooled_block=d[12] / max(d[13], 1) / 100, head_tile=d[14] / max(d[15], 1) / 100,
                              team_wait_per_task=d[16] / max(d[17], 1) / 100)
-            row['front_phase_us'] = dict(zip(['update', 'commit_seed', 'query', 'sampling', 'gather(+small medians)', 'big medians'],
-                                             [float(x) / max(d[1], 1) / 100 for x in d[21:27]]))
+            row['front_phase_us'] = dict(zip(['update', 'commit_seed', 'query', 'sampling', 'gather(+small medians)', 'big medians', 'gather alone', 'one median alone'],
+                                             [float(x) / max(d[1], 1) / 100 for x in list(d[21:28]) + [d[20]]]))
             if d[32] > 0:      # LRG_TRACE build: mean cycles since the tile began at each stamp
                 names = ['staged'] + [x for l in range(5) for x in ('L%d start' % l, 'L%d end' % l)] + \
                         [x for c in range(4) for x in ('pass%d mfma' % c, 'pass%d epilogue' % c)] + ['end']
