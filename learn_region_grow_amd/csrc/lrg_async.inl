@@ -72,8 +72,12 @@ struct LrgAsyncArgs {
                                  // 3 last pooled-product block in, 4 last head tile in, 5 seen by the front workgroup, 6 evaluations;
                                  // 8 + 2 t busy ticks of task type t, 9 + 2 t their number; 16 ticks teams waited for a task, 17 waits
 };
+#ifndef LRG_ASYNC_DEBUG
+#define LRG_ASYNC_DEBUG 0        // 1: the tick accumulators of LrgAsyncBuffers.debug_ticks are compiled in (tools/free_run_perf.py builds with it);
+#endif                           // off by default: the stamps keep 64-bit values alive through the front and cost it registers
+#define LRG_DBG(A) (LRG_ASYNC_DEBUG && (A).dbg)
 __device__ __forceinline__ void lrg_dbg_add(const LrgAsyncArgs &A, int i, long long v) {
-    if (A.dbg) atomicAdd(&A.dbg[i], (unsigned long long)v);
+    if (LRG_DBG(A)) atomicAdd(&A.dbg[i], (unsigned long long)v);
 }
 
 __device__ __forceinline__ void lrg_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -193,7 +197,7 @@ LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
     lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps,
                                                                                             LrgNoWait(), part, A.branch_parts);
 #if LRG_TRACE == 2176
-    if (tid == 0 && A.dbg) {      // cycles since the tile began, at every stamp (tools/free_run_perf.py prints their means)
+    if (tid == 0 && LRG_DBG(A)) {      // cycles since the tile began, at every stamp (tools/free_run_perf.py prints their means)
         for (int i = 1; i < 21; ++i) if (stamps[i] > stamps[0]) lrg_dbg_add(A, 32 + i, stamps[i] - stamps[0]);
         lrg_dbg_add(A, 32, 1);
     }
@@ -205,7 +209,7 @@ LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
         if (lane == 0) {
             const int done = __hip_atomic_fetch_add(&sy[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             last = done == lrg_ld_coh(&sy[1]);
-            if (A.dbg) {
+            if (LRG_DBG(A)) {
                 const long long now = wall_clock64();
                 lrg_dbg_add(A, 8 + 2 * LRG_TASK_BRANCH, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_BRANCH, 1);
                 if (last) lrg_dbg_add(A, 2, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
@@ -237,7 +241,7 @@ LRG_ASYNC_ROLE int lrg_async_task_gemv(lrg_kargs_ptr kp_, int code_, int sm_off_
             const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             last = done == lrg_ld_coh(&sy[3]);
             if (last) { nt_in = lrg_ld_coh(&sy[6]); nt_nb = lrg_ld_coh(&sy[7]); }
-            if (A.dbg) {
+            if (LRG_DBG(A)) {
                 const long long now = wall_clock64();
                 lrg_dbg_add(A, 8 + 2 * LRG_TASK_GEMV, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_GEMV, 1);
                 if (last) lrg_dbg_add(A, 3, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
@@ -267,7 +271,7 @@ LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;
     lrg_fused_tile<32 * 260, 32 * 68, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[2 + side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps);
 #if LRG_TRACE == 8320
-    if (tid == 0 && A.dbg) {
+    if (tid == 0 && LRG_DBG(A)) {
         for (int i = 1; i < 21; ++i) if (stamps[i] > stamps[0]) lrg_dbg_add(A, 32 + i, stamps[i] - stamps[0]);
         lrg_dbg_add(A, 32, 1);
     }
@@ -276,7 +280,7 @@ LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     team.sync();
     if (tid == 0) {
         const int done = __hip_atomic_fetch_add(&sy[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-        if (A.dbg) {
+        if (LRG_DBG(A)) {
             const long long now = wall_clock64();
             lrg_dbg_add(A, 8 + 2 * LRG_TASK_HEAD, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_HEAD, 1);
             if (done == lrg_ld_coh(&sy[5])) lrg_dbg_add(A, 4, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
@@ -298,7 +302,7 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
     for (;;) {
         long long t_task = 0;
         if (tid == 0) {
-            const long long t_wait = A.dbg ? wall_clock64() : 0;
+            const long long t_wait = LRG_DBG(A) ? wall_clock64() : 0;
             const bool leave = false;
             if (leave) { word[0] = -1; }
             else {
@@ -322,7 +326,7 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
             if (code > 0) lrg_st_coh(slot, 0);
             word[0] = code;
             t_task = wall_clock64();
-            if (A.dbg) { lrg_dbg_add(A, 16, t_task - t_wait); lrg_dbg_add(A, 17, 1); }
+            if (LRG_DBG(A)) { lrg_dbg_add(A, 16, t_task - t_wait); lrg_dbg_add(A, 17, 1); }
             }
         }
         team.sync();
@@ -343,6 +347,16 @@ struct LrgAsyncFrontCtl {
     int bc[4];                           // broadcasts of thread 0
 };
 
+// ---- one slot's front step, a function of its own: the register allocation of lrg_front_greedy_kernel (no spills) instead of the
+//      ~230 spill instructions it had inlined into the serving loop below, for ~100 saved / restored registers per step ----
+LRG_ASYNC_ROLE int lrg_async_front_step(lrg_kargs_ptr kp_, int s_) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int s = lrg_uniform(s_);
+    const LrgAsyncKArgs &K = LRG_ASYNC_KARGS();
+    LrgFrontShared &SH = *reinterpret_cast<LrgFrontShared *>(lrg_async_smem);
+    return lrg_front_greedy_slot<true>(SH, K.slots, K.rooms, K.A.n_slots, K.prm, K.A.front, K.A.big, s);
+}
+
 // ---- a front workgroup: serves the slots f, f + n_front, ... ----
 __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_launch) {      // (the kernel's own body: no call, no saved registers)
     const LrgAsyncKArgs &K = LRG_ASYNC_KARGS();
@@ -351,7 +365,6 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
     LrgSlot *slots = K.slots;
     LrgRoom *rooms = K.rooms;
     const int tid = threadIdx.x, lane = tid & 63;
-    LrgFrontShared &SH = *reinterpret_cast<LrgFrontShared *>(smem);
     LrgAsyncFrontCtl &C = *reinterpret_cast<LrgAsyncFrontCtl *>(reinterpret_cast<char *>(smem) + ((sizeof(LrgFrontShared) + 15) & ~(size_t)15));
     const int f = blockIdx.x;
     const int n_served = (A.n_slots - f + A.n_front - 1) / A.n_front;          // slots f, f + n_front, ...
@@ -395,7 +408,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 __syncthreads();
                 if (!ready) continue;
                 st = 0;
-                if (A.dbg && tid == 0) {
+                if (LRG_DBG(A) && tid == 0) {
                     lrg_dbg_add(A, 5, (int)((unsigned)wall_clock64() - (unsigned)lrg_ld_coh(&A.sync[(long)s * LRG_ASYNC_SYNC_WORDS + 8])));
                     lrg_dbg_add(A, 6, 1);
                 }
@@ -409,8 +422,8 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
             const int stop = C.bc[1];
             __syncthreads();
             if (stop) { if (tid == 0) C.state[i] = 2; continue; }
-            const long long t_front = A.dbg ? wall_clock64() : 0;
-            const int r = lrg_front_greedy_slot<true>(SH, slots, rooms, A.n_slots, K.prm, A.front, A.big, s);
+            const long long t_front = LRG_DBG(A) ? wall_clock64() : 0;
+            const int r = __builtin_amdgcn_readfirstlane(lrg_async_front_step(kp, s));
             if (r == 0) {
                 // no evaluation: the slot is idle / its room finished (-> finished for this launch), or it stopped a region / goes on
                 // looking for a seed (-> served again at once)
@@ -443,7 +456,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 C.tgt[i][0] += (nt_in + nt_nb) * A.branch_parts; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb;
                 lrg_st_coh(&sy[1], C.tgt[i][0]); lrg_st_coh(&sy[3], C.tgt[i][1]); lrg_st_coh(&sy[5], C.tgt[i][2]);
                 lrg_st_coh(&sy[6], nt_in); lrg_st_coh(&sy[7], nt_nb);
-                if (A.dbg) {
+                if (LRG_DBG(A)) {
                     const long long now = wall_clock64();
                     lrg_st_coh(&sy[8], (int)(unsigned)now);
                     lrg_dbg_add(A, 0, now - t_front); lrg_dbg_add(A, 1, 1);

@@ -17,6 +17,9 @@
 // lrg_grow_step (same arithmetic on the same rows; the max-pool and the atomics are order-independent).
 
 #define LRG_FRONT_THREADS 1024
+#ifndef LRG_ASYNC_DEBUG
+#define LRG_ASYNC_DEBUG 0
+#endif
 #define LRG_FRONT_MAXCHUNK 32                         // 32 x 4096 points: rooms up to 131072 points (KITTI scenes: ~100 k)
 #define LRG_FRONT_MAXSAMPLE 1024                      // n_inlier, n_neighbor <= 1024
 
@@ -771,9 +774,9 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
     const int entry_status = status;
     TRACE2(s, 0);
-    long long t_phase = (ASYNC && a.phase_dbg) ? wall_clock64() : 0;
+    long long t_phase = (ASYNC && LRG_ASYNC_DEBUG && a.phase_dbg) ? wall_clock64() : 0;
     auto phase = [&](int i) {      // ticks since the last stamp -> accumulator i (thread 0)
-        if constexpr (ASYNC) if (a.phase_dbg && tid == 0) { const long long now = wall_clock64(); atomicAdd(&a.phase_dbg[i], (unsigned long long)(now - t_phase)); t_phase = now; }
+        if constexpr (ASYNC && LRG_ASYNC_DEBUG) if (a.phase_dbg && tid == 0) { const long long now = wall_clock64(); atomicAdd(&a.phase_dbg[i], (unsigned long long)(now - t_phase)); t_phase = now; }
     };
     const long long tick0 = a.phase_ticks ? wall_clock64() : 0;
 
@@ -1293,7 +1296,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
 #endif
         return (rin << 16) | rnb;
     }
-    const long long t_small = (ASYNC && a.phase_dbg) ? wall_clock64() : 0;
+    const long long t_small = (ASYNC && LRG_ASYNC_DEBUG && a.phase_dbg) ? wall_clock64() : 0;
     if (wave < 9) {                                              // one wavefront per centred channel, keys in registers
         const int ch = lrg_centred_channel(wave, F);
         if (ch >= 0) {
@@ -1303,10 +1306,10 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
                                        : lrg_median_wave_r64(cs.base, cur_idx, cs.stride, nc);
             if (lane == 0) sh_c[ch] = m;
         }
-        if constexpr (ASYNC) if (a.phase_dbg && tid == 0) atomicAdd(&a.phase_dbg[0], (unsigned long long)(wall_clock64() - t_small));      // (one median)
+        if constexpr (ASYNC && LRG_ASYNC_DEBUG) if (a.phase_dbg && tid == 0) atomicAdd(&a.phase_dbg[0], (unsigned long long)(wall_clock64() - t_small));      // (one median)
     } else {
         lrg_front_gather<PAD, ASYNC>(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
-        if constexpr (ASYNC) if (a.phase_dbg && tid == 9 * 64) atomicAdd(&a.phase_dbg[7], (unsigned long long)(wall_clock64() - t_small));  // (the gather)
+        if constexpr (ASYNC && LRG_ASYNC_DEBUG) if (a.phase_dbg && tid == 9 * 64) atomicAdd(&a.phase_dbg[7], (unsigned long long)(wall_clock64() - t_small));  // (the gather)
     }
     __syncthreads();
     TRACE2(s, 5); phase(5);

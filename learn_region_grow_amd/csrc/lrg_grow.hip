@@ -71,7 +71,7 @@ __global__ void lrg_hash_build_kernel(const int32_t *vox, int n, uint64_t *keys,
 // pageable host-to-device copy blocks the host until the stream has drained, which starves the other lanes)
 // ------------------------------------------------------------------------------------------------
 // (a device function: the free-running kernel rebinds a slot whose room is finished to the next room of its queue itself)
-__device__ __forceinline__ void lrg_bind_group_device(LrgSlot *slots, LrgRoom *rooms, int first_slot, int group_size, int room, int reset_room,
+__device__ __noinline__ void lrg_bind_group_device(LrgSlot *slots, LrgRoom *rooms, int first_slot, int group_size, int room, int reset_room,
                                                       int clear_masks) {
     const int tid = threadIdx.x;
     if (room >= 0 && reset_room) {                                            // test_region_grow.py:176-178 for a fresh pass
