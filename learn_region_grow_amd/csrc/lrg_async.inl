@@ -392,7 +392,8 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
         const int aborted = C.bc[2];
         __syncthreads();
         if (aborted) {
-            if (tid == 0 && A.front.stats) atomicAdd(reinterpret_cast<unsigned long long *>(&A.front.stats[3]), 1ULL);
+            if (tid == 0 && A.front.stats)      // (count of front workgroups that left this way; the reasons seen, one byte each, above it)
+                atomicAdd(reinterpret_cast<unsigned long long *>(&A.front.stats[3]), 1ULL | ((unsigned long long)(aborted & 0xFF) << 32));
             break;
         }
         int live = 0;

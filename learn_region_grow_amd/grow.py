@@ -513,10 +513,9 @@ class RegionGrower:
         self._seen_done = done_total
         self.last_stats = (int(st[0]), int(st[1]), int(st[2]))
         if int(st[3]):
-            code = int(self.a_queue[48].item()) if getattr(self, 'a_queue', None) is not None else -1
-            raise _lib.LrgHipError('lrg_grow_async gave up on a hand-over between workgroups (%d front workgroups; reason %d: 1 launch past its '
-                                   'time limit, 2 a team waited too long for a task, 3 a team lost a wavefront at a barrier): results are invalid'
-                                   % (int(st[3]), code))
+            raise _lib.LrgHipError('lrg_grow_async gave up on a hand-over between workgroups (%d front workgroups; sum of their reasons %d -- 1 launch '
+                                   'past its time limit, 2 a team waited too long for a task, 3 a team lost a wavefront at a barrier): results are invalid'
+                                   % (int(st[3]) & 0xFFFFFFFF, int(st[3]) >> 32))
         return out
 
     # ------------------------------------------------------------------------------------------
@@ -862,6 +861,10 @@ class LanedRegionGrower:
                     kw.get('packed', None) is not False and os.environ.get('LRG_FREE_RUN', '1') != '0'):
                 lanes = 1
         lanes = max(1, min(int(lanes), int(rooms_in_flight)))
+        if lanes > 1 and kw.get('free_run', None) is None:
+            # lanes are lock-step growers side by side; a free-running launch wants every CU for itself (two of them on two streams take
+            # turns CU by CU as the other's workgroups leave: correct, but neither is ever whole)
+            kw = dict(kw, free_run=False)
         share = [rooms_in_flight // lanes + (1 if k < rooms_in_flight % lanes else 0) for k in range(lanes)]
         self.streams = lane_streams(net.device, lanes, cu_partition)
         self.growers = []
