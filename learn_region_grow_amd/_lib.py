@@ -86,7 +86,7 @@ class LrgPackedBuffers(ctypes.Structure):
 
 class LrgAsyncBuffers(ctypes.Structure):
     _fields_ = [('queue', _fp), ('queue_bytes', ctypes.c_size_t), ('sync', _fp), ('front_workgroups', ctypes.c_int32), ('teams', ctypes.c_int32),
-                ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('branch_parts', ctypes.c_int32), ('pad', ctypes.c_int32), ('room_queue', _fp), ('work', _fp), ('debug_ticks', _fp)]
+                ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('branch_parts', ctypes.c_int32), ('gemv_units', ctypes.c_int32), ('room_queue', _fp), ('work', _fp), ('debug_ticks', _fp)]
 
 
 class LrgBeamGroup(ctypes.Structure):
@@ -258,7 +258,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lrg_abi_version() != 5:
+    if lib.lrg_abi_version() != 6:
         raise LrgHipError('ABI version mismatch')
     for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LrgBeamGroup, LrgAsyncBuffers)):
         if lib.lrg_struct_size(which) != ctypes.sizeof(st):

@@ -38,7 +38,8 @@
 #define LRG_AQ_FRONTS_DONE 32
 #define LRG_AQ_ABORT 48
 #define LRG_AQ_SECOND 64
-#define LRG_AQ_RING 128          // ring 0, then ring 1 (qmask + 1 entries each)
+#define LRG_AQ_GTAIL 96          // entries written to the pooled-product units' ring so far
+#define LRG_AQ_RING 128          // ring 0, then ring 1 (qmask + 1 entries each), then the units' ring (gmask + 1 entries)
 #define LRG_ASYNC_SYNC_WORDS 16  // per slot: 0 branch tiles done, 1 their target, 2 pooled-product blocks done, 3 target, 4 head tiles done, 5 target,
                                  //           6 inlier tiles, 7 neighbour tiles of the evaluation in flight
 #define LRG_ASYNC_MAX_SERVED 8   // slots per front workgroup
@@ -60,6 +61,9 @@ struct LrgAsyncArgs {
     int32_t *big;
     int32_t *room_queue;         // nullable: [0] rooms handed out so far, [1] rooms queued, [2 + k] = room index | reset << 30
     int qmask;                   // ring entries - 1 (power of two)
+    int gmask;                   // entries of the pooled-product units' ring - 1 (power of two, at least 2 n_slots)
+    int gemv_units;              // workgroups n_front .. n_front + gemv_units - 1 hold 32 columns each of the heads' pooled kernels in LDS (0: the
+                                 // pooled product is a task of the tile teams, 128 columns each)
     int n_slots, n_front, teams;
     int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
     int branch_parts;            // tasks per branch tile (1, 2, 4): they share the column blocks of the pooled layer (lrg_fused_tile)
@@ -139,6 +143,22 @@ __device__ __forceinline__ void lrg_async_gemv(const LrgGemvArgs &g, int slot, i
     }
 }
 
+
+// ---- pooled-product units: the heads' pooled kernels stay in LDS ----
+// As a task of the tile teams the pooled product of a slot is four trips of 512 KB from L2 (7.7 us each, 12.5 us from the last branch
+// tile to the last block with the queueing, profiles/r03_free8_perf.log) in the middle of the slot's chain of latencies.  The
+// kernels are the same for every slot: 2 x [P = 1024, C = 256] floats = 2 MB = sixteen CUs' LDS at 32 columns each.  A unit
+// (workgroup) loads its [P, 32] slice once per launch; its four teams of four wavefronts take the slots whose branch tiles have
+// all arrived from ONE ring that every unit reads (entry i: (generation of i) << 20 | slot, written once by the last branch tile
+// to arrive; team t of every unit takes the entries i = t (mod 4), no head pointer, nothing to reserve); a task = the slot's 4 KB
+// pooled row from L2, 128 FMAs per lane from LDS, 32 sums out.  Summation order: that of lrg_head_gemv_kernel (eight K ranges, MFMA
+// k order inside, the partial sums in order, the bias last) -- bit for bit what the tile teams' blocks give.
+#define LRG_GEMV_UNIT_COLS 32
+#define LRG_GEMV_UNIT_TEAMS 4
+#define LRG_GEMV_UNIT_TEAM_FLOATS(P) ((P) + 8 * LRG_GEMV_UNIT_COLS + 16)      // pooled row, partial sums, task word + barrier counter
+#define LRG_GEMV_UNIT_FLOATS(P) ((P) * LRG_GEMV_UNIT_COLS + LRG_GEMV_UNIT_TEAMS * LRG_GEMV_UNIT_TEAM_FLOATS(P))
+__device__ __forceinline__ int lrg_gemv_ring_tag(int i, int gmask) { return (((unsigned)i / (unsigned)(gmask + 1)) % 2047u) + 1; }
+
 // ---- the launch's arguments ----
 // ONE kernel parameter, so that every role below can be a function of its own (own register allocation: the tile code needs 112
 // VGPRs, a 1024-thread workgroup has 128 per lane -- inlined into one kernel body, the three task types and the front spilled
@@ -205,10 +225,13 @@ LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
     lrg_drain_stores();                              // conv[1] rows and the pooled maxima are out before the arrival
     team.sync();
     if (tid < 64) {
-        int last = 0;
+        int last = 0, nt_in = 0, nt_nb = 0;
         if (lane == 0) {
+            // (the evaluation's targets and tile counts were written before its tasks were published: fetched beside the arrival, not after it)
+            const int tgt = lrg_ld_coh(&sy[1]);
+            if (A.gemv_units) { nt_in = lrg_ld_coh(&sy[6]); nt_nb = lrg_ld_coh(&sy[7]); }
             const int done = __hip_atomic_fetch_add(&sy[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-            last = done == lrg_ld_coh(&sy[1]);
+            last = done == tgt;
             if (LRG_DBG(A)) {
                 const long long now = wall_clock64();
                 lrg_dbg_add(A, 8 + 2 * LRG_TASK_BRANCH, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_BRANCH, 1);
@@ -216,31 +239,54 @@ LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
             }
         }
         if (__shfl(last, 0)) {                       // the slot's pooled feature is complete: its product with the heads' first layers
-            const int nb = (A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS;
-            lrg_async_push(A, A.teams > 1 ? 1 : 0, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
+            if (A.gemv_units) {
+                // one entry for all units; and the head tiles at once -- they stage their rows and run the first pass of MFMAs while the
+                // units work, and wait for the product in front of that pass's epilogue (LrgWaitPooled)
+                if (lane == 0) {
+                    const int i = __hip_atomic_fetch_add(&A.queue[LRG_AQ_GTAIL], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    lrg_st_coh(&A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (i & A.gmask)], (lrg_gemv_ring_tag(i, A.gmask) << 20) | slot);
+                }
+                nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
+                lrg_async_push(A, A.teams > 1 ? 1 : 0, nt_nb + nt_in, lane, [&](int i) {
+                    return i < nt_nb ? LRG_TASK(LRG_TASK_HEAD, slot, 0, i) : LRG_TASK(LRG_TASK_HEAD, slot, 1, i - nt_nb);
+                });
+            } else {
+                const int nb = (A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS;
+                lrg_async_push(A, A.teams > 1 ? 1 : 0, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
+            }
         }
     }
     return team.target;
 }
 
-LRG_ASYNC_ROLE int lrg_async_task_gemv(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task) {
-    const lrg_kargs_ptr kp = lrg_uniform(kp_);
-    const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
-    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
-    float *sm = lrg_async_smem + sm_off;
-    const LrgLdsTeam team = lrg_async_team(A, sm, target);
+// a block of a slot's pooled product is out: the last one publishes the slot's head tiles
+template <class TEAM>
+__device__ __forceinline__ void lrg_async_gemv_arrive(const LrgAsyncArgs &A, const TEAM &team, int slot, long long t_task) {
     const int tid = team.tid(), lane = tid & 63;
-    const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
     int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
-    lrg_async_gemv(A.gemv, slot, side, idx, sm, team);
     lrg_drain_stores();
     team.sync();
+    if (A.gemv_units) {
+        // the head tiles of the slot are in flight already and poll this counter (LrgWaitPooled): nothing to come back for
+        if (tid == 0) {
+            if (LRG_DBG(A)) {
+                const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                const long long now = wall_clock64();
+                lrg_dbg_add(A, 8 + 2 * LRG_TASK_GEMV, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_GEMV, 1);
+                if (done == lrg_ld_coh(&sy[3])) lrg_dbg_add(A, 3, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+            } else {
+                __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
     if (tid < 64) {
         int last = 0, nt_in = 0, nt_nb = 0;
         if (lane == 0) {
+            const int tgt = lrg_ld_coh(&sy[3]);
+            nt_in = lrg_ld_coh(&sy[6]); nt_nb = lrg_ld_coh(&sy[7]);
             const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-            last = done == lrg_ld_coh(&sy[3]);
-            if (last) { nt_in = lrg_ld_coh(&sy[6]); nt_nb = lrg_ld_coh(&sy[7]); }
+            last = done == tgt;
             if (LRG_DBG(A)) {
                 const long long now = wall_clock64();
                 lrg_dbg_add(A, 8 + 2 * LRG_TASK_GEMV, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_GEMV, 1);
@@ -254,10 +300,139 @@ LRG_ASYNC_ROLE int lrg_async_task_gemv(lrg_kargs_ptr kp_, int code_, int sm_off_
             });
         }
     }
+}
+
+LRG_ASYNC_ROLE int lrg_async_task_gemv(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    float *sm = lrg_async_smem + sm_off;
+    const LrgLdsTeam team = lrg_async_team(A, sm, target);
+    const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
+    lrg_async_gemv(A.gemv, slot, side, idx, sm, team);
+    lrg_async_gemv_arrive(A, team, slot, t_task);
     return team.target;
 }
 
-LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task) {
+// ---- a pooled-product unit (see LRG_GEMV_UNIT_COLS above): `unit` = 0 .. gemv_units - 1, all sixteen wavefronts arrive here ----
+LRG_ASYNC_ROLE void lrg_async_gemv_unit(lrg_kargs_ptr kp_, int unit_, long long t_launch) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int unit = lrg_uniform(unit_);
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    const LrgGemvArgs &g = A.gemv;
+    const int P = g.P, kq = P >> 3;
+    const int upz = g.C / LRG_GEMV_UNIT_COLS;                 // units per head
+    const int z = unit / upz, col0 = (unit - z * upz) * LRG_GEMV_UNIT_COLS;
+    float *wl = lrg_async_smem;                                // [P][32] this unit's columns of head z's pooled kernel
+    {   // the slice, once per launch: 16-byte loads, eight per row
+        const float *w = g.w[z] + col0;
+        for (int i = threadIdx.x; i < P * (LRG_GEMV_UNIT_COLS / 4); i += LRG_FRONT_THREADS) {
+            const int row = i >> 3, q = i & 7;
+            *reinterpret_cast<float4 *>(wl + row * LRG_GEMV_UNIT_COLS + 4 * q) = *reinterpret_cast<const float4 *>(w + (long)row * g.ldw + 4 * q);
+        }
+    }
+    const int t = lrg_uniform((int)threadIdx.x >> 8);
+    float *sm = lrg_async_smem + P * LRG_GEMV_UNIT_COLS + t * LRG_GEMV_UNIT_TEAM_FLOATS(P);
+    float *pl = sm, *part = sm + P;
+    int *word = reinterpret_cast<int *>(part + 8 * LRG_GEMV_UNIT_COLS);      // [0] task of this round, [4] barrier counter
+    int *ticket = reinterpret_cast<int *>(lrg_async_smem + LRG_GEMV_UNIT_FLOATS(P));      // the unit's next ring entry: taken by whichever team is free
+    if ((threadIdx.x & 255) == 0) { word[0] = 0; word[4] = 0; }
+    if (threadIdx.x == 0) *ticket = 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // the slice is in place; from here on the teams go their own ways
+    LrgLdsTeam team;
+    team.cnt = &word[4];
+    team.target = 0;
+    team.base = (int)(threadIdx.x & ~255u);
+    team.gave_up = &A.queue[LRG_AQ_ABORT];
+    const int tid = team.tid(), lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, r = 2 * wave + (lane >> 5);      // this lane's column and K range
+    const float bias = g.bias[z] ? g.bias[z][col0 + (tid & 31)] : 0.f;
+    const int32_t *ring = A.queue + LRG_AQ_RING + 2 * (A.qmask + 1);
+    for (;;) {
+        long long t_task = 0;
+        if (tid == 0) {
+            const int i = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int32_t *e = ring + (i & A.gmask);
+            const int tag = lrg_gemv_ring_tag(i, A.gmask);
+            int code = 0;
+            for (unsigned spin = 0;; ++spin) {
+                code = lrg_ld_coh(e);
+                if ((code >> 20) == tag) break;
+                code = -1;
+                if ((spin & 7) == 7) {
+                    if (lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front || lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) break;
+                    if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) {
+                        lrg_st_coh(&A.queue[LRG_AQ_ABORT], 4);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            word[0] = code < 0 ? -1 : (code & 0xFFFFF);
+            if (LRG_DBG(A)) t_task = wall_clock64();
+        }
+        team.sync();
+        const int slot = word[0];
+        team.sync();                                          // (read by everybody before thread 0 writes the next one)
+        if (slot < 0) return;
+        {   // the slot's pooled row: one 16-byte load per lane
+            const float *src = g.pooled + (long)slot * P;
+            for (int j = tid; j < (P >> 2); j += FTHREADS)
+                *reinterpret_cast<float4 *>(pl + 4 * j) = lrg_ld_coh4(src, (unsigned)j * 16u);
+        }
+        team.sync();
+        {
+            const float *w = wl + (r * kq) * LRG_GEMV_UNIT_COLS + c;
+            const float *p = pl + r * kq;
+            float acc = 0.f;
+            for (int kb = 0; kb < kq; kb += 16) {
+                float wv[16];
+                float4 pv[4];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = w[(kb + u) * LRG_GEMV_UNIT_COLS];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pv[u] = *reinterpret_cast<const float4 *>(p + kb + 4 * u);
+                const float pk[16] = {pv[0].x, pv[0].y, pv[0].z, pv[0].w, pv[1].x, pv[1].y, pv[1].z, pv[1].w,
+                                      pv[2].x, pv[2].y, pv[2].z, pv[2].w, pv[3].x, pv[3].y, pv[3].z, pv[3].w};
+#pragma unroll
+                for (int uu = 0; uu < 16; ++uu) {
+                    const int u = (uu & 8) | ((uu & 1) << 2) | ((uu >> 1) & 3);      // k = 8g + 0, 4, 1, 5, 2, 6, 3, 7 (lrg_async_gemv)
+                    acc = fmaf(pk[u], wv[u], acc);
+                }
+            }
+            part[r * LRG_GEMV_UNIT_COLS + c] = acc;
+        }
+        team.sync();
+        if (tid < LRG_GEMV_UNIT_COLS) {
+            float s = part[tid];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) s += part[q * LRG_GEMV_UNIT_COLS + tid];
+            lrg_st_coh(g.hb[z] + (long)slot * g.C + col0 + tid, s + bias);
+        }
+        lrg_async_gemv_arrive(A, team, slot, t_task);
+    }
+}
+
+// a head tile that was started beside the pooled-product units waits here for its slot's product (lrg_fused_tile, WAIT::late)
+struct LrgWaitPooled {
+    static constexpr bool late = true;
+    const int32_t *sy;           // the slot's arrival counters
+    int32_t *queue;
+    long long t_launch, abort_ticks;
+    __device__ __forceinline__ void operator()() const {
+        const int tgt = lrg_ld_coh(&sy[3]);
+        for (unsigned spin = 1; lrg_ld_coh(&sy[2]) < tgt; ++spin) {
+            if ((spin & 255u) == 0) {
+                if (lrg_ld_coh(&queue[LRG_AQ_ABORT])) break;
+                if (wall_clock64() - t_launch > abort_ticks) { lrg_st_coh(&queue[LRG_AQ_ABORT], 5); break; }
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+};
+
+LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task, long long t_launch) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
@@ -269,7 +444,14 @@ LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
     const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
     long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;
-    lrg_fused_tile<32 * 260, 32 * 68, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[2 + side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps);
+    if (A.gemv_units) {
+        LrgWaitPooled wait;
+        wait.sy = sy; wait.queue = A.queue; wait.t_launch = t_launch; wait.abort_ticks = A.abort_ticks;
+        lrg_fused_tile<32 * 260, 32 * 68, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true, LrgWaitPooled>(A.prob[2 + side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm,
+                                                                                                               team, stamps, wait);
+    } else {
+        lrg_fused_tile<32 * 260, 32 * 68, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[2 + side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps);
+    }
 #if LRG_TRACE == 8320
     if (tid == 0 && LRG_DBG(A)) {
         for (int i = 1; i < 21; ++i) if (stamps[i] > stamps[0]) lrg_dbg_add(A, 32 + i, stamps[i] - stamps[0]);
@@ -336,7 +518,7 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
         const int type = (code >> 28) & 7;
         if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task);
         else if (type == LRG_TASK_GEMV) team.target = lrg_async_task_gemv(kp, code, sm_off, team.target, t_task);
-        else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task);
+        else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task, t_launch);
     }
 }
 
@@ -369,7 +551,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
     const int f = blockIdx.x;
     const int n_served = (A.n_slots - f + A.n_front - 1) / A.n_front;          // slots f, f + n_front, ...
     const int row_stride = A.front.row_stride;
-    const int n_gemv = 2 * ((A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS);
+    const int n_gemv = A.gemv_units ? A.gemv_units : 2 * ((A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS);
     if (tid < LRG_ASYNC_MAX_SERVED) { C.state[tid] = tid < n_served ? 0 : 2; C.steps[tid] = 0; C.tgt[tid][0] = C.tgt[tid][1] = C.tgt[tid][2] = 0; }
     // a slot's rows have a fixed place in the row arrays: their tags are written once per launch
     for (int i = 0; i < n_served; ++i) {
@@ -496,6 +678,10 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgAs
 #else
     lrg_kargs_ptr kp = nullptr;
 #endif
+    if ((int)blockIdx.x >= K.A.n_front && (int)blockIdx.x < K.A.n_front + K.A.gemv_units) {
+        lrg_async_gemv_unit(kp, (int)blockIdx.x - K.A.n_front, t_launch);
+        return;
+    }
     if ((int)blockIdx.x >= K.A.n_front) {
         // worker workgroup: teams of four consecutive wavefronts (one per SIMD), each on its own part of the LDS
         const int t = tid >> 8;

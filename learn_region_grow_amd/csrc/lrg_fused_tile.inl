@@ -202,9 +202,11 @@ __device__ __forceinline__ void tile_mfma_first(f32x16 (&acc)[RT], const float *
 // ONE (with PACKED): all rows of the tile belong to ONE instance, `inst`, and all of them are live (the free-running kernel: a slot's
 // rows have a place of their own, padded to whole tiles with copies of its last row) -- no run detection, the centre and the
 // per-instance bias addressed by `inst` directly (no trip through row_inst first).
-struct LrgNoWait { __device__ __forceinline__ void operator()() const {} };
+struct LrgNoWait { static constexpr bool late = false; __device__ __forceinline__ void operator()() const {} };
 // before_inst_bias: called by every thread right before the first per-instance bias (the hoisted pooled product of a head) is read --
-// the free-running kernel's head tiles wait there for the pooled blocks of their slot.
+// the free-running kernel's head tiles wait there for the pooled product of their slot.  WAIT::late (ONE only): the first pass of that
+// layer runs its MFMAs first and waits (and fetches its bias values) in front of its epilogue -- a tile that was started before the
+// pooled product is complete has the staging and a pass of MFMAs to do meanwhile.
 // part / nparts (ONE only, nparts 1, 2 or 4): the column blocks of the POOLED layer -- 128 -> 512: four passes, more than half of a branch
 // tile's time -- are shared among nparts tasks that each run the layers before it again (a quarter of the FLOPs); the column maxima
 // are independent of each other, part 0 alone stores conv[1].  A tile's latency for its work, where teams are idle anyway.
@@ -363,9 +365,13 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             // GEMM kernel on another XCD a moment ago)
             constexpr int RB = 4;
             float bk[RB] = {0.f, 0.f, 0.f, 0.f};
+            bool late_bias = false;
             if constexpr (PACKED) {
-                if ((L.flags & LRG_FL_INST_BIAS) && L.bias && cb == cb_lo) before_inst_bias();
-                if (wave_on && (L.flags & LRG_FL_INST_BIAS) && L.bias) {
+                if ((L.flags & LRG_FL_INST_BIAS) && L.bias && cb == cb_lo) {
+                    if constexpr (WAIT::late && ONE) late_bias = true;
+                    else before_inst_bias();
+                }
+                if (wave_on && (L.flags & LRG_FL_INST_BIAS) && L.bias && !late_bias) {
 #pragma unroll
                     for (int k = 0; k < (ONE ? 1 : RB); ++k) {
                         const int ins = ONE ? inst : k < nruns ? run_inst[k] : -1;
@@ -403,6 +409,12 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             }
             TRACE_PASS(l, cb, 0);
             if (inplace) team.sync();                // the output overlays this layer's input: everyone must be done reading
+            if constexpr (PACKED && ONE && WAIT::late) {
+                if (late_bias) {
+                    before_inst_bias();
+                    if (wave_on) bk[0] = COH ? lrg_ld_coh(L.bias + (long)inst * L.N + col0 + li) : L.bias[(long)inst * L.N + col0 + li];
+                }
+            }
             if (wave_on) {
                 // ---- epilogue: bias, ReLU, keep in LDS / copy to HBM / column max ----
                 const int col = col0 + li;

@@ -1392,11 +1392,20 @@ int lrg_grow_step_packed(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_po
 }
 
 
-size_t lrg_grow_async_queue_bytes(int n_slots) {
-    if (n_slots <= 0) return 0;
+static size_t async_ring_entries(int n_slots) {
     size_t ring = 1 << 14;                                   // entries: far more than the tasks that can be outstanding (~80 per slot)
     while (ring < (size_t)n_slots * 512) ring <<= 1;
-    return (LRG_AQ_RING + 2 * ring) * sizeof(int32_t);      // (two rings: branch tiles | pooled blocks and head tiles)
+    return ring;
+}
+static size_t async_unit_ring_entries(int n_slots) {         // the pooled-product units' ring: a slot has one entry outstanding at most
+    size_t ring = 256;
+    while (ring < (size_t)n_slots * 2) ring <<= 1;
+    return ring;
+}
+size_t lrg_grow_async_queue_bytes(int n_slots) {
+    if (n_slots <= 0) return 0;
+    // (two task rings: branch tiles | pooled blocks and head tiles; then the units' ring)
+    return (LRG_AQ_RING + 2 * async_ring_entries(n_slots) + async_unit_ring_entries(n_slots)) * sizeof(int32_t);
 }
 
 int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params, const LrgWeights *weights,
@@ -1465,8 +1474,19 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // of latencies); three where the teams are the bottleneck
     const int teams = ab->teams > 0 ? min(ab->teams, 3) : (n_slots <= 96 ? 1 : 3);
     A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.room_queue = ab->room_queue; A.work = reinterpret_cast<unsigned long long *>(ab->work); A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
-    A.qmask = ((int)(qbytes / sizeof(int32_t)) - LRG_AQ_RING) / 2 - 1;
+    A.qmask = (int)async_ring_entries(n_slots) - 1;
+    A.gmask = (int)async_unit_ring_entries(n_slots) - 1;
     A.n_slots = n_slots; A.n_front = n_front; A.teams = teams;
+    // Pooled-product units (lrg_async.inl): sixteen CUs for the LrgNet of the paper (2 heads x 256 columns, 1024 pooled features).
+    // Off (-1), or where the slices do not fit / would leave the tile teams fewer than half of the CUs: the teams' 128-column blocks.
+    {
+        const LrgGemvArgs &g = A.gemv;
+        int units = (g.C % LRG_GEMV_UNIT_COLS == 0) ? 2 * g.C / LRG_GEMV_UNIT_COLS : 0;
+        if (ab->gemv_units < 0 || (size_t)LRG_GEMV_UNIT_FLOATS(g.P) * sizeof(float) + 16 > 160 * 1024 || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
+            n_front + units > wgs / 2 + wgs / 4 || n_slots >= (1 << 20))
+            units = 0;
+        A.gemv_units = units;
+    }
     A.poll_sleep = ab->poll_sleep > 0 ? ab->poll_sleep : 1;
     // few slots, most teams idle: a branch tile as two tasks that share its pooled layer (tile 22.8 -> 18.4 us; eight 100 k-point scenes
     // 75.9 k -> 78.1 k instance-steps/s, four tasks 75.0 k; 68 rooms: 559 k -> 505 k, the teams are busy there: profiles/r03_parts_perf.log)
@@ -1480,7 +1500,8 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     LRG_HIP_CHECK(hipMemsetAsync(ab->sync, 0, (size_t)n_slots * LRG_ASYNC_SYNC_WORDS * sizeof(int32_t), st));
     const size_t front_lds = ((sizeof(LrgFrontShared) + 15) & ~(size_t)15) + sizeof(LrgAsyncFrontCtl);
     const size_t team_lds = (size_t)teams * LRG_ASYNC_TEAM_FLOATS * sizeof(float);
-    const size_t lds = (max(front_lds, team_lds) + 15) & ~(size_t)15;
+    const size_t unit_lds = A.gemv_units ? (size_t)LRG_GEMV_UNIT_FLOATS(A.gemv.P) * sizeof(float) + 16 : 0;
+    const size_t lds = (max(max(front_lds, team_lds), unit_lds) + 15) & ~(size_t)15;
     static bool attr_done[LRG_MAX_DEVICES] = {};
     const int dev = lrg_current_device();
     if (!attr_done[dev]) {

@@ -335,6 +335,7 @@ class RegionGrower:
                 ab.compute_units = int(os.environ.get('LRG_FREE_RUN_CUS', '0'))
                 ab.poll_sleep = int(os.environ.get('LRG_FREE_RUN_POLL', '0'))
                 ab.branch_parts = int(os.environ.get('LRG_FREE_RUN_PARTS', '0'))
+                ab.gemv_units = int(os.environ.get('LRG_FREE_RUN_UNITS', '0'))          # -1: the pooled product as tasks of the tile teams
                 self.a_work = torch.zeros(4, dtype=torch.int64, device=dev)      # evaluations, inlier rows, neighbour rows, tiles
                 ab.work = self.a_work.data_ptr()
                 if os.environ.get('LRG_FREE_RUN_DEBUG') == '1':          # stage-by-stage tick accumulators (tools/free_run_perf.py)
