@@ -415,6 +415,7 @@ def main():
 
     iterate(args.warmup, False)
     barrier()
+    dbg0 = leg.gr.free_run_ticks() if leg.free else None      # (debug builds only: stage-by-stage ticks of the timed launches -> stderr)
     s0 = leg.stats()
     w0 = leg.work() if leg.free else None
     t0 = time.perf_counter()
@@ -423,6 +424,8 @@ def main():
     t1 = time.perf_counter()
     s1 = leg.stats()
     w1 = leg.work() if leg.free else None
+    if dbg0 is not None and rank == 0:
+        print(json.dumps(leg.gr.free_run_breakdown(since=dbg0)), file=sys.stderr)
     elapsed = lrg_dist.allreduce_max(t1 - t0, device=coll_dev)
     inst_steps, rooms_cycled, seeds = lrg_dist.allreduce_sum([float(s1[2] - s0[2]), float(s1[1] - s0[1]), float(s1[0] - s0[0])], device=coll_dev)
     if int(s1[3]):

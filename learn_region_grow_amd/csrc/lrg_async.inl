@@ -150,13 +150,18 @@ __device__ __forceinline__ void lrg_async_gemv(const LrgGemvArgs &g, int slot, i
 // kernels are the same for every slot: 2 x [P = 1024, C = 256] floats = 2 MB = sixteen CUs' LDS at 32 columns each.  A unit
 // (workgroup) loads its [P, 32] slice once per launch; its four teams of four wavefronts take the slots whose branch tiles have
 // all arrived from ONE ring that every unit reads (entry i: (generation of i) << 20 | slot, written once by the last branch tile
-// to arrive; team t of every unit takes the entries i = t (mod 4), no head pointer, nothing to reserve); a task = the slot's 4 KB
-// pooled row from L2, 128 FMAs per lane from LDS, 32 sums out.  Summation order: that of lrg_head_gemv_kernel (eight K ranges, MFMA
-// k order inside, the partial sums in order, the bias last) -- bit for bit what the tile teams' blocks give.
+// to arrive; a unit's teams take the entries in turn -- a ticket counter in the unit's LDS, nothing to reserve in memory); a task =
+// the slot's 4 KB pooled row from L2, 128 FMAs per lane from LDS, 32 sums out, one more arrival on the slot's pooled-product counter,
+// which the slot's head tiles poll (LrgWaitPooled).  Summation order: that of lrg_head_gemv_kernel (eight K ranges, MFMA k order
+// inside, the partial sums in order, the bias last) -- bit for bit what the tile teams' blocks give.
+// (Tried: mailboxes instead of the ring -- a 64-bit word per slot, arrivals | target << 32, every branch tile adds itself, one team per
+// unit watches all slots -- so that the units start ~2 us earlier, before the last tile knows it was the last: 808 k -> 795 k
+// instance-steps/s at 68 slots, the second atomic per tile and the watchers' loads cost more than the earlier start gains.)
 #define LRG_GEMV_UNIT_COLS 32
 #define LRG_GEMV_UNIT_TEAMS 4
-#define LRG_GEMV_UNIT_TEAM_FLOATS(P) ((P) + 8 * LRG_GEMV_UNIT_COLS + 16)      // pooled row, partial sums, task word + barrier counter
-#define LRG_GEMV_UNIT_FLOATS(P) ((P) * LRG_GEMV_UNIT_COLS + LRG_GEMV_UNIT_TEAMS * LRG_GEMV_UNIT_TEAM_FLOATS(P))
+#define LRG_GEMV_UNIT_TEAM_FLOATS(P) ((P) + 8 * LRG_GEMV_UNIT_COLS + 16)      // pooled row, partial sums, task words + barrier counter
+#define LRG_GEMV_UNIT_FLOATS(P) ((P) * LRG_GEMV_UNIT_COLS + LRG_GEMV_UNIT_TEAMS * LRG_GEMV_UNIT_TEAM_FLOATS(P))      // + n_slots claim words behind
+#define LRG_GEMV_UNIT_MAX_SLOTS 2048
 __device__ __forceinline__ int lrg_gemv_ring_tag(int i, int gmask) { return (((unsigned)i / (unsigned)(gmask + 1)) % 2047u) + 1; }
 
 // ---- the launch's arguments ----
@@ -229,7 +234,9 @@ LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
         if (lane == 0) {
             // (the evaluation's targets and tile counts were written before its tasks were published: fetched beside the arrival, not after it)
             const int tgt = lrg_ld_coh(&sy[1]);
-            if (A.gemv_units) { nt_in = lrg_ld_coh(&sy[6]); nt_nb = lrg_ld_coh(&sy[7]); }
+            if (A.gemv_units) {
+                nt_in = lrg_ld_coh(&sy[6]); nt_nb = lrg_ld_coh(&sy[7]);
+            }
             const int done = __hip_atomic_fetch_add(&sy[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             last = done == tgt;
             if (LRG_DBG(A)) {
@@ -266,20 +273,6 @@ __device__ __forceinline__ void lrg_async_gemv_arrive(const LrgAsyncArgs &A, con
     int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
     lrg_drain_stores();
     team.sync();
-    if (A.gemv_units) {
-        // the head tiles of the slot are in flight already and poll this counter (LrgWaitPooled): nothing to come back for
-        if (tid == 0) {
-            if (LRG_DBG(A)) {
-                const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-                const long long now = wall_clock64();
-                lrg_dbg_add(A, 8 + 2 * LRG_TASK_GEMV, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_GEMV, 1);
-                if (done == lrg_ld_coh(&sy[3])) lrg_dbg_add(A, 3, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
-            } else {
-                __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        return;
-    }
     if (tid < 64) {
         int last = 0, nt_in = 0, nt_nb = 0;
         if (lane == 0) {
@@ -334,10 +327,10 @@ LRG_ASYNC_ROLE void lrg_async_gemv_unit(lrg_kargs_ptr kp_, int unit_, long long 
     const int t = lrg_uniform((int)threadIdx.x >> 8);
     float *sm = lrg_async_smem + P * LRG_GEMV_UNIT_COLS + t * LRG_GEMV_UNIT_TEAM_FLOATS(P);
     float *pl = sm, *part = sm + P;
-    int *word = reinterpret_cast<int *>(part + 8 * LRG_GEMV_UNIT_COLS);      // [0] task of this round, [4] barrier counter
-    int *ticket = reinterpret_cast<int *>(lrg_async_smem + LRG_GEMV_UNIT_FLOATS(P));      // the unit's next ring entry: taken by whichever team is free
-    if ((threadIdx.x & 255) == 0) { word[0] = 0; word[4] = 0; }
-    if (threadIdx.x == 0) *ticket = 0;
+    int *word = reinterpret_cast<int *>(part + 8 * LRG_GEMV_UNIT_COLS);      // [0], [1] the task of even / odd rounds, [4] barrier counter
+    int *ctl = reinterpret_cast<int *>(lrg_async_smem + LRG_GEMV_UNIT_FLOATS(P));          // [0] the unit's next ring entry
+    if ((threadIdx.x & 255) == 0) { word[0] = 0; word[1] = 0; word[4] = 0; }
+    if (threadIdx.x < 4) ctl[threadIdx.x] = 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                              // the slice is in place; from here on the teams go their own ways
     LrgLdsTeam team;
@@ -349,33 +342,34 @@ LRG_ASYNC_ROLE void lrg_async_gemv_unit(lrg_kargs_ptr kp_, int unit_, long long 
     const int c = lane & 31, r = 2 * wave + (lane >> 5);      // this lane's column and K range
     const float bias = g.bias[z] ? g.bias[z][col0 + (tid & 31)] : 0.f;
     const int32_t *ring = A.queue + LRG_AQ_RING + 2 * (A.qmask + 1);
-    for (;;) {
+    for (int round = 0;; round ^= 1) {
         long long t_task = 0;
-        if (tid == 0) {
-            const int i = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wave == 0) {
+            // the unit's next ring entry, taken by whichever team is free; the other wavefronts wait at the barrier below
+            int slot = -2;
+            int i = 0;
+            if (lane == 0) i = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            i = __shfl(i, 0);
             const int32_t *e = ring + (i & A.gmask);
             const int tag = lrg_gemv_ring_tag(i, A.gmask);
-            int code = 0;
-            for (unsigned spin = 0;; ++spin) {
-                code = lrg_ld_coh(e);
-                if ((code >> 20) == tag) break;
-                code = -1;
+            for (unsigned spin = 0; slot == -2; ++spin) {
+                const int code = lrg_ld_coh(e);
+                if ((code >> 20) == tag) { slot = code & 0xFFFFF; break; }
                 if ((spin & 7) == 7) {
-                    if (lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front || lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) break;
-                    if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) {
+                    if (lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front || lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) slot = -1;
+                    else if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) {
                         lrg_st_coh(&A.queue[LRG_AQ_ABORT], 4);
-                        break;
+                        slot = -1;
                     }
                 }
-                __builtin_amdgcn_s_sleep(2);
+                if (slot == -2) __builtin_amdgcn_s_sleep(2);
             }
-            word[0] = code < 0 ? -1 : (code & 0xFFFFF);
-            if (LRG_DBG(A)) t_task = wall_clock64();
+            if (lane == 0) word[round] = slot;
         }
         team.sync();
-        const int slot = word[0];
-        team.sync();                                          // (read by everybody before thread 0 writes the next one)
+        const int slot = word[round];                         // (the other word is written next round: no second barrier)
         if (slot < 0) return;
+        if (LRG_DBG(A)) t_task = wall_clock64();
         {   // the slot's pooled row: one 16-byte load per lane
             const float *src = g.pooled + (long)slot * P;
             for (int j = tid; j < (P >> 2); j += FTHREADS)
@@ -404,13 +398,27 @@ LRG_ASYNC_ROLE void lrg_async_gemv_unit(lrg_kargs_ptr kp_, int unit_, long long 
             part[r * LRG_GEMV_UNIT_COLS + c] = acc;
         }
         team.sync();
-        if (tid < LRG_GEMV_UNIT_COLS) {
-            float s = part[tid];
+        // the sums and the arrival by the LAST wavefront: the first is back at the mailboxes while these stores drain
+        if (wave == 3) {
+            if (lane < LRG_GEMV_UNIT_COLS) {
+                float sum = part[lane];
 #pragma unroll
-            for (int q = 1; q < 8; ++q) s += part[q * LRG_GEMV_UNIT_COLS + tid];
-            lrg_st_coh(g.hb[z] + (long)slot * g.C + col0 + tid, s + bias);
+                for (int q = 1; q < 8; ++q) sum += part[q * LRG_GEMV_UNIT_COLS + lane];
+                lrg_st_coh(g.hb[z] + (long)slot * g.C + col0 + lane, sum + bias);
+            }
+            lrg_drain_stores();
+            if (lane == 0) {
+                int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
+                if (LRG_DBG(A)) {
+                    const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                    const long long now = wall_clock64();
+                    lrg_dbg_add(A, 8 + 2 * LRG_TASK_GEMV, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_GEMV, 1);
+                    if (done == lrg_ld_coh(&sy[3])) lrg_dbg_add(A, 3, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+                } else {
+                    __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
-        lrg_async_gemv_arrive(A, team, slot, t_task);
     }
 }
 
@@ -480,7 +488,7 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
     LrgLdsTeam team = lrg_async_team(A, sm, 0);
     const int tid = team.tid();
     int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);       // [0] task of this round
-    const bool secondary = sm_off != 0;
+    const bool secondary = sm_off != 0;      // (letting some of the second teams run branch tiles too: 809 k -> 783 k instance-steps/s at 68 slots -- two branch tiles on a CU slow each other)
     for (;;) {
         long long t_task = 0;
         if (tid == 0) {

@@ -1463,30 +1463,31 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     LRG_HIP_CHECK(hipGetDeviceProperties(&prop, lrg_current_device()));
     int wgs = prop.multiProcessorCount;
     if (ab->compute_units > 0 && ab->compute_units < wgs) wgs = ab->compute_units;
-    // Front workgroups: one per two slots (68 slots on one MI355X: 34 x 1 team 612 k instance-steps/s, 68 x 2 teams 579 k, 68 x 3 teams
-    // 548 k, profiles/r03_free11_perf.log -- a front workgroup is busy a third of the time, and a CU it holds is a CU without tile teams)
+    // Front workgroups: one per two slots (a front step takes ~23 us of a ~85 us step, and a CU a front workgroup holds is a CU without
+    // tile teams: 68 slots, two teams: 34 / 40 / 46 / 68 front workgroups 806 / 810 / 807 / 792 k instance-steps/s, profiles/r03_units_sweep.log)
     int n_front = ab->front_workgroups > 0 ? ab->front_workgroups : (n_slots + 1) / 2;
     n_front = min(n_front, n_slots);
     n_front = max(n_front, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED);
     n_front = min(n_front, wgs / 2);                         // (at least half of the CUs for the tile teams)
     if (n_front < (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED) return LRG_EINVAL - 8;      // more slots than the front workgroups can serve
-    // one team per worker CU while the slots are few (a tile beside another takes 1.2-1.4x as long, and at 68 slots a step is a chain
-    // of latencies); three where the teams are the bottleneck
-    const int teams = ab->teams > 0 ? min(ab->teams, 3) : (n_slots <= 96 ? 1 : 3);
-    A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.room_queue = ab->room_queue; A.work = reinterpret_cast<unsigned long long *>(ab->work); A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
-    A.qmask = (int)async_ring_entries(n_slots) - 1;
-    A.gmask = (int)async_unit_ring_entries(n_slots) - 1;
-    A.n_slots = n_slots; A.n_front = n_front; A.teams = teams;
     // Pooled-product units (lrg_async.inl): sixteen CUs for the LrgNet of the paper (2 heads x 256 columns, 1024 pooled features).
     // Off (-1), or where the slices do not fit / would leave the tile teams fewer than half of the CUs: the teams' 128-column blocks.
     {
         const LrgGemvArgs &g = A.gemv;
         int units = (g.C % LRG_GEMV_UNIT_COLS == 0) ? 2 * g.C / LRG_GEMV_UNIT_COLS : 0;
-        if (ab->gemv_units < 0 || (size_t)LRG_GEMV_UNIT_FLOATS(g.P) * sizeof(float) + 16 > 160 * 1024 || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
+        if (ab->gemv_units < 0 || (size_t)LRG_GEMV_UNIT_FLOATS(g.P) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
             n_front + units > wgs / 2 + wgs / 4 || n_slots >= (1 << 20))
             units = 0;
         A.gemv_units = units;
     }
+    // Teams per worker CU: two -- the first runs branch tiles, the second head tiles (a tile beside another takes 1.2 x as long, but
+    // the head tiles wait inside for the pooled-product units, and at 68 slots the teams are what a step queues for: 1 / 2 / 3 teams
+    // 751 / 806 / 771 k instance-steps/s with 34 front workgroups, profiles/r03_units_sweep.log); three where hundreds of slots are in flight
+    const int teams = ab->teams > 0 ? min(ab->teams, 3) : (n_slots <= 96 ? (A.gemv_units ? 2 : 1) : 3);
+    A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.room_queue = ab->room_queue; A.work = reinterpret_cast<unsigned long long *>(ab->work); A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
+    A.qmask = (int)async_ring_entries(n_slots) - 1;
+    A.gmask = (int)async_unit_ring_entries(n_slots) - 1;
+    A.n_slots = n_slots; A.n_front = n_front; A.teams = teams;
     A.poll_sleep = ab->poll_sleep > 0 ? ab->poll_sleep : 1;
     // few slots, most teams idle: a branch tile as two tasks that share its pooled layer (tile 22.8 -> 18.4 us; eight 100 k-point scenes
     // 75.9 k -> 78.1 k instance-steps/s, four tasks 75.0 k; 68 rooms: 559 k -> 505 k, the teams are busy there: profiles/r03_parts_perf.log)

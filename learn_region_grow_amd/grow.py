@@ -468,6 +468,34 @@ class RegionGrower:
         self.iterations += self.graph_iterations
         self._record_poll()
 
+    def free_run_breakdown(self, since=None):
+        """Stage-by-stage microseconds of the free-running launches so far (LRG_FREE_RUN_DEBUG=1 and a -DLRG_ASYNC_DEBUG=1 build; layout:
+        csrc/lrg_async.inl, LrgAsyncArgs.dbg), or None.  `since`: an earlier return value of free_run_ticks() to take the difference to."""
+        d = self.free_run_ticks()
+        if d is None:
+            return None
+        if since is not None:
+            d = d - since
+        ev = max(d[6], 1.0)
+        row = {'us': dict(front_busy_per_step=d[0] / max(d[1], 1) / 100, last_branch_tile_in=d[2] / ev / 100, last_pooled_block_in=d[3] / ev / 100,
+                          last_head_tile_in=d[4] / ev / 100, seen_by_front=d[5] / ev / 100,
+                          branch_tile=d[10] / max(d[11], 1) / 100, pooled_block=d[12] / max(d[13], 1) / 100, head_tile=d[14] / max(d[15], 1) / 100,
+                          team_wait_per_task=d[16] / max(d[17], 1) / 100),
+               'front_phase_us': dict(zip(['update', 'commit_seed', 'query', 'sampling', 'gather(+small medians)', 'big medians', 'gather alone', 'one median alone'],
+                                          [float(x) / max(d[1], 1) / 100 for x in list(d[21:28]) + [d[20]]])),
+               'tasks_per_evaluation': dict(branch=d[11] / ev, pooled=d[13] / ev, head=d[15] / ev), 'evaluations': float(d[6]), 'front_steps': float(d[1])}
+        if d[32] > 0:      # LRG_TRACE build: mean cycles since the tile began at each stamp
+            names = ['staged'] + [x for l in range(5) for x in ('L%d start' % l, 'L%d end' % l)] + \
+                    [x for c in range(4) for x in ('pass%d mfma' % c, 'pass%d epilogue' % c)] + ['end']
+            row['tile_cycles'] = {n: int(d[33 + i] / d[32]) for i, n in enumerate(names) if d[33 + i] > 0}
+        return row
+
+    def free_run_ticks(self):
+        import numpy as _np
+        if getattr(self, 'a_dbg', None) is None:
+            return None
+        return self.a_dbg.cpu().numpy().astype(_np.float64)
+
     def enqueue_free_run(self, steps=None, budget_us=None):
         """One free-running launch: every slot up to `steps` grow steps at its own pace (lrg_grow_async)."""
         steps = self.free_run_steps if steps is None else int(steps)

@@ -43,20 +43,9 @@ def main():
     results = []
 
     def breakdown(gr, row):
-        if getattr(gr, 'a_dbg', None) is not None:      # LRG_FREE_RUN_DEBUG=1: ticks of 10 ns -> microseconds
-            d = gr.a_dbg.cpu().numpy().astype(np.float64)
-            ev = max(d[6], 1.0)
-            row['us'] = dict(front_busy_per_step=d[0] / max(d[1], 1) / 100, last_branch_tile_in=d[2] / ev / 100, last_pooled_block_in=d[3] / ev / 100,
-                             last_head_tile_in=d[4] / ev / 100, seen_by_front=d[5] / ev / 100,
-                             branch_tile=d[10] / max(d[11], 1) / 100, pooled_block=d[12] / max(d[13], 1) / 100, head_tile=d[14] / max(d[15], 1) / 100,
-                             team_wait_per_task=d[16] / max(d[17], 1) / 100)
-            row['front_phase_us'] = dict(zip(['update', 'commit_seed', 'query', 'sampling', 'gather(+small medians)', 'big medians', 'gather alone', 'one median alone'],
-                                             [float(x) / max(d[1], 1) / 100 for x in list(d[21:28]) + [d[20]]]))
-            if d[32] > 0:      # LRG_TRACE build: mean cycles since the tile began at each stamp
-                names = ['staged'] + [x for l in range(5) for x in ('L%d start' % l, 'L%d end' % l)] + \
-                        [x for c in range(4) for x in ('pass%d mfma' % c, 'pass%d epilogue' % c)] + ['end']
-                row['tile_cycles'] = {n: int(d[33 + i] / d[32]) for i, n in enumerate(names) if d[33 + i] > 0}
-            row['tasks_per_evaluation'] = dict(branch=d[11] / ev, pooled=d[13] / ev, head=d[15] / ev)
+        b = gr.free_run_breakdown()      # LRG_FREE_RUN_DEBUG=1: ticks of 10 ns -> microseconds
+        if b:
+            row.update(b)
 
     def run(gr, label):
         with torch.cuda.stream(stream):

@@ -5,9 +5,9 @@ OUT=gpurun_out/r03_units_perf.log; : > $OUT
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
 timeout 600 python -m pytest tests/test_gpu_free_run.py -m gpu -x -q --tb=short -p no:cacheprovider 2>&1 | tail -5 | tee -a $OUT
 for u in 0 -1 0 -1; do
-  LRG_FREE_RUN_UNITS=$u timeout 300 python tools/free_run_perf.py --lockstep 0 --seconds 1.5 --configs 34:1:100000:5000 2>&1 | grep '^{' | sed "s/^/units=$u /" | tee -a $OUT
+  LRG_FREE_RUN_UNITS=$u timeout 300 python tools/free_run_perf.py --lockstep 0 --seconds 1.5 --configs ${CFG:-34:2:100000:5000} 2>&1 | grep '^{' | sed "s/^/units=$u /" | tee -a $OUT
 done
 export LRG_FREE_RUN_DEBUG=1 LRG_HIPCC_FLAGS="$LRG_HIPCC_FLAGS -DLRG_ASYNC_DEBUG=1"; python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
 for u in 0 -1; do
-  LRG_FREE_RUN_UNITS=$u timeout 300 python tools/free_run_perf.py --lockstep 0 --seconds 1.0 --configs 34:1:100000:5000 2>&1 | grep '^{' | sed "s/^/debug units=$u /" | tee -a $OUT
+  LRG_FREE_RUN_UNITS=$u timeout 300 python tools/free_run_perf.py --lockstep 0 --seconds 1.0 --configs ${CFG:-34:2:100000:5000} 2>&1 | grep '^{' | sed "s/^/debug units=$u /" | tee -a $OUT
 done
