@@ -1064,6 +1064,77 @@ __global__ __launch_bounds__(256) void lrg_nn1_search_kernel(const float *points
     }
 }
 
+// The same search with the feature count known at compile time and TWO candidate rows per step of a lane: the rows of a chunk are
+// staged as pairs interleaved feature by feature ([pair][feature][2]), so that one 8-byte LDS read feeds one packed subtraction,
+// multiplication and addition (v_pk_*_f32: two candidates per instruction) -- each candidate's sum still formed in
+// lrg_np_sqdist's order, operation by operation, so the distances are the same bits.  (The generic kernel above spends a third of its
+// instructions on `l < F` selects and issues one 4-byte LDS read and three scalar-width VALU operations per candidate and feature:
+// profiles/r03_fill_kernels.txt.)
+typedef float lrg_f2 __attribute__((ext_vector_type(2)));
+template <int FT>
+__device__ __forceinline__ lrg_f2 lrg_np_sqdist2(const float *pair_rows, const lrg_f2 (&me2)[FT]) {
+    lrg_f2 t[FT];
+#pragma unroll
+    for (int l = 0; l < FT; ++l) {
+        const lrg_f2 c = *reinterpret_cast<const lrg_f2 *>(pair_rows + 2 * l);
+        const lrg_f2 d = c - me2[l];
+        t[l] = d * d;
+    }
+    if constexpr (FT < 8) {
+        lrg_f2 sum = t[0];
+#pragma unroll
+        for (int l = 1; l < FT; ++l) sum = sum + t[l];
+        return sum;
+    } else {
+        lrg_f2 sum = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+#pragma unroll
+        for (int l = 8; l < FT; ++l) sum = sum + t[l];
+        return sum;
+    }
+}
+
+template <int FT>
+__global__ __launch_bounds__(256) void lrg_nn1_search_pairs_kernel(const float *points, int n, const int32_t *label_in, const int32_t *list,
+                                                                    const int32_t *count, unsigned long long *best) {
+    __shared__ __attribute__((aligned(16))) float rows[LRG_NN1_C * FT];      // [pair][feature][2]
+    __shared__ int lab[LRG_NN1_C];
+    __shared__ unsigned long long part[4][LRG_NN1_Q];
+    const int U = *count;
+    if ((int)blockIdx.x * LRG_NN1_Q >= U) return;
+    const int c0 = blockIdx.y * LRG_NN1_C;
+    const int nc = min(LRG_NN1_C, n - c0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < LRG_NN1_C * FT; e += blockDim.x) {
+        const int r = e / FT, l = e - r * FT;
+        rows[(r >> 1) * 2 * FT + 2 * l + (r & 1)] = r < nc ? points[(long)c0 * FT + e] : 0.f;      // (contiguous block of rows; a chunk's tail: zeros, never labeled)
+    }
+    for (int r = threadIdx.x; r < LRG_NN1_C; r += blockDim.x) lab[r] = r < nc ? label_in[c0 + r] : 0;
+    constexpr int PER = LRG_NN1_C / 2 / 4;                             // pairs per wavefront
+    for (int q0 = blockIdx.x * LRG_NN1_Q; q0 < U; q0 += gridDim.x * LRG_NN1_Q) {
+        const int qi = list[min(q0 + lane, U - 1)];
+        lrg_f2 me2[FT];
+#pragma unroll
+        for (int l = 0; l < FT; ++l) { const float v = points[(long)qi * FT + l]; me2[l] = lrg_f2{v, v}; }
+        __syncthreads();                                               // rows staged / part[] of the previous round consumed
+        unsigned long long bk = ~0ull;
+#pragma unroll 2
+        for (int p = wave * PER; p < (wave + 1) * PER; ++p) {
+            const lrg_f2 d = lrg_np_sqdist2<FT>(rows + p * 2 * FT, me2);
+            const int2 lb = *reinterpret_cast<const int2 *>(&lab[2 * p]);
+            const unsigned long long k0 = ((unsigned long long)__float_as_uint(d.x) << 32) | (unsigned)(c0 + 2 * p);
+            const unsigned long long k1 = ((unsigned long long)__float_as_uint(d.y) << 32) | (unsigned)(c0 + 2 * p + 1);
+            bk = min(bk, lb.x != 0 ? k0 : ~0ull);
+            bk = min(bk, lb.y != 0 ? k1 : ~0ull);
+        }
+        part[wave][lane] = bk;
+        __syncthreads();
+        if (wave == 0 && q0 + lane < U) {
+            bk = min(min(part[0][lane], part[1][lane]), min(part[2][lane], part[3][lane]));
+            if (bk != ~0ull) atomicMin(&best[qi], bk);
+        }
+    }
+}
+
 __global__ void lrg_nn1_write_kernel(const int32_t *label_in, int n, const unsigned long long *best, int32_t *label_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1627,8 +1698,14 @@ int lrg_nn1_fill_ws(const float *points, int n, int F, const int32_t *label_in, 
     unsigned long long *best = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + lrg_align_up((size_t)n * 4 + 64, 256));
     LRG_HIP_CHECK(hipMemsetAsync(count, 0, 64, st));
     hipLaunchKernelGGL(lrg_nn1_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, label_in, n, list, count, best);
-    hipLaunchKernelGGL(lrg_nn1_search_kernel, dim3(min(16, (n + LRG_NN1_Q - 1) / LRG_NN1_Q), (n + LRG_NN1_C - 1) / LRG_NN1_C), dim3(256), 0, st,
-                       points, n, F, label_in, list, count, best);
+    const dim3 grid(min(16, (n + LRG_NN1_Q - 1) / LRG_NN1_Q), (n + LRG_NN1_C - 1) / LRG_NN1_C);
+    static const bool generic = getenv("LRG_NN1_GENERIC") != nullptr;      // (A/B switch)
+    // the feature counts of the reference's variants (test_region_grow.py:72-77) are compiled in; any other goes the generic way
+    if (F == 13 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<13>, grid, dim3(256), 0, st, points, n, label_in, list, count, best);
+    else if (F == 12 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<12>, grid, dim3(256), 0, st, points, n, label_in, list, count, best);
+    else if (F == 9 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<9>, grid, dim3(256), 0, st, points, n, label_in, list, count, best);
+    else if (F == 6 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<6>, grid, dim3(256), 0, st, points, n, label_in, list, count, best);
+    else hipLaunchKernelGGL(lrg_nn1_search_kernel, grid, dim3(256), 0, st, points, n, F, label_in, list, count, best);
     hipLaunchKernelGGL(lrg_nn1_write_kernel, dim3((n + 255) / 256), dim3(256), 0, st, label_in, n, best, label_out);
     LRG_LAUNCH_CHECK();
     return 0;

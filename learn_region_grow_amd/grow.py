@@ -53,13 +53,19 @@ class RegionGrower:
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
                  skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np', free_run=None,
-                 free_run_steps=1 << 20, free_run_budget_us=5000, free_run_fronts=0, free_run_teams=0):
+                 free_run_steps=1 << 20, free_run_budget_us=5000, free_run_fronts=0, free_run_teams=0, free_run_fill_cus=None):
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
         graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*).
         free_run: True / None (= where it applies and is the faster formulation: packed greedy growing, lite 0 / 2, at most 96 slots) /
         False: one host call = ONE launch in which every slot takes up to free_run_steps grow steps at its own pace (lrg_grow_async),
-        starting none after free_run_budget_us microseconds (0 = no time limit); same results as the lock-step iterations."""
+        starting none after free_run_budget_us microseconds (0 = no time limit); same results as the lock-step iterations.
+        free_run_fill_cus: > 0: that many CUs are left out of the free-running launches, and the fill-ins of finished rooms
+        (test_region_grow.py:308-316) run on a stream of their own beside the next launch instead of between two launches (a
+        launch holds every CU it is given for its whole duration).  Off by default: a kernel on a second stream is only placed when
+        every shader engine has a CU to spare -- 32 CUs on an MI355X, fewer and it waits for the launch to end
+        (tools/r03_side_stream.py) -- and 32 CUs cost the launches what the fill-ins between them cost (816 k against 814 k
+        instance-steps/s, 502 against 530 rooms/s: profiles/r03_units_sweep.log)."""
         self.lib = _lib.load()
         self.net = net
         self.dev = net.device
@@ -107,6 +113,7 @@ class RegionGrower:
         self.free_run_budget_us = int(free_run_budget_us)
         self.free_run_fronts = int(free_run_fronts)
         self.free_run_teams = int(free_run_teams)
+        self.free_run_fill_cus = free_run_fill_cus
         self.debug_hook = None      # tests: called once per active slot per legacy iteration with the step's data
         self._rooms_loaded = False
 
@@ -333,6 +340,9 @@ class RegionGrower:
                 ab.front_workgroups = self.free_run_fronts or int(os.environ.get('LRG_FREE_RUN_FRONTS', '0'))
                 ab.teams = self.free_run_teams or int(os.environ.get('LRG_FREE_RUN_TEAMS', '0'))
                 ab.compute_units = int(os.environ.get('LRG_FREE_RUN_CUS', '0'))
+                self.fill_cus = int(os.environ.get('LRG_FREE_RUN_FILL_CUS', '0' if self.free_run_fill_cus is None else str(int(self.free_run_fill_cus))))
+                if self.fill_cus > 0 and ab.compute_units == 0:
+                    ab.compute_units = max(64, torch.cuda.get_device_properties(dev).multi_processor_count - self.fill_cus)
                 ab.poll_sleep = int(os.environ.get('LRG_FREE_RUN_POLL', '0'))
                 ab.branch_parts = int(os.environ.get('LRG_FREE_RUN_PARTS', '0'))
                 ab.gemv_units = int(os.environ.get('LRG_FREE_RUN_UNITS', '0'))          # -1: the pooled product as tasks of the tile teams
@@ -356,6 +366,8 @@ class RegionGrower:
     # ------------------------------------------------------------------------------------------
     def reset_room(self, r):
         """Return room r to its pristine state (visited / labels cleared, cursor at 0)."""
+        if getattr(self, 'fill_stream', None) is not None:      # (a fill-in of the room may still be reading its labels)
+            torch.cuda.current_stream(self.dev).wait_stream(self.fill_stream)
         if self.rng == 'counter' and self.device_bind:
             self._reset_pending.add(r)          # folded into the device-side bind that follows (one launch, no upload)
             return
@@ -405,7 +417,19 @@ class RegionGrower:
         self.group_room[group] = r
 
     def fill(self, r):
-        """1-NN fill-in of room r's unlabeled points (test_region_grow.py:308-316) into d_filled."""
+        """1-NN fill-in of room r's unlabeled points (test_region_grow.py:308-316) into d_filled.  Free-running launches with CUs
+        left out for it (free_run_fill_cus): on the fill stream, beside the next launch -- the room was reported finished by a launch
+        that has completed (poll_done), its labels are final; wait_fills() before reading d_filled."""
+        if getattr(self, 'free_run', False) and getattr(self, 'fill_cus', 0) > 0 and not getattr(self, '_in_fill_stream', False):
+            if getattr(self, 'fill_stream', None) is None:
+                self.fill_stream = torch.cuda.Stream(device=self.dev)
+            self._in_fill_stream = True
+            try:
+                with torch.cuda.stream(self.fill_stream):
+                    self.fill(r)
+            finally:
+                self._in_fill_stream = False
+            return
         o, n = int(self.room_off[r]), self.room_n[r]
         F = self.net.feature_size
         if getattr(self, '_fill_ws', None) is None:
@@ -414,6 +438,11 @@ class RegionGrower:
                                             ctypes.c_void_p(self.d_label.data_ptr() + o * 4),
                                             ctypes.c_void_p(self.d_filled.data_ptr() + o * 4), _ptr(self._fill_ws),
                                             self._fill_ws.numel(), _stream_ptr(self.dev)), 'lrg_nn1_fill_ws')
+
+    def wait_fills(self):
+        """Fill-ins enqueued on the fill stream are complete on return."""
+        if getattr(self, 'fill_stream', None) is not None:
+            self.fill_stream.synchronize()
 
     # ------------------------------------------------------------------------------------------
     def _release_graph(self):
@@ -592,6 +621,7 @@ class RegionGrower:
         while self.rooms_finished < self.n_rooms:
             self.free_run_step(fill)
         torch.cuda.current_stream(self.dev).synchronize()
+        self.wait_fills()
         self.async_buffers.room_queue = None
         return self.n_rooms
 
@@ -797,6 +827,7 @@ class RegionGrower:
         return self.collect(fill)
 
     def collect(self, fill=True):
+        self.wait_fills()
         rooms = self._read_rooms()
         label = self.d_label.cpu().numpy()
         filled = self.d_filled.cpu().numpy() if fill else None

@@ -143,3 +143,32 @@ def test_nn1_fill_tiled(cuda_device, hip_lib, F, n, frac):
     _lib.check(hip_lib.lrg_nn1_fill(_ptr(dP), n, F, _ptr(dlab), _ptr(ref), _stream_ptr()), 'nn1')
     np.testing.assert_array_equal(ref.cpu().numpy(), want)
     assert hip_lib.lrg_nn1_fill_ws(_ptr(dP), n, F, _ptr(dlab), _ptr(out), _ptr(ws), 16, _stream_ptr()) <= -1000
+
+
+def test_nn1_fill_tiled_on_a_room(cuda_device, hip_lib):
+    """Points in object order, as rooms come (the pruned pairs of lrg_nn1_fill_ws: most chunks are farther from a query in xyz than its
+    best so far): the result is that of the exhaustive one-workgroup-per-point search, ties included (duplicated rows), with whole
+    objects unlabeled and a stretch of points without any labeled neighbour nearby."""
+    import torch
+    from learn_region_grow_amd import _lib, workloads
+    from learn_region_grow_amd.lrgnet import _ptr, _stream_ptr
+    room = workloads.area5_rooms(3, seed_base=1000, cache_dir='/tmp/lrg_cache')[2]
+    P = np.ascontiguousarray(room['points'][:40000], dtype=np.float32)
+    n, F = P.shape
+    rs = np.random.RandomState(11)
+    obj = np.asarray(room['obj_id'])[:n]
+    lab = (obj % 7 + 1).astype(np.int32)
+    lab[rs.rand(n) < 0.15] = 0                               # scattered unlabeled points
+    for o in np.unique(obj)[::5]:
+        lab[obj == o] = 0                                    # whole objects unlabeled
+    lab[1000:3000] = 0
+    P[5000:5064] = P[17000:17064]                            # exact ties between far-apart indices
+    P[123] = P[124]
+    dP, dlab = dev(P, cuda_device), dev(lab, cuda_device)
+    out = torch.full((n,), -7, dtype=torch.int32, device=cuda_device)
+    ref = torch.zeros(n, dtype=torch.int32, device=cuda_device)
+    ws = torch.empty(hip_lib.lrg_nn1_fill_workspace_bytes(n), dtype=torch.uint8, device=cuda_device)
+    _lib.check(hip_lib.lrg_nn1_fill_ws(_ptr(dP), n, F, _ptr(dlab), _ptr(out), _ptr(ws), ws.numel(), _stream_ptr()), 'nn1 ws')
+    _lib.check(hip_lib.lrg_nn1_fill(_ptr(dP), n, F, _ptr(dlab), _ptr(ref), _stream_ptr()), 'nn1')
+    np.testing.assert_array_equal(out.cpu().numpy(), ref.cpu().numpy())
+    assert (out.cpu().numpy() != 0).all()
