@@ -211,7 +211,7 @@ class _Leg:
         from learn_region_grow_amd.grow import LanedRegionGrower, RegionGrower
         self.torch, self.dev, self.jobs, self.fill = torch, dev, jobs, bool(args.fill)
         greedy = args.restarts == 1
-        small = max(len(j['points']) for j in jobs) <= 65536 if jobs else True      # (_lib.LRG_FREE_RUN_AUTO_POINTS: one front workgroup walks a room)
+        small = max(len(j['points']) for j in jobs) <= 32 * 4096 if jobs else True      # (_lib.LRG_FREE_RUN_AUTO_POINTS)
         self.free = greedy and (mode == 'free' or (mode == 'auto' and slots <= 96 and small)) and bool(grow_kw.get('packed'))
         self.slots = slots
         if self.free:

@@ -103,8 +103,8 @@ LRG_PACKED_MAX_POINTS = 32 * 4096      # lrg_grow_step_packed: rooms up to 13107
 LRG_PACKED_AUTO_POINTS = 32 * 4096     # ... chosen by default up to its limit (round 2 stopped at 65536: the chunk-parallel scans of lrg_grow_step
                                        # won on 100 k-point scenes then; eight KITTI-shaped scenes under the trained weights and the Bernoulli
                                        # policy now: packed 88 k against 69 k instance-steps/s, profiles/r03_kitti_*.json)
-LRG_FREE_RUN_AUTO_POINTS = 65536       # free-running launches by default up to this room size: one front workgroup walks a room, and on 100 k-point
-                                       # scenes the lock-step launches do better (88 k against 78 k)
+LRG_FREE_RUN_AUTO_POINTS = 32 * 4096   # free-running launches by default up to the packed limit too: eight 100 k-point scenes, one front workgroup per
+                                       # scene, one team per CU: 108 k instance-steps/s against 88 k lock-step (profiles/r03_kitti2_*.json)
 LRG_VGRID_MAX_CELLS = 1 << 26          # dense voxel grid of a room (LrgRoom.vgrid): at most 64 M cells (256 MB) per room ...
 LRG_VGRID_TOTAL_CELLS = 1 << 31        # ... and 8 GB for the rooms of one grower
 LRG_DONE_RING = 1020

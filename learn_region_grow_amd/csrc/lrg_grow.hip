@@ -1535,8 +1535,9 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     int wgs = prop.multiProcessorCount;
     if (ab->compute_units > 0 && ab->compute_units < wgs) wgs = ab->compute_units;
     // Front workgroups: one per two slots (a front step takes ~23 us of a ~85 us step, and a CU a front workgroup holds is a CU without
-    // tile teams: 68 slots, two teams: 34 / 40 / 46 / 68 front workgroups 806 / 810 / 807 / 792 k instance-steps/s, profiles/r03_units_sweep.log)
-    int n_front = ab->front_workgroups > 0 ? ab->front_workgroups : (n_slots + 1) / 2;
+    // tile teams: 68 slots, two teams: 34 / 40 / 46 / 68 front workgroups 806 / 810 / 807 / 792 k instance-steps/s, profiles/r03_units_sweep.log);
+    // one per slot while the slots are few and CUs plenty (eight 100 k-point scenes: 8 / 4 front workgroups 97 k / 86 k, profiles/r03_kitti2_*.json)
+    int n_front = ab->front_workgroups > 0 ? ab->front_workgroups : n_slots <= 24 ? n_slots : (n_slots + 1) / 2;
     n_front = min(n_front, n_slots);
     n_front = max(n_front, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED);
     n_front = min(n_front, wgs / 2);                         // (at least half of the CUs for the tile teams)
@@ -1553,8 +1554,9 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     }
     // Teams per worker CU: two -- the first runs branch tiles, the second head tiles (a tile beside another takes 1.2 x as long, but
     // the head tiles wait inside for the pooled-product units, and at 68 slots the teams are what a step queues for: 1 / 2 / 3 teams
-    // 751 / 806 / 771 k instance-steps/s with 34 front workgroups, profiles/r03_units_sweep.log); three where hundreds of slots are in flight
-    const int teams = ab->teams > 0 ? min(ab->teams, 3) : (n_slots <= 96 ? (A.gemv_units ? 2 : 1) : 3);
+    // 751 / 806 / 771 k instance-steps/s with 34 front workgroups, profiles/r03_units_sweep.log); one while the slots are few (nothing
+    // queues, a tile alone is faster: eight scenes 108 k against 97 k); three where hundreds of slots are in flight
+    const int teams = ab->teams > 0 ? min(ab->teams, 3) : n_slots <= 24 ? 1 : n_slots <= 96 ? (A.gemv_units ? 2 : 1) : 3;
     A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.room_queue = ab->room_queue; A.work = reinterpret_cast<unsigned long long *>(ab->work); A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
     A.qmask = (int)async_ring_entries(n_slots) - 1;
     A.gmask = (int)async_unit_ring_entries(n_slots) - 1;

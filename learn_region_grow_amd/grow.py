@@ -53,7 +53,7 @@ class RegionGrower:
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
                  skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np', free_run=None,
-                 free_run_steps=1 << 20, free_run_budget_us=5000, free_run_fronts=0, free_run_teams=0, free_run_fill_cus=None):
+                 free_run_steps=1 << 20, free_run_budget_us=5000, free_run_fronts=0, free_run_teams=0, free_run_fill_cus=None, free_run_units=0):
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
         graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*).
@@ -114,6 +114,7 @@ class RegionGrower:
         self.free_run_fronts = int(free_run_fronts)
         self.free_run_teams = int(free_run_teams)
         self.free_run_fill_cus = free_run_fill_cus
+        self.free_run_units = int(free_run_units)      # 0 = pooled-product units where they fit, -1 = the tile teams' 128-column blocks
         self.debug_hook = None      # tests: called once per active slot per legacy iteration with the step's data
         self._rooms_loaded = False
 
@@ -345,7 +346,7 @@ class RegionGrower:
                     ab.compute_units = max(64, torch.cuda.get_device_properties(dev).multi_processor_count - self.fill_cus)
                 ab.poll_sleep = int(os.environ.get('LRG_FREE_RUN_POLL', '0'))
                 ab.branch_parts = int(os.environ.get('LRG_FREE_RUN_PARTS', '0'))
-                ab.gemv_units = int(os.environ.get('LRG_FREE_RUN_UNITS', '0'))          # -1: the pooled product as tasks of the tile teams
+                ab.gemv_units = self.free_run_units or int(os.environ.get('LRG_FREE_RUN_UNITS', '0'))          # -1: the pooled product as tasks of the tile teams
                 self.a_work = torch.zeros(4, dtype=torch.int64, device=dev)      # evaluations, inlier rows, neighbour rows, tiles
                 ab.work = self.a_work.data_ptr()
                 if os.environ.get('LRG_FREE_RUN_DEBUG') == '1':          # stage-by-stage tick accumulators (tools/free_run_perf.py)

@@ -25,13 +25,16 @@ def _rooms():
            [small_room(300, 1500, furniture=4, room_id=13), small_room(301, 2500, furniture=6, room_id=14)]
 
 
-@pytest.mark.parametrize('steps,fronts,teams,in_flight', [(1, 0, 0, 5), (7, 0, 0, 5), (64, 1, 1, 3), (64, 5, 3, 5), (16, 2, 2, 2), (64, 0, 0, 9)])
-def test_free_run_equals_lock_step(net, steps, fronts, teams, in_flight):
+@pytest.mark.parametrize('steps,fronts,teams,in_flight,units', [(1, 0, 0, 5, 0), (7, 0, 0, 5, 0), (64, 1, 1, 3, 0), (64, 5, 3, 5, 0), (16, 2, 2, 2, 0), (64, 0, 0, 9, 0),
+                                                                 (64, 3, 1, 5, -1), (16, 2, 2, 4, -1)])
+def test_free_run_equals_lock_step(net, steps, fronts, teams, in_flight, units):
+    """units: 0 = the pooled-product units (the heads' pooled kernels in the LDS of workgroups of their own, head tiles started beside them),
+    -1 = the pooled product as 128-column blocks of the tile teams."""
     from learn_region_grow_amd.grow import RegionGrower
     rooms = _rooms()
     kw = dict(rooms_in_flight=in_flight, rng='counter', seed=123, policy='net')
     want = RegionGrower(net, free_run=False, **kw).run(rooms)
-    gr = RegionGrower(net, free_run=True, free_run_steps=steps, free_run_fronts=fronts, free_run_teams=teams, **kw)
+    gr = RegionGrower(net, free_run=True, free_run_steps=steps, free_run_fronts=fronts, free_run_teams=teams, free_run_units=units, **kw)
     got = gr.run(rooms)
     assert gr.free_run
     for g, w in zip(got, want):
