@@ -58,7 +58,7 @@ def parse():
                     help='auto: free-running launches (lrg_grow_async) up to 96 greedy slots per GPU, lock-step iterations above')
     ap.add_argument('--step-ms', type=float, default=25.0, help='free-running launches: budget of one launch = one step')
     ap.add_argument('--iters-per-step', type=int, default=512, help='lock-step iterations per (macro-)step')
-    ap.add_argument('--best-slots', default='68,136,272', help='slot counts of the fixed_work_best sweep (empty = skip)')
+    ap.add_argument('--best-slots', default='68,96,136,272', help='slot counts of the fixed_work_best sweep (empty = skip)')
     ap.add_argument('--rooms', type=int, default=68, help='rooms in flight per GPU (the Area-5 set has 68)')
     ap.add_argument('--restarts', type=int, default=1)
     ap.add_argument('--workload', default='area5', choices=['area5', 'kitti', 'scannet'],
@@ -203,6 +203,11 @@ def _respawn_under_torchrun(args):
     os.execv(sys.executable, cmd)
 
 
+def _lib_auto_slots():
+    from learn_region_grow_amd import _lib
+    return _lib.LRG_FREE_RUN_AUTO_SLOTS
+
+
 class _Leg:
     """One grower configuration over a list of room jobs: free-running launches on one stream, or lock-step lanes."""
 
@@ -212,7 +217,7 @@ class _Leg:
         self.torch, self.dev, self.jobs, self.fill = torch, dev, jobs, bool(args.fill)
         greedy = args.restarts == 1
         small = max(len(j['points']) for j in jobs) <= 32 * 4096 if jobs else True      # (_lib.LRG_FREE_RUN_AUTO_POINTS)
-        self.free = greedy and (mode == 'free' or (mode == 'auto' and slots <= 96 and small)) and bool(grow_kw.get('packed'))
+        self.free = greedy and (mode == 'free' or (mode == 'auto' and slots <= _lib_auto_slots() and small)) and bool(grow_kw.get('packed'))
         self.slots = slots
         if self.free:
             self.stream = torch.cuda.Stream(device=dev)
@@ -341,7 +346,7 @@ def main():
     # steady leg
     # ------------------------------------------------------------------------------------------------------------------
     step_us = args.step_ms * 1e3
-    free_steady = args.restarts == 1 and packed and (args.mode == 'free' or (args.mode == 'auto' and slots <= 96 and
+    free_steady = args.restarts == 1 and packed and (args.mode == 'free' or (args.mode == 'auto' and slots <= _lib.LRG_FREE_RUN_AUTO_SLOTS and
                                                                          max(len(r['points']) for r in base) <= _lib.LRG_FREE_RUN_AUTO_POINTS))
     ev_pairs = []
     if free_steady:

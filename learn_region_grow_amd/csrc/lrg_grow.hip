@@ -1540,14 +1540,17 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     int n_front = ab->front_workgroups > 0 ? ab->front_workgroups : n_slots <= 24 ? n_slots : (n_slots + 1) / 2;
     n_front = min(n_front, n_slots);
     n_front = max(n_front, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED);
-    n_front = min(n_front, wgs / 2);                         // (at least half of the CUs for the tile teams)
+    n_front = min(n_front, ab->front_workgroups > 0 ? wgs / 2 : max(wgs / 4, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED));      // (by default three quarters of the CUs for the tile teams:
+                                                             //  272 slots, 128 / 64 front workgroups: 0.40 M / see profiles/r03_d_bench_272_free.json)
     if (n_front < (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED) return LRG_EINVAL - 8;      // more slots than the front workgroups can serve
     // Pooled-product units (lrg_async.inl): sixteen CUs for the LrgNet of the paper (2 heads x 256 columns, 1024 pooled features).
-    // Off (-1), or where the slices do not fit / would leave the tile teams fewer than half of the CUs: the teams' 128-column blocks.
+    // Off (-1), or where the slices do not fit / would leave the tile teams fewer than half of the CUs: the teams' 128-column blocks.  Off
+    // above 96 slots too: sixteen units take ~1 M pooled products a second, the head tiles that wait for them hold their teams, and
+    // 272 slots in flight fell from 0.82 M to 0.31 M instance-steps/s (profiles/r03_d_bench_272_free.json; lock-step: 1.20 M).
     {
         const LrgGemvArgs &g = A.gemv;
         int units = (g.C % LRG_GEMV_UNIT_COLS == 0) ? 2 * g.C / LRG_GEMV_UNIT_COLS : 0;
-        if (ab->gemv_units < 0 || (size_t)LRG_GEMV_UNIT_FLOATS(g.P) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
+        if (ab->gemv_units < 0 || (ab->gemv_units == 0 && n_slots > 96) || (size_t)LRG_GEMV_UNIT_FLOATS(g.P) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
             n_front + units > wgs / 2 + wgs / 4 || n_slots >= (1 << 20))
             units = 0;
         A.gemv_units = units;

@@ -57,7 +57,7 @@ class RegionGrower:
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
         graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*).
-        free_run: True / None (= where it applies and is the faster formulation: packed greedy growing, lite 0 / 2, at most 96 slots) /
+        free_run: True / None (= where it applies and is the faster formulation: packed greedy growing, lite 0 / 2, at most 144 slots) /
         False: one host call = ONE launch in which every slot takes up to free_run_steps grow steps at its own pace (lrg_grow_async),
         starting none after free_run_budget_us microseconds (0 = no time limit); same results as the lock-step iterations.
         free_run_fill_cus: > 0: that many CUs are left out of the free-running launches, and the fill-ins of finished rooms
@@ -328,8 +328,8 @@ class RegionGrower:
                                  'at most 512 + 512 points per set and lite 0 or 2')
             if self.want_free_run is None:
                 # (auto: where a step is a chain of latencies -- up to ~100 slots; with hundreds of slots in flight the lock-step
-                #  launches, whose tiles pack the rows of all slots, get more out of the chip: 272 rooms 1.17 M against 0.82 M)
-                self.free_run = can_free and S <= 96 and max(ns) <= _lib.LRG_FREE_RUN_AUTO_POINTS and os.environ.get('LRG_FREE_RUN', '1') != '0'
+                #  launches, whose tiles pack the rows of all slots, get more out of the chip: 272 rooms 1.20 M against 0.80 M)
+                self.free_run = can_free and S <= _lib.LRG_FREE_RUN_AUTO_SLOTS and max(ns) <= _lib.LRG_FREE_RUN_AUTO_POINTS and os.environ.get('LRG_FREE_RUN', '1') != '0'
             else:
                 self.free_run = bool(self.want_free_run)
             if self.free_run:
@@ -918,7 +918,7 @@ class LanedRegionGrower:
         if lanes is None or int(lanes) <= 0:
             lanes = auto_lanes(int(rooms_in_flight) * int(kw.get('restarts', 1)))
             # free-running launches (RegionGrower's choice up to 96 greedy slots) fill the chip by themselves: one lane
-            if (kw.get('free_run', None) is not False and int(kw.get('restarts', 1)) == 1 and int(rooms_in_flight) <= 96 and
+            if (kw.get('free_run', None) is not False and int(kw.get('restarts', 1)) == 1 and int(rooms_in_flight) <= _lib.LRG_FREE_RUN_AUTO_SLOTS and
                     kw.get('packed', None) is not False and os.environ.get('LRG_FREE_RUN', '1') != '0'):
                 lanes = 1
         lanes = max(1, min(int(lanes), int(rooms_in_flight)))

@@ -68,7 +68,9 @@ def test_bench_two_ranks_started_by_the_script_itself(cuda_device, tmp_path):
     collectives over gloo: LRG_BENCH_ONE_DEVICE=1), shards the fixed work over them and gathers every room's labels."""
     common = ['--steps', '2', '--warmup', '1', '--step-ms', '2', '--rooms', '4', '--fixed-rooms', '8', '--best-slots', '', '--cpu-seconds', '0',
               '--p0-rooms', '0', '--cache', str(tmp_path / 'cache')]
-    r2, l2 = run_bench(['--gpus', '2'] + common, env={'LRG_BENCH_ONE_DEVICE': '1'})
+    # (both ranks share the one device here: lock-step launches -- two free-running launches side by side on one chip each assume that all
+    #  their workgroups are resident at once, DESIGN.md section 4; on a multi-GPU node every rank has a device to itself)
+    r2, l2 = run_bench(['--gpus', '2', '--mode', 'lockstep', '--iters-per-step', '16'] + common, env={'LRG_BENCH_ONE_DEVICE': '1'})
     assert r2.returncode == 0, r2.stderr[-3000:]
     assert len(l2) == 1
     d2 = json.loads(l2[0])
