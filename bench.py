@@ -58,6 +58,7 @@ def parse():
                     help='auto: free-running launches (lrg_grow_async) up to 96 greedy slots per GPU, lock-step iterations above')
     ap.add_argument('--step-ms', type=float, default=25.0, help='free-running launches: budget of one launch = one step')
     ap.add_argument('--iters-per-step', type=int, default=512, help='lock-step iterations per (macro-)step')
+    ap.add_argument('--fill-cus', type=int, default=0, help='free-running launches: CUs left out of the launches for the fill-ins of finished rooms (0: fill-ins between two launches)')
     ap.add_argument('--best-slots', default='68,96,136,272', help='slot counts of the fixed_work_best sweep (empty = skip)')
     ap.add_argument('--rooms', type=int, default=68, help='rooms in flight per GPU (the Area-5 set has 68)')
     ap.add_argument('--restarts', type=int, default=1)
@@ -220,10 +221,13 @@ class _Leg:
         self.free = greedy and (mode == 'free' or (mode == 'auto' and slots <= _lib_auto_slots() and small)) and bool(grow_kw.get('packed'))
         self.slots = slots
         if self.free:
-            self.stream = torch.cuda.Stream(device=dev)
+            # (fill-ins beside the next launch: --fill-cus CUs are left out of the launches, grow.fill_streams)
+            from learn_region_grow_amd.grow import fill_streams
+            fill_cus = int(os.environ.get('LRG_FREE_RUN_FILL_CUS', args.fill_cus))
+            self.stream = fill_streams(dev, fill_cus)[0] if fill_cus > 0 else torch.cuda.Stream(device=dev)
             with torch.cuda.stream(self.stream):
                 self.gr = RegionGrower(net, rooms_in_flight=slots, seed=seed, free_run=True, free_run_budget_us=int(step_budget_us),
-                                       **{k: v for k, v in grow_kw.items() if k != 'graph_iterations'})
+                                       free_run_fill_cus=fill_cus, **{k: v for k, v in grow_kw.items() if k != 'graph_iterations'})
                 self.gr.load_rooms(jobs)
             self.growers = [self.gr]
             self.lanes = 1
@@ -620,6 +624,7 @@ def main():
                                     ', test_random_restart.py loop with %d restarts per seed batched per launch' % args.restarts),
                        'step': step_what, 'formulation': 'free-running launches (lrg_grow_async)' if free_steady else 'lock-step iterations (lrg_grow_step_packed)' if packed else 'lrg_grow_step',
                        'rooms_in_flight_per_gpu': S, 'slots_per_gpu': S * args.restarts, 'lanes': 1 if free_steady else n_lanes, 'policy': args.policy,
+                       'compute_units_left_to_the_fill_ins': (int(os.environ.get('LRG_FREE_RUN_FILL_CUS', args.fill_cus)) if free_steady else 0),
                        'restarts': args.restarts, 'points': '512 inlier + 512 neighbour x 13 features', 'rng': 'counter (Philox) stream',
                        'weights': ('trained on synthetic Area-5-shaped rooms by train_region_grow.py (learn_region_grow_amd/weights)'
                                    if args.weights == 'trained' else 'random, seed 0'), 'net_mode': args.net_mode,

@@ -61,11 +61,11 @@ class RegionGrower:
         False: one host call = ONE launch in which every slot takes up to free_run_steps grow steps at its own pace (lrg_grow_async),
         starting none after free_run_budget_us microseconds (0 = no time limit); same results as the lock-step iterations.
         free_run_fill_cus: > 0: that many CUs are left out of the free-running launches, and the fill-ins of finished rooms
-        (test_region_grow.py:308-316) run on a stream of their own beside the next launch instead of between two launches (a
-        launch holds every CU it is given for its whole duration).  Off by default: a kernel on a second stream is only placed when
-        every shader engine has a CU to spare -- 32 CUs on an MI355X, fewer and it waits for the launch to end
-        (tools/r03_side_stream.py) -- and 32 CUs cost the launches what the fill-ins between them cost (816 k against 814 k
-        instance-steps/s, 502 against 530 rooms/s: profiles/r03_units_sweep.log)."""
+        (test_region_grow.py:308-316) run on them beside the next launch instead of between two launches: the caller runs the grower on
+        the first stream of fill_streams(device, free_run_fill_cus) (grower.main_stream), the fill-ins go to the second by themselves.
+        None = LRG_FREE_RUN_FILL_CUS, else 0 (fill-ins on the launches' stream).  Measured at 68 rooms in flight: 8 CUs 838-843 k against
+        836 k instance-steps/s, 541 against 547 rooms/s fixed work; 6 CUs cannot keep up (728 k), 12 cost more than the fill-ins
+        (profiles/r03_units_sweep.log) -- an option, off by default."""
         self.lib = _lib.load()
         self.net = net
         self.dev = net.device
@@ -342,8 +342,10 @@ class RegionGrower:
                 ab.teams = self.free_run_teams or int(os.environ.get('LRG_FREE_RUN_TEAMS', '0'))
                 ab.compute_units = int(os.environ.get('LRG_FREE_RUN_CUS', '0'))
                 self.fill_cus = int(os.environ.get('LRG_FREE_RUN_FILL_CUS', '0' if self.free_run_fill_cus is None else str(int(self.free_run_fill_cus))))
+                self.main_stream = None
                 if self.fill_cus > 0 and ab.compute_units == 0:
                     ab.compute_units = max(64, torch.cuda.get_device_properties(dev).multi_processor_count - self.fill_cus)
+                    self.main_stream, self.fill_stream = fill_streams(dev, self.fill_cus)
                 ab.poll_sleep = int(os.environ.get('LRG_FREE_RUN_POLL', '0'))
                 ab.branch_parts = int(os.environ.get('LRG_FREE_RUN_PARTS', '0'))
                 ab.gemv_units = self.free_run_units or int(os.environ.get('LRG_FREE_RUN_UNITS', '0'))          # -1: the pooled product as tasks of the tile teams
@@ -422,8 +424,6 @@ class RegionGrower:
         left out for it (free_run_fill_cus): on the fill stream, beside the next launch -- the room was reported finished by a launch
         that has completed (poll_done), its labels are final; wait_fills() before reading d_filled."""
         if getattr(self, 'free_run', False) and getattr(self, 'fill_cus', 0) > 0 and not getattr(self, '_in_fill_stream', False):
-            if getattr(self, 'fill_stream', None) is None:
-                self.fill_stream = torch.cuda.Stream(device=self.dev)
             self._in_fill_stream = True
             try:
                 with torch.cuda.stream(self.fill_stream):
@@ -610,14 +610,27 @@ class RegionGrower:
         self.enqueue_free_run(steps, budget_us)
         self.poll_done(wait=wait)
         n = len(self.done_rooms)
+        # (the last rooms of a pass: no launch follows that their fill-ins could run beside -- on the launches' stream, with the whole chip)
+        last = getattr(self, 'fill_cus', 0) > 0 and self.rooms_finished + n >= self.n_rooms
+        if last:
+            self.wait_fills()
+            self._in_fill_stream = True
         for r in self.done_rooms:
             if fill:
                 self.fill(r)
+        if last:
+            self._in_fill_stream = False
         self.rooms_finished += n
         self.done_rooms = []
         return n
 
     def _grow_loaded_free_run(self, fill=True):
+        main = getattr(self, 'main_stream', None)
+        if main is not None and torch.cuda.current_stream(self.dev).cuda_stream != main.cuda_stream:
+            # CUs left out for the fill-ins: the launches go to the stream confined to the rest (fill_streams)
+            main.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(main):
+                return self._grow_loaded_free_run(fill)
         self.free_run_begin()
         while self.rooms_finished < self.n_rooms:
             self.free_run_step(fill)
@@ -868,6 +881,35 @@ def auto_lanes(slots_in_flight):
 
 
 _LANE_STREAMS = {}       # (device index, CU-masked lane count or 0) -> ([torch streams], [raw handles]), one set per process
+
+
+_FILL_STREAMS = {}
+
+
+def fill_streams(device, fill_cus):
+    """-> (launch stream, fill stream) of `device`, process-wide: the first confined to all CUs but `fill_cus` of them, the second to those
+    (lrg_stream_create_cu_mask).  A free-running launch holds every CU it is given for its whole duration; on plain streams a kernel of
+    another stream is only placed beside it when EVERY shader engine has a CU to spare (32 CUs of an MI355X, tools/r03_side_stream.py);
+    with the two streams masked to disjoint sets the fill-ins run on their few CUs while the launch runs on the rest
+    (tools/r03_masked_streams.py: CUs 0 .. 7 of the mask's numbering work, one CU in eight does not)."""
+    device = torch.device(device)
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev_index, int(fill_cus))
+    if key not in _FILL_STREAMS:
+        lib = _lib.load()
+        ncu = torch.cuda.get_device_properties(device).multi_processor_count
+        words = (ncu + 31) // 32
+        out = []
+        with torch.cuda.device(device):
+            for cus in (range(int(fill_cus), ncu), range(int(fill_cus))):
+                mask = (ctypes.c_uint32 * words)()
+                for b in cus:
+                    mask[b // 32] |= 1 << (b % 32)
+                h = ctypes.c_void_p()
+                _lib.check(lib.lrg_stream_create_cu_mask(mask, words, ctypes.byref(h)), 'lrg_stream_create_cu_mask')
+                out.append((h, torch.cuda.ExternalStream(h.value, device=device)))
+        _FILL_STREAMS[key] = out
+    return _FILL_STREAMS[key][0][1], _FILL_STREAMS[key][1][1]
 
 
 def lane_streams(device, lanes, cu_partition=False):
