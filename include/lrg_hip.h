@@ -462,9 +462,9 @@ typedef struct LrgAsyncBuffers {
     int32_t poll_sleep;         /* idle tile teams poll the queue every poll_sleep x ~0.25 us; 0 = default                  */
     int32_t branch_parts;       /* tasks per branch tile (1, 2 or 4: they share the four column blocks of its pooled layer and each run the
                                    layers before it again); 0 = by the number of slots (2 up to 12 slots, else 1)                    */
-    int32_t gemv_units;         /* 0 = default: up to 96 slots the heads' pooled kernels stay in the LDS of 2 C / 32 workgroups of their own (32
+    int32_t gemv_units;         /* 0 = default: up to 176 slots the heads' pooled kernels stay in the LDS of 2 C / 32 workgroups of their own (32
                                    columns each; a slot's pooled product = one 4 KB row in, 32 sums out per unit, and its head tiles start
-                                   beside it) where that fits; 1 = also above 96 slots; -1 = the tile teams compute it in 128-column
+                                   beside it) where that fits; 1 = also above 176 slots; -1 = the tile teams compute it in 128-column
                                    blocks from L2                                                                                 */
     int32_t *room_queue;        /* nullable: rooms waiting for a slot -- [0] rooms handed out so far (the caller zeroes it when it refills
                                    the queue), [1] rooms queued, [2 + k] = room index | reset << 30 (reset: clear visited / labels /

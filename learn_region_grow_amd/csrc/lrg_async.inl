@@ -65,6 +65,9 @@ struct LrgAsyncArgs {
     int gemv_units;              // workgroups n_front .. n_front + gemv_units - 1 hold 32 columns each of the heads' pooled kernels in LDS (0: the
                                  // pooled product is a task of the tile teams, 128 columns each)
     int n_slots, n_front, teams;
+    int head_ring;               // the ring pooled blocks and head tiles are published to: 1, or 0 = one ring for all tasks and all teams
+    int ring0_halves;            // more than one team per workgroup: team t of worker workgroup w runs branch tiles (ring 0) if 2 t + (w & 1) < ring0_halves,
+                                 // else pooled blocks and head tiles (ring 1) -- 2: the first team everywhere, 3: one and a half teams on average, ...
     int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
     int branch_parts;            // tasks per branch tile (1, 2, 4): they share the column blocks of the pooled layer (lrg_fused_tile)
     int max_steps;               // evaluations per slot in this launch
@@ -254,12 +257,12 @@ LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
                     lrg_st_coh(&A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (i & A.gmask)], (lrg_gemv_ring_tag(i, A.gmask) << 20) | slot);
                 }
                 nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
-                lrg_async_push(A, A.teams > 1 ? 1 : 0, nt_nb + nt_in, lane, [&](int i) {
+                lrg_async_push(A, A.head_ring, nt_nb + nt_in, lane, [&](int i) {
                     return i < nt_nb ? LRG_TASK(LRG_TASK_HEAD, slot, 0, i) : LRG_TASK(LRG_TASK_HEAD, slot, 1, i - nt_nb);
                 });
             } else {
                 const int nb = (A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS;
-                lrg_async_push(A, A.teams > 1 ? 1 : 0, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
+                lrg_async_push(A, A.head_ring, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
             }
         }
     }
@@ -288,7 +291,7 @@ __device__ __forceinline__ void lrg_async_gemv_arrive(const LrgAsyncArgs &A, con
         }
         if (__shfl(last, 0)) {                       // head 0 = add on the neighbour rows, head 1 = remove on the inlier rows
             nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
-            lrg_async_push(A, A.teams > 1 ? 1 : 0, nt_nb + nt_in, lane, [&](int i) {
+            lrg_async_push(A, A.head_ring, nt_nb + nt_in, lane, [&](int i) {
                 return i < nt_nb ? LRG_TASK(LRG_TASK_HEAD, slot, 0, i) : LRG_TASK(LRG_TASK_HEAD, slot, 1, i - nt_nb);
             });
         }
@@ -488,7 +491,10 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
     LrgLdsTeam team = lrg_async_team(A, sm, 0);
     const int tid = team.tid();
     int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);       // [0] task of this round
-    const bool secondary = sm_off != 0;      // (letting some of the second teams run branch tiles too: 809 k -> 783 k instance-steps/s at 68 slots -- two branch tiles on a CU slow each other)
+    const int team_no = sm_off / LRG_ASYNC_TEAM_FLOATS, wg_no = (int)blockIdx.x - A.n_front - A.gemv_units;
+    const bool secondary = A.head_ring == 1 && 2 * team_no + (wg_no & 1) >= A.ring0_halves;
+    // (at 68 slots two branch tiles on a CU slow each other: 809 k -> 783 k instance-steps/s with some second teams on ring 0; at 272 slots
+    //  with three teams a single branch team per CU is what every slot queues for: 257 us from publishing to the last branch tile)
     for (;;) {
         long long t_task = 0;
         if (tid == 0) {

@@ -1537,20 +1537,22 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // Front workgroups: one per two slots (a front step takes ~23 us of a ~85 us step, and a CU a front workgroup holds is a CU without
     // tile teams: 68 slots, two teams: 34 / 40 / 46 / 68 front workgroups 806 / 810 / 807 / 792 k instance-steps/s, profiles/r03_units_sweep.log);
     // one per slot while the slots are few and CUs plenty (eight 100 k-point scenes: 8 / 4 front workgroups 97 k / 86 k, profiles/r03_kitti2_*.json)
-    int n_front = ab->front_workgroups > 0 ? ab->front_workgroups : n_slots <= 24 ? n_slots : (n_slots + 1) / 2;
+    // ... and never more than an eighth of the CUs (+ 2: 34 of 256) by default: a front step takes ~24 us whatever the number of slots, so
+    // ~1 M steps/s keep ~25 front workgroups busy, and every CU beyond that is a CU without tile teams (192 slots: 24 / 28 / 34 / 48 front
+    // workgroups 0.92 / 1.06 / 1.17 / 1.11 M instance-steps/s; 272 slots: 34 / 40 / 48 / 64 / 96: 1.11 / 1.07 / 1.02 / 0.94 / 0.76 M)
+    int n_front = ab->front_workgroups > 0 ? ab->front_workgroups : n_slots <= 24 ? n_slots : min((n_slots + 1) / 2, wgs / 8 + 2);
     n_front = min(n_front, n_slots);
     n_front = max(n_front, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED);
-    n_front = min(n_front, ab->front_workgroups > 0 ? wgs / 2 : max(wgs / 4, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED));      // (by default three quarters of the CUs for the tile teams:
-                                                             //  272 slots, 128 / 64 front workgroups: 0.40 M / see profiles/r03_d_bench_272_free.json)
+    n_front = min(n_front, wgs / 2);                         // (at least half of the CUs for the tile teams)
     if (n_front < (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED) return LRG_EINVAL - 8;      // more slots than the front workgroups can serve
     // Pooled-product units (lrg_async.inl): sixteen CUs for the LrgNet of the paper (2 heads x 256 columns, 1024 pooled features).
     // Off (-1), or where the slices do not fit / would leave the tile teams fewer than half of the CUs: the teams' 128-column blocks.  Off
-    // above 96 slots too: sixteen units take ~1 M pooled products a second, the head tiles that wait for them hold their teams, and
-    // 272 slots in flight fell from 0.82 M to 0.31 M instance-steps/s (profiles/r03_d_bench_272_free.json; lock-step: 1.20 M).
+    // above 176 slots too: sixteen units take ~1.1 M pooled products a second, and the head tiles that wait for them hold their teams
+    // (136 / 160 / 192 / 272 slots with | without units: 1.13 | 1.03, 1.15 | 1.11, 1.14 | 1.17, 1.06 | 1.11 M instance-steps/s, profiles/r03_slots_sweep.log).
     {
         const LrgGemvArgs &g = A.gemv;
         int units = (g.C % LRG_GEMV_UNIT_COLS == 0) ? 2 * g.C / LRG_GEMV_UNIT_COLS : 0;
-        if (ab->gemv_units < 0 || (ab->gemv_units == 0 && n_slots > 96) || (size_t)LRG_GEMV_UNIT_FLOATS(g.P) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
+        if (ab->gemv_units < 0 || (ab->gemv_units == 0 && n_slots > 176) || (size_t)LRG_GEMV_UNIT_FLOATS(g.P) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
             n_front + units > wgs / 2 + wgs / 4 || n_slots >= (1 << 20))
             units = 0;
         A.gemv_units = units;
@@ -1559,11 +1561,16 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // the head tiles wait inside for the pooled-product units, and at 68 slots the teams are what a step queues for: 1 / 2 / 3 teams
     // 751 / 806 / 771 k instance-steps/s with 34 front workgroups, profiles/r03_units_sweep.log); one while the slots are few (nothing
     // queues, a tile alone is faster: eight scenes 108 k against 97 k); three where hundreds of slots are in flight
-    const int teams = ab->teams > 0 ? min(ab->teams, 3) : n_slots <= 24 ? 1 : n_slots <= 96 ? (A.gemv_units ? 2 : 1) : 3;
+    const int teams = ab->teams > 0 ? min(ab->teams, 3) : n_slots <= 24 ? 1 : n_slots <= 96 ? (A.gemv_units ? 2 : 1) : 3;      // (112 slots: 2 / 3 teams 1.02 / 1.04 M; 96: 1.00 / 0.96 M)
     A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.room_queue = ab->room_queue; A.work = reinterpret_cast<unsigned long long *>(ab->work); A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
     A.qmask = (int)async_ring_entries(n_slots) - 1;
     A.gmask = (int)async_unit_ring_entries(n_slots) - 1;
     A.n_slots = n_slots; A.n_front = n_front; A.teams = teams;
+    {
+        static const int r0_env = getenv("LRG_ASYNC_RING0_HALVES") ? atoi(getenv("LRG_ASYNC_RING0_HALVES")) : 0;
+        A.ring0_halves = r0_env > 0 ? r0_env : teams >= 3 ? 3 : 2;
+        A.head_ring = (teams > 1 && r0_env >= 0) ? 1 : 0;      // (LRG_ASYNC_RING0_HALVES=-1: one ring)
+    }
     A.poll_sleep = ab->poll_sleep > 0 ? ab->poll_sleep : 1;
     // few slots, most teams idle: a branch tile as two tasks that share its pooled layer (tile 22.8 -> 18.4 us; eight 100 k-point scenes
     // 75.9 k -> 78.1 k instance-steps/s, four tasks 75.0 k; 68 rooms: 559 k -> 505 k, the teams are busy there: profiles/r03_parts_perf.log)

@@ -57,7 +57,7 @@ class RegionGrower:
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
         graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*).
-        free_run: True / None (= where it applies and is the faster formulation: packed greedy growing, lite 0 / 2, at most 144 slots) /
+        free_run: True / None (= where it applies and is the faster formulation: packed greedy growing, lite 0 / 2, at most 240 slots) /
         False: one host call = ONE launch in which every slot takes up to free_run_steps grow steps at its own pace (lrg_grow_async),
         starting none after free_run_budget_us microseconds (0 = no time limit); same results as the lock-step iterations.
         free_run_fill_cus: > 0: that many CUs are left out of the free-running launches, and the fill-ins of finished rooms
