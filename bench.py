@@ -371,9 +371,8 @@ def main():
                         e1.record(leg.stream)
                         ev_pairs.append((e0, e1))
                         gr.poll_done()
-                        for r in gr.done_rooms:
-                            if args.fill:
-                                gr.fill(r)
+                        if args.fill:
+                            gr.fill_many(gr.done_rooms)
                         gr.rooms_finished += len(gr.done_rooms)
                         gr.done_rooms = []
                     else:
@@ -413,10 +412,11 @@ def main():
                 for lane, g_ in enumerate(growers):
                     with torch.cuda.stream(lane_streams_[lane]):
                         g_.enqueue()
-                        for g in g_.poll_done():          # finished rooms get their fill-in (:308-316) and restart at once
+                        gs = g_.poll_done()               # finished rooms get their fill-in (:308-316) and restart at once
+                        if args.fill:
+                            g_.fill_many([g_.group_room[g] for g in gs])
+                        for g in gs:
                             r = g_.group_room[g]
-                            if args.fill:
-                                g_.fill(r)
                             g_.reset_room(r)
                             g_.bind(g, r)
         step_what = '%d lock-step iterations of lrg_grow_step_packed (every in-flight room takes one region-grow step per iteration)' % args.iters_per_step

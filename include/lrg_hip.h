@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define LRG_ABI_VERSION 6
+#define LRG_ABI_VERSION 7
 #define LRG_EINVAL (-1000)
 
 #define LRG_MAX_CONV 5 /* branch layers: lite=0 -> 5, lite=1 -> 2, lite=2 -> 3  (learn_region_grow_util.py:77-85) */
@@ -30,7 +30,7 @@ extern "C" {
 int lrg_abi_version(void);
 /* Name of the code object's target ("gfx950"); a build sanity hook for the loader. */
 const char *lrg_target_arch(void);
-/* sizeof() of the ABI structs as compiled (0 LrgWeights, 1 LrgRoom, 2 LrgSlot, 3 LrgGrowParams, 4 LrgStepBuffers, 5 LrgPackedBuffers, 6 LrgBeamGroup, 7 LrgAsyncBuffers), so that a
+/* sizeof() of the ABI structs as compiled (0 LrgWeights, 1 LrgRoom, 2 LrgSlot, 3 LrgGrowParams, 4 LrgStepBuffers, 5 LrgPackedBuffers, 6 LrgBeamGroup, 7 LrgAsyncBuffers, 8 LrgFillJob), so that a
  * foreign-language binding can verify its mirror of the layout at load time. */
 size_t lrg_struct_size(int which);
 
@@ -530,6 +530,17 @@ int lrg_nn1_fill(const float *points, int n, int F, const int32_t *label_in, int
 size_t lrg_nn1_fill_workspace_bytes(int n);
 int lrg_nn1_fill_ws(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *workspace,
                     size_t workspace_bytes, void *stream);
+/* Several rooms at once (the rooms that finish during one free-running launch): the same result as lrg_nn1_fill_ws room by room, three
+ * launches per 16 rooms.  `jobs` is host memory; n = 0 rooms are skipped.  workspace: lrg_nn1_fill_batch_workspace_bytes(jobs, n_jobs) bytes. */
+typedef struct LrgFillJob {
+    const float *points;         /* [n, F] */
+    const int32_t *label_in;     /* [n], 0 = unlabeled */
+    int32_t *label_out;          /* [n] */
+    int32_t n;
+    int32_t reserved;
+} LrgFillJob;
+size_t lrg_nn1_fill_batch_workspace_bytes(const LrgFillJob *jobs, int n_jobs);
+int lrg_nn1_fill_batch(const LrgFillJob *jobs, int n_jobs, int F, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * tf_ops/grouping replacements.  Same argument order as the reference launchers

@@ -89,6 +89,10 @@ class LrgAsyncBuffers(ctypes.Structure):
                 ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('branch_parts', ctypes.c_int32), ('gemv_units', ctypes.c_int32), ('room_queue', _fp), ('work', _fp), ('debug_ticks', _fp)]
 
 
+class LrgFillJob(ctypes.Structure):
+    _fields_ = [('points', _fp), ('label_in', _fp), ('label_out', _fp), ('n', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
 class LrgBeamGroup(ctypes.Structure):
     _fields_ = [('parent', _fp), ('cap', ctypes.c_int32), ('room', ctypes.c_int32), ('seed', ctypes.c_int32), ('level', ctypes.c_int32),
                 ('stuck', ctypes.c_int32), ('steps', ctypes.c_int32), ('nq', ctypes.c_int32), ('pending', ctypes.c_int32),
@@ -220,6 +224,8 @@ _SIGS = {
     'lrg_nn1_fill': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
     'lrg_nn1_fill_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
     'lrg_nn1_fill_ws': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]),
+    'lrg_nn1_fill_batch_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(LrgFillJob), ctypes.c_int]),
+    'lrg_nn1_fill_batch': (ctypes.c_int, [ctypes.POINTER(LrgFillJob), ctypes.c_int, ctypes.c_int, _fp, ctypes.c_size_t, _fp]),
     'lrg_query_ball_point': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _fp,
                                             _fp, _fp, _fp, _fp]),
     'lrg_selection_sort': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
@@ -261,9 +267,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lrg_abi_version() != 6:
+    if lib.lrg_abi_version() != 7:
         raise LrgHipError('ABI version mismatch')
-    for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LrgBeamGroup, LrgAsyncBuffers)):
+    for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LrgBeamGroup, LrgAsyncBuffers, LrgFillJob)):
         if lib.lrg_struct_size(which) != ctypes.sizeof(st):
             raise LrgHipError('struct layout mismatch for %s: C %d vs ctypes %d' %
                               (st.__name__, lib.lrg_struct_size(which), ctypes.sizeof(st)))

@@ -1020,22 +1020,40 @@ __global__ __launch_bounds__(256) void lrg_nn1_fill_kernel(const float *points, 
 // queries instead of once per query.
 #define LRG_NN1_Q 64
 #define LRG_NN1_C 256
-__global__ void lrg_nn1_prep_kernel(const int32_t *label_in, int n, int32_t *list, int32_t *count, unsigned long long *best) {
+// Up to LRG_FILL_BATCH rooms per launch (blockIdx.z = the room): the rooms that finish during one free-running launch are filled in
+// together -- three launches for all of them instead of four per room (their gaps and tails were a third of a 13 k-point room's 35 us).
+#define LRG_FILL_BATCH 16
+struct LrgFillBatchArgs {
+    const float *points[LRG_FILL_BATCH];
+    const int32_t *label_in[LRG_FILL_BATCH];
+    int32_t *label_out[LRG_FILL_BATCH];
+    int32_t *list[LRG_FILL_BATCH];
+    unsigned long long *best[LRG_FILL_BATCH];
+    int32_t n[LRG_FILL_BATCH];
+    int32_t *counts;         // [LRG_FILL_BATCH] unlabeled points of each room (zero before the prep kernel)
+};
+
+__global__ void lrg_nn1_prep_kernel(LrgFillBatchArgs B) {
+    const int job = blockIdx.z, n = B.n[job];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    best[i] = ~0ull;
-    if (label_in[i] == 0) list[atomicAdd(count, 1)] = i;
+    B.best[job][i] = ~0ull;
+    if (B.label_in[job][i] == 0) B.list[job][atomicAdd(B.counts + job, 1)] = i;
 }
 
-__global__ __launch_bounds__(256) void lrg_nn1_search_kernel(const float *points, int n, int F, const int32_t *label_in,
-                                                              const int32_t *list, const int32_t *count, unsigned long long *best) {
+__global__ __launch_bounds__(256) void lrg_nn1_search_kernel(LrgFillBatchArgs B, int F) {
     __shared__ float rows[LRG_NN1_C * 13 + 64];
     __shared__ int lab[LRG_NN1_C];
     __shared__ unsigned long long part[4][LRG_NN1_Q];
-    const int U = *count;
+    const int job = blockIdx.z, n = B.n[job];
+    const float *points = B.points[job];
+    const int32_t *label_in = B.label_in[job], *list = B.list[job];
+    unsigned long long *best = B.best[job];
+    const int U = B.counts[job];
     if ((int)blockIdx.x * LRG_NN1_Q >= U) return;                  // (the host does not know U: a fixed, small number of query
                                                                    //  columns, each looping over its share of the list)
     const int c0 = blockIdx.y * LRG_NN1_C;
+    if (c0 >= n) return;                                           // (the grid covers the largest room of the batch)
     const int nc = min(LRG_NN1_C, n - c0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int e = threadIdx.x; e < nc * F; e += blockDim.x) rows[e] = points[(long)c0 * F + e];       // contiguous block of rows
@@ -1094,14 +1112,18 @@ __device__ __forceinline__ lrg_f2 lrg_np_sqdist2(const float *pair_rows, const l
 }
 
 template <int FT>
-__global__ __launch_bounds__(256) void lrg_nn1_search_pairs_kernel(const float *points, int n, const int32_t *label_in, const int32_t *list,
-                                                                    const int32_t *count, unsigned long long *best) {
+__global__ __launch_bounds__(256) void lrg_nn1_search_pairs_kernel(LrgFillBatchArgs B) {
     __shared__ __attribute__((aligned(16))) float rows[LRG_NN1_C * FT];      // [pair][feature][2]
     __shared__ int lab[LRG_NN1_C];
     __shared__ unsigned long long part[4][LRG_NN1_Q];
-    const int U = *count;
+    const int job = blockIdx.z, n = B.n[job];
+    const float *points = B.points[job];
+    const int32_t *label_in = B.label_in[job], *list = B.list[job];
+    unsigned long long *best = B.best[job];
+    const int U = B.counts[job];
     if ((int)blockIdx.x * LRG_NN1_Q >= U) return;
     const int c0 = blockIdx.y * LRG_NN1_C;
+    if (c0 >= n) return;                                           // (the grid covers the largest room of the batch)
     const int nc = min(LRG_NN1_C, n - c0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int e = threadIdx.x; e < LRG_NN1_C * FT; e += blockDim.x) {
@@ -1135,13 +1157,15 @@ __global__ __launch_bounds__(256) void lrg_nn1_search_pairs_kernel(const float *
     }
 }
 
-__global__ void lrg_nn1_write_kernel(const int32_t *label_in, int n, const unsigned long long *best, int32_t *label_out) {
+__global__ void lrg_nn1_write_kernel(LrgFillBatchArgs B) {
+    const int job = blockIdx.z, n = B.n[job];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int32_t *label_in = B.label_in[job];
     const int li = label_in[i];
-    if (li != 0) { label_out[i] = li; return; }
-    const unsigned long long k = best[i];
-    label_out[i] = k == ~0ull ? 0 : label_in[(int)(k & 0xFFFFFFFFull)];
+    if (li != 0) { B.label_out[job][i] = li; return; }
+    const unsigned long long k = B.best[job][i];
+    B.label_out[job][i] = k == ~0ull ? 0 : label_in[(int)(k & 0xFFFFFFFFull)];
 }
 
 #include "lrg_front.inl"
@@ -1697,30 +1721,65 @@ int lrg_stream_destroy(void *stream) {
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-size_t lrg_nn1_fill_workspace_bytes(int n) { return n <= 0 ? 0 : lrg_align_up((size_t)n * 4 + 64, 256) + (size_t)n * 8; }
+// workspace of one room: [64 bytes: counts of a batch] | list [n] | best [n] (64-bit); a batch: the counts once, then list | best per room
+static size_t nn1_room_bytes(int n) { return lrg_align_up((size_t)n * 4, 256) + lrg_align_up((size_t)n * 8, 256); }
+size_t lrg_nn1_fill_workspace_bytes(int n) { return n <= 0 ? 0 : 256 + nn1_room_bytes(n); }
+size_t lrg_nn1_fill_batch_workspace_bytes(const LrgFillJob *jobs, int n_jobs) {
+    if (!jobs || n_jobs <= 0) return 0;
+    size_t worst = 0;
+    for (int g = 0; g < n_jobs; g += LRG_FILL_BATCH) {      // (groups of LRG_FILL_BATCH rooms run one after the other in the same workspace)
+        size_t b = 256;
+        for (int j = g; j < min(n_jobs, g + LRG_FILL_BATCH); ++j) b += jobs[j].n > 0 ? nn1_room_bytes(jobs[j].n) : 0;
+        worst = max(worst, b);
+    }
+    return worst;
+}
+
+int lrg_nn1_fill_batch(const LrgFillJob *jobs, int n_jobs, int F, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n_jobs == 0) return 0;
+    if (!jobs || n_jobs < 0 || F < 1 || F > 13) return LRG_EINVAL - 1;
+    for (int j = 0; j < n_jobs; ++j)
+        if (jobs[j].n < 0 || (jobs[j].n > 0 && (!jobs[j].points || !jobs[j].label_in || !jobs[j].label_out))) return LRG_EINVAL - 1;
+    if (!workspace || workspace_bytes < lrg_nn1_fill_batch_workspace_bytes(jobs, n_jobs) || ((uintptr_t)workspace & 255)) return LRG_EINVAL - 2;
+    hipStream_t st = (hipStream_t)stream;
+    static const bool generic = getenv("LRG_NN1_GENERIC") != nullptr;      // (A/B switch)
+    for (int g = 0; g < n_jobs; g += LRG_FILL_BATCH) {
+        LrgFillBatchArgs B = {};
+        B.counts = static_cast<int32_t *>(workspace);
+        char *w = static_cast<char *>(workspace) + 256;
+        int nb = 0, nmax = 0;
+        for (int j = g; j < min(n_jobs, g + LRG_FILL_BATCH); ++j) {
+            const int n = jobs[j].n;
+            if (n == 0) continue;
+            B.points[nb] = jobs[j].points; B.label_in[nb] = jobs[j].label_in; B.label_out[nb] = jobs[j].label_out; B.n[nb] = n;
+            B.list[nb] = reinterpret_cast<int32_t *>(w);
+            B.best[nb] = reinterpret_cast<unsigned long long *>(w + lrg_align_up((size_t)n * 4, 256));
+            w += nn1_room_bytes(n);
+            nmax = max(nmax, n);
+            ++nb;
+        }
+        if (!nb) continue;
+        LRG_HIP_CHECK(hipMemsetAsync(B.counts, 0, 64, st));
+        hipLaunchKernelGGL(lrg_nn1_prep_kernel, dim3((nmax + 255) / 256, 1, nb), dim3(256), 0, st, B);
+        const dim3 grid(min(16, (nmax + LRG_NN1_Q - 1) / LRG_NN1_Q), (nmax + LRG_NN1_C - 1) / LRG_NN1_C, nb);
+        // the feature counts of the reference's variants (test_region_grow.py:72-77) are compiled in; any other goes the generic way
+        if (F == 13 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<13>, grid, dim3(256), 0, st, B);
+        else if (F == 12 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<12>, grid, dim3(256), 0, st, B);
+        else if (F == 9 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<9>, grid, dim3(256), 0, st, B);
+        else if (F == 6 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<6>, grid, dim3(256), 0, st, B);
+        else hipLaunchKernelGGL(lrg_nn1_search_kernel, grid, dim3(256), 0, st, B, F);
+        hipLaunchKernelGGL(lrg_nn1_write_kernel, dim3((nmax + 255) / 256, 1, nb), dim3(256), 0, st, B);
+        LRG_LAUNCH_CHECK();
+    }
+    return 0;
+}
 
 int lrg_nn1_fill_ws(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *workspace,
                     size_t workspace_bytes, void *stream) {
     if (!points || !label_in || !label_out || n < 0 || F < 1 || F > 13) return LRG_EINVAL - 1;
     if (n == 0) return 0;
-    if (!workspace || workspace_bytes < lrg_nn1_fill_workspace_bytes(n) || ((uintptr_t)workspace & 255)) return LRG_EINVAL - 2;
-    hipStream_t st = (hipStream_t)stream;
-    int32_t *count = static_cast<int32_t *>(workspace);
-    int32_t *list = count + 16;
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + lrg_align_up((size_t)n * 4 + 64, 256));
-    LRG_HIP_CHECK(hipMemsetAsync(count, 0, 64, st));
-    hipLaunchKernelGGL(lrg_nn1_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, label_in, n, list, count, best);
-    const dim3 grid(min(16, (n + LRG_NN1_Q - 1) / LRG_NN1_Q), (n + LRG_NN1_C - 1) / LRG_NN1_C);
-    static const bool generic = getenv("LRG_NN1_GENERIC") != nullptr;      // (A/B switch)
-    // the feature counts of the reference's variants (test_region_grow.py:72-77) are compiled in; any other goes the generic way
-    if (F == 13 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<13>, grid, dim3(256), 0, st, points, n, label_in, list, count, best);
-    else if (F == 12 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<12>, grid, dim3(256), 0, st, points, n, label_in, list, count, best);
-    else if (F == 9 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<9>, grid, dim3(256), 0, st, points, n, label_in, list, count, best);
-    else if (F == 6 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<6>, grid, dim3(256), 0, st, points, n, label_in, list, count, best);
-    else hipLaunchKernelGGL(lrg_nn1_search_kernel, grid, dim3(256), 0, st, points, n, F, label_in, list, count, best);
-    hipLaunchKernelGGL(lrg_nn1_write_kernel, dim3((n + 255) / 256), dim3(256), 0, st, label_in, n, best, label_out);
-    LRG_LAUNCH_CHECK();
-    return 0;
+    LrgFillJob job = {points, label_in, label_out, n, 0};
+    return lrg_nn1_fill_batch(&job, 1, F, workspace, workspace_bytes, stream);
 }
 
 int lrg_nn1_fill(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *stream) {

@@ -863,6 +863,7 @@ size_t lrg_struct_size(int which) {
     case 5: return sizeof(LrgPackedBuffers);
     case 6: return sizeof(LrgBeamGroup);
     case 7: return sizeof(LrgAsyncBuffers);
+    case 8: return sizeof(LrgFillJob);
     }
     return 0;
 }

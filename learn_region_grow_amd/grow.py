@@ -440,6 +440,27 @@ class RegionGrower:
                                             ctypes.c_void_p(self.d_filled.data_ptr() + o * 4), _ptr(self._fill_ws),
                                             self._fill_ws.numel(), _stream_ptr(self.dev)), 'lrg_nn1_fill_ws')
 
+    def fill_many(self, rs):
+        """fill(r) for every r of rs, the rooms filled in together (lrg_nn1_fill_batch: three launches per 16 rooms instead of four per
+        room; the rooms that finish during one free-running launch)."""
+        rs = list(rs)
+        if len(rs) <= 1 or (getattr(self, 'free_run', False) and getattr(self, 'fill_cus', 0) > 0 and not getattr(self, '_in_fill_stream', False)):
+            for r in rs:
+                self.fill(r)
+            return
+        F = self.net.feature_size
+        jobs = (_lib.LrgFillJob * len(rs))()
+        for k, r in enumerate(rs):
+            o, n = int(self.room_off[r]), self.room_n[r]
+            jobs[k].points = self.d_points.data_ptr() + o * F * 4
+            jobs[k].label_in = self.d_label.data_ptr() + o * 4
+            jobs[k].label_out = self.d_filled.data_ptr() + o * 4
+            jobs[k].n = n
+        need = self.lib.lrg_nn1_fill_batch_workspace_bytes(jobs, len(rs))
+        if getattr(self, '_fill_ws', None) is None or self._fill_ws.numel() < need:
+            self._fill_ws = torch.empty(max(need, self.lib.lrg_nn1_fill_workspace_bytes(max(self.room_n))), dtype=torch.uint8, device=self.dev)
+        _lib.check(self.lib.lrg_nn1_fill_batch(jobs, len(rs), F, _ptr(self._fill_ws), self._fill_ws.numel(), _stream_ptr(self.dev)), 'lrg_nn1_fill_batch')
+
     def wait_fills(self):
         """Fill-ins enqueued on the fill stream are complete on return."""
         if getattr(self, 'fill_stream', None) is not None:
@@ -615,9 +636,8 @@ class RegionGrower:
         if last:
             self.wait_fills()
             self._in_fill_stream = True
-        for r in self.done_rooms:
-            if fill:
-                self.fill(r)
+        if fill:
+            self.fill_many(self.done_rooms)
         if last:
             self._in_fill_stream = False
         self.rooms_finished += n
@@ -651,9 +671,10 @@ class RegionGrower:
         finished = 0
         while finished < self.n_rooms:
             self.enqueue()
-            for g in self.poll_done():
-                if fill:
-                    self.fill(self.group_room[g])
+            gs = self.poll_done()
+            if fill:
+                self.fill_many([self.group_room[g] for g in gs])
+            for g in gs:
                 finished += 1
                 self.bind(g, queue.pop(0) if queue else -1)
         torch.cuda.current_stream(self.dev).synchronize()
@@ -829,10 +850,10 @@ class RegionGrower:
         else:
             while finished < self.n_rooms:
                 self.enqueue()
-                for g in self.poll_done():
-                    r = self.group_room[g]
-                    if fill:
-                        self.fill(r)
+                gs = self.poll_done()
+                if fill:
+                    self.fill_many([self.group_room[g] for g in gs])
+                for g in gs:
                     finished += 1
                     self.bind(g, queue.pop(0) if queue else -1)
                 if max_iterations and self.iterations >= max_iterations:
@@ -1023,10 +1044,10 @@ class LanedRegionGrower:
                     continue
                 with torch.cuda.stream(self.streams[k]):
                     gr.enqueue()
-                    for g in gr.poll_done():
-                        r = gr.group_room[g]
-                        if fill:
-                            gr.fill(r)
+                    gs = gr.poll_done()
+                    if fill:
+                        gr.fill_many([gr.group_room[g] for g in gs])
+                    for g in gs:
                         finished += 1
                         done[k] += 1
                         gr.bind(g, queues[k].pop(0) if queues[k] else -1)

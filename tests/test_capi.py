@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_abi_and_struct_layout(hip_lib):
     from learn_region_grow_amd import _lib
-    assert hip_lib.lrg_abi_version() == 6
+    assert hip_lib.lrg_abi_version() == 7
     assert hip_lib.lrg_target_arch() == b'gfx950'
     for which, st in enumerate((_lib.LrgWeights, _lib.LrgRoom, _lib.LrgSlot, _lib.LrgGrowParams, _lib.LrgStepBuffers,
                                _lib.LrgPackedBuffers, _lib.LrgBeamGroup, _lib.LrgAsyncBuffers)):

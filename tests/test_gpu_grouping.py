@@ -172,3 +172,33 @@ def test_nn1_fill_tiled_on_a_room(cuda_device, hip_lib):
     _lib.check(hip_lib.lrg_nn1_fill(_ptr(dP), n, F, _ptr(dlab), _ptr(ref), _stream_ptr()), 'nn1')
     np.testing.assert_array_equal(out.cpu().numpy(), ref.cpu().numpy())
     assert (out.cpu().numpy() != 0).all()
+
+
+def test_nn1_fill_batch_equals_room_by_room(cuda_device, hip_lib):
+    """lrg_nn1_fill_batch over 19 rooms of different sizes (two groups of launches; an empty room, a room without unlabeled points, a room
+    without labeled points among them) = lrg_nn1_fill_ws room by room."""
+    import ctypes
+    import torch
+    from learn_region_grow_amd import _lib
+    from learn_region_grow_amd.lrgnet import _ptr, _stream_ptr
+    rs = np.random.RandomState(5)
+    F = 13
+    sizes = [3000, 64, 1, 0, 777, 5000, 257, 256, 255, 1200, 90, 4100, 33, 2048, 600, 17, 999, 1500, 320]
+    P, L, O, R = [], [], [], []
+    for k, n in enumerate(sizes):
+        pts = (rs.randn(max(n, 1), F) * 10 ** rs.uniform(-1, 1, (max(n, 1), F))).astype(np.float32)[:n]
+        lab = ((rs.rand(n) < (0.0 if k == 4 else 1.0 if k == 6 else 0.4)) * rs.randint(1, 9, n)).astype(np.int32)
+        P.append(dev(pts.reshape(n, F) if n else np.zeros((1, F), np.float32), cuda_device)); L.append(dev(lab if n else np.zeros(1, np.int32), cuda_device))
+        O.append(torch.full((max(n, 1),), -7, dtype=torch.int32, device=cuda_device)); R.append(torch.full((max(n, 1),), -7, dtype=torch.int32, device=cuda_device))
+    jobs = (_lib.LrgFillJob * len(sizes))()
+    for k, n in enumerate(sizes):
+        jobs[k].points, jobs[k].label_in, jobs[k].label_out, jobs[k].n = P[k].data_ptr(), L[k].data_ptr(), O[k].data_ptr(), n
+    need = hip_lib.lrg_nn1_fill_batch_workspace_bytes(jobs, len(sizes))
+    ws = torch.empty(need, dtype=torch.uint8, device=cuda_device)
+    _lib.check(hip_lib.lrg_nn1_fill_batch(jobs, len(sizes), F, _ptr(ws), ws.numel(), _stream_ptr()), 'batch')
+    ws1 = torch.empty(hip_lib.lrg_nn1_fill_workspace_bytes(max(sizes)), dtype=torch.uint8, device=cuda_device)
+    for k, n in enumerate(sizes):
+        if n:
+            _lib.check(hip_lib.lrg_nn1_fill_ws(_ptr(P[k]), n, F, _ptr(L[k]), _ptr(R[k]), _ptr(ws1), ws1.numel(), _stream_ptr()), 'ws')
+            np.testing.assert_array_equal(O[k].cpu().numpy()[:n], R[k].cpu().numpy()[:n])
+    assert hip_lib.lrg_nn1_fill_batch(jobs, len(sizes), F, _ptr(ws), 64, _stream_ptr()) <= -1000
