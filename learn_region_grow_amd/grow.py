@@ -444,7 +444,15 @@ class RegionGrower:
         """fill(r) for every r of rs, the rooms filled in together (lrg_nn1_fill_batch: three launches per 16 rooms instead of four per
         room; the rooms that finish during one free-running launch)."""
         rs = list(rs)
-        if len(rs) <= 1 or (getattr(self, 'free_run', False) and getattr(self, 'fill_cus', 0) > 0 and not getattr(self, '_in_fill_stream', False)):
+        if getattr(self, 'free_run', False) and getattr(self, 'fill_cus', 0) > 0 and not getattr(self, '_in_fill_stream', False):
+            self._in_fill_stream = True          # (CUs left out for the fill-ins: on the fill stream, as fill() does)
+            try:
+                with torch.cuda.stream(self.fill_stream):
+                    self.fill_many(rs)
+            finally:
+                self._in_fill_stream = False
+            return
+        if len(rs) <= 1:
             for r in rs:
                 self.fill(r)
             return
