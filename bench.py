@@ -304,6 +304,8 @@ def main():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     # LRG_BENCH_ONE_DEVICE=1 (testing on a 1-GPU box): every rank uses cuda:0 and the collectives go over gloo
     one_dev = os.environ.get('LRG_BENCH_ONE_DEVICE') == '1'
+    if one_dev and world > 1 and args.mode == 'auto':
+        args.mode = 'lockstep'      # (ranks sharing one chip: no two free-running launches side by side)
     if one_dev:
         local = 0
     torch.cuda.set_device(local)

@@ -170,6 +170,10 @@ def main(argv=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     one_dev = os.environ.get('LRG_BENCH_ONE_DEVICE') == '1'      # testing on a 1-GPU box: every rank on cuda:0, collectives over gloo
     device = torch.device(args.device if args.device else 'cuda:%d' % (0 if one_dev else local))
+    if one_dev and world > 1:
+        # ranks sharing one chip: lock-step iterations -- a free-running launch needs all its workgroups resident at once, and two of them
+        # side by side can each hold CUs the other waits for
+        os.environ['LRG_FREE_RUN'] = '0'
     torch.cuda.set_device(device)                                # every launch below goes to this device's current stream
     coll_dev = device
     if world > 1:
