@@ -139,13 +139,20 @@ __device__ __forceinline__ void lrg_block_bbox(int &cnt, int &mn0, int &mn1, int
         r[0] = cnt; r[1] = mn0; r[2] = mn1; r[3] = mn2; r[4] = mx0; r[5] = mx1; r[6] = mx2;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nw = blockDim.x >> 6;
-        for (int i = 1; i < nw; ++i) {
-            const int *r = red7 + 8 * i;
-            cnt += r[0];
-            mn0 = min(mn0, r[1]); mn1 = min(mn1, r[2]); mn2 = min(mn2, r[3]);
-            mx0 = max(mx0, r[4]); mx1 = max(mx1, r[5]); mx2 = max(mx2, r[6]);
+    if (threadIdx.x < 64) {
+        // the (at most 16) wavefronts' partials: one per lane, combined by four shuffle steps (thread 0 reading them one after the other
+        // was ~1 000 cycles of the mask update's 1.3 us reduction, profiles/r03_update_subphases.txt)
+        const int nw = blockDim.x >> 6, lane = threadIdx.x;
+        const int *r = red7 + 8 * min(lane, nw - 1);
+        const bool on = lane < nw;
+        cnt = on ? r[0] : 0;
+        mn0 = on ? r[1] : INT_MAX; mn1 = on ? r[2] : INT_MAX; mn2 = on ? r[3] : INT_MAX;
+        mx0 = on ? r[4] : INT_MIN; mx1 = on ? r[5] : INT_MIN; mx2 = on ? r[6] : INT_MIN;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            cnt += __shfl_xor(cnt, o);
+            mn0 = min(mn0, __shfl_xor(mn0, o)); mn1 = min(mn1, __shfl_xor(mn1, o)); mn2 = min(mn2, __shfl_xor(mn2, o));
+            mx0 = max(mx0, __shfl_xor(mx0, o)); mx1 = max(mx1, __shfl_xor(mx1, o)); mx2 = max(mx2, __shfl_xor(mx2, o));
         }
     }
 }
