@@ -526,9 +526,8 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
             }
         }
         team.sync();
-        const int code = word[0];
-        team.sync();                                         // (read by everybody before thread 0 writes the next one)
-        if (code < 0) return;
+        const int code = word[0];                            // (no barrier behind the read: thread 0 writes the next task only after the barriers
+        if (code < 0) return;                                //  INSIDE this one, which every wavefront reaches after it has read the word)
         const int type = (code >> 28) & 7;
         if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task);
         else if (type == LRG_TASK_GEMV) team.target = lrg_async_task_gemv(kp, code, sm_off, team.target, t_task);
