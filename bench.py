@@ -30,6 +30,7 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 import zlib
@@ -59,6 +60,7 @@ def parse():
     ap.add_argument('--step-ms', type=float, default=25.0, help='free-running launches: budget of one launch = one step')
     ap.add_argument('--iters-per-step', type=int, default=512, help='lock-step iterations per (macro-)step')
     ap.add_argument('--fill-cus', type=int, default=0, help='free-running launches: CUs left out of the launches for the fill-ins of finished rooms (0: fill-ins between two launches)')
+    ap.add_argument('--steady-slots', default='192', help='the steady leg again with this many rooms in flight, reported as steady_more_rooms_in_flight (empty = skip)')
     ap.add_argument('--best-slots', default='68,96,136,192,272', help='slot counts of the fixed_work_best sweep (empty = skip)')
     ap.add_argument('--rooms', type=int, default=68, help='rooms in flight per GPU (the Area-5 set has 68)')
     ap.add_argument('--restarts', type=int, default=1)
@@ -641,6 +643,22 @@ def main():
             out['fixed_work'] = fixed
         if best:
             out['fixed_work_best'] = best
+        if world == 1 and args.steady_slots and args.workload == 'area5' and args.restarts == 1:
+            # the steady leg again with more rooms of the same set in flight (a run of this script of its own; `value` stays the
+            # 68-room configuration the metric is quoted on)
+            sweep = {}
+            for sl in [int(x) for x in args.steady_slots.split(',') if x]:
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--rooms', str(sl), '--steps', str(max(4, args.steps // 2)),
+                                        '--warmup', str(args.warmup), '--step-ms', str(args.step_ms), '--fixed-rooms', '0', '--best-slots', '', '--steady-slots', '',
+                                        '--cpu-seconds', '0', '--p0-rooms', '0', '--policy', args.policy, '--weights', args.weights, '--cache', args.cache],
+                                       capture_output=True, text=True, timeout=600)
+                    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+                    sweep[str(sl)] = {'value': d['value'], 'unit': d['unit'], 'formulation': d['config']['formulation'],
+                                      'us_per_instance_step_per_slot': d.get('us_per_instance_step_per_slot')}
+                except Exception as e:      # (informational leg: never fails the line)
+                    sweep[str(sl)] = {'error': repr(e)[:200]}
+            out['steady_more_rooms_in_flight'] = sweep
         if world == 1 and args.cpu_seconds > 0:
             out['cpu_baseline'] = cpu_baseline(base, weights, args.cpu_seconds, args.policy, room_steps)
         if world == 1 and args.p0_rooms > 0:

@@ -27,7 +27,7 @@ def run_bench(argv, env=None, timeout=1200):
 @pytest.mark.parametrize('mode,lanes,graph', [('free', 0, 0), ('lockstep', 1, 0), ('lockstep', 2, 4)])
 def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
     r, lines = run_bench(['--gpus', '1', '--steps', '3', '--warmup', '2', '--iters-per-step', '16', '--step-ms', '2', '--rooms', '6', '--fixed-rooms', '12',
-                          '--best-slots', '3,6', '--cpu-seconds', '3', '--p0-rooms', '1', '--mode', mode, '--lanes', str(lanes), '--graph', str(graph),
+                          '--best-slots', '3,6', '--steady-slots', '9' if mode == 'free' else '', '--cpu-seconds', '3', '--p0-rooms', '1', '--mode', mode, '--lanes', str(lanes), '--graph', str(graph),
                           '--cache', str(tmp_path / 'cache')])
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1
@@ -61,12 +61,14 @@ def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
         assert k in cb, k
     assert cb['kind'] == 'port' and cb['value'] > 0 and cb['strong']['value'] > 0 and cb['rooms_per_sec'] > 0
     assert d['preprocessing_p0']['gpu_rooms_per_sec'] > 0
+    if mode == 'free':
+        assert d['steady_more_rooms_in_flight']['9']['value'] > 0
 
 
 def test_bench_two_ranks_started_by_the_script_itself(cuda_device, tmp_path):
     """`python bench.py --gpus 2` with no torch.distributed environment: the script starts its two ranks (here both on cuda:0,
     collectives over gloo: LRG_BENCH_ONE_DEVICE=1), shards the fixed work over them and gathers every room's labels."""
-    common = ['--steps', '2', '--warmup', '1', '--step-ms', '2', '--rooms', '4', '--fixed-rooms', '8', '--best-slots', '', '--cpu-seconds', '0',
+    common = ['--steps', '2', '--warmup', '1', '--step-ms', '2', '--rooms', '4', '--fixed-rooms', '8', '--best-slots', '', '--steady-slots', '', '--cpu-seconds', '0',
               '--p0-rooms', '0', '--cache', str(tmp_path / 'cache')]
     # (both ranks share the one device here: lock-step launches -- two free-running launches side by side on one chip each assume that all
     #  their workgroups are resident at once, DESIGN.md section 4; on a multi-GPU node every rank has a device to itself)

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 export LRG_FREE_RUN_DEBUG=1 LRG_HIPCC_FLAGS="$LRG_HIPCC_FLAGS -DLRG_ASYNC_DEBUG=1"
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
-env ${2:-X=1} timeout 600 python bench.py --gpus 1 --steps 10 --warmup 4 --cpu-seconds 0 --p0-rooms 0 --best-slots "" --fixed-rooms 0 --rooms $1 --mode free 2> gpurun_out/bench_dbg.err | python -c "
+env ${2:-X=1} timeout 600 python bench.py --gpus 1 --steps 10 --warmup 4 --cpu-seconds 0 --p0-rooms 0 --best-slots "" --steady-slots "" --fixed-rooms 0 --rooms $1 --mode free 2> gpurun_out/bench_dbg.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$1 slots ${2}: %.0f %s, %.1f us/step/slot' % (d['value'], d['unit'], d['us_per_instance_step_per_slot']))

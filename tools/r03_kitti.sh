@@ -2,7 +2,7 @@
 # Semantic-KITTI-shaped scenes (8 x ~100 k points at 0.3 m, configs[4]) under the formulations of the loop
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
-C="--workload kitti --rooms 8 --steps 6 --warmup 3 --fixed-rooms 16 --best-slots= --cpu-seconds 0 --p0-rooms 0"
+C="--workload kitti --rooms 8 --steps 6 --warmup 3 --fixed-rooms 16 --best-slots= --steady-slots= --cpu-seconds 0 --p0-rooms 0"
 for v in "lockstep_chunked:--mode lockstep --packed 1" "lockstep_packed:--mode lockstep --packed 2 --iters-per-step 256" "free_4fronts:--mode free --packed 2" ; do
   name=${v%%:*}; flags=${v#*:}
   timeout 600 python bench.py $C $flags > gpurun_out/r03_kitti_$name.json 2> gpurun_out/r03_kitti_$name.err

@@ -2,7 +2,7 @@
 # Semantic-KITTI-shaped scenes (8 x ~100 k points at 0.3 m) with the round's later free-running kernel: rate per formulation, then the stage breakdown (debug build)
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
-C="--workload kitti --rooms 8 --steps 6 --warmup 3 --fixed-rooms 16 --best-slots= --cpu-seconds 0 --p0-rooms 0"
+C="--workload kitti --rooms 8 --steps 6 --warmup 3 --fixed-rooms 16 --best-slots= --steady-slots= --cpu-seconds 0 --p0-rooms 0"
 run() { # name, env, flags
   env $2 timeout 600 python bench.py $C $3 > gpurun_out/r03_kitti2_$1.json 2> gpurun_out/r03_kitti2_$1.err
   python - $1 <<'PY'
