@@ -30,6 +30,9 @@
 // padded to whole tiles with copies of its last row, which neither the max-pool nor anybody's logits notice), the pooled product
 // in the one summation order all formulations share (lrg_head_gemv_kernel, lrg_net.hip).
 
+#ifndef LRG_ASYNC_HEAD_PRIO
+#define LRG_ASYNC_HEAD_PRIO 1       // wave priority (s_setprio) of a team while it runs a head tile
+#endif
 #ifndef LRG_ASYNC_FD
 #define LRG_ASYNC_FD 4              // depth of the tile teams' weight ring (k-groups in flight)
 #endif
@@ -455,6 +458,9 @@ LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
     const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
     long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;
+    // (a head tile shares its CU with a branch tile of another slot and is the shorter of the two: issued first where both want a SIMD --
+    //  852 -> 856 k instance-steps/s at 68 rooms in flight; the branch tiles first: 847 k)
+    __builtin_amdgcn_s_setprio(LRG_ASYNC_HEAD_PRIO);
     if (A.gemv_units) {
         LrgWaitPooled wait;
         wait.sy = sy; wait.queue = A.queue; wait.t_launch = t_launch; wait.abort_ticks = A.abort_ticks;
@@ -469,6 +475,7 @@ LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
         lrg_dbg_add(A, 32, 1);
     }
 #endif
+    __builtin_amdgcn_s_setprio(0);
     lrg_drain_stores();                              // the logits are out before the arrival the front workgroup polls
     team.sync();
     if (tid == 0) {
