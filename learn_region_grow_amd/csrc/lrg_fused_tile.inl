@@ -52,7 +52,9 @@ struct LrgLdsTeam {
                         break;
                     }
                 }
+#ifdef LRG_TEAM_SPIN_SLEEP      // (a tight spin: 856 -> 859 k instance-steps/s at 68 rooms in flight; the waiting lane is alone in its wavefront's slot)
                 __builtin_amdgcn_s_sleep(1);
+#endif
             }
         }
         asm volatile("" ::: "memory");
