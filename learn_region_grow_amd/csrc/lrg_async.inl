@@ -33,6 +33,9 @@
 #ifndef LRG_ASYNC_HEAD_PRIO
 #define LRG_ASYNC_HEAD_PRIO 1       // wave priority (s_setprio) of a team while it runs a head tile
 #endif
+#ifndef LRG_WORKER_POLL_SLEEP
+#define LRG_WORKER_POLL_SLEEP 8    // s_sleep argument (x 64 cycles) between two looks of an idle team at its ring entry (x LrgAsyncBuffers.poll_sleep)
+#endif
 #ifndef LRG_ASYNC_FD
 #define LRG_ASYNC_FD 4              // depth of the tile teams' weight ring (k-groups in flight)
 #endif
@@ -524,7 +527,7 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
                         break;
                     }
                 }
-                for (int q = 0; q < A.poll_sleep; ++q) __builtin_amdgcn_s_sleep(8);
+                for (int q = 0; q < A.poll_sleep; ++q) __builtin_amdgcn_s_sleep(LRG_WORKER_POLL_SLEEP);
             }
             if (code > 0) lrg_st_coh(slot, 0);
             word[0] = code;
