@@ -509,9 +509,6 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
         long long t_task = 0;
         if (tid == 0) {
             const long long t_wait = LRG_DBG(A) ? wall_clock64() : 0;
-            const bool leave = false;
-            if (leave) { word[0] = -1; }
-            else {
             const int ring = secondary ? 1 : 0;      // (more than one team per workgroup: the first teams run the branch tiles, the others the rest)
             const int t = __hip_atomic_fetch_add(&A.queue[LRG_AQ_HEAD + ring * LRG_AQ_SECOND], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int *slot = &A.queue[LRG_AQ_RING + ring * (A.qmask + 1) + (t & A.qmask)];
@@ -533,7 +530,6 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
             word[0] = code;
             t_task = wall_clock64();
             if (LRG_DBG(A)) { lrg_dbg_add(A, 16, t_task - t_wait); lrg_dbg_add(A, 17, 1); }
-            }
         }
         team.sync();
         const int code = word[0];                            // (no barrier behind the read: thread 0 writes the next task only after the barriers
