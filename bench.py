@@ -635,6 +635,12 @@ def main():
                        'hip_graph_iterations': 0 if free_steady else graph},
             'roofline': roof,
         }
+        # P2 (bbox + box query, test_region_grow.py:221-235) priced the way SURVEY.md 8a does -- a pass over the room, ~14 bytes per point and
+        # step -- against the HBM peak: what the reference's formulation would stream at this step rate (the front answers most boxes from the
+        # room's voxel grid, O(box) instead of O(room): this is an algorithmic figure, not traffic)
+        mean_n = float(np.mean([len(r['points']) for r in base]))
+        out['p2_box_query'] = {'points_per_room_mean': mean_n, 'algorithmic_bytes_per_instance_step': 14.0 * mean_n,
+                               'GBps': 14.0 * mean_n * out['value'] / 1e9, 'frac_of_hbm_peak': 14.0 * mean_n * out['value'] / 1e9 / 8000.0}
         if iterations:
             out['ms_per_iteration'] = 1e3 * elapsed / iterations
             out['config']['iterations_per_step'] = args.iters_per_step
