@@ -12,6 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(HERE, 'liblrg_hip.so')
 SOURCES = ['lrg_net.hip', 'lrg_fused.hip', 'lrg_grow.hip', 'lrg_grouping.hip', 'lrg_preprocess.hip', 'lrg_train.hip']
 
+LRG_ABI_VERSION = 7       # what this binding was written against (include/lrg_hip.h: LRG_ABI_VERSION; tests/test_capi.py compares them and INTEGRATION.md)
 LRG_MAX_CONV = 5
 LRG_MAX_HEAD = 3
 LRG_FWD_FUSE_POOL = 1
@@ -267,8 +268,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lrg_abi_version() != 7:
-        raise LrgHipError('ABI version mismatch')
+    if lib.lrg_abi_version() != LRG_ABI_VERSION:
+        raise LrgHipError('ABI version mismatch: the library is %d, this binding %d' % (lib.lrg_abi_version(), LRG_ABI_VERSION))
     for which, st in enumerate((LrgWeights, LrgRoom, LrgSlot, LrgGrowParams, LrgStepBuffers, LrgPackedBuffers, LrgBeamGroup, LrgAsyncBuffers, LrgFillJob)):
         if lib.lrg_struct_size(which) != ctypes.sizeof(st):
             raise LrgHipError('struct layout mismatch for %s: C %d vs ctypes %d' %

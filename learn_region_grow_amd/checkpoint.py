@@ -401,8 +401,11 @@ def lrgnet_checkpoint_tensors(weights, adam_m=None, adam_v=None, step=0, beta1=0
         out[k] = w
         out[k + '/Adam'] = np.asarray(adam_m[k], dtype=np.float32).reshape(w.shape) if adam_m is not None else np.zeros_like(w)
         out[k + '/Adam_1'] = np.asarray(adam_v[k], dtype=np.float32).reshape(w.shape) if adam_v is not None else np.zeros_like(w)
-    out['beta1_power'] = np.float32(float(beta1) ** int(step))
-    out['beta2_power'] = np.float32(float(beta2) ** int(step))
+    # TF1's AdamOptimizer creates the two accumulators AT beta (not 1) and multiplies them once per applied step, so a
+    # checkpoint at global step t holds beta ** (t + 1); a freshly built optimizer (t = 0) holds beta itself -- with 1.0 there a
+    # resumed reference run would compute lr * sqrt(1 - 1) / (1 - 1).
+    out['beta1_power'] = np.float32(float(beta1) ** (int(step) + 1))
+    out['beta2_power'] = np.float32(float(beta2) ** (int(step) + 1))
     out['Variable'] = np.int32(step)
     return out
 

@@ -563,7 +563,7 @@ class RegionGrower:
                                      ctypes.byref(self.net._w), ctypes.byref(self.packed_buffers), ctypes.byref(self.async_buffers),
                                      steps, budget, _stream_ptr(self.dev))
         _lib.check(rc, 'lrg_grow_async')
-        self.iterations += steps
+        self.launches = getattr(self, 'launches', 0) + 1      # (`iterations` counts lock-step iterations only; the steps taken: instance_steps)
         self._record_poll()
 
     def enqueue(self):
@@ -830,6 +830,10 @@ class RegionGrower:
 
     def _run(self, rooms, fill, max_iterations, legacy_seeds, legacy_shared_seed=None):
         self.load_rooms(rooms)
+        if self.rng != 'legacy' and self.free_run and not max_iterations:
+            self._grow_loaded_free_run(fill)          # (binds the first rooms itself, the rest wait in the device-side queue)
+            torch.cuda.synchronize()
+            return self.collect(fill)
         queue = list(range(self.n_rooms))
         for g in range(self.n_groups):
             self.bind(g, queue.pop(0) if queue else -1)
@@ -853,11 +857,12 @@ class RegionGrower:
                         self.bind(g, queue.pop(0) if queue else -1)
                 if max_iterations and self.iterations >= max_iterations:
                     break
-        elif self.free_run and not max_iterations:
-            self._grow_loaded_free_run(fill)
         else:
+            # (max_iterations counts lock-step iterations: a free-running grower takes them one by one too -- the two formulations
+            #  share their buffers and give the same results -- instead of one launch of up to free_run_steps steps per slot)
+            step = self.enqueue_iteration if (self.free_run and max_iterations) else self.enqueue
             while finished < self.n_rooms:
-                self.enqueue()
+                step()
                 gs = self.poll_done()
                 if fill:
                     self.fill_many([self.group_room[g] for g in gs])
@@ -986,12 +991,18 @@ class LanedRegionGrower:
         if kw.get('rng', 'counter') != 'counter':
             raise ValueError("lanes need rng='counter' (the legacy stream is replayed on the host, one iteration at a time)")
         self.net = net
+        self._rebuild = None
         if lanes is None or int(lanes) <= 0:
             lanes = auto_lanes(int(rooms_in_flight) * int(kw.get('restarts', 1)))
+            lockstep_lanes = lanes
             # free-running launches (RegionGrower's choice up to 96 greedy slots) fill the chip by themselves: one lane
             if (kw.get('free_run', None) is not False and int(kw.get('restarts', 1)) == 1 and int(rooms_in_flight) <= _lib.LRG_FREE_RUN_AUTO_SLOTS and
                     kw.get('packed', None) is not False and os.environ.get('LRG_FREE_RUN', '1') != '0'):
                 lanes = 1
+                if lockstep_lanes > 1:
+                    # RegionGrower decides on free-running launches only when it sees the rooms (load_rooms: packed voxel words, point
+                    # counts, lite); if it falls back to lock-step iterations the lanes are rebuilt as auto_lanes would have them
+                    self._rebuild = dict(rooms_in_flight=rooms_in_flight, lanes=lockstep_lanes, cu_partition=cu_partition, kw=dict(kw, free_run=False))
         lanes = max(1, min(int(lanes), int(rooms_in_flight)))
         if lanes > 1 and kw.get('free_run', None) is None:
             # lanes are lock-step growers side by side; a free-running launch wants every CU for itself (two of them on two streams take
@@ -1016,6 +1027,18 @@ class LanedRegionGrower:
             room = dict(rooms[i])
             room.setdefault('room_id', i)
             parts[k].append(room)
+        if self._rebuild is not None and L == 1 and rooms:
+            # one lane was chosen in the expectation of free-running launches: the grower decides when it sees the rooms
+            gr = self.growers[0]
+            with torch.cuda.stream(self.streams[0]):
+                gr.load_rooms(parts[0])
+            if not gr.free_run:
+                rb, self._rebuild = self._rebuild, None
+                self.__init__(self.net, rooms_in_flight=rb['rooms_in_flight'], lanes=rb['lanes'], cu_partition=rb['cu_partition'], **rb['kw'])
+                return self.load_rooms(rooms)
+            gr.room_index = list(order)
+            torch.cuda.synchronize()
+            return
         for k, gr in enumerate(self.growers):
             gr.n_rooms = 0
             gr.room_index = [i for i in range(len(rooms)) if self.where[i][0] == k]      # input index of the lane's rooms,
@@ -1034,6 +1057,14 @@ class LanedRegionGrower:
     def grow_loaded(self, fill=True):
         """Grow (and fill in) every loaded room, device-resident from start to end: on return the labels are final in each
         lane's d_label / d_filled.  Returns the number of rooms grown."""
+        if len(self.growers) == 1 and self.growers[0].free_run and self.growers[0].n_rooms:
+            # one free-running lane: the grower's own loop, whose rooms wait in the device-side queue and are taken by whichever slot
+            # finishes (binding them here, between launches, would leave a finished slot idle for the rest of its launch and the
+            # read-back pipeline behind it)
+            with torch.cuda.stream(self.streams[0]):
+                n = self.growers[0].grow_loaded(fill)
+            torch.cuda.synchronize()
+            return n
         queues, finished = [], 0
         for k, gr in enumerate(self.growers):
             with torch.cuda.stream(self.streams[k]):

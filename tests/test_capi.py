@@ -25,7 +25,12 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_abi_and_struct_layout(hip_lib):
     from learn_region_grow_amd import _lib
-    assert hip_lib.lrg_abi_version() == 7
+    header = int(re.search(r'#define\s+LRG_ABI_VERSION\s+(\d+)', open(os.path.join(REPO, 'include', 'lrg_hip.h')).read()).group(1))
+    assert hip_lib.lrg_abi_version() == header == _lib.LRG_ABI_VERSION
+    # the binding INTEGRATION.md shows asserts the same number
+    doc = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    quoted = [int(m) for m in re.findall(r'lrg_abi_version\(\)\s*==\s*(\d+)', doc)]
+    assert quoted and all(q == header for q in quoted), 'INTEGRATION.md asserts ABI %s, the header says %d' % (quoted, header)
     assert hip_lib.lrg_target_arch() == b'gfx950'
     for which, st in enumerate((_lib.LrgWeights, _lib.LrgRoom, _lib.LrgSlot, _lib.LrgGrowParams, _lib.LrgStepBuffers,
                                _lib.LrgPackedBuffers, _lib.LrgBeamGroup, _lib.LrgAsyncBuffers)):

@@ -73,7 +73,10 @@ def test_written_checkpoint_has_the_key_set_of_the_reference_bundle(tmp_path):
         assert tuple(got[k].shape) == tuple(ref[k].shape) and got[k].dtype == ref[k].dtype, k
     back = ck.load_bundle(prefix)
     assert int(back['Variable']) == 123 and back['Variable'].dtype == np.int32
-    np.testing.assert_allclose(back['beta1_power'], 0.9 ** 123, rtol=1e-6)
+    np.testing.assert_allclose(back['beta1_power'], 0.9 ** 124, rtol=1e-6)      # TF1 Adam: beta at step 0, one factor per applied step
+    np.testing.assert_allclose(back['beta2_power'], 0.999 ** 124, rtol=1e-6)
+    fresh = ck.lrgnet_checkpoint_tensors(w, step=0)
+    assert fresh['beta1_power'] == np.float32(0.9) and fresh['beta2_power'] == np.float32(0.999)
     np.testing.assert_array_equal(back['lrg_kernel0/Adam'], m['lrg_kernel0'])
     np.testing.assert_array_equal(back['lrg_add_kernel0/Adam_1'], v['lrg_add_kernel0'])
     assert set(ck.load_lrgnet_weights(prefix)) == set(w)

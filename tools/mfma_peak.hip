@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // MODE bit0: A from LDS (ds_read_b128 per tile per group); bit1: B from global through a ring of FD k-groups that never
 // drains (refilled across iterations); bit2: B pre-packed so that a lane's four values are one dwordx4 load.
@@ -28,14 +29,40 @@ __global__ __launch_bounds__(256, 2) void k(const float *w, float *out, int iter
     };
     auto wrow_of = [&](int it) { return (MODE & 4) ? w + ((it & 3) * 4 + wn) * 16 * 256 : w + wn * 32 + (it & 3) * 128; };
     for (int g = 0; g < FD; ++g) bq[g] = (MODE & 2) ? loadb(wrow_of(0), g) : make_float4(1.f, 2.f, 0.5f, 0.25f);
+    f32x4 c4[4];
+    for (int t = 0; t < 4; ++t) for (int i = 0; i < 4; ++i) c4[t][i] = 0.f;
+    const float *ap16 = smem + (lane & 15) * 132 + 2 * (lane >> 4);
+    float2 a2[3][2];
+    for (int u = 0; u < 3; ++u) { a2[u][0] = make_float2(1.f, 2.f); a2[u][1] = make_float2(3.f, 4.f); }
     for (int it = 0; it < iters; ++it) {
         const float *wrow = wrow_of(it), *wnext = wrow_of(it + 1);
+        if ((MODE & 16) && (MODE & 1)) {
+            a2[0][0] = *reinterpret_cast<const float2 *>(ap16); a2[0][1] = *reinterpret_cast<const float2 *>(ap16 + 16 * 132);
+            a2[1][0] = *reinterpret_cast<const float2 *>(ap16 + 8); a2[1][1] = *reinterpret_cast<const float2 *>(ap16 + 16 * 132 + 8);
+        }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            if (MODE & 1)
+            if ((MODE & 1) && !(MODE & 16))
 #pragma unroll
                 for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const float4 *>(ap + t * 32 * 132 + 8 * g);
             const float4 b = bq[g % FD];
+            if (MODE & 16) {      // v_mfma_f32_16x16x4_f32: the wave's 32 x 32 strip as 2 x 2 blocks = four accumulator chains; A as one ds_read_b64 per row half
+                                  // and k-group (two groups ahead), B the same dwordx4 per lane and k-group
+                if (MODE & 1) {
+                    if (g + 2 < 16) { a2[(g + 2) % 3][0] = *reinterpret_cast<const float2 *>(ap16 + 8 * (g + 2)); a2[(g + 2) % 3][1] = *reinterpret_cast<const float2 *>(ap16 + 16 * 132 + 8 * (g + 2)); }
+                }
+                const float2 x0 = a2[g % 3][0], x1 = a2[g % 3][1];
+                c4[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, b.x, c4[0], 0, 0, 0);
+                c4[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, b.z, c4[1], 0, 0, 0);
+                c4[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, b.x, c4[2], 0, 0, 0);
+                c4[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, b.z, c4[3], 0, 0, 0);
+                c4[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, b.y, c4[0], 0, 0, 0);
+                c4[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, b.w, c4[1], 0, 0, 0);
+                c4[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, b.y, c4[2], 0, 0, 0);
+                c4[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, b.w, c4[3], 0, 0, 0);
+                if (MODE & 2) bq[g % FD] = (g + FD < 16) ? loadb(wrow, g + FD) : loadb(wnext, g + FD - 16);
+                continue;
+            }
             if (MODE & 8) {       // one tile, two accumulator chains: the MFMAs of a k-group alternate between them
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b.x, acc[0], 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b.y, acc2, 0, 0, 0);
@@ -56,6 +83,16 @@ __global__ __launch_bounds__(256, 2) void k(const float *w, float *out, int iter
         }
         constexpr int DA = (MODE & 1) ? 2 : 0;
         constexpr int NV = (MODE & 2) ? ((MODE & 4) ? 1 : 4) : 0;
+        if (MODE & 16) {
+            if (DA) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                if (DA && g + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                if (NV) __builtin_amdgcn_sched_group_barrier(0x020, NV, 0);
+            }
+            continue;
+        }
         if (DA) __builtin_amdgcn_sched_group_barrier(0x100, RT * DA, 0);
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -66,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void k(const float *w, float *out, int iter
     }
     float s = 0.f;
     for (int t = 0; t < RT; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i] + acc2[i];
+    for (int t = 0; t < 4; ++t) for (int i = 0; i < 4; ++i) s += c4[t][i];
     for (int g = 0; g < FD; ++g) s += bq[g].x;
     if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
 }
@@ -105,6 +143,10 @@ int main() {
             run<0, 1, 4>("RT=1 registers only, one chain", w, out, grid, wgs);
             run<8, 1, 4>("RT=1 registers only, two chains", w, out, grid, wgs);
             run<15, 1, 4>("RT=1 A lds + B packed ring, two chains", w, out, grid, wgs);
+            run<16, 1, 4>("16x16x4 2x2 blocks, registers only", w, out, grid, wgs);
+            run<17, 1, 4>("16x16x4 2x2 blocks, A lds b64", w, out, grid, wgs);
+            run<23, 1, 4>("16x16x4 2x2 blocks, A lds b64 + B packed ring", w, out, grid, wgs);
+            run<23, 1, 8>("16x16x4 2x2 blocks, A lds b64 + B packed ring", w, out, grid, wgs);
         }
     }
     return 0;

@@ -4,7 +4,9 @@
 and Adam (learn_region_grow_util.py:165-189), the reference's epoch lines, weights saved as a TensorFlow checkpoint bundle
 that ``region_grow.py`` (and the reference's ``Saver.restore``) reads.
 
-    python train_region_grow.py --train-area 1,2,3,4,6 --val-area 5            # data/staged_area<k>.h5 -> models/lrgnet_model5.ckpt
+    python train_region_grow.py --train-area 1,2,3,4,6 --val-area 5            # data/multiseed/seed<e % 8>_area<k>.h5 (training areas, one seed
+                                                                               # per epoch), data/staged_area5.h5 (validation) -> models/lrgnet_model5.ckpt
+    python train_region_grow.py --multiseed 0 --train-area 1,2,3,4,6           # data/staged_area<k>.h5
     python train_region_grow.py --staged my_tuples.h5 --ckpt out/lrgnet.ckpt --epochs 20
 
 Options of the reference that are kept: --train-area, --val-area, --lite, --multiseed (data/multiseed/seed<k>_area<a>.h5, one seed
@@ -55,11 +57,12 @@ def model_path(args):
     return os.path.join(d, 'lrgnet_model%s%s.ckpt' % (val, suffix))
 
 
-def staged_path(args, area, epoch):
-    """train_region_grow.py:69-78."""
+def staged_path(args, area, epoch, is_train=True):
+    """train_region_grow.py:69-78: the multiseed files are for the TRAINING areas only (`elif MULTISEED > 0 and AREA in TRAIN_AREA`);
+    a validation area always reads data/staged_area<a>.h5."""
     if str(area).startswith('synthetic'):
         return os.path.join(args.data_dir, 'staged_%s.h5' % area)
-    if args.multiseed > 0:
+    if args.multiseed > 0 and is_train:
         return os.path.join(args.data_dir, 'multiseed', 'seed%d_area%s.h5' % (epoch % args.multiseed, area))
     return os.path.join(args.data_dir, 'staged_area%s.h5' % area)
 
@@ -108,6 +111,8 @@ def main(argv=None):
                     print('Loading %s ...' % f)
                     parts.append(stage.load_staged(f, args.feature_size))
             if not parts:
+                # (the reference skips a missing multiseed file, :75-76, and would then fail on an empty training set)
+                print('warning: epoch %d: none of %s exists -- nothing to train on' % (epoch, ', '.join(files)), file=sys.stderr)
                 continue
             data = {k: [x for p in parts for x in p[k]] for k in ('points', 'remove', 'neighbor_points', 'add')}
             loaded = files
@@ -118,13 +123,19 @@ def main(argv=None):
         print('Epoch %d loss %.2f add %.2f/%.2f rmv %.2f/%.2f' % (epoch, ls, ap, ar, rp, rr))          # :183
         if val_areas and epoch % args.val_step == args.val_step - 1:                                   # :185-219
             if val is None:
-                vparts = [stage.load_staged(staged_path(args, a, 0), args.feature_size) for a in val_areas if os.path.exists(staged_path(args, a, 0))]
+                vfiles = [staged_path(args, a, 0, is_train=False) for a in val_areas]
+                for f in vfiles:
+                    if not os.path.exists(f):
+                        print('warning: validation file %s does not exist' % f, file=sys.stderr)
+                vparts = [stage.load_staged(f, args.feature_size) for f in vfiles if os.path.exists(f)]
                 val = {k: [x for p in vparts for x in p[k]] for k in ('points', 'remove', 'neighbor_points', 'add')} if vparts else None
             if val:
                 ls, ap, ar, rp, rr = run_epoch(trainer, val, rs, args.batch_size, train=False, shuffle=False)
                 print('Validation %d loss %.2f add %.2f/%.2f rmv %.2f/%.2f' % (epoch, ls, ap, ar, rp, rr))
-    if epoch_time:
-        print('Avg Epoch Time: %.3f' % np.mean(epoch_time))
+    if not epoch_time:
+        raise SystemExit('no staged training file was found in any epoch (looked for e.g. %s): nothing trained, no checkpoint written'
+                         % (args.staged or staged_path(args, train_areas[0], 0)))
+    print('Avg Epoch Time: %.3f' % np.mean(epoch_time))
     out = model_path(args)
     os.makedirs(os.path.dirname(out) or '.', exist_ok=True)
     checkpoint.write_bundle(out, trainer.checkpoint_numpy())      # variables + Adam slots + beta powers + global step (99 entries)
