@@ -233,7 +233,8 @@ def grow_room(points, obj_id, order, weights, stream, *, cls_id=None, classes=No
         rec = dict(seed=int(seed_id), target=int(target_id), steps=int(steps), points=int(np.sum(bestMask)),
                    gt=int(np.sum(gt_mask)),
                    iou=float(1.0 * np.sum(np.logical_and(gt_mask, bestMask)) / np.sum(np.logical_or(gt_mask, bestMask))),
-                   add_acc=float(add_acc), rmv_acc=float(rmv_acc), reason=last_reason, labeled=labeled)
+                   add_acc=float(add_acc), rmv_acc=float(rmv_acc), reason=last_reason, labeled=labeled,
+                   best_restart=int(np.argmax(restart_score)), restart_scores=[float(x) for x in restart_score])
         if labeled:
             cluster_label[bestMask] = cluster_id                  # :214
             cluster_id += 1                                       # :215

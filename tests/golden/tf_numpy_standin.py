@@ -23,6 +23,7 @@ bool_ = np.bool_
 _VARIABLES = {}          # name -> Variable node (current "default graph")
 RESTORE_WEIGHTS = {}     # name -> ndarray, consumed by Saver.restore
 H5_FILES = {}            # filename -> {dataset: ndarray}
+H5_WRITTEN = {}          # filename -> {dataset: ndarray}, what a script wrote through the stub h5py
 
 
 class Node:
@@ -228,12 +229,19 @@ def install():
 
     class File:
         def __init__(self, filename, mode='r'):
+            self.filename = filename
+            if mode == 'w':                      # stage_data.py:251-258 writes its tuples: kept in memory (H5_WRITTEN)
+                self.d = H5_WRITTEN[filename] = {}
+                return
             if mode != 'r' or filename not in H5_FILES:
                 raise IOError('stand-in h5py: %s not registered' % filename)
             self.d = H5_FILES[filename]
 
         def __getitem__(self, k):
             return self.d[k]
+
+        def create_dataset(self, name, data=None, dtype=None, **kw):
+            self.d[name] = np.array(data, dtype=dtype)
 
         def close(self):
             pass

@@ -26,6 +26,12 @@ def net(cuda_device):
     return LrgNetHIP(1, 1, 512, 512, 13, 0, device=cuda_device).load_weights(synthetic.make_synthetic_weights(**WEIGHT_KW))
 
 
+@pytest.fixture(scope='module')
+def net_trained(cuda_device):
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    return LrgNetHIP(1, 1, 512, 512, 13, 0, device=cuda_device).load_weights(synthetic.load_trained_weights())
+
+
 def gpu_net_fn(net):
     def fn(xi, xn):
         _, add, _, rmv, _ = net.run(xi, xn)
@@ -103,6 +109,30 @@ def test_legacy_matches_reference_script_output(net, name, restarts):
     # against the reference script's own output (tests/golden: test_region_grow.py / test_random_restart.py run unmodified): the inputs are
     # fixed, so this either holds or it does not -- the closest Bernoulli draw of these two runs keeps a relative distance of
     # > 1e-5 from its confidence (the oracle's min_rel_margin), far above what float32 rounding of the logits can move
+    assert want.min_rel_margin > OTHER_NETWORK_MARGIN / 100
+    np.testing.assert_array_equal(res.filled_label, g['filled_label'])
+
+
+@pytest.mark.parametrize('name,restarts,labeled', [('greedy_trained_room114', 1, 51), ('restart_trained_room137', 10, 20)])
+def test_legacy_matches_reference_script_output_under_trained_weights(net_trained, name, restarts, labeled):
+    """The reference's scripts run unmodified under the weights this repository trained (tests/golden/make_golden.py trained): realistic
+    dynamics -- 51 labelled regions over 518 network steps (test_region_grow.py:208-316), and 20 labelled regions of ten restarts each of
+    which 15 are won by a restart other than the first (argmax(restart_score), test_random_restart.py:177).  Labels must equal the
+    script's own output; regions and labels must equal the oracle loop driven by the GPU network."""
+    from learn_region_grow_amd.grow import RegionGrower
+    room, g = golden_room(name)
+    want = grow_ref.grow_room(room['points'], room['obj_id'], room['order'], None, rng_ref.LegacyStream(0),
+                              net_fn=gpu_net_fn(net_trained), restarts=0 if restarts == 1 else restarts)
+    res = RegionGrower(net_trained, rooms_in_flight=1, rng='legacy', restarts=restarts).run([room])[0]
+    same_regions(res.regions, want.regions)
+    np.testing.assert_array_equal(res.filled_label, want.filled_label)
+    lab = [r for r in want.regions if r['labeled']]
+    assert len(lab) == labeled and {r['reason'] for r in lab} == {'noexpand', 'stuck', 'noneighbor'}
+    if restarts > 1:
+        assert sum(1 for r in lab if r['best_restart'] != 0) >= 10
+    # the rooms were picked (of twelve each) for the distance their closest Bernoulli draw keeps from its confidence in the NumPy
+    # evaluation of the network (1.8e-4 / 2.0e-5 relative): float32 rounding differences between the GPU's and NumPy's logits do not
+    # reach it, so the script's own labels are reproduced exactly
     assert want.min_rel_margin > OTHER_NETWORK_MARGIN / 100
     np.testing.assert_array_equal(res.filled_label, g['filled_label'])
 

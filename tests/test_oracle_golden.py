@@ -58,10 +58,13 @@ def test_confidence_is_scipy_softmax():
     np.testing.assert_array_equal(lrgnet_ref.confidence(x), scipy.special.softmax(x, axis=-1)[:, 1])
 
 
-@pytest.mark.parametrize('name,restarts', [('greedy_room100', 0), ('greedy_room101', 0), ('restart_room103', 10)])
+@pytest.mark.parametrize('name,restarts', [('greedy_room100', 0), ('greedy_room101', 0), ('restart_room103', 10),
+                                           ('greedy_trained_room114', 0), ('restart_trained_room137', 10)])
 def test_grow_loop_reproduces_reference_script(name, restarts):
     g = np.load(os.path.join(GOLDEN, name + '.npz'))
-    w = synthetic.make_synthetic_weights(**WEIGHT_KW)
+    # (the *_trained_* goldens: the reference scripts under the weights this repository trained -- 51 and 20 labelled regions, all three
+    #  stop reasons, 15 of the 20 restart regions won by a restart other than the first)
+    w = synthetic.load_trained_weights() if str(g['weight_kw']) == 'trained' else synthetic.make_synthetic_weights(**WEIGHT_KW)
     assert digest(w) == str(g['weights_digest'])
     raw = g['raw_room']
     # preprocessing: oracle loop and the product's vectorised version both equal the reference's output
@@ -76,6 +79,13 @@ def test_grow_loop_reproduces_reference_script(name, restarts):
     assert list(r.lines) == [str(x) for x in g['region_lines']]
     m = metrics_ref.room_metrics(g['obj_id'], r.filled_label)
     np.testing.assert_allclose([m['nmi'], m['ami'], m['ars'], m['prc'], m['rcl'], m['iou']], g['metrics'], rtol=1e-9)
+    if 'trained' in name:
+        lab = [x for x in r.regions if x['labeled']]
+        assert {x['reason'] for x in lab} == {'noexpand', 'stuck', 'noneighbor'}
+        if restarts:
+            assert len(lab) == 20 and sum(1 for x in lab if x['best_restart'] != 0) == 15      # argmax(restart_score), test_random_restart.py:177, matters
+        else:
+            assert len(lab) == 51 and r.total_steps > 500
 
 
 def test_beam_search_reproduces_reference_script():

@@ -87,3 +87,39 @@ def test_staging_round_trip_and_flags(tmp_path):
     xi, xn, ia, ir = train_ref.assemble_batch(ld['points'], ld['remove'], ld['neighbor_points'], ld['add'], np.arange(4), np.random.RandomState(0),
                                               batch_size=4, n_inlier=64, n_neighbor=64)
     assert xi.shape == (4, 64, 13) and xn.shape == (4, 64, 13) and ia.shape == (4, 64) and ir.shape == (4, 64)
+
+
+def test_staging_reproduces_reference_script():
+    """stage_data.py executed unmodified (tests/golden/make_golden.py stage: ``--area 5`` on one synthetic room, global legacy generator
+    seeded 0, :11) against learn_region_grow_amd.stage on the room that script equalised: the same tuples in the same order -- counts,
+    add / remove flags, steps per object, completeness -- and the same centred rows (:242-249), bit for bit (the first ten tuples are
+    stored in full, the complete row arrays as SHA-256)."""
+    import hashlib
+    from conftest import GOLDEN
+    from learn_region_grow_amd import preprocess
+    g = np.load(os.path.join(GOLDEN, 'stage_room150.npz'))
+    raw = g['raw_room']
+    p = preprocess.preprocess_room(raw[:, :6], raw[:, 6].astype(int), raw[:, 7].astype(int))      # stage_data.py:58-113 = test_region_grow.py:119-173
+    np.testing.assert_array_equal(p['points'], g['room_points'])
+    np.testing.assert_array_equal(p['obj_id'], g['room_obj_id'])
+    lines = []
+    st = stage.stage_room(g['room_points'], g['room_obj_id'], np.random.RandomState(0), log=lines.append)
+    stage.center_tuples(st)
+    assert len(st['points']) == len(g['staged_count']) == 191
+    np.testing.assert_array_equal([len(x) for x in st['points']], g['staged_count'])
+    np.testing.assert_array_equal([len(x) for x in st['neighbor_points']], g['staged_neighbor_count'])
+    np.testing.assert_array_equal(np.concatenate(st['add']), g['staged_add'])
+    np.testing.assert_array_equal(np.concatenate(st['remove']), g['staged_remove'])
+    np.testing.assert_array_equal(st['steps'], g['staged_steps'])
+    np.testing.assert_array_equal(np.asarray(st['complete'], dtype=np.float32), g['staged_complete'])
+    for k in ('points', 'neighbor_points'):
+        a = np.ascontiguousarray(np.vstack(st[k]), dtype=np.float32)
+        assert tuple(a.shape) == tuple(g['staged_%s_shape' % k])
+        head = g['staged_%s_head' % k]
+        np.testing.assert_array_equal(a[:len(head)], head)
+        assert hashlib.sha256(a.tobytes()).hexdigest() == str(g['staged_%s_sha256' % k])
+    # the script's log lines name the objects in the order they were grown, with their step counts and sizes
+    assert len(lines) == len(g['log_lines'])
+    for mine, ref in zip(lines, [str(x) for x in g['log_lines']]):
+        t, rest = mine.split(':')          # 'target 7: 12 steps 143/143'
+        assert ('target %d:' % int(t.split()[1])) in ref and rest.strip() in ref, (mine, ref)
