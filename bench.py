@@ -19,10 +19,12 @@ WORLD_SIZE that contradicts --gpus is an error.  Inputs (13-D room features, wei
       An instance-step is counted per slot and iteration of the loop, whatever the number of rows its LrgNet evaluation needed: the
       distinct rows of a 512 + 512 set are evaluated, the copies that pad it are not (``rows_evaluated_fraction``), so the unit is a
       PADDED-EQUIVALENT one -- the roofline object prices the rows that were evaluated, not 271.7 MFLOP per instance-step.
-  fixed-work leg (``rooms_per_sec``).  R = 544 room jobs (the 68 geometries x 8 random-stream keys) sharded over the N ranks by point
-      count (longest first), pushed through `--rooms` slots per GPU from reset to final labels (grow + fill-in), the labels gathered
-      over RCCL -- the only collective of the path.  Same R for every N (strong scaling).  ``fixed_work_best``: the same R jobs with
-      the number of slots per GPU chosen by a short sweep (rooms/s is not a property of 68 slots).
+  fixed-work leg (``rooms_per_sec``).  R = max(8 per geometry, 4 waves x 8 GPUs x slots per GPU) room jobs (2 176 at 68 slots: the 68
+      geometries x 32 random-stream keys) sharded over the N ranks by point count (longest first), pushed through
+      `--rooms` slots per GPU from reset to final labels (grow + fill-in), the labels gathered over RCCL -- the only collective of
+      the path.  Same R for every N (strong scaling): at N = 8 a rank still has four waves of rooms per slot (``waves_per_rank``), so
+      its time is throughput, not the critical path of its longest room.  ``fixed_work_best``: the same R jobs with the number of
+      slots per GPU chosen by a short sweep (rooms/s is not a property of 68 slots).
 
 Prints ONE JSON line on rank 0.
 """
@@ -82,7 +84,8 @@ def parse():
     ap.add_argument('--lanes', type=int, default=0, help='groups of slots on their own HIP streams; 0 = auto')
     ap.add_argument('--cu-partition', type=int, default=0, help='1: lanes on disjoint sets of compute units')
     ap.add_argument('--fixed-rooms', type=int, default=-1,
-                    help='room jobs of the fixed-work leg over ALL ranks (0 = skip; default: 8 jobs per geometry = 544 for the Area-5 set)')
+                    help='room jobs of the fixed-work leg over ALL ranks (0 = skip; default: max(8 jobs per geometry, 4 waves x 8 GPUs x slots per GPU) -- '
+                         'SURVEY.md 8e: the same R for every N, and at N = 8 every rank still pushes four waves of rooms through its slots)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
     ap.add_argument('--p0-rooms', type=int, default=4, help='rooms of the preprocessing (P0) side measurement (0 = skip)')
@@ -467,7 +470,7 @@ def main():
                                          'copies that pad a set to 512 rows and the copies that pad a slot\'s rows to whole 32-row tiles are NOT counted',
                      'evaluations': dw[0], 'rows_evaluated': [dw[1], dw[2]], 'rows_evaluated_fraction': (dw[1] + dw[2]) / max(dw[0] * 1024.0, 1.0),
                      'tiles_run_per_stack': dw[3], 'rows_in_tiles_fraction': (dw[1] + dw[2]) / max(dw[3] * 32.0, 1.0),
-                     'reproduce': 'rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps %d --warmup %d  (profiles/r03_bench_kernel_stats.csv)'
+                     'reproduce': 'rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps %d --warmup %d  (profiles/r04_bench_kernel_stats.csv)'
                                   % (args.steps, args.warmup)})
     else:
         reps = 20
@@ -531,7 +534,9 @@ def main():
     # HBM traffic / matrix-pipe occupancy of the loop's kernel: PMC passes of their own (tools/pmc_free_run.sh), quoted from the committed
     # file only when it was measured on this ABI and formulation
     roof['traffic'] = None
-    tpath = os.path.join(REPO, 'profiles', 'r03_pmc_free_run.json' if leg.free else 'r02_traffic_loop.json')
+    tpath = os.path.join(REPO, 'profiles', 'r04_pmc_free_run.json' if leg.free else 'r02_traffic_loop.json')
+    if leg.free and not os.path.exists(tpath):
+        tpath = os.path.join(REPO, 'profiles', 'r03_pmc_free_run.json')
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if leg.free and tj.get('abi') == _lib.load().lrg_abi_version():
@@ -579,7 +584,8 @@ def main():
         for k, v in fl.room_steps().items():
             room_steps.setdefault(mine[k] % len(base), v)
         out = {'rooms': int(f_rooms), 'seconds': el, 'rooms_per_sec': f_rooms / el, 'instance_steps': f_steps, 'instance_steps_per_sec': f_steps / el,
-               'scaling': 'strong', 'slots_per_gpu': fl.slots, 'formulation': 'free-running launches' if fl.free else 'lock-step iterations',
+               'scaling': 'strong', 'slots_per_gpu': fl.slots, 'waves_per_rank': R / float(world) / max(fl.slots, 1),
+               'waves_per_rank_at_8_gpus': R / 8.0 / max(n_slots, 1), 'formulation': 'free-running launches' if fl.free else 'lock-step iterations',
                'lanes': fl.lanes, 'grow_seconds_rank0': tf_grow, 'gather_seconds_rank0': tf1 - tg0, 'rccl_ranks': world,
                'collective_backend': backend, 'all_rooms_labeled_after_gather': bool(ok), 'labels_crc32': int(crc), 'given_up': int(st[3]),
                'what': '%d room jobs = the %d geometries x %d random-stream keys, LPT-sharded by point count over %d rank(s), reset -> grow -> '
@@ -591,7 +597,7 @@ def main():
 
     fixed = best = None
     if args.fixed_rooms < 0:
-        args.fixed_rooms = 8 * len(base)
+        args.fixed_rooms = max(8 * len(base), 4 * 8 * slots)      # R >= 8 GPUs x slots per GPU x 4 waves, the same R for every N
     if args.fixed_rooms > 0 and args.restarts == 1:
         fixed = fixed_work(args.fixed_rooms, slots)
         sweep = [int(x) for x in args.best_slots.split(',') if x.strip()] if args.workload != 'kitti' else []
@@ -647,6 +653,16 @@ def main():
             out['config']['active_fraction'] = inst_steps / (iterations * S * args.restarts * world)
         if fixed:
             out['fixed_work'] = fixed
+            # what the static LPT sharding (dist.shard_rooms_lpt, by point count) leaves of an 8-rank run of these R jobs: mean / max of the
+            # ranks' loads, by points (what the sharding sees) and by the instance-steps the rooms actually took in this run (what time follows)
+            jobs8 = jobs_of(args.fixed_rooms, 100000)
+            sizes8 = [len(j['points']) for j in jobs8]
+            steps8 = [float(room_steps.get(j % len(base), 0)) for j in range(len(jobs8))]
+            sh8 = lrg_dist.shard_rooms_lpt(sizes8, 8)
+            lp, ls = [sum(sizes8[j] for j in s_) for s_ in sh8], [sum(steps8[j] for j in s_) for s_ in sh8]
+            fixed['lpt_balance_at_8_gpus'] = {'by_points': float(np.mean(lp) / max(max(lp), 1)), 'by_instance_steps': float(np.mean(ls) / max(max(ls), 1.0)),
+                                              'note': 'mean / max of the eight ranks\' loads under the sharding by point count: the efficiency an 8-GPU run of this leg can '
+                                                      'reach at best (no 1 -> 8 curve has been measured by the builder: one GPU per box)'}
         if best:
             out['fixed_work_best'] = best
         if world == 1 and args.steady_slots and args.workload == 'area5' and args.restarts == 1:

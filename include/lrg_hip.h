@@ -23,6 +23,7 @@ extern "C" {
 
 #define LRG_ABI_VERSION 7
 #define LRG_EINVAL (-1000)
+#define LRG_ERESIDENCY (-1100)  /* lrg_grow_async: the launch's workgroups cannot all be resident at once on this stream / device (see there) */
 
 #define LRG_MAX_CONV 5 /* branch layers: lite=0 -> 5, lite=1 -> 2, lite=2 -> 3  (learn_region_grow_util.py:77-85) */
 #define LRG_MAX_HEAD 3 /* head layers incl. the final 2-wide one: lite=0 -> 3, lite=1 -> 2, lite=2 -> 3        */
@@ -482,8 +483,16 @@ size_t lrg_grow_async_queue_bytes(int n_slots);
 /* One free-running launch: every slot takes up to max_steps evaluations (grow steps), and starts no new one once budget_us
  * microseconds have passed since the launch began (0 = no time limit); slots whose room is finished or that are not bound
  * leave at once.  `buffers` are those of lrg_grow_step_packed with row_cap >= n_slots * 32 * ceil(max(n_inlier, n_neighbor) / 32)
- * (slot s owns that many rows from s * that number on).  A hand-over that was given up (no progress for seconds) is counted in
- * stats[3]; the caller must treat a non-zero count as a failed call. */
+ * (slot s owns that many rows from s * that number on).
+ * Residency: the launch is one workgroup per CU whose roles wait for each other, so all of them must run at once.  Refused with
+ * LRG_ERESIDENCY, before anything is enqueued, when the kernel does not fit a CU or the stream's CU mask (hipExtStreamCreateWithCUMask)
+ * leaves it fewer CUs than the launch has workgroups (AsyncBuffers.compute_units: pass the number of CUs the stream may use).  CUs held
+ * by somebody else (another process, a kernel of another stream) cannot be seen from the host: every workgroup reports in when it
+ * starts, and a launch whose workgroups have not all started within 20 ms gives up at once (reason 6 in stats[3]) instead of
+ * stalling.  A hand-over that was given up is counted in stats[3] (low word: workgroups that left this way, high word: sum of
+ * their reasons -- 1 launch past its time limit, 2 a team waited too long for a task, 3 a team lost a wavefront at a barrier, 4 / 5 a
+ * pooled-product unit / a head tile waited too long, 6 not all workgroups resident); the caller must treat a non-zero count as a
+ * failed call. */
 int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params,
                    const LrgWeights *weights, const LrgPackedBuffers *buffers, const LrgAsyncBuffers *async_buffers,
                    int max_steps, int budget_us, void *stream);

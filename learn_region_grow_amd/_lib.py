@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(HERE, 'liblrg_hip.so')
 SOURCES = ['lrg_net.hip', 'lrg_fused.hip', 'lrg_grow.hip', 'lrg_grouping.hip', 'lrg_preprocess.hip', 'lrg_train.hip']
 
 LRG_ABI_VERSION = 7       # what this binding was written against (include/lrg_hip.h: LRG_ABI_VERSION; tests/test_capi.py compares them and INTEGRATION.md)
+LRG_EINVAL = -1000
+LRG_ERESIDENCY = -1100     # lrg_grow_async: its workgroups cannot all be resident at once on this stream / device
 LRG_MAX_CONV = 5
 LRG_MAX_HEAD = 3
 LRG_FWD_FUSE_POOL = 1
@@ -279,5 +281,9 @@ def load():
 
 
 def check(rc, what):
+    if rc == LRG_ERESIDENCY:
+        raise LrgHipError('%s refused (LRG_ERESIDENCY): the launch is one workgroup per compute unit and all of them must run at once, but the '
+                          'kernel does not fit a CU or the stream may use fewer CUs than the launch has workgroups (a CU-masked stream: pass the '
+                          'number of CUs it may use as LrgAsyncBuffers.compute_units)' % what)
     if rc != 0:
         raise LrgHipError('%s failed with code %d' % (what, rc))

@@ -45,6 +45,10 @@
 #define LRG_AQ_ABORT 48
 #define LRG_AQ_SECOND 64
 #define LRG_AQ_GTAIL 96          // entries written to the pooled-product units' ring so far
+#define LRG_AQ_ARRIVED 112       // workgroups of this launch that have started (the start rendezvous of the front workgroups)
+#ifndef LRG_ASYNC_START_TICKS
+#define LRG_ASYNC_START_TICKS 2000000LL      // 20 ms (wall_clock64: 100 MHz): by then every workgroup of the launch has started, or never will while the others wait
+#endif
 #define LRG_AQ_RING 128          // ring 0, then ring 1 (qmask + 1 entries each), then the units' ring (gmask + 1 entries)
 #define LRG_ASYNC_SYNC_WORDS 16  // per slot: 0 branch tiles done, 1 their target, 2 pooled-product blocks done, 3 target, 4 head tiles done, 5 target,
                                  //           6 inlier tiles, 7 neighbour tiles of the evaluation in flight
@@ -581,6 +585,18 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
         }
     }
     lrg_drain_stores();
+    // Start rendezvous: front workgroups, units and tile teams wait for each other, so every workgroup of the launch must be running
+    // (one per CU).  On a chip the launch has to itself they all start within a microsecond; when something else holds CUs (another
+    // process, a kernel of another stream) some never start while these wait -- found out here within 20 ms and reported (reason 6),
+    // not by the hand-overs' bounds seconds later.
+    if (tid == 0) {
+        const int all = (int)gridDim.x;
+        for (unsigned spin = 0; lrg_ld_coh(&A.queue[LRG_AQ_ARRIVED]) < all; ++spin) {
+            if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) break;
+            if ((spin & 15) == 15 && wall_clock64() - t_launch > LRG_ASYNC_START_TICKS) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 6); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
     __syncthreads();
     for (;;) {
         // a hand-over given up anywhere (or this launch far beyond any sane duration): everybody leaves, the host reports it
@@ -697,6 +713,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgAs
 #else
     lrg_kargs_ptr kp = nullptr;
 #endif
+    if (tid == 0) __hip_atomic_fetch_add(&K.A.queue[LRG_AQ_ARRIVED], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody waits for the result)
     if ((int)blockIdx.x >= K.A.n_front && (int)blockIdx.x < K.A.n_front + K.A.gemv_units) {
         lrg_async_gemv_unit(kp, (int)blockIdx.x - K.A.n_front, t_launch);
         return;

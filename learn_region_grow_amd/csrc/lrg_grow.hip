@@ -1623,6 +1623,25 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_grow_async_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev] = true;
     }
+    // Residency: front workgroups, units and tile teams wait for each other, so the launch is only correct when ALL its workgroups run at
+    // once -- one per CU.  Checked here instead of found out by a spin bound seconds later: the kernel as compiled must fit a CU with this
+    // much LDS, and the stream must be allowed at least `wgs` CUs (a CU-masked stream, hipExtStreamCreateWithCUMask, is allowed fewer).
+    // What cannot be seen from here (another process or stream holding CUs) is caught by the launch's own start rendezvous within
+    // LRG_ASYNC_START_TICKS (lrg_async.inl: abort reason 6), not by the hand-overs' multi-second bounds.
+    {
+        int per_cu = 0;
+        LRG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(lrg_grow_async_kernel), LRG_FRONT_THREADS, lds));
+        if (per_cu < 1) return LRG_ERESIDENCY;
+        uint32_t cumask[32] = {};
+        const uint32_t words = (uint32_t)min(32, (prop.multiProcessorCount + 31) / 32);
+        if (hipExtStreamGetCUMask(st, words, cumask) == hipSuccess) {
+            int visible = 0;
+            for (uint32_t i = 0; i < words; ++i) visible += __builtin_popcount(cumask[i]);
+            if (visible > 0 && visible < wgs) return LRG_ERESIDENCY;      // (no bit set: no mask reported)
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(lrg_grow_async_kernel, dim3(wgs), dim3(LRG_FRONT_THREADS), lds, st, K);
     LRG_LAUNCH_CHECK();
     return 0;

@@ -602,7 +602,9 @@ class RegionGrower:
         self.last_stats = (int(st[0]), int(st[1]), int(st[2]))
         if int(st[3]):
             raise _lib.LrgHipError('lrg_grow_async gave up on a hand-over between workgroups (%d front workgroups; sum of their reasons %d -- 1 launch '
-                                   'past its time limit, 2 a team waited too long for a task, 3 a team lost a wavefront at a barrier): results are invalid'
+                                   'past its time limit, 2 a team waited too long for a task, 3 a team lost a wavefront at a barrier, 4 / 5 a pooled-product '
+                                   'unit / a head tile waited too long, 6 not all workgroups of the launch were resident within 20 ms: something else holds '
+                                   'compute units of this device): results are invalid'
                                    % (int(st[3]) & 0xFFFFFFFF, int(st[3]) >> 32))
         return out
 

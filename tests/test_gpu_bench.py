@@ -86,6 +86,14 @@ def test_bench_two_ranks_started_by_the_script_itself(cuda_device, tmp_path):
     d1 = json.loads(l1[0])
     assert d1['n_gpus'] == 1 and d1['fixed_work']['instance_steps'] == d2['fixed_work']['instance_steps']
     assert d1['fixed_work']['labels_crc32'] == d2['fixed_work']['labels_crc32']      # the gathered labels of all rooms equal the one-rank run's
+    assert abs(d2['fixed_work']['waves_per_rank'] - 1.0) < 1e-9 and abs(d1['fixed_work']['waves_per_rank'] - 2.0) < 1e-9      # 8 jobs, 4 slots, 2 / 1 ranks
+    # the default sizing of the leg: the same R for every N, and four waves of rooms per slot and rank at N = 8
+    r3, l3 = run_bench(['--gpus', '1', '--steps', '1', '--warmup', '1', '--step-ms', '2', '--rooms', '3', '--best-slots', '', '--steady-slots', '', '--cpu-seconds', '0',
+                        '--p0-rooms', '0', '--cache', str(tmp_path / 'cache')])
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    d3 = json.loads(l3[0])
+    assert d3['fixed_work']['rooms'] == 4 * 8 * 3 and d3['fixed_work']['waves_per_rank_at_8_gpus'] >= 4.0
+    assert 0 < d3['fixed_work']['lpt_balance_at_8_gpus']['by_points'] <= 1.0
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus(cuda_device, tmp_path):

@@ -88,3 +88,49 @@ def test_free_run_alternates_with_lock_step(net):
     for g, w in zip(got, want):
         same_regions(g.regions, w.regions)
         np.testing.assert_array_equal(g.filled_label, w.filled_label)
+
+
+def test_free_run_refuses_a_stream_with_too_few_compute_units(net, cuda_device):
+    """A free-running launch is one workgroup per CU whose roles wait for each other: on a stream confined to fewer CUs than the launch has
+    workgroups (hipExtStreamCreateWithCUMask) it could never be resident as a whole.  Refused with LRG_ERESIDENCY before anything is
+    enqueued -- not found out by a spin bound seconds later (the reference has one session and one device to itself, test_region_grow.py:86-90).
+    Told how many CUs the stream may use (LrgAsyncBuffers.compute_units), the same launch runs there and gives the lock-step labels."""
+    import ctypes
+    import time
+    import torch
+    from learn_region_grow_amd import _lib
+    from learn_region_grow_amd.grow import RegionGrower
+    lib = _lib.load()
+    ncu = torch.cuda.get_device_properties(cuda_device).multi_processor_count
+    words = (ncu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    allowed = ncu // 2
+    for b in range(allowed):
+        mask[b // 32] |= 1 << (b % 32)
+    h = ctypes.c_void_p()
+    _lib.check(lib.lrg_stream_create_cu_mask(mask, words, ctypes.byref(h)), 'lrg_stream_create_cu_mask')
+    stream = torch.cuda.ExternalStream(h.value, device=cuda_device)
+    rooms = _rooms()[:3]
+    want = RegionGrower(net, rooms_in_flight=3, rng='counter', seed=5, free_run=False).run(rooms)
+    try:
+        with torch.cuda.stream(stream):
+            gr = RegionGrower(net, rooms_in_flight=3, rng='counter', seed=5, free_run=True)
+            gr.load_rooms(rooms)
+            gr.free_run_begin()
+            t0 = time.perf_counter()
+            rc = lib.lrg_grow_async(gr.d_slots.data_ptr(), gr.d_rooms.data_ptr(), gr.S, gr.cap, ctypes.byref(gr.params), ctypes.byref(gr.net._w),
+                                    ctypes.byref(gr.packed_buffers), ctypes.byref(gr.async_buffers), 16, 1000, ctypes.c_void_p(stream.cuda_stream))
+            assert rc == _lib.LRG_ERESIDENCY and time.perf_counter() - t0 < 0.5
+            with pytest.raises(_lib.LrgHipError, match='LRG_ERESIDENCY'):
+                gr.enqueue_free_run()
+            stream.synchronize()
+            assert int(gr.d_stats[3].item()) == 0 and int(gr.d_stats[2].item()) == 0      # nothing ran, nothing gave up
+            # the same stream, the launch sized for it
+            gr.async_buffers.compute_units = allowed
+            got = gr._grow_loaded_free_run(True)
+            res = gr.collect(True)
+        for g, w in zip(res, want):
+            same_regions(g.regions, w.regions)
+            np.testing.assert_array_equal(g.filled_label, w.filled_label)
+    finally:
+        torch.cuda.synchronize()      # (the stream is left to the process, as grow.fill_streams leaves its masked streams: events recorded on it outlive the test)
