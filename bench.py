@@ -558,7 +558,7 @@ def main():
     # ------------------------------------------------------------------------------------------------------------------
     room_steps = {}
 
-    def fixed_work(R, n_slots):
+    def fixed_work(R, n_slots, measure_fill=False):
         jobs = jobs_of(R, 100000)
         sizes = [len(j['points']) for j in jobs]
         mine = sorted(lrg_dist.shard_rooms_lpt(sizes, world)[rank], key=lambda j: -sizes[j])      # largest first: the small rooms fill the tail
@@ -590,6 +590,28 @@ def main():
                'collective_backend': backend, 'all_rooms_labeled_after_gather': bool(ok), 'labels_crc32': int(crc), 'given_up': int(st[3]),
                'what': '%d room jobs = the %d geometries x %d random-stream keys, LPT-sharded by point count over %d rank(s), reset -> grow -> '
                        '1-NN fill-in -> all_gather of the labels' % (R, len(base), (R + len(base) - 1) // len(base), world)}
+        if measure_fill and fl.free and rank == 0:
+            # P14 (the 1-NN fill-in, test_region_grow.py:308-316; "k-NN at scale" of configs[4]) priced by itself: the fill-ins of this leg's rooms
+            # once more (labels are final: the same result), HIP events on the leg's stream; work = 3 x F x U x L FLOP per room (a subtract, a
+            # multiply and an add per feature and (unlabeled, labeled) pair) against the fp32 vector peak
+            g_ = fl.gr
+            lab = g_.d_label.cpu().numpy()
+            ul = [(int((lab[int(g_.room_off[k]):int(g_.room_off[k]) + g_.room_n[k]] == 0).sum()), int((lab[int(g_.room_off[k]):int(g_.room_off[k]) + g_.room_n[k]] > 0).sum()))
+                  for k in range(min(g_.n_rooms, 64))]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(fl.stream):
+                g_.fill_many(list(range(len(ul))))
+                e0.record(fl.stream)
+                for _ in range(5):
+                    g_.fill_many(list(range(len(ul))))
+                e1.record(fl.stream)
+            torch.cuda.synchronize()
+            sec = e0.elapsed_time(e1) * 1e-3 / 5
+            fl_flops = 3.0 * 13 * sum(u * l for u, l in ul)
+            out['p14_fill'] = {'rooms': len(ul), 'unlabeled_mean': float(np.mean([u for u, _ in ul])), 'labeled_mean': float(np.mean([l for _, l in ul])),
+                               'algorithmic_flops': fl_flops, 'seconds': sec, 'achieved': fl_flops / sec / 1e12, 'unit': 'TFLOP/s', 'peak': FP32_MATRIX_PEAK_TFLOPS,
+                               'frac': fl_flops / sec / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 'bound': 'fp32 vector (the pairwise float32 order of the reference is kept: no MFMA)',
+                               'what': 'lrg_nn1_fill_batch over %d finished rooms of this leg, 3 x 13 x U x L FLOP per room' % len(ul)}
         fl.close()
         del fl
         torch.cuda.empty_cache()
@@ -599,7 +621,7 @@ def main():
     if args.fixed_rooms < 0:
         args.fixed_rooms = max(8 * len(base), 4 * 8 * slots)      # R >= 8 GPUs x slots per GPU x 4 waves, the same R for every N
     if args.fixed_rooms > 0 and args.restarts == 1:
-        fixed = fixed_work(args.fixed_rooms, slots)
+        fixed = fixed_work(args.fixed_rooms, slots, measure_fill=True)
         sweep = [int(x) for x in args.best_slots.split(',') if x.strip()] if args.workload != 'kitti' else []
         tried = {slots: fixed}
         for n_slots in sweep:
@@ -652,6 +674,8 @@ def main():
             out['config']['iterations_per_step'] = args.iters_per_step
             out['config']['active_fraction'] = inst_steps / (iterations * S * args.restarts * world)
         if fixed:
+            if 'p14_fill' in fixed:
+                out['p14_fill'] = fixed.pop('p14_fill')
             out['fixed_work'] = fixed
             # what the static LPT sharding (dist.shard_rooms_lpt, by point count) leaves of an 8-rank run of these R jobs: mean / max of the
             # ranks' loads, by points (what the sharding sees) and by the instance-steps the rooms actually took in this run (what time follows)

@@ -2,6 +2,7 @@
 // The reference launches <<<b,256>>> -- one block per batch item, one THREAD per query row, serial over n.
 // Here one 64-lane wavefront owns a query / a row and scans n with ballots, so a launch fills the chip.
 #include "lrg_common.h"
+#include <type_traits>
 
 // ---- ball query (tf_grouping_g.cu:3-36): FIRST nsample points with max(sqrt(d2),1e-20) < radius ----
 __global__ __launch_bounds__(256) void lrg_query_ball_kernel(int b, int n, int m, float radius, int nsample,
@@ -71,6 +72,82 @@ __global__ void lrg_group_point_grad_kernel(long total, int n, int c, int m, int
     long bi = g / ((long)m * nsample);
     int ii = idx[g];
     atomicAdd(&grad_points[(bi * n + ii) * c + l], grad_out[e]);
+}
+
+// The same scatter-add without a single global atomic: a workgroup OWNS the gradient of (batch item, 16 channels) -- n x 16 floats in LDS.
+// The reference's kernel -- and the one above -- send every element to memory as an atomic of its own: b x m x nsample rows of c floats
+// onto b x n target rows, and the ball query pads its index lists with copies of the first hit (tf_grouping_g.cu:20-23), so most atomics
+// of a query land on the same few rows and serialise there (203 us for 67 MB of gradients = 0.045 of the HBM peak,
+// profiles/r03_grouping_rates.json; pre-reduced per (batch item, row range) in LDS and flushed with one atomic per target element: 97 us --
+// the flush is still millions of atomics).  Here the workgroup streams its 64-byte slice of every gradient row of the batch item
+// (16 bytes per lane, eight loads in flight), adds it into LDS (ds_add_f32: nothing leaves the CU) and stores its n x 16 sums with plain
+// stores.  Every input byte is read once, every output byte written once; the order of the additions differs from launch to launch as
+// the reference's does (atomicAdd, :61-78).
+#define LRG_GPG_SLICE 16
+__global__ __launch_bounds__(512) void lrg_group_point_grad_lds_kernel(int n, int c, int m_ns, const float *grad_out, const int *idx,
+                                                                       float *grad_points, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float gp_acc[];      // [n][16]
+    const int tid = threadIdx.x, bi = blockIdx.y, ch0 = blockIdx.x * LRG_GPG_SLICE;
+    const int total = n * LRG_GPG_SLICE;
+    for (int e = 4 * tid; e < total; e += 4 * 512) *reinterpret_cast<float4 *>(gp_acc + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // 128 rows per pass, four lanes (16 bytes each) per row.  A wavefront holds 16 consecutive rows; lane = 16 * piece + row, so that the
+    // rows of one 16-byte piece are the 16 lanes of a DPP row and "the row before" is a row_shr -- no LDS crossbar trip per shuffle
+    const int lane = tid & 63;
+    const int ri = lane & 15, l = lane >> 4, rl = (tid >> 6) * 16 + ri;
+    const float *go = grad_out + (size_t)bi * m_ns * c + ch0 + 4 * l;
+    const int *ix = idx + (size_t)bi * m_ns;
+    constexpr int U = 8;
+#define LRG_DPP_SHR(x, d) __builtin_amdgcn_update_dpp(0, (x), 0x110 + (d), 0xf, 0xf, true)
+    auto shr_f = [](float x, auto D) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x110 + decltype(D)::value, 0xf, 0xf, true)); };
+    for (int rb = 0; rb < m_ns; rb += U * 128) {
+        float4 v[U];
+        int ii[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = rb + u * 128 + rl;
+            ii[u] = -1;
+            if (r < m_ns) { ii[u] = ix[r]; v[u] = *reinterpret_cast<const float4 *>(go + (size_t)r * c); }
+        }
+        // A padded index list repeats one index over its tail: rows of equal index are added up inside the wavefront first (a segmented scan
+        // over the RUNS of equal index among its 16 rows; a later run of the same index adds separately) and one lane per run and piece goes
+        // to LDS.  Sixteen lanes adding to one LDS word are sixteen serialised updates otherwise (176 us against 60).
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int key = ii[u];
+            float4 w = (key >= 0 && key < n) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (key >= n) key = -1;
+            int run = 1;              // rows of my run up to and including mine
+            auto step = [&](auto D) {
+                constexpr int d = decltype(D)::value;
+                const int okey = __builtin_amdgcn_update_dpp(-2, key, 0x110 + d, 0xf, 0xf, false);
+                const int orun = __builtin_amdgcn_update_dpp(0, run, 0x110 + d, 0xf, 0xf, false);
+                const float ox = shr_f(w.x, D), oy = shr_f(w.y, D), oz = shr_f(w.z, D), ow = shr_f(w.w, D);
+                if (ri >= d && okey == key && run == d) {      // my partial is exactly the d rows up to mine, and the one before continues the run
+                    w.x += ox; w.y += oy; w.z += oz; w.w += ow;
+                    run += orun;
+                }
+            };
+            step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());
+            step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 8>());
+            const int nkey = __builtin_amdgcn_update_dpp(-2, key, 0x100 + 1, 0xf, 0xf, false);      // row_shl:1 -- the next row's index
+            const bool last = ri == 15 || nkey != key;
+            if (key >= 0 && last) {
+                float *a = gp_acc + key * LRG_GPG_SLICE + 4 * l;
+                atomicAdd(a + 0, w.x); atomicAdd(a + 1, w.y); atomicAdd(a + 2, w.z); atomicAdd(a + 3, w.w);
+            }
+        }
+    }
+#undef LRG_DPP_SHR
+    __syncthreads();
+    float *gp = grad_points + (size_t)bi * n * c + ch0;
+    for (int e = tid; e < n * 4; e += 512) {             // (point, quarter of the slice): 16 bytes
+        const int p = e >> 2, q = e & 3;
+        float4 sum = *reinterpret_cast<const float4 *>(gp_acc + p * LRG_GPG_SLICE + 4 * q);
+        float4 *dst = reinterpret_cast<float4 *>(gp + (size_t)p * c + 4 * q);
+        if (accumulate) { const float4 o = *dst; sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w; }      // (the op ADDS into grad_points, which the caller zeroed)
+        *dst = sum;
+    }
 }
 
 // ---- partial selection sort (tf_grouping_g.cu:83-123), one wave per row, exact swap sequence ----
@@ -289,6 +366,21 @@ int lrg_group_point_grad(int b, int n, int c, int m, int nsample, const float *g
     if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || !grad_out || !idx || !grad_points) return LRG_EINVAL - 1;
     long total = (long)b * m * nsample * c;
     if (total == 0) return 0;
+    const size_t lds = (size_t)n * LRG_GPG_SLICE * sizeof(float);
+    const long m_ns = (long)m * nsample;
+    if (c % LRG_GPG_SLICE == 0 && c / LRG_GPG_SLICE <= 65535 && lds <= 144 * 1024 && m_ns < (1L << 30) && b <= 65535 &&
+        ((((uintptr_t)grad_out) | ((uintptr_t)grad_points)) & 15) == 0 && m_ns >= 256) {
+        static bool attr_done[LRG_MAX_DEVICES] = {};
+        const int dev = lrg_current_device();
+        if (!attr_done[dev]) {
+            LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_group_point_grad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            attr_done[dev] = true;
+        }
+        hipLaunchKernelGGL(lrg_group_point_grad_lds_kernel, dim3(c / LRG_GPG_SLICE, b), dim3(512), lds, (hipStream_t)stream, n, c, (int)m_ns, grad_out, idx,
+                           grad_points, 1);
+        LRG_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(lrg_group_point_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, total, n, c, m, nsample, grad_out, idx, grad_points);
     LRG_LAUNCH_CHECK();

@@ -54,7 +54,7 @@ def _format_region(room_id, r, class_name):
 def grow_room(points, obj_id, order, weights, stream, *, cls_id=None, classes=None, room_id=0,
               resolution=0.1, lite=0, num_inlier=512, num_neighbor=512, cluster_threshold=10,
               policy='net', restarts=0, faithful=False, net_fn=None, hook=None, max_region_steps=None,
-              fill=True, scoring='np'):
+              fill=True, scoring='np', max_total_steps=None):
     """Grow all regions of one room.  restarts=0 -> test_region_grow.py; restarts=R>0 ->
     test_random_restart.py with NUM_RESTARTS=R and --scoring np (default) or ml.
 
@@ -84,6 +84,8 @@ def grow_room(points, obj_id, order, weights, stream, *, cls_id=None, classes=No
     for seed_id in np.arange(N)[np.asarray(order)]:               # :186
         if visited[seed_id]:                                      # :187-188
             continue
+        if max_total_steps is not None and res.total_steps >= max_total_steps:
+            break          # test extension: a PREFIX of the room's regions (whole regions only) -- 100 k-point scenes within a CPU budget
         seed_voxel = point_voxels[seed_id]
         target_id = obj_id[seed_id]
         gt_mask = obj_id == target_id
