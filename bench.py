@@ -186,6 +186,7 @@ def p0_rates(n_rooms, dev):
     preprocess_gpu.preprocess_room(*raws[0], device=dev)
     out = {}
     for name, fn in (('gpu', lambda raw: preprocess_gpu.preprocess_room(*raw, device=dev)),
+                     ('gpu_exact', lambda raw: preprocess_gpu.preprocess_room(*raw, eig='exact', device=dev)),
                      ('gpu_lapack_finish', lambda raw: preprocess_gpu.preprocess_room(*raw, eig='lapack', device=dev)),
                      ('host_numpy', lambda raw: preprocess.preprocess_room(*raw))):
         torch.cuda.synchronize()

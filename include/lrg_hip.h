@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define LRG_ABI_VERSION 7
+#define LRG_ABI_VERSION 8
 #define LRG_EINVAL (-1000)
 #define LRG_ERESIDENCY (-1100)  /* lrg_grow_async: the launch's workgroups cannot all be resident at once on this stream / device (see there) */
 
@@ -616,6 +616,11 @@ int lrg_adam_step(float *params, const float *grads, float *m, float *v, long n,
  *             order); the host finishes with numpy.linalg.svd exactly as the reference does.  points may be NULL.
  * eig_mode 1: also points [N,feature_size] float32 (:165-172), obj_out / cls_out [N], curvatures [N] float64 (:163), with the
  *             3x3 decompositions done here by Jacobi iteration in float64 (agrees with LAPACK to ~1e-16 |cov|).
+ * eig_mode 2: eig_mode 1 prepared for an exact finish on the host (learn_region_grow_amd.preprocess_gpu, eig='exact'): cov is written too,
+ *             curvatures stay UN-normalised (S[2]/sum(S), :160-161 -- the division by the maximum, :163, is the host's, with LAPACK's own
+ *             maximum), and lrg_preprocess_unsafe_normals tells which points' float32 normals are not certain to equal what
+ *             numpy.linalg.svd would give (near-degenerate eigenvalue pairs, components next to a float32 rounding boundary): the host
+ *             redoes those few with LAPACK and gets the reference's features and seed order bit for bit at the all-GPU rate.
  * workspace: lrg_preprocess_workspace_bytes(n_raw) bytes, 256-byte aligned.  Points whose voxel falls outside a 21-bit
  * window per axis are reported by lrg_preprocess_status (1) and left out. */
 size_t lrg_preprocess_workspace_bytes(int n_raw);
@@ -624,6 +629,8 @@ int lrg_preprocess(const float *raw, int raw_stride, const int32_t *obj_id, cons
                    int32_t *cls_out, double *curvatures, int32_t *equalized_idx, int32_t *unequalized_idx, double *cov,
                    int32_t *n_equalized, void *stream);
 int lrg_preprocess_status(const void *workspace, int n_raw, int32_t *host_status, void *stream);
+/* after lrg_preprocess(..., eig_mode 2, ...) on this workspace: flags_out [n_equalized] int32 (device), 1 = redo this point's decomposition with LAPACK */
+int lrg_preprocess_unsafe_normals(const void *workspace, int n_raw, int n_equalized, int32_t *flags_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(HERE, 'liblrg_hip.so')
 SOURCES = ['lrg_net.hip', 'lrg_fused.hip', 'lrg_grow.hip', 'lrg_grouping.hip', 'lrg_preprocess.hip', 'lrg_train.hip']
 
-LRG_ABI_VERSION = 7       # what this binding was written against (include/lrg_hip.h: LRG_ABI_VERSION; tests/test_capi.py compares them and INTEGRATION.md)
+LRG_ABI_VERSION = 8       # what this binding was written against (include/lrg_hip.h: LRG_ABI_VERSION; tests/test_capi.py compares them and INTEGRATION.md)
 LRG_EINVAL = -1000
 LRG_ERESIDENCY = -1100     # lrg_grow_async: its workgroups cannot all be resident at once on this stream / device
 LRG_MAX_CONV = 5
@@ -248,6 +248,7 @@ _SIGS = {
     'lrg_preprocess': (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp,
                                       ctypes.c_size_t, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     'lrg_preprocess_status': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), _fp]),
+    'lrg_preprocess_unsafe_normals': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp]),
 }
 
 EXPORTS = sorted(_SIGS)

@@ -188,6 +188,7 @@ __global__ void prep_sort_lists_kernel(const int32_t *hash_off, const int32_t *c
     }
 }
 
+#define PREP_EIG_SLACK (256.0 * 2.220446049250313e-16)
 // Eigen-decomposition of a symmetric 3x3 matrix, cyclic Jacobi in float64.  w: eigenvalues, V[k][:]: eigenvector k.
 __device__ void prep_jacobi3(const double *c, double *w, double (*V)[3]) {
     double a[3][3] = {{c[0], c[1], c[2]}, {c[1], c[4], c[5]}, {c[2], c[5], c[8]}};
@@ -224,7 +225,7 @@ __device__ void prep_jacobi3(const double *c, double *w, double (*V)[3]) {
 __global__ __launch_bounds__(PREP_THREADS) void prep_cov_kernel(const float *raw, int ld, float res, const int32_t *equalized_idx,
                                                               const int32_t *scal_n, const uint64_t *keys, const int32_t *hash_off,
                                                               const int32_t *count, int mask, const int32_t *list, double *cov_out,
-                                                              int eig_mode, double *normal, double *curv, int32_t *scal) {
+                                                              int eig_mode, double *normal, double *curv, int32_t *scal, int32_t *nflag) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= *scal_n) return;
     const float *pe = raw + (long)equalized_idx[e] * ld;
@@ -281,6 +282,23 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_cov_kernel(const float *raw
     normal[(long)e * 3 + 0] = fabs(V[i2][0]); normal[(long)e * 3 + 1] = fabs(V[i2][1]); normal[(long)e * 3 + 2] = fabs(V[i2][2]);
     const double cv = fabs(s[i2] / (s[i0] + s[i1] + s[i2]));                                         // S[2]/(S[0]+S[1]+S[2]) (:160-161)
     curv[e] = cv;
+    if (eig_mode == 2 && nflag) {
+        // Would LAPACK's decomposition of the same matrix round to the same float32 normal?  Both solvers are backward stable: their
+        // eigenvectors of the smallest eigenvalue differ by at most ~p eps |A| / (gap to the next eigenvalue) with a small p; with
+        // PREP_EIG_SLACK = 256 eps (an order of magnitude above either solver's constant) a component whose float32 rounding is the
+        // same at both ends of that interval is the same float32 number under LAPACK.  Everything else -- near-degenerate pairs of
+        // eigenvalues, components next to a rounding boundary, NaN -- is flagged and redone by the host's LAPACK call (preprocess_gpu).
+        const double gap = s[i1] - s[i2];
+        int unsafe = !(gap > 1e-6 * s[i0]) || !(cv == cv);
+        if (!unsafe) {
+            const double dv = PREP_EIG_SLACK * s[i0] / gap;
+            for (int k = 0; k < 3; ++k) {
+                const double x = fabs(V[i2][k]);
+                if ((float)(x - dv) != (float)(x + dv) || x < dv) unsafe = 1;
+            }
+        }
+        nflag[e] = unsafe;
+    }
     if (cv != cv) scal[10] = 1;                                                                     // numpy's max() propagates NaN
     else atomicMax(reinterpret_cast<unsigned long long *>(&scal[8]), (unsigned long long)__double_as_longlong(cv));
 }
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_cov_kernel(const float *raw
 // the feature stack (:163-172)
 __global__ void prep_features_kernel(const float *raw, int ld, const int32_t *obj, const int32_t *cls, const int32_t *equalized_idx,
                                      const int32_t *scal, const double *normal, double *curv, int F, float *points, int32_t *obj_out,
-                                     int32_t *cls_out) {
+                                     int32_t *cls_out, int keep_raw_curv) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= scal[0]) return;
     const int i = equalized_idx[e];
@@ -306,7 +324,7 @@ __global__ void prep_features_kernel(const float *raw, int ld, const int32_t *ob
     const double cmax = scal[10] ? __longlong_as_double(0x7ff8000000000000LL)
                                  : __longlong_as_double(*reinterpret_cast<const long long *>(&scal[8]));
     const double c = curv[e] / cmax;                                                                 // (:163)
-    curv[e] = c;
+    if (!keep_raw_curv) curv[e] = c;      // (eig_mode 2: the host normalises with LAPACK's own maximum)
     if (F >= 13) o[12] = (float)c;
     if (obj_out) obj_out[e] = obj ? obj[i] : 0;
     if (cls_out) cls_out[e] = cls ? cls[i] : 0;
@@ -331,9 +349,9 @@ int lrg_preprocess(const float *raw, int raw_stride, const int32_t *obj_id, cons
     if (workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return LRG_EINVAL - 53;
     if (!(resolution > 0.f)) return LRG_EINVAL - 54;
     if (feature_size != 6 && feature_size != 9 && feature_size != 12 && feature_size != 13) return LRG_EINVAL - 55;
-    if (eig_mode != 0 && eig_mode != 1) return LRG_EINVAL - 56;
-    if (eig_mode == 1 && (!points || !curvatures)) return LRG_EINVAL - 57;
-    if (eig_mode == 0 && !cov) return LRG_EINVAL - 58;
+    if (eig_mode != 0 && eig_mode != 1 && eig_mode != 2) return LRG_EINVAL - 56;
+    if (eig_mode >= 1 && (!points || !curvatures)) return LRG_EINVAL - 57;
+    if ((eig_mode == 0 || eig_mode == 2) && !cov) return LRG_EINVAL - 58;
     hipStream_t st = (hipStream_t)stream;
     char *ws = static_cast<char *>(workspace);
     uint64_t *keys = reinterpret_cast<uint64_t *>(ws + L.keys);
@@ -362,11 +380,23 @@ int lrg_preprocess(const float *raw, int raw_stride, const int32_t *obj_id, cons
     hipLaunchKernelGGL(prep_fill_kernel, dim3(gm), dim3(PREP_THREADS), 0, st, slot, hoff, hrank, cursor, n_raw, list, unequalized_idx);
     hipLaunchKernelGGL(prep_sort_lists_kernel, dim3(gc), dim3(PREP_THREADS), 0, st, hoff, count, cap, list);
     hipLaunchKernelGGL(prep_cov_kernel, dim3(gm), dim3(PREP_THREADS), 0, st, raw, raw_stride, resolution, equalized_idx, scal, keys,
-                       hoff, count, mask, list, cov, eig_mode, normal, curv, scal);
-    if (eig_mode == 1)
+                       hoff, count, mask, list, cov, eig_mode, normal, curv, scal, flag);
+    if (eig_mode >= 1)
         hipLaunchKernelGGL(prep_features_kernel, dim3(gm), dim3(PREP_THREADS), 0, st, raw, raw_stride, obj_id, cls_id, equalized_idx, scal,
-                           normal, curv, feature_size, points, obj_out, cls_out);
+                           normal, curv, feature_size, points, obj_out, cls_out, eig_mode == 2 ? 1 : 0);
     LRG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* eig_mode 2: which equalised points' float32 normals are not certain to equal LAPACK's (1) -- copied out of the workspace */
+int lrg_preprocess_unsafe_normals(const void *workspace, int n_raw, int n_equalized, int32_t *flags_out, void *stream) {
+    LrgPrepLayout L;
+    int rc = prep_layout(n_raw, &L);
+    if (rc) return rc;
+    if (!workspace || !flags_out || n_equalized < 0 || n_equalized > n_raw) return LRG_EINVAL - 52;
+    if (n_equalized == 0) return 0;
+    LRG_HIP_CHECK(hipMemcpyAsync(flags_out, static_cast<const char *>(workspace) + L.flag, (size_t)n_equalized * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
     return 0;
 }
 

@@ -73,10 +73,12 @@ def parse(argv=None):
     ap.add_argument('--quiet-regions', action='store_true', help='do not print the per-region lines (test_region_grow.py:217)')
     ap.add_argument('--timing', action='store_true',
                     help="the reference's timing table (test_region_grow.py:382-390): rooms one at a time, HIP events round every launch")
-    ap.add_argument('--preprocess', default='gpu-lapack', choices=['gpu-lapack', 'gpu', 'host'],
-                    help="equalisation / normals / curvature (test_region_grow.py:119-173): 'gpu-lapack' = GPU gathering and "
-                         "covariances + the reference's numpy.linalg.svd on the host (bit-identical features); 'gpu' = all on the "
-                         "GPU (Jacobi eigen-solve, features equal to float32 rounding); 'host' = vectorised NumPy")
+    ap.add_argument('--preprocess', default='gpu-exact', choices=['gpu-exact', 'gpu-lapack', 'gpu', 'host'],
+                    help="equalisation / normals / curvature (test_region_grow.py:119-173): 'gpu-exact' = all on the GPU (Jacobi eigen-solve), "
+                         "the few points whose float32 features or seed-order position could differ under LAPACK redone with the reference's "
+                         "numpy.linalg.svd on the host (features and seed order bit-identical, 4.5 x the rate of 'gpu-lapack'); 'gpu-lapack' = GPU "
+                         "gathering and covariances + numpy.linalg.svd for every point (every output bit-identical); 'gpu' = all on the GPU "
+                         "(features equal to float32 rounding, seed order up to near-ties); 'host' = vectorised NumPy")
     args = ap.parse_args(argv)
     if args.beam > 0:
         bad = [o for o, on in (('--rng legacy', args.rng != 'counter'), ('--restarts', args.restarts > 1), ('--lanes', args.lanes > 1),
@@ -224,7 +226,7 @@ def main(argv=None):
             else:
                 pre.append(preprocess_gpu.preprocess_room(all_points[r], all_obj_id[r], all_cls_id[r], resolution=args.resolution,
                                                           feature_size=args.feature_size, device=device,
-                                                          eig='lapack' if args.preprocess == 'gpu-lapack' else 'jacobi'))
+                                                          eig={'gpu-lapack': 'lapack', 'gpu-exact': 'exact'}.get(args.preprocess, 'jacobi')))
             t_feat.append(time.time() - t0)
         rooms = [dict(points=p['points'], obj_id=p['obj_id'], order=p['order'].astype(np.int32), room_id=r) for r, p in zip(my_rooms, pre)]
         in_flight = max(1, min(args.rooms_in_flight, len(rooms)))

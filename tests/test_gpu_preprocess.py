@@ -104,3 +104,45 @@ def test_degenerate_inputs(cuda_device, hip_lib):
     with pytest.raises(_lib.LrgHipError):
         preprocess_gpu.preprocess_room(far, obj, obj, device=cuda_device)
     assert hip_lib.lrg_preprocess_workspace_bytes(0) == 0
+
+
+@pytest.mark.parametrize('seed,F', [(1, 13), (2, 12), (5, 13), (7, 13)])
+def test_exact_mode_equals_the_reference_where_the_loop_reads(cuda_device, seed, F):
+    """eig='exact': the Jacobi solve on the GPU with the points whose float32 features or seed-order position could differ under LAPACK
+    redone with LAPACK -- features and seed order (all the region-grow loop reads, test_region_grow.py:172,183) equal the oracle bit for
+    bit, and only a small share of the points needed the host."""
+    from learn_region_grow_amd import preprocess_gpu
+    raw, obj, cls = raw_room(seed)
+    want = preprocess_ref.preprocess_room(raw, obj, cls, feature_size=F)
+    got = preprocess_gpu.preprocess_room(raw, obj, cls, feature_size=F, eig='exact', device=cuda_device)
+    for k in ('equalized_idx', 'unequalized_idx', 'obj_id', 'cls_id', 'points'):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    np.testing.assert_array_equal(got['order'], np.argsort(want['curvatures']))
+    assert np.abs(got['curvatures'] - want['curvatures']).max() < 1e-12
+    assert got['exact_stats']['lapack_points'] <= 0.15 * got['exact_stats']['points'] + 8, got['exact_stats']      # (small rooms: runs of equal curvature)
+
+
+def test_exact_mode_full_size_and_degenerate_rooms(cuda_device):
+    """The 20 k-point Area-5-shaped room, three more Area-5-shaped rooms, and the degenerate input (isolated points: NaN curvatures, a
+    crowded voxel) -- points and order bit for bit."""
+    from learn_region_grow_amd import preprocess_gpu
+    rooms = [synthetic.area5_shaped_room(20000, 1234), synthetic.area5_shaped_room(9000, 77), synthetic.area5_shaped_room(5000, 78),
+             synthetic.area5_shaped_room(3000, 79)]
+    for r in rooms:
+        r = r.astype(np.float32)
+        raw = (r[:, :6], r[:, 6].astype(int), r[:, 7].astype(int))
+        want = preprocess.preprocess_room(*raw)                      # (the host version: itself bit-equal to the oracle loop, tests/test_oracle_golden.py)
+        got = preprocess_gpu.preprocess_room(*raw, eig='exact', device=cuda_device)
+        np.testing.assert_array_equal(got['points'], want['points'])
+        np.testing.assert_array_equal(got['order'], want['order'])
+        np.testing.assert_array_equal(got['obj_id'], want['obj_id'])
+        assert got['exact_stats']['lapack_points'] <= 0.15 * got['exact_stats']['points'] + 8, got['exact_stats']      # (small rooms: runs of equal curvature)
+    rs = np.random.RandomState(0)
+    raw = np.zeros((400, 6), np.float32)
+    raw[:300, :3] = 0.5 + rs.rand(300, 3) * 0.04
+    raw[300:, :3] = rs.rand(100, 3) * 3
+    raw[:, 3:6] = rs.rand(400, 3)
+    obj = np.arange(400) % 7
+    want = preprocess_ref.preprocess_room(raw, obj, obj)
+    got = preprocess_gpu.preprocess_room(raw, obj, obj, eig='exact', device=cuda_device)
+    np.testing.assert_array_equal(got['points'], want['points'])          # (NaN rows included: assert_array_equal treats NaN == NaN)
