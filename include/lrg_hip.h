@@ -474,11 +474,16 @@ typedef struct LrgAsyncBuffers {
     uint64_t *work;             /* nullable: [4] running totals (never cleared by the library) of what the launches evaluated: LrgNet
                                    evaluations, distinct inlier rows, distinct neighbour rows, 32-row tiles per stack (branch = head) --
                                    the algorithmic FLOPs of the launches follow from these                                        */
+    float *pool_rows;           /* nullable: lrg_grow_async_pool_rows_bytes(weights, n_slots) bytes, 16-byte aligned -- with the pooled-product units a
+                                   branch tile leaves the column maxima of its rows as one row here (16-byte stores) and the units take the maximum
+                                   over a slot's tiles; NULL: one atomicMax per column and tile on the pooled feature (ABI 8)              */
+    size_t pool_rows_bytes;
     uint64_t *debug_ticks;      /* nullable: [64] accumulators (never cleared by the library) of wall-clock ticks by stage of the
                                    launch, for tools/free_run_perf.py (layout: csrc/lrg_async.inl, LrgAsyncArgs.dbg)            */
 } LrgAsyncBuffers;
 
 size_t lrg_grow_async_queue_bytes(int n_slots);
+size_t lrg_grow_async_pool_rows_bytes(const LrgWeights *weights, int n_slots);
 
 /* One free-running launch: every slot takes up to max_steps evaluations (grow steps), and starts no new one once budget_us
  * microseconds have passed since the launch began (0 = no time limit); slots whose room is finished or that are not bound

@@ -89,7 +89,8 @@ class LrgPackedBuffers(ctypes.Structure):
 
 class LrgAsyncBuffers(ctypes.Structure):
     _fields_ = [('queue', _fp), ('queue_bytes', ctypes.c_size_t), ('sync', _fp), ('front_workgroups', ctypes.c_int32), ('teams', ctypes.c_int32),
-                ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('branch_parts', ctypes.c_int32), ('gemv_units', ctypes.c_int32), ('room_queue', _fp), ('work', _fp), ('debug_ticks', _fp)]
+                ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('branch_parts', ctypes.c_int32), ('gemv_units', ctypes.c_int32), ('room_queue', _fp), ('work', _fp),
+                ('pool_rows', _fp), ('pool_rows_bytes', ctypes.c_size_t), ('debug_ticks', _fp)]
 
 
 class LrgFillJob(ctypes.Structure):
@@ -248,6 +249,7 @@ _SIGS = {
     'lrg_preprocess': (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp,
                                       ctypes.c_size_t, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     'lrg_preprocess_status': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), _fp]),
+    'lrg_grow_async_pool_rows_bytes': (ctypes.c_size_t, [ctypes.POINTER(LrgWeights), ctypes.c_int]),
     'lrg_preprocess_unsafe_normals': (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp]),
 }
 

@@ -78,6 +78,8 @@ struct LrgAsyncArgs {
     int head_ring;               // the ring pooled blocks and head tiles are published to: 1, or 0 = one ring for all tasks and all teams
     int ring0_halves;            // more than one team per workgroup: team t of worker workgroup w runs branch tiles (ring 0) if 2 t + (w & 1) < ring0_halves,
                                  // else pooled blocks and head tiles (ring 1) -- 2: the first team everywhere, 3: one and a half teams on average, ...
+    float *pool_rows;            // nullable (with the units): [n_slots][2 sides][16 tiles][P / 2] column maxima by branch tile, instead of atomicMax on the pooled feature
+    int pool_rows_stride;        // 2 * 16 * (P / 2)
     int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
     int branch_parts;            // tasks per branch tile (1, 2, 4): they share the column blocks of the pooled layer (lrg_fused_tile)
     int max_steps;               // evaluations per slot in this launch
@@ -263,8 +265,10 @@ LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
                 // one entry for all units; and the head tiles at once -- they stage their rows and run the first pass of MFMAs while the
                 // units work, and wait for the product in front of that pass's epilogue (LrgWaitPooled)
                 if (lane == 0) {
+                    // (entry: generation tag | tiles per side - 1, four bits each | slot -- the units take the maximum over the slot's tile rows)
                     const int i = __hip_atomic_fetch_add(&A.queue[LRG_AQ_GTAIL], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    lrg_st_coh(&A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (i & A.gmask)], (lrg_gemv_ring_tag(i, A.gmask) << 20) | slot);
+                    lrg_st_coh(&A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (i & A.gmask)],
+                               (lrg_gemv_ring_tag(i, A.gmask) << 20) | (((nt_in - 1) & 15) << 16) | (((nt_nb - 1) & 15) << 12) | slot);
                 }
                 nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
                 lrg_async_push(A, A.head_ring, nt_nb + nt_in, lane, [&](int i) {
@@ -367,7 +371,7 @@ LRG_ASYNC_ROLE void lrg_async_gemv_unit(lrg_kargs_ptr kp_, int unit_, long long 
             const int tag = lrg_gemv_ring_tag(i, A.gmask);
             for (unsigned spin = 0; slot == -2; ++spin) {
                 const int code = lrg_ld_coh(e);
-                if ((code >> 20) == tag) { slot = code & 0xFFFFF; break; }
+                if ((code >> 20) == tag) { slot = code & 0xFFFFF; break; }      // (slot | tile counts: unpacked below)
                 if ((spin & 7) == 7) {
                     if (lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front || lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) slot = -1;
                     else if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) {
@@ -380,10 +384,36 @@ LRG_ASYNC_ROLE void lrg_async_gemv_unit(lrg_kargs_ptr kp_, int unit_, long long 
             if (lane == 0) word[round] = slot;
         }
         team.sync();
-        const int slot = word[round];                         // (the other word is written next round: no second barrier)
-        if (slot < 0) return;
+        const int entry = word[round];                        // (the other word is written next round: no second barrier)
+        if (entry < 0) return;
+        const int slot = entry & 0xFFF;                       // (units serve at most LRG_GEMV_UNIT_MAX_SLOTS = 2048 slots)
         if (LRG_DBG(A)) t_task = wall_clock64();
-        {   // the slot's pooled row: one 16-byte load per lane
+        if (A.pool_rows) {
+            // the slot's pooled feature (:122-125) = the maximum over its branch tiles' rows of column maxima, taken here on the way into LDS:
+            // every lane owns 16 bytes of the feature and has one load per tile of that side in flight (the values are >= 0: their
+            // order is that of their bit patterns, as in the atomicMax formulation)
+            const int nt_in = ((entry >> 16) & 15) + 1, nt_nb = ((entry >> 12) & 15) + 1;
+            const int half4 = P >> 3;                          // 16-byte pieces per side
+            const float *rows = A.pool_rows + (long)slot * A.pool_rows_stride;
+            for (int j = tid; j < (P >> 2); j += FTHREADS) {
+                const int side = j >= half4 ? 1 : 0, c4 = j - side * half4, nt = side ? nt_nb : nt_in;
+                const float *src = rows + (long)side * 16 * (P >> 1);
+                int4 m = make_int4(0, 0, 0, 0);
+                for (int t0 = 0; t0 < nt; t0 += 8) {          // (eight loads in flight: a side has 3.5 tiles on average, 16 at most)
+                    float4 v[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (t0 + t < nt) v[t] = lrg_ld_coh4(src, (unsigned)((t0 + t) * (P >> 1) + 4 * c4) * 4u);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (t0 + t < nt) {
+                            m.x = max(m.x, __float_as_int(v[t].x)); m.y = max(m.y, __float_as_int(v[t].y));
+                            m.z = max(m.z, __float_as_int(v[t].z)); m.w = max(m.w, __float_as_int(v[t].w));
+                        }
+                }
+                *reinterpret_cast<int4 *>(pl + 4 * j) = m;
+            }
+        } else {   // the slot's pooled row: one 16-byte load per lane
             const float *src = g.pooled + (long)slot * P;
             for (int j = tid; j < (P >> 2); j += FTHREADS)
                 *reinterpret_cast<float4 *>(pl + 4 * j) = lrg_ld_coh4(src, (unsigned)j * 16u);

@@ -27,6 +27,9 @@ struct LrgFusedProb {
     const int *tile_count; // nullable pair: *tile_count live tiles, tile_list[b] = instance * 64 + tile of workgroup b
     const int *tile_list;
     float *zero_pool;    // nullable: after the stack, the tile-0 workgroup of instance i clears zero_pool[i*zero_count .. +zero_count)
+    float *pool_rows;    // nullable (single-instance tiles of the free-running kernel): the tile's column maxima of the pooled layer go to
+    int pool_rows_stride;  // pool_rows[inst * pool_rows_stride + tile * N + col] as ONE row of 16-byte write-through stores instead of N atomicMax
+                         // on pool; whoever consumes the pooled feature takes the maximum over the instance's tiles (lrg_async.inl: the units)
     // packed rows (lrg_forward_packed): x holds the distinct rows of ALL instances back to back, *nrows of them; row r belongs
     // to instance row_inst[r].  Tiles are 32 consecutive packed rows and may span instances: the max-pool and the
     // per-instance bias are applied per run of equal row_inst inside the tile.

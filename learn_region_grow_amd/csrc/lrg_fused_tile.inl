@@ -533,7 +533,13 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
         }
         team.sync();                                 // layer boundary: outputs visible, inputs dead
         if constexpr (PACKED) {
-            if ((L.flags & LRG_FL_POOL) && !(L.flags & LRG_FL_KEEP)) {
+            if (ONE && COH && P.pool_rows && (L.flags & LRG_FL_POOL) && !(L.flags & LRG_FL_KEEP)) {
+                // the tile's maxima as one row for whoever takes the maximum over the slot's tiles (the pooled-product units): 16 bytes
+                // per lane, write-through -- N atomics per tile were N write transactions and N acknowledgements to drain before the arrival
+                float *dst = P.pool_rows + (long)inst * P.pool_rows_stride + (long)tile * L.N;
+                for (int c4 = (cb_lo * FBN >> 2) + tid; c4 < (min(L.N, cb_hi * FBN) >> 2); c4 += FTHREADS)
+                    lrg_st_coh4(dst, (unsigned)c4 * 16u, *reinterpret_cast<const float4 *>(act_out + 4 * c4));
+            } else if ((L.flags & LRG_FL_POOL) && !(L.flags & LRG_FL_KEEP)) {
                 // the parked per-run maxima -> the pooled features (:122-125), coalesced, nothing waits for them
                 const int runcap = (act_out == buf1 ? CAP1 : CAP0) / L.N;
                 const int nk = nruns < runcap ? nruns : runcap;

@@ -1510,6 +1510,11 @@ size_t lrg_grow_async_queue_bytes(int n_slots) {
     return (LRG_AQ_RING + 2 * async_ring_entries(n_slots) + async_unit_ring_entries(n_slots)) * sizeof(int32_t);
 }
 
+size_t lrg_grow_async_pool_rows_bytes(const LrgWeights *weights, int n_slots) {
+    if (!weights || n_slots <= 0 || weights->n_conv < 1) return 0;
+    return (size_t)n_slots * 2 * 16 * (size_t)weights->conv_ch[weights->n_conv - 1] * sizeof(float);      // [slot][side][tile][columns of the pooled layer]
+}
+
 int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, const LrgGrowParams *params, const LrgWeights *weights,
                    const LrgPackedBuffers *b, const LrgAsyncBuffers *ab, int max_steps, int budget_us, void *stream) {
     int rc = check_params(params);
@@ -1587,6 +1592,20 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
             n_front + units > wgs / 2 + wgs / 4 || n_slots >= (1 << 20))
             units = 0;
         A.gemv_units = units;
+    }
+    // With the units, a branch tile leaves its column maxima of the pooled layer as one row of 16-byte stores (pool_rows) and the units take
+    // the maximum over a slot's tiles while loading: no atomicMax per column (7 k atomics = write transactions per evaluation, each to
+    // be acknowledged before the tile may report in), no zeroing of the pooled feature by the front workgroup.
+    A.pool_rows = nullptr; A.pool_rows_stride = 0;
+    if (A.gemv_units && ab->pool_rows && row_stride <= 512 && n_slots <= 4096) {
+        const size_t need = (size_t)n_slots * 2 * 16 * (A.gemv.P / 2) * sizeof(float);
+        if (ab->pool_rows_bytes < need || ((uintptr_t)ab->pool_rows & 15)) return LRG_EINVAL - 6;
+        A.pool_rows = ab->pool_rows; A.pool_rows_stride = 2 * 16 * (A.gemv.P / 2);
+        for (int side = 0; side < 2; ++side) {
+            A.prob[side].pool_rows = ab->pool_rows + (size_t)side * 16 * (A.gemv.P / 2);
+            A.prob[side].pool_rows_stride = A.pool_rows_stride;
+        }
+        a.pooled = nullptr;          // (nobody accumulates into it)
     }
     // Teams per worker CU: two -- the first runs branch tiles, the second head tiles (a tile beside another takes 1.2 x as long, but
     // the head tiles wait inside for the pooled-product units, and at 68 slots the teams are what a step queues for: 1 / 2 / 3 teams

@@ -349,6 +349,14 @@ class RegionGrower:
                 ab.poll_sleep = int(os.environ.get('LRG_FREE_RUN_POLL', '0'))
                 ab.branch_parts = int(os.environ.get('LRG_FREE_RUN_PARTS', '0'))
                 ab.gemv_units = self.free_run_units or int(os.environ.get('LRG_FREE_RUN_UNITS', '0'))          # -1: the pooled product as tasks of the tile teams
+                # LRG_FREE_RUN_POOL_ROWS=1: a branch tile leaves its column maxima as ONE row of 16-byte stores and the pooled-product units take
+                # the maximum over a slot's tiles while loading (no atomicMax per column, no zeroing by the front workgroup).  Same labels;
+                # measured 832 k against 850 k instance-steps/s at 68 rooms in flight (profiles/r04_pool_rows_ab.txt): each of the sixteen
+                # units then loads ~3.5 rows per side instead of one pooled row, on the step's critical path -- off by default.
+                if os.environ.get('LRG_FREE_RUN_POOL_ROWS', '0') == '1':
+                    nb = self.lib.lrg_grow_async_pool_rows_bytes(ctypes.byref(self.net._w), S)
+                    self.a_pool_rows = torch.zeros(nb // 4, dtype=torch.float32, device=dev)
+                    ab.pool_rows, ab.pool_rows_bytes = self.a_pool_rows.data_ptr(), nb
                 self.a_work = torch.zeros(4, dtype=torch.int64, device=dev)      # evaluations, inlier rows, neighbour rows, tiles
                 ab.work = self.a_work.data_ptr()
                 if os.environ.get('LRG_FREE_RUN_DEBUG') == '1':          # stage-by-stage tick accumulators (tools/free_run_perf.py)
