@@ -3,7 +3,7 @@
 # rocprofv3 --pmc passes of their own (FETCH_SIZE | WRITE_SIZE | SQ counters), the byte counters corrected on a 256 MiB copy as
 # MI355X_MICROARCH.md prescribes (tools/pmc_calib.py), the launch duration from a --kernel-trace pass of the same command.
 #   usage (GPU box): tools/pmc_free_run.sh <commit> [out.json]
-R=$GRAFT_REPO_ROOT; COMMIT=${1:-unknown}; OUT=${2:-gpurun_out/r03_pmc_free_run.json}
+R=$GRAFT_REPO_ROOT; COMMIT=${1:-unknown}; OUT=${2:-gpurun_out/r04_pmc_free_run.json}
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pmcf && mkdir -p /tmp/pmcf
 B="python $R/bench.py --gpus 1 --steps 6 --warmup 4 --cpu-seconds 0 --p0-rooms 0 --fixed-rooms 0 --steady-slots="
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pmcf/kt -o kt --output-format csv -- $B > /tmp/pmcf/kt.log 2>&1
@@ -12,7 +12,7 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmcf/write -o w --output-format c
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY -d /tmp/pmcf/sq -o s --output-format csv -- $B > /tmp/pmcf/s.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmcf/calib_fetch -o cf --output-format csv -- python $R/tools/pmc_calib.py > /tmp/pmcf/cf.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmcf/calib_write -o cw --output-format csv -- python $R/tools/pmc_calib.py > /tmp/pmcf/cw.log 2>&1
-cp $(find /tmp/pmcf/kt -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r03_pmc_free_run_kernel_stats.csv 2>/dev/null
+cp $(find /tmp/pmcf/kt -name "*kernel_stats.csv" | head -1) $R/${OUT%.json}_kernel_stats.csv 2>/dev/null
 python - /tmp/pmcf "$R/$OUT" "$COMMIT" "$R" <<'PY'
 import csv, glob, json, os, sys
 root, outp, commit, repo = sys.argv[1:5]
