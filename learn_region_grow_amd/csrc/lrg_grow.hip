@@ -1118,17 +1118,25 @@ __device__ __forceinline__ lrg_f2 lrg_np_sqdist2(const float *pair_rows, const l
     }
 }
 
+// QL query rows per lane (registers).  Measured with two (a candidate pair read from LDS then feeds four distances): the 64 largest rooms of the Area-5 set
+// 3.23 ms either way, 64 KITTI-shaped scenes 9.96-10.04 ms against 6.87-6.88 ms with one (profiles/r04_fill_ql_ab.txt) -- the loop is not waiting for its LDS
+// broadcasts; per candidate pair and query it issues 38 packed subtract / multiply / add (NumPy's order: no FMA) plus ~16 operations for the two 64-bit
+// (distance, index) keys and their minima, i.e. ~0.41 of the quoted fp32 vector peak at best.  One query per lane.
+#ifndef LRG_NN1_QL
+#define LRG_NN1_QL 1
+#endif
 template <int FT>
 __global__ __launch_bounds__(256) void lrg_nn1_search_pairs_kernel(LrgFillBatchArgs B) {
+    constexpr int QL = LRG_NN1_QL, QB = LRG_NN1_Q * QL;                  // queries per workgroup and round
     __shared__ __attribute__((aligned(16))) float rows[LRG_NN1_C * FT];      // [pair][feature][2]
     __shared__ int lab[LRG_NN1_C];
-    __shared__ unsigned long long part[4][LRG_NN1_Q];
+    __shared__ unsigned long long part[4][QB];
     const int job = blockIdx.z, n = B.n[job];
     const float *points = B.points[job];
     const int32_t *label_in = B.label_in[job], *list = B.list[job];
     unsigned long long *best = B.best[job];
     const int U = B.counts[job];
-    if ((int)blockIdx.x * LRG_NN1_Q >= U) return;
+    if ((int)blockIdx.x * QB >= U) return;
     const int c0 = blockIdx.y * LRG_NN1_C;
     if (c0 >= n) return;                                           // (the grid covers the largest room of the batch)
     const int nc = min(LRG_NN1_C, n - c0);
@@ -1139,27 +1147,37 @@ __global__ __launch_bounds__(256) void lrg_nn1_search_pairs_kernel(LrgFillBatchA
     }
     for (int r = threadIdx.x; r < LRG_NN1_C; r += blockDim.x) lab[r] = r < nc ? label_in[c0 + r] : 0;
     constexpr int PER = LRG_NN1_C / 2 / 4;                             // pairs per wavefront
-    for (int q0 = blockIdx.x * LRG_NN1_Q; q0 < U; q0 += gridDim.x * LRG_NN1_Q) {
-        const int qi = list[min(q0 + lane, U - 1)];
-        lrg_f2 me2[FT];
+    for (int q0 = blockIdx.x * QB; q0 < U; q0 += gridDim.x * QB) {
+        int qi[QL];
+        lrg_f2 me2[QL][FT];
 #pragma unroll
-        for (int l = 0; l < FT; ++l) { const float v = points[(long)qi * FT + l]; me2[l] = lrg_f2{v, v}; }
-        __syncthreads();                                               // rows staged / part[] of the previous round consumed
-        unsigned long long bk = ~0ull;
-#pragma unroll 2
-        for (int p = wave * PER; p < (wave + 1) * PER; ++p) {
-            const lrg_f2 d = lrg_np_sqdist2<FT>(rows + p * 2 * FT, me2);
-            const int2 lb = *reinterpret_cast<const int2 *>(&lab[2 * p]);
-            const unsigned long long k0 = ((unsigned long long)__float_as_uint(d.x) << 32) | (unsigned)(c0 + 2 * p);
-            const unsigned long long k1 = ((unsigned long long)__float_as_uint(d.y) << 32) | (unsigned)(c0 + 2 * p + 1);
-            bk = min(bk, lb.x != 0 ? k0 : ~0ull);
-            bk = min(bk, lb.y != 0 ? k1 : ~0ull);
+        for (int q = 0; q < QL; ++q) {
+            qi[q] = list[min(q0 + q * LRG_NN1_Q + lane, U - 1)];
+#pragma unroll
+            for (int l = 0; l < FT; ++l) { const float v = points[(long)qi[q] * FT + l]; me2[q][l] = lrg_f2{v, v}; }
         }
-        part[wave][lane] = bk;
+        __syncthreads();                                               // rows staged / part[] of the previous round consumed
+        unsigned long long bk[QL];
+#pragma unroll
+        for (int q = 0; q < QL; ++q) bk[q] = ~0ull;
+        for (int p = wave * PER; p < (wave + 1) * PER; ++p) {
+            const int2 lb = *reinterpret_cast<const int2 *>(&lab[2 * p]);
+#pragma unroll
+            for (int q = 0; q < QL; ++q) {
+                const lrg_f2 d = lrg_np_sqdist2<FT>(rows + p * 2 * FT, me2[q]);      // (the QL queries' reads of the pair: the same addresses, merged by the compiler)
+                const unsigned long long k0 = ((unsigned long long)__float_as_uint(d.x) << 32) | (unsigned)(c0 + 2 * p);
+                const unsigned long long k1 = ((unsigned long long)__float_as_uint(d.y) << 32) | (unsigned)(c0 + 2 * p + 1);
+                bk[q] = min(bk[q], lb.x != 0 ? k0 : ~0ull);
+                bk[q] = min(bk[q], lb.y != 0 ? k1 : ~0ull);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < QL; ++q) part[wave][q * LRG_NN1_Q + lane] = bk[q];
         __syncthreads();
-        if (wave == 0 && q0 + lane < U) {
-            bk = min(min(part[0][lane], part[1][lane]), min(part[2][lane], part[3][lane]));
-            if (bk != ~0ull) atomicMin(&best[qi], bk);
+        if (wave < QL && q0 + wave * LRG_NN1_Q + lane < U) {
+            const int j = wave * LRG_NN1_Q + lane;
+            const unsigned long long m = min(min(part[0][j], part[1][j]), min(part[2][j], part[3][j]));
+            if (m != ~0ull) atomicMin(&best[list[q0 + j]], m);
         }
     }
 }
