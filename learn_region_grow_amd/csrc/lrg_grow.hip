@@ -1145,7 +1145,8 @@ __global__ __launch_bounds__(256) void lrg_nn1_search_pairs_kernel(LrgFillBatchA
         const int r = e / FT, l = e - r * FT;
         rows[(r >> 1) * 2 * FT + 2 * l + (r & 1)] = r < nc ? points[(long)c0 * FT + e] : 0.f;      // (contiguous block of rows; a chunk's tail: zeros, never labeled)
     }
-    for (int r = threadIdx.x; r < LRG_NN1_C; r += blockDim.x) lab[r] = r < nc ? label_in[c0 + r] : 0;
+    // lab[r]: 0 for a labeled candidate, all ones for one without a label (or past the chunk's end) -- OR-ed into the distance's bit pattern below
+    for (int r = threadIdx.x; r < LRG_NN1_C; r += blockDim.x) lab[r] = (r < nc && label_in[c0 + r] != 0) ? 0 : -1;
     constexpr int PER = LRG_NN1_C / 2 / 4;                             // pairs per wavefront
     for (int q0 = blockIdx.x * QB; q0 < U; q0 += gridDim.x * QB) {
         int qi[QL];
@@ -1157,22 +1158,29 @@ __global__ __launch_bounds__(256) void lrg_nn1_search_pairs_kernel(LrgFillBatchA
             for (int l = 0; l < FT; ++l) { const float v = points[(long)qi[q] * FT + l]; me2[q][l] = lrg_f2{v, v}; }
         }
         __syncthreads();                                               // rows staged / part[] of the previous round consumed
-        unsigned long long bk[QL];
+        // A wavefront walks its candidates in index order: "smaller distance, then smaller index" (numpy.argmin's first minimum) is a strict
+        // compare of the distances' bit patterns as unsigned integers (distances are >= 0, so their order is that of their patterns; NaN after
+        // +inf, exactly as in the 64-bit (distance, index) keys the rounds are combined with) -- an OR, a compare, a minimum and a select per
+        // candidate instead of building such a key and taking its 64-bit minimum.
+        unsigned bd[QL];
+        int bi[QL];
 #pragma unroll
-        for (int q = 0; q < QL; ++q) bk[q] = ~0ull;
+        for (int q = 0; q < QL; ++q) { bd[q] = 0xFFFFFFFFu; bi[q] = -1; }
         for (int p = wave * PER; p < (wave + 1) * PER; ++p) {
             const int2 lb = *reinterpret_cast<const int2 *>(&lab[2 * p]);
 #pragma unroll
             for (int q = 0; q < QL; ++q) {
                 const lrg_f2 d = lrg_np_sqdist2<FT>(rows + p * 2 * FT, me2[q]);      // (the QL queries' reads of the pair: the same addresses, merged by the compiler)
-                const unsigned long long k0 = ((unsigned long long)__float_as_uint(d.x) << 32) | (unsigned)(c0 + 2 * p);
-                const unsigned long long k1 = ((unsigned long long)__float_as_uint(d.y) << 32) | (unsigned)(c0 + 2 * p + 1);
-                bk[q] = min(bk[q], lb.x != 0 ? k0 : ~0ull);
-                bk[q] = min(bk[q], lb.y != 0 ? k1 : ~0ull);
+                const unsigned d0 = __float_as_uint(d.x) | (unsigned)lb.x, d1 = __float_as_uint(d.y) | (unsigned)lb.y;      // (no label: 0xFFFFFFFF, never smaller)
+                bi[q] = d0 < bd[q] ? 2 * p : bi[q];
+                bd[q] = min(bd[q], d0);
+                bi[q] = d1 < bd[q] ? 2 * p + 1 : bi[q];
+                bd[q] = min(bd[q], d1);
             }
         }
 #pragma unroll
-        for (int q = 0; q < QL; ++q) part[wave][q * LRG_NN1_Q + lane] = bk[q];
+        for (int q = 0; q < QL; ++q)
+            part[wave][q * LRG_NN1_Q + lane] = bi[q] >= 0 ? (((unsigned long long)bd[q] << 32) | (unsigned)(c0 + bi[q])) : ~0ull;
         __syncthreads();
         if (wave < QL && q0 + wave * LRG_NN1_Q + lane < U) {
             const int j = wave * LRG_NN1_Q + lane;
