@@ -380,7 +380,7 @@ def main():
                         ev_pairs.append((e0, e1))
                         gr.poll_done()
                         if args.fill:
-                            gr.fill_many(gr.done_rooms)
+                            gr.fill_many([r_ for r_, f_ in zip(gr.done_rooms, gr.done_filled) if not f_])      # (none with the in-launch fill-in)
                         gr.rooms_finished += len(gr.done_rooms)
                         gr.done_rooms = []
                     else:

@@ -474,6 +474,18 @@ typedef struct LrgAsyncBuffers {
     uint64_t *work;             /* nullable: [4] running totals (never cleared by the library) of what the launches evaluated: LrgNet
                                    evaluations, distinct inlier rows, distinct neighbour rows, 32-row tiles per stack (branch = head) --
                                    the algorithmic FLOPs of the launches follow from these                                        */
+    /* In-launch fill-in (ABI 8; all five non-NULL, 13 features): a room that finishes during the launch gets its 1-NN fill-in
+       (test_region_grow.py:308-316) from tile teams of the same launch instead of from lrg_nn1_fill_batch between launches; such rooms
+       carry bit 31 in the slot word of their done-ring entry.  The arenas are laid out like the label arena the rooms' LrgRoom.label
+       pointers point into (fill_label_base = its first element): a room's lists live at its label offset.                              */
+    int32_t *fill_list;         /* [points of all rooms] int32                                                                          */
+    uint64_t *fill_best;        /* [points of all rooms] 8-byte aligned                                                                  */
+    int32_t *fill_sync;         /* [fill_rooms, 4] int32                                                                                 */
+    const int32_t *fill_label_base;
+    int32_t *fill_out_base;     /* the filled labels (label_out of lrg_nn1_fill), same layout                                            */
+    int32_t fill_rooms;         /* rooms in the LrgRoom array                                                                            */
+    int32_t fill_wgs;           /* worker workgroups with a team for the fill-in ring (one more than the others have, up to two tile teams;
+                                   else their last team); 0 = default (32)                                                                */
     float *pool_rows;           /* nullable: lrg_grow_async_pool_rows_bytes(weights, n_slots) bytes, 16-byte aligned -- with the pooled-product units a
                                    branch tile leaves the column maxima of its rows as one row here (16-byte stores) and the units take the maximum
                                    over a slot's tiles; NULL: one atomicMax per column and tile on the pooled feature (ABI 8)              */

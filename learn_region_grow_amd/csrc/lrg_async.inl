@@ -49,7 +49,11 @@
 #ifndef LRG_ASYNC_START_TICKS
 #define LRG_ASYNC_START_TICKS 2000000LL      // 20 ms (wall_clock64: 100 MHz): by then every workgroup of the launch has started, or never will while the others wait
 #endif
-#define LRG_AQ_RING 128          // ring 0, then ring 1 (qmask + 1 entries each), then the units' ring (gmask + 1 entries)
+#define LRG_AQ_FTAIL 128         // the fill-in ring (tasks of the in-launch 1-NN fill-in, test_region_grow.py:308-316): entries reserved / taken
+#define LRG_AQ_FHEAD 144
+#define LRG_AQ_RING 192          // ring 0, then ring 1 (qmask + 1 entries each), then the units' ring (gmask + 1 entries), then the fill-in ring (fmask + 1)
+#define LRG_ASYNC_FILL_RING 8192 // entries of the fill-in ring: one per 256 candidate points of a finished room (a 131 072-point scene: 512)
+#define LRG_TASK_FILL 4
 #define LRG_ASYNC_SYNC_WORDS 16  // per slot: 0 branch tiles done, 1 their target, 2 pooled-product blocks done, 3 target, 4 head tiles done, 5 target,
                                  //           6 inlier tiles, 7 neighbour tiles of the evaluation in flight
 #define LRG_ASYNC_MAX_SERVED 8   // slots per front workgroup
@@ -78,6 +82,14 @@ struct LrgAsyncArgs {
     int head_ring;               // the ring pooled blocks and head tiles are published to: 1, or 0 = one ring for all tasks and all teams
     int ring0_halves;            // more than one team per workgroup: team t of worker workgroup w runs branch tiles (ring 0) if 2 t + (w & 1) < ring0_halves,
                                  // else pooled blocks and head tiles (ring 1) -- 2: the first team everywhere, 3: one and a half teams on average, ...
+    // in-launch fill-in (nullable: fill_list == nullptr -> the host fills finished rooms in between launches)
+    int32_t *fill_list;          // [points of all rooms] per room (at the room's offset in the arenas): indices of its unlabeled points
+    unsigned long long *fill_best;   // [points of all rooms] best (distance bits << 32 | index) per point
+    int32_t *fill_sync;          // [n_rooms, 4]: unlabeled points, candidate chunks done, chunks in all, filled
+    const int32_t *fill_label_base;  // the label arena (LrgRoom.label points into it) and the filled-label arena of the same layout
+    int32_t *fill_out_base;
+    int fill_wgs;                // the last team of the first fill_wgs worker workgroups serves the fill-in ring only
+    int fill_extra;              // 1: ... and that team is one more than the other workgroups have (where LDS and threads allow: up to two tile teams)
     float *pool_rows;            // nullable (with the units): [n_slots][2 sides][16 tiles][P / 2] column maxima by branch tile, instead of atomicMax on the pooled feature
     int pool_rows_stride;        // 2 * 16 * (P / 2)
     int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
@@ -526,6 +538,145 @@ LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     return team.target;
 }
 
+// ---- the 1-NN fill-in of a finished room (test_region_grow.py:308-316) as tasks of the same launch ----
+// Between launches the fill-ins of the ~13 rooms that finish during a 25 ms launch cost ~2 % of the steady leg (lrg_nn1_fill_batch).  Here the
+// front workgroup that finishes a room lists its unlabeled points, makes the room's labels visible (one release: they were plain stores of its CU) and
+// publishes one task per 256 candidate points to a ring of their own, served by one team each of a few worker workgroups (fill_wgs: the tile teams'
+// tasks are 15-25 us pieces of a slot's critical path and must not queue behind 30 us searches).  A task = lrg_nn1_search_pairs_kernel's work for its
+// chunk and ALL unlabeled points: distances in NumPy's pairwise float32 order, first minimum, 64-bit atomicMin per query; the last chunk to arrive writes
+// the room's filled labels.  Same labels as the host-launched kernels (tests/test_gpu_free_run.py), and the host no longer has anything to do
+// between two launches but to read the statistics block.
+template <int FT, class TEAM>
+__device__ __forceinline__ void lrg_async_fill_chunk(const float *points, const int32_t *label_in, const int32_t *list, unsigned long long *best, int U,
+                                                     int n, int c0, float *sm, const TEAM &team) {
+    float *rows = sm;                                              // [128 pairs][FT][2]
+    int *lab = reinterpret_cast<int *>(sm + LRG_NN1_C * FT);       // [256] 0 = labeled, -1 = no label / past the end
+    unsigned long long *part = reinterpret_cast<unsigned long long *>(sm + ((LRG_NN1_C * FT + LRG_NN1_C + 3) & ~3));      // [4][64]
+    const int tid = team.tid(), lane = tid & 63, wave = tid >> 6;
+    const int nc = min(LRG_NN1_C, n - c0);
+    for (int e = tid; e < LRG_NN1_C * FT; e += FTHREADS) {
+        const int r = e / FT, l = e - r * FT;
+        rows[(r >> 1) * 2 * FT + 2 * l + (r & 1)] = r < nc ? points[(long)c0 * FT + e] : 0.f;
+    }
+    for (int r = tid; r < LRG_NN1_C; r += FTHREADS) lab[r] = (r < nc && label_in[c0 + r] != 0) ? 0 : -1;
+    constexpr int PER = LRG_NN1_C / 2 / 4;
+    for (int q0 = 0; q0 < U; q0 += LRG_NN1_Q) {
+        const int qi = list[min(q0 + lane, U - 1)];
+        lrg_f2 me2[FT];
+#pragma unroll
+        for (int l = 0; l < FT; ++l) { const float v = points[(long)qi * FT + l]; me2[l] = lrg_f2{v, v}; }
+        team.sync();                                               // rows staged / part[] of the previous round consumed
+        unsigned bd = 0xFFFFFFFFu;
+        int bi = -1;
+        for (int p = wave * PER; p < (wave + 1) * PER; ++p) {
+            const int2 lb = *reinterpret_cast<const int2 *>(&lab[2 * p]);
+            const lrg_f2 d = lrg_np_sqdist2<FT>(rows + p * 2 * FT, me2);
+            const unsigned d0 = __float_as_uint(d.x) | (unsigned)lb.x, d1 = __float_as_uint(d.y) | (unsigned)lb.y;
+            bi = d0 < bd ? 2 * p : bi;
+            bd = min(bd, d0);
+            bi = d1 < bd ? 2 * p + 1 : bi;
+            bd = min(bd, d1);
+        }
+        part[wave * LRG_NN1_Q + lane] = bi >= 0 ? (((unsigned long long)bd << 32) | (unsigned)(c0 + bi)) : ~0ull;
+        team.sync();
+        if (wave == 0 && q0 + lane < U) {
+            const unsigned long long m = min(min(part[lane], part[LRG_NN1_Q + lane]), min(part[2 * LRG_NN1_Q + lane], part[3 * LRG_NN1_Q + lane]));
+            if (m != ~0ull) atomicMin(&best[qi], m);
+        }
+    }
+}
+
+LRG_ASYNC_ROLE int lrg_async_task_fill(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
+    const LrgAsyncKArgs &K = LRG_ASYNC_KARGS();
+    const LrgAsyncArgs &A = K.A;
+    float *sm = lrg_async_smem + sm_off;
+    const LrgLdsTeam team = lrg_async_team(A, sm, target);
+    const int tid = team.tid();
+    const int room = (code >> 10) & 0x3FFFF, chunk = code & 1023;
+    const LrgRoom *R = &K.rooms[room];
+    const int n = R->n;
+    const long off = R->label - A.fill_label_base;                 // the room's place in the arenas
+    const int32_t *label_in = R->label;
+    const int32_t *list = A.fill_list + off;
+    unsigned long long *best = A.fill_best + off;
+    int32_t *fs = A.fill_sync + 4 * (long)room;
+    // the room's labels, the list and the reset `best` words were plain stores of the publishing workgroup, released before the task was published
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int U = fs[0];
+    if (U > 0) lrg_async_fill_chunk<13>(R->points, label_in, list, best, U, n, chunk * LRG_NN1_C, sm, team);
+    lrg_drain_stores();                                            // this chunk's atomicMin are out before the arrival
+    team.sync();
+    int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
+    if (tid == 0) {
+        const int done = __hip_atomic_fetch_add(&fs[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        word[2] = done == fs[2];
+    }
+    team.sync();
+    if (word[2]) {                                                 // the last chunk: the room's filled labels (:316)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        int32_t *out = A.fill_out_base + off;
+        for (int i = tid; i < n; i += FTHREADS) {
+            const int li = label_in[i];
+            int v = li;
+            if (li == 0) {
+                const unsigned long long k = __hip_atomic_load(&best[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = k == ~0ull ? 0 : label_in[(int)(k & 0xFFFFFFFFull)];
+            }
+            out[i] = v;
+        }
+        if (tid == 0) fs[3] = 1;
+    }
+    team.sync();
+    return team.target;
+}
+
+// the front workgroup (all its threads) that has just finished `room`: list of the unlabeled points, release, tasks
+__device__ __noinline__ void lrg_async_fill_publish(lrg_kargs_ptr kp_, int room_) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int room = lrg_uniform(room_);
+    const LrgAsyncKArgs &K = LRG_ASYNC_KARGS();
+    const LrgAsyncArgs &A = K.A;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const LrgRoom *R = &K.rooms[room];
+    const int n = R->n;
+    const long off = R->label - A.fill_label_base;
+    const int32_t *label = R->label;
+    int32_t *list = A.fill_list + off;
+    unsigned long long *best = A.fill_best + off;
+    int32_t *fs = A.fill_sync + 4 * (long)room;
+    int *cnt = reinterpret_cast<int *>(lrg_async_smem) + 8;        // (LrgFrontShared.flags: free between two front steps)
+    if (tid == 0) *cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += LRG_FRONT_THREADS) {
+        best[i] = ~0ull;
+        if (label[i] == 0) list[atomicAdd(cnt, 1)] = i;            // (any order: every query is looked up by its own index)
+    }
+    __syncthreads();
+    const int chunks = (n + LRG_NN1_C - 1) / LRG_NN1_C;
+    if (tid == 0) { fs[0] = *cnt; fs[1] = 0; fs[2] = chunks; fs[3] = 0; }
+    __syncthreads();                                               // every wavefront's stores are issued ...
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // ... and written back (labels, visited marks of this room included)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int fmask = LRG_ASYNC_FILL_RING - 1;
+        int32_t *ring = A.queue + LRG_AQ_RING + 2 * (A.qmask + 1) + (A.gmask + 1);
+        for (int c0 = 0; c0 < chunks; c0 += 64) {
+            const int m = min(64, chunks - c0);
+            int base = 0;
+            if (lane == 0) base = __hip_atomic_fetch_add(&A.queue[LRG_AQ_FTAIL], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base = __shfl(base, 0);
+            if (lane < m) lrg_st_coh(&ring[(base + lane) & fmask], (LRG_TASK_FILL << 28) | (room << 10) | (c0 + lane));
+        }
+    }
+    __syncthreads();
+}
+// (the caller then parks the slot as idle: a finished room is published once, not again by the next launch that finds the slot still bound to it)
+
 // ---- a worker team: tasks until every front workgroup is done ----
 LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t_launch) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
@@ -537,6 +688,7 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
     int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);       // [0] task of this round
     const int team_no = sm_off / LRG_ASYNC_TEAM_FLOATS, wg_no = (int)blockIdx.x - A.n_front - A.gemv_units;
     const bool secondary = A.head_ring == 1 && 2 * team_no + (wg_no & 1) >= A.ring0_halves;
+    const bool filler = A.fill_list && wg_no < A.fill_wgs && team_no == A.teams - 1 + A.fill_extra;      // this team serves the fill-in ring only (fill_extra: a team MORE on these workgroups)
     // (at 68 slots two branch tiles on a CU slow each other: 809 k -> 783 k instance-steps/s with some second teams on ring 0; at 272 slots
     //  with three teams a single branch team per CU is what every slot queues for: 257 us from publishing to the last branch tile)
     for (;;) {
@@ -544,8 +696,9 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
         if (tid == 0) {
             const long long t_wait = LRG_DBG(A) ? wall_clock64() : 0;
             const int ring = secondary ? 1 : 0;      // (more than one team per workgroup: the first teams run the branch tiles, the others the rest)
-            const int t = __hip_atomic_fetch_add(&A.queue[LRG_AQ_HEAD + ring * LRG_AQ_SECOND], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int *slot = &A.queue[LRG_AQ_RING + ring * (A.qmask + 1) + (t & A.qmask)];
+            const int t = __hip_atomic_fetch_add(&A.queue[filler ? LRG_AQ_FHEAD : LRG_AQ_HEAD + ring * LRG_AQ_SECOND], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int *slot = filler ? &A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (A.gmask + 1) + (t & (LRG_ASYNC_FILL_RING - 1))]
+                               : &A.queue[LRG_AQ_RING + ring * (A.qmask + 1) + (t & A.qmask)];
             int code = 0;
             for (unsigned spin = 0;; ++spin) {
                 code = lrg_ld_coh(slot);
@@ -569,7 +722,8 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
         const int code = word[0];                            // (no barrier behind the read: thread 0 writes the next task only after the barriers
         if (code < 0) return;                                //  INSIDE this one, which every wavefront reaches after it has read the word)
         const int type = (code >> 28) & 7;
-        if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task);
+        if (type == LRG_TASK_FILL) team.target = lrg_async_task_fill(kp, code, sm_off, team.target);
+        else if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task);
         else if (type == LRG_TASK_GEMV) team.target = lrg_async_task_gemv(kp, code, sm_off, team.target, t_task);
         else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task, t_launch);
     }
@@ -676,6 +830,11 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 // no evaluation: the slot is idle / its room finished (-> finished for this launch), or it stopped a region / goes on
                 // looking for a seed (-> served again at once)
                 __syncthreads();
+                if (A.fill_list && slots[s].room >= 0 && slots[s].status == LRG_DONE) {      // (uniform: plain loads of the slot this workgroup owns)
+                    lrg_async_fill_publish(kp, slots[s].room);       // the room is finished: its fill-in as tasks of this launch
+                    if (tid == 0) slots[s].status = LRG_IDLE;
+                    __syncthreads();
+                }
                 if (tid == 0) {
                     const int status = slots[s].status;
                     const bool idle = slots[s].room < 0 || status == LRG_DONE || status == LRG_IDLE;
@@ -751,7 +910,7 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgAs
     if ((int)blockIdx.x >= K.A.n_front) {
         // worker workgroup: teams of four consecutive wavefronts (one per SIMD), each on its own part of the LDS
         const int t = tid >> 8;
-        if (t >= K.A.teams) return;
+        if (t >= K.A.teams + (((int)blockIdx.x - K.A.n_front - K.A.gemv_units < K.A.fill_wgs && K.A.fill_list) ? K.A.fill_extra : 0)) return;
         const int sm_off = t * LRG_ASYNC_TEAM_FLOATS;
         int *word = reinterpret_cast<int *>(lrg_async_smem + sm_off + LRG_ASYNC_TILE_FLOATS);
         if ((tid & 255) == 0) { word[4] = 0; word[5] = 0; }  // the team's barrier counter, its 'at work' flag

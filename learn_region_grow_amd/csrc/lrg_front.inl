@@ -43,6 +43,7 @@ struct LrgFrontArgs {
     int own_medians;         // greedy front kernel: 1 = every slot's workgroup computes its nine medians itself (no launch of their own)
     unsigned long long *phase_dbg;   // nullable (free-running kernel): [8] accumulated wall-clock ticks of the front's phases
     int row_stride;          // free-running kernel: slot s owns the rows [s * row_stride, (s + 1) * row_stride) of the row arrays
+    int fill_in_launch;      // free-running kernel: finished rooms are filled in (:308-316) by tile teams of the same launch -- flagged in the done ring (bit 31 of the slot word)
 };
 
 // ---- (1) mask update of the evaluation just finished + count / bounding box of the new mask + stop decision ----
@@ -988,7 +989,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
                     S->status = LRG_DONE;
                     if (a.stats) {
                         unsigned long long k = atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[1]), 1ULL);
-                        a.stats[4 + (k % LRG_DONE_RING)] = (int64_t)s | ((int64_t)room << 32);      // (slot, room: a free-running launch may have rebound the slot by the time the host looks)
+                        a.stats[4 + (k % LRG_DONE_RING)] = (int64_t)s | (a.fill_in_launch ? (int64_t)1 << 31 : 0) | ((int64_t)room << 32);      // (slot, room: a free-running launch may have rebound the slot by the time the host looks)
                     }
                     a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0;
                 }

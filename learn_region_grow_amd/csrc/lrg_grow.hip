@@ -1471,7 +1471,7 @@ static int front_step_impl(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_
     size_t poff = 0, pcnt = 0;
     if ((rc = lrg_forward_packed_pooled_view(weights, n_slots, b->row_cap, &poff, &pcnt))) return rc;
     if (b->workspace_bytes < lrg_forward_packed_workspace_bytes(weights, n_slots, b->row_cap)) return LRG_EINVAL - 6;
-    LrgFrontArgs a;
+    LrgFrontArgs a = {};
     a.center = b->center; a.sample_in = b->sample_in; a.sample_nb = b->sample_nb;
     a.x_in = b->x_in; a.x_nb = b->x_nb; a.row_slot_in = b->row_slot_in; a.row_slot_nb = b->row_slot_nb;
     a.upd_in = reinterpret_cast<float4 *>(b->upd_in); a.upd_nb = reinterpret_cast<float4 *>(b->upd_nb); a.rmv_logits = b->rmv_logits; a.add_logits = b->add_logits;
@@ -1532,8 +1532,8 @@ static size_t async_unit_ring_entries(int n_slots) {         // the pooled-produ
 }
 size_t lrg_grow_async_queue_bytes(int n_slots) {
     if (n_slots <= 0) return 0;
-    // (two task rings: branch tiles | pooled blocks and head tiles; then the units' ring)
-    return (LRG_AQ_RING + 2 * async_ring_entries(n_slots) + async_unit_ring_entries(n_slots)) * sizeof(int32_t);
+    // (two task rings: branch tiles | pooled blocks and head tiles; then the units' ring; then the fill-in ring)
+    return (LRG_AQ_RING + 2 * async_ring_entries(n_slots) + async_unit_ring_entries(n_slots) + LRG_ASYNC_FILL_RING) * sizeof(int32_t);
 }
 
 size_t lrg_grow_async_pool_rows_bytes(const LrgWeights *weights, int n_slots) {
@@ -1622,6 +1622,17 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // With the units, a branch tile leaves its column maxima of the pooled layer as one row of 16-byte stores (pool_rows) and the units take
     // the maximum over a slot's tiles while loading: no atomicMax per column (7 k atomics = write transactions per evaluation, each to
     // be acknowledged before the tile may report in), no zeroing of the pooled feature by the front workgroup.
+    // In-launch fill-in (lrg_async.inl): the caller's arenas for the lists of unlabeled points and the best (distance, index) words, laid out like
+    // the label arena; 13 features (the compiled-in search); one team each of up to sixteen worker workgroups serves the fill-in ring.
+    A.fill_list = nullptr; A.fill_best = nullptr; A.fill_sync = nullptr; A.fill_label_base = nullptr; A.fill_out_base = nullptr; A.fill_wgs = 0; A.fill_extra = 0;
+    a.fill_in_launch = 0;
+    if (ab->fill_list && ab->fill_best && ab->fill_sync && ab->fill_label_base && ab->fill_out_base && params->feature_size == 13 && ab->fill_rooms > 0 &&
+        ab->fill_rooms <= (1 << 18) && max_points <= 1024 * LRG_NN1_C) {
+        if ((uintptr_t)ab->fill_best & 7) return LRG_EINVAL - 6;
+        A.fill_list = ab->fill_list; A.fill_best = reinterpret_cast<unsigned long long *>(ab->fill_best); A.fill_sync = ab->fill_sync;
+        A.fill_label_base = ab->fill_label_base; A.fill_out_base = ab->fill_out_base;
+        a.fill_in_launch = 1;
+    }
     A.pool_rows = nullptr; A.pool_rows_stride = 0;
     if (A.gemv_units && ab->pool_rows && row_stride <= 512 && n_slots <= 4096) {
         const size_t need = (size_t)n_slots * 2 * 16 * (A.gemv.P / 2) * sizeof(float);
@@ -1642,6 +1653,14 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     A.qmask = (int)async_ring_entries(n_slots) - 1;
     A.gmask = (int)async_unit_ring_entries(n_slots) - 1;
     A.n_slots = n_slots; A.n_front = n_front; A.teams = teams;
+    if (A.fill_list) {
+        const int workers = wgs - n_front - A.gemv_units;
+        // (16 / 32 / 64 / 103 such workgroups at 68 rooms in flight: 852 / 858 / 857 / 857 k instance-steps/s, 6: 804 k -- a big room's ~170 tasks queue for
+        //  them; without the in-launch fill-in 852 k: profiles/r04_fill_in_launch_ab.txt)
+        A.fill_wgs = ab->fill_wgs > 0 ? min(ab->fill_wgs, workers / 2) : min(32, workers / 4);
+        if (A.fill_wgs < 1) { A.fill_list = nullptr; a.fill_in_launch = 0; }      // (too few workgroups: the host fills in)
+        A.fill_extra = (A.fill_list && teams <= 2) ? 1 : 0;
+    }
     {
         static const int r0_env = getenv("LRG_ASYNC_RING0_HALVES") ? atoi(getenv("LRG_ASYNC_RING0_HALVES")) : 0;
         A.ring0_halves = r0_env > 0 ? r0_env : teams >= 3 ? 3 : 2;
@@ -1659,7 +1678,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     LRG_HIP_CHECK(hipMemsetAsync(ab->queue, 0, qbytes, st));
     LRG_HIP_CHECK(hipMemsetAsync(ab->sync, 0, (size_t)n_slots * LRG_ASYNC_SYNC_WORDS * sizeof(int32_t), st));
     const size_t front_lds = ((sizeof(LrgFrontShared) + 15) & ~(size_t)15) + sizeof(LrgAsyncFrontCtl);
-    const size_t team_lds = (size_t)teams * LRG_ASYNC_TEAM_FLOATS * sizeof(float);
+    const size_t team_lds = (size_t)(teams + A.fill_extra) * LRG_ASYNC_TEAM_FLOATS * sizeof(float);
     const size_t unit_lds = A.gemv_units ? (size_t)LRG_GEMV_UNIT_FLOATS(A.gemv.P) * sizeof(float) + 16 : 0;
     const size_t lds = (max(max(front_lds, team_lds), unit_lds) + 15) & ~(size_t)15;
     static bool attr_done[LRG_MAX_DEVICES] = {};

@@ -357,6 +357,17 @@ class RegionGrower:
                     nb = self.lib.lrg_grow_async_pool_rows_bytes(ctypes.byref(self.net._w), S)
                     self.a_pool_rows = torch.zeros(nb // 4, dtype=torch.float32, device=dev)
                     ab.pool_rows, ab.pool_rows_bytes = self.a_pool_rows.data_ptr(), nb
+                # in-launch fill-in (lrg_async.inl): finished rooms are filled in (:308-316) by tile teams of the same launch; the host only
+                # reads the statistics block between two launches.  LRG_FREE_RUN_FILL=0: lrg_nn1_fill_batch between the launches, as in round 3.
+                self.fill_in_launch = F == 13 and os.environ.get('LRG_FREE_RUN_FILL', '1') != '0' and getattr(self, 'fill_cus', 0) == 0
+                if self.fill_in_launch:
+                    self.a_fill_list = torch.zeros(tot, dtype=torch.int32, device=dev)
+                    self.a_fill_best = torch.zeros(tot, dtype=torch.int64, device=dev)
+                    self.a_fill_sync = torch.zeros((len(rooms), 4), dtype=torch.int32, device=dev)
+                    ab.fill_list, ab.fill_best, ab.fill_sync = self.a_fill_list.data_ptr(), self.a_fill_best.data_ptr(), self.a_fill_sync.data_ptr()
+                    ab.fill_label_base, ab.fill_out_base = self.d_label.data_ptr(), self.d_filled.data_ptr()
+                    ab.fill_rooms = len(rooms)
+                    ab.fill_wgs = int(os.environ.get('LRG_FREE_RUN_FILL_WGS', '0'))
                 self.a_work = torch.zeros(4, dtype=torch.int64, device=dev)      # evaluations, inlier rows, neighbour rows, tiles
                 ab.work = self.a_work.data_ptr()
                 if os.environ.get('LRG_FREE_RUN_DEBUG') == '1':          # stage-by-stage tick accumulators (tools/free_run_perf.py)
@@ -587,6 +598,7 @@ class RegionGrower:
     def poll_done(self, wait=False):
         """Groups whose room finished, as seen `depth-1` read-backs ago (or at the latest one, if wait)."""
         self.done_rooms = []          # room of each finished group as the device saw it (greedy front kernels: slot | room << 32)
+        self.done_filled = []         # ... and whether the launch that finished it also filled it in
         if self._polls == 0:
             return []
         if wait:
@@ -604,8 +616,9 @@ class RegionGrower:
             raise _lib.LrgHipError('done ring overflow')
         for j in range(self._seen_done, done_total):
             e = int(st[4 + (j % LRG_DONE_RING)])
-            out.append((e & 0xFFFFFFFF) // self.G)
+            out.append((e & 0x7FFFFFFF) // self.G)
             self.done_rooms.append(e >> 32)
+            self.done_filled.append(bool(e & 0x80000000))      # (a free-running launch filled the room in itself: LrgAsyncBuffers.fill_list)
         self._seen_done = done_total
         self.last_stats = (int(st[0]), int(st[1]), int(st[2]))
         if int(st[3]):
@@ -655,7 +668,7 @@ class RegionGrower:
             self.wait_fills()
             self._in_fill_stream = True
         if fill:
-            self.fill_many(self.done_rooms)
+            self.fill_many([r for r, f in zip(self.done_rooms, self.done_filled) if not f])
         if last:
             self._in_fill_stream = False
         self.rooms_finished += n
