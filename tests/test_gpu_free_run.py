@@ -134,3 +134,28 @@ def test_free_run_refuses_a_stream_with_too_few_compute_units(net, cuda_device):
             np.testing.assert_array_equal(g.filled_label, w.filled_label)
     finally:
         torch.cuda.synchronize()      # (the stream is left to the process, as grow.fill_streams leaves its masked streams: events recorded on it outlive the test)
+
+
+def test_fill_in_inside_the_launch_equals_the_fill_in_between_launches(net, monkeypatch):
+    """The rooms that finish during a free-running launch get their 1-NN fill-in (test_region_grow.py:308-316) from tile teams of the same
+    launch (LrgAsyncBuffers.fill_list: one task per 256 candidate points, the last one writes the filled labels) -- the done ring says so
+    (bit 31 of the slot word), the host launches nothing, and the filled labels are those of lrg_nn1_fill_batch and of the C oracle."""
+    from learn_region_grow_amd.grow import RegionGrower
+    from oracle import grouping_ref
+    rooms = _rooms() + [small_room(310, 4000, furniture=8, room_id=15)]
+    kw = dict(rooms_in_flight=3, rng='counter', seed=11, policy='net')
+    gr = RegionGrower(net, free_run=True, free_run_budget_us=300, **kw)      # (short launches: rooms finish in many different ones)
+    calls = []
+    orig = gr.fill_many
+    gr.fill_many = lambda rs: (calls.append(list(rs)), orig(rs))[1]
+    got = gr.run(rooms)
+    assert gr.free_run and gr.fill_in_launch and sum(len(c) for c in calls) == 0      # nothing left for the host to fill in
+    monkeypatch.setenv('LRG_FREE_RUN_FILL', '0')
+    ref = RegionGrower(net, free_run=True, **kw)
+    want = ref.run(rooms)
+    assert not ref.fill_in_launch
+    for room, g, w in zip(rooms, got, want):
+        same_regions(g.regions, w.regions)
+        np.testing.assert_array_equal(g.cluster_label, w.cluster_label)
+        np.testing.assert_array_equal(g.filled_label, w.filled_label)
+        np.testing.assert_array_equal(g.filled_label, grouping_ref.nn1_fill(room['points'], g.cluster_label))
