@@ -486,6 +486,9 @@ typedef struct LrgAsyncBuffers {
     int32_t fill_rooms;         /* rooms in the LrgRoom array                                                                            */
     int32_t fill_wgs;           /* worker workgroups with a team for the fill-in ring (one more than the others have, up to two tile teams;
                                    else their last team); 0 = default (32)                                                                */
+    int32_t rows16;             /* 1: buffers->x_in / x_nb hold row_cap x 16 floats (16-byte aligned): lrg_grow_async gathers its rows at a 64-byte stride
+                                   in 16-byte pieces (9 .. 16 features); 0: row_cap x feature_size floats, one element per store (ABI 8)            */
+    int32_t reserved;
     float *pool_rows;           /* nullable: lrg_grow_async_pool_rows_bytes(weights, n_slots) bytes, 16-byte aligned -- with the pooled-product units a
                                    branch tile leaves the column maxima of its rows as one row here (16-byte stores) and the units take the maximum
                                    over a slot's tiles; NULL: one atomicMax per column and tile on the pooled feature (ABI 8)              */

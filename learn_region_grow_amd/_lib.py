@@ -90,7 +90,7 @@ class LrgPackedBuffers(ctypes.Structure):
 class LrgAsyncBuffers(ctypes.Structure):
     _fields_ = [('queue', _fp), ('queue_bytes', ctypes.c_size_t), ('sync', _fp), ('front_workgroups', ctypes.c_int32), ('teams', ctypes.c_int32),
                 ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('branch_parts', ctypes.c_int32), ('gemv_units', ctypes.c_int32), ('room_queue', _fp), ('work', _fp),
-                ('fill_list', _fp), ('fill_best', _fp), ('fill_sync', _fp), ('fill_label_base', _fp), ('fill_out_base', _fp), ('fill_rooms', ctypes.c_int32), ('fill_wgs', ctypes.c_int32),
+                ('fill_list', _fp), ('fill_best', _fp), ('fill_sync', _fp), ('fill_label_base', _fp), ('fill_out_base', _fp), ('fill_rooms', ctypes.c_int32), ('fill_wgs', ctypes.c_int32), ('rows16', ctypes.c_int32), ('reserved', ctypes.c_int32),
                 ('pool_rows', _fp), ('pool_rows_bytes', ctypes.c_size_t), ('debug_ticks', _fp)]
 
 

@@ -455,11 +455,13 @@ LRG_ASYNC_ROLE void lrg_async_gemv_unit(lrg_kargs_ptr kp_, int unit_, long long 
         team.sync();
         // the sums and the arrival by the LAST wavefront: the first is back at the mailboxes while these stores drain
         if (wave == 3) {
-            if (lane < LRG_GEMV_UNIT_COLS) {
-                float sum = part[lane];
+            {   // (32 sums, stored as eight 16-byte pieces)
+                float sum = part[lane & (LRG_GEMV_UNIT_COLS - 1)];
 #pragma unroll
-                for (int q = 1; q < 8; ++q) sum += part[q * LRG_GEMV_UNIT_COLS + lane];
-                lrg_st_coh(g.hb[z] + (long)slot * g.C + col0 + lane, sum + bias);
+                for (int q = 1; q < 8; ++q) sum += part[q * LRG_GEMV_UNIT_COLS + (lane & (LRG_GEMV_UNIT_COLS - 1))];
+                sum += bias;
+                const float v0 = __shfl(sum, 4 * (lane & 7)), v1 = __shfl(sum, 4 * (lane & 7) + 1), v2 = __shfl(sum, 4 * (lane & 7) + 2), v3 = __shfl(sum, 4 * (lane & 7) + 3);
+                if (lane < LRG_GEMV_UNIT_COLS / 4) lrg_st_coh4(g.hb[z] + (long)slot * g.C + col0, (unsigned)lane * 16u, make_float4(v0, v1, v2, v3));
             }
             lrg_drain_stores();
             if (lane == 0) {

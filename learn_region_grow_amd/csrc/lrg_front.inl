@@ -43,6 +43,7 @@ struct LrgFrontArgs {
     int own_medians;         // greedy front kernel: 1 = every slot's workgroup computes its nine medians itself (no launch of their own)
     unsigned long long *phase_dbg;   // nullable (free-running kernel): [8] accumulated wall-clock ticks of the front's phases
     int row_stride;          // free-running kernel: slot s owns the rows [s * row_stride, (s + 1) * row_stride) of the row arrays
+    int rows16;              // free-running kernel: 1 = the gathered rows are written at a 64-byte stride (16 floats, zero-padded) in 16-byte pieces
     int fill_in_launch;      // free-running kernel: finished rooms are filled in (:308-316) by tile teams of the same launch -- flagged in the done ring (bit 31 of the slot word)
 };
 
@@ -570,6 +571,46 @@ __device__ __forceinline__ void lrg_front_gather_rows(int target, const float *p
     }
 }
 
+// The same gather for the free-running kernel with rows at a 64-byte stride (LrgFrontArgs.rows16): an item = (row, quarter of the row) -- up to four
+// source floats in, ONE 16-byte write-through store out.  As 13 dword stores per row every element was a fabric write of its own (MI355X_MICROARCH.md:
+// a dword `sc1` store costs ~6 x the time per byte of a 16-byte one): the 1 024-row gather of a 100 k-point scene took 10.6 us of a 38 us front step, the
+// ~220 rows of an Area-5 step 3.3 of 23.6 (profiles/r04_kitti_breakdown.log); the tile teams stage such a row with four 16-byte loads.
+template <int U, int PAD>
+__device__ __forceinline__ void lrg_front_gather_rows16(int target, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
+                                                        const LrgFrontArgs &a, const int (*sh_src)[512], int rin, int rnb, int offi, int offn,
+                                                        int tid, int bd) {
+    const int rin_p = LRG_PAD_ROWS_TO(rin, PAD), rnb_p = LRG_PAD_ROWS_TO(rnb, PAD);      // (rows past the set: copies of its last row)
+    const int nit_in = rin_p * 4, nit = nit_in + rnb_p * 4;
+    float *out_in = a.x_in + (long)offi * 16, *out_nb = a.x_nb + (long)offn * 16;
+    float4 *upd_in = a.upd_in + (long)s * ni, *upd_nb = a.upd_nb + (long)s * nn;
+    for (int i0 = tid; i0 < nit; i0 += U * bd) {
+        float v[U][4];
+        int ob[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = min(i0 + u * bd, nit - 1);
+            const int side = it >= nit_in ? 1 : 0, l = it - (side ? nit_in : 0);
+            const int j = l >> 2, q = l & 3;
+            const int src = sh_src[side][min(j, (side ? rnb : rin) - 1)];
+            const float *p = points + (long)src * F + 4 * q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = 4 * q + k < F ? p[k] : 0.f;
+            ob[u] = (q == 0 && obj) ? obj[src] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = i0 + u * bd;
+            if (it < nit) {
+                const int side = it >= nit_in ? 1 : 0, l = it - (side ? nit_in : 0);
+                const int j = l >> 2, q = l & 3;
+                lrg_st_coh4(side ? out_nb : out_in, (unsigned)l * 16u, make_float4(v[u][0], v[u][1], v[u][2], v[u][3]));
+                if (q == 0 && j < (side ? rnb : rin))
+                    (side ? upd_nb : upd_in)[j] = make_float4(v[u][0], v[u][1], v[u][2], (obj && (side ? ob[u] == target : ob[u] != target)) ? 1.f : 0.f);
+            }
+        }
+    }
+}
+
 template <int PAD, bool COH>
 __device__ __forceinline__ void lrg_front_gather(int target, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
                                                  const LrgFrontArgs &a, const int (*sh_src)[512], int rin,
@@ -579,6 +620,15 @@ __device__ __forceinline__ void lrg_front_gather(int target, const float *points
     if constexpr (!COH) {         // (the free-running kernel: a slot's rows have a fixed place, the tags were written once)
         for (int j = tid; j < LRG_PAD_ROWS_TO(rin, PAD); j += bd) a.row_slot_in[offi + j] = s;
         for (int j = tid; j < LRG_PAD_ROWS_TO(rnb, PAD); j += bd) a.row_slot_nb[offn + j] = s;
+    }
+    if constexpr (COH) {
+        if (a.rows16) {
+            const int nit = (LRG_PAD_ROWS_TO(rin, PAD) + LRG_PAD_ROWS_TO(rnb, PAD)) * 4;
+            if (nit <= bd) lrg_front_gather_rows16<1, PAD>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
+            else if (nit <= 2 * bd) lrg_front_gather_rows16<2, PAD>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
+            else lrg_front_gather_rows16<4, PAD>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
+            return;
+        }
     }
     const int nel = (LRG_PAD_ROWS_TO(rin, PAD) + LRG_PAD_ROWS_TO(rnb, PAD)) * F;
     if (nel <= 2 * bd) lrg_front_gather_rows<2, PAD, COH>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
@@ -705,7 +755,7 @@ struct LrgFrontShared {
     __attribute__((aligned(16))) uint8_t flags[LRG_FRONT_FLAG_BYTES];
     int tab[512], tabc[512], tabe[512];
     int src[2][512];         // during the update: [0] = indices switched on by this step
-    float c[16];
+    __attribute__((aligned(16))) float c[16];
     int red[16 * 8];
     int i[8];                // 0 updated, 1 added count, 2 status, 3 seed-search minimum, 4 probe count, 5 add_acc, 6 remove_acc
     int list[32];
@@ -753,9 +803,18 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     // for memory, not for arithmetic
     int sj = 0;
     if (a.pooled)                    // the last evaluation's pooled feature has been consumed: zero for the next one
-        for (int c = tid; c < a.pooled_stride; c += LRG_FRONT_THREADS) {
-            if constexpr (ASYNC) lrg_st_coh(a.pooled + (long)s * a.pooled_stride + c, 0.f); else a.pooled[(long)s * a.pooled_stride + c] = 0.f;
+    {
+        if constexpr (ASYNC) {      // (16 bytes per store: a dword written through is a fabric write of its own)
+            if ((a.pooled_stride & 3) == 0 && (((uintptr_t)a.pooled) & 15) == 0) {
+                for (int c4 = tid; c4 < (a.pooled_stride >> 2); c4 += LRG_FRONT_THREADS)
+                    lrg_st_coh4(a.pooled + (long)s * a.pooled_stride, (unsigned)c4 * 16u, make_float4(0.f, 0.f, 0.f, 0.f));
+            } else {
+                for (int c = tid; c < a.pooled_stride; c += LRG_FRONT_THREADS) lrg_st_coh(a.pooled + (long)s * a.pooled_stride + c, 0.f);
+            }
+        } else {
+            for (int c = tid; c < a.pooled_stride; c += LRG_FRONT_THREADS) a.pooled[(long)s * a.pooled_stride + c] = 0.f;
         }
+    }
     if (room < 0) {
         if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
         return 0;
@@ -1287,7 +1346,8 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
             __syncthreads();
             lrg_front_all_medians(R, cur_idx, nc, F, reinterpret_cast<int *>(sh_flags), sh_c);
             __syncthreads();
-            if (tid < 16) { if constexpr (ASYNC) lrg_st_coh(a.center + s * 16 + tid, sh_c[tid]); else a.center[s * 16 + tid] = sh_c[tid]; }
+            if constexpr (ASYNC) { if (tid < 4) lrg_st_coh4(a.center + s * 16, (unsigned)tid * 16u, *reinterpret_cast<const float4 *>(sh_c + 4 * tid)); }      // (16-byte write-through stores)
+            else if (tid < 16) a.center[s * 16 + tid] = sh_c[tid];
         }
         phase(6);
         if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
@@ -1314,9 +1374,9 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     }
     __syncthreads();
     TRACE2(s, 5); phase(5);
-    if (tid < 16) {                                              // the branch kernels and the next update centre with it (:243-247,:271,:275)
-        if constexpr (ASYNC) lrg_st_coh(a.center + s * 16 + tid, sh_c[tid]); else a.center[s * 16 + tid] = sh_c[tid];
-    }
+    // the branch kernels and the next update centre with it (:243-247,:271,:275)
+    if constexpr (ASYNC) { if (tid < 4) lrg_st_coh4(a.center + s * 16, (unsigned)tid * 16u, *reinterpret_cast<const float4 *>(sh_c + 4 * tid)); }
+    else if (tid < 16) a.center[s * 16 + tid] = sh_c[tid];
     TRACE2(s, 6);
     if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 1] += wall_clock64() - tick1;
     TRACE2(s, 7);

@@ -276,6 +276,15 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             }
             *reinterpret_cast<float4 *>(&buf1[row * ld_x + 4 * c4]) = v;
         }
+    } else if (PACKED && ONE && COH && P.center && P.ldx == 16 && Kp == 16) {
+        // rows at a 64-byte stride (the free-running kernel's gather, LrgFrontArgs.rows16): four 16-byte loads per row, the centre's sixteen
+        // floats likewise; columns past Kin are zeros on both sides
+        for (int idx = tid; idx < FM * 4; idx += FTHREADS) {
+            const int row = idx >> 2, c4 = idx & 3;
+            const float4 xv = lrg_ld_coh4(P.x + r0 * 16, (unsigned)(row * 16 + 4 * c4) * 4u);
+            const float4 cv = lrg_ld_coh4(P.center + (long)inst * 16, (unsigned)(4 * c4) * 4u);
+            *reinterpret_cast<float4 *>(&buf1[row * ld_x + 4 * c4]) = make_float4(__fsub_rn(xv.x, cv.x), __fsub_rn(xv.y, cv.y), __fsub_rn(xv.z, cv.z), __fsub_rn(xv.w, cv.w));
+        }
     } else if (PACKED && P.center) {
         // uncentred rows: subtract the owning instance's centre while staging (same float32 subtraction the gather would do)
         for (int idx = tid; idx < FM * Kp; idx += FTHREADS) {
@@ -598,7 +607,12 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
         }
 #pragma unroll
         for (int m = 1; m < LPR; m <<= 1) { s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); }
-        if (q == 0) {
+        if constexpr (COH && LPR >= 2) {
+            // two rows' logits per 16-byte write-through store: the lane of the even row takes the odd row's pair from its neighbour LPR lanes on
+            const float t0 = s0 + P.fb[0], t1 = s1 + P.fb[1];
+            const float u0 = __shfl_down(t0, LPR), u1 = __shfl_down(t1, LPR);
+            if (q == 0 && !(row & 1)) lrg_st_coh4(P.fout + r0 * 2, (unsigned)row * 8u, make_float4(t0, t1, u0, u1));
+        } else if (q == 0) {
             if constexpr (COH) lrg_st_coh2(P.fout + (r0 + row) * 2, s0 + P.fb[0], s1 + P.fb[1]);
             else *reinterpret_cast<float2 *>(P.fout + (r0 + row) * 2) = make_float2(s0 + P.fb[0], s1 + P.fb[1]);
         }

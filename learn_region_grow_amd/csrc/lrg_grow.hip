@@ -1590,6 +1590,12 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     a.stats = b->stats;
     a.phase_ticks = nullptr;
     a.own_medians = 1; a.row_stride = row_stride;
+    a.rows16 = 0;
+    if (ab->rows16 && params->feature_size <= 16 && params->feature_size > 8 && (((uintptr_t)b->x_in | (uintptr_t)b->x_nb | (uintptr_t)b->center) & 15) == 0) {
+        // the caller's row arrays hold row_cap x 16 floats: gathered rows at a 64-byte stride, written and read in 16-byte pieces
+        a.rows16 = 1;
+        A.prob[0].ldx = 16; A.prob[1].ldx = 16;
+    }
     a.phase_dbg = ab->debug_ticks ? reinterpret_cast<unsigned long long *>(ab->debug_ticks) + 20 : nullptr;
 
     hipDeviceProp_t prop;

@@ -294,8 +294,10 @@ class RegionGrower:
             cap_rows = S * ((max(Ni, Nn) + 31) // 32 * 32)     # (a slot's rows are allocated in multiples of 8 -- or, free-running, have
                                                                  #  a place of their own of whole 32-row tiles)
             self.row_cap = cap_rows
-            self.p_xin = torch.zeros((cap_rows, F), dtype=torch.float32, device=dev)
-            self.p_xnb = torch.zeros((cap_rows, F), dtype=torch.float32, device=dev)
+            # (room for rows at a 64-byte stride: the free-running kernel gathers and stages its rows in 16-byte pieces, LrgAsyncBuffers.rows16; the
+            #  lock-step launches use the first cap_rows x F floats of the same arrays)
+            self.p_xin = torch.zeros((cap_rows, max(F, 16)), dtype=torch.float32, device=dev)
+            self.p_xnb = torch.zeros((cap_rows, max(F, 16)), dtype=torch.float32, device=dev)
             self.p_rsin = torch.zeros(cap_rows, dtype=torch.int32, device=dev)
             self.p_rsnb = torch.zeros(cap_rows, dtype=torch.int32, device=dev)
             self.p_updin = torch.zeros((S, Ni, 4), dtype=torch.float32, device=dev)
@@ -349,6 +351,7 @@ class RegionGrower:
                 ab.poll_sleep = int(os.environ.get('LRG_FREE_RUN_POLL', '0'))
                 ab.branch_parts = int(os.environ.get('LRG_FREE_RUN_PARTS', '0'))
                 ab.gemv_units = self.free_run_units or int(os.environ.get('LRG_FREE_RUN_UNITS', '0'))          # -1: the pooled product as tasks of the tile teams
+                ab.rows16 = 1 if (9 <= F <= 16 and os.environ.get('LRG_FREE_RUN_ROWS16', '1') != '0') else 0
                 # LRG_FREE_RUN_POOL_ROWS=1: a branch tile leaves its column maxima as ONE row of 16-byte stores and the pooled-product units take
                 # the maximum over a slot's tiles while loading (no atomicMax per column, no zeroing by the front workgroup).  Same labels;
                 # measured 832 k against 850 k instance-steps/s at 68 rooms in flight (profiles/r04_pool_rows_ab.txt): each of the sixteen
