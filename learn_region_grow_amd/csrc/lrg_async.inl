@@ -54,8 +54,8 @@
 #define LRG_AQ_RING 192          // ring 0, then ring 1 (qmask + 1 entries each), then the units' ring (gmask + 1 entries), then the fill-in ring (fmask + 1)
 #define LRG_ASYNC_FILL_RING 8192 // entries of the fill-in ring: one per 256 candidate points of a finished room (a 131 072-point scene: 512)
 #define LRG_TASK_FILL 4
-#define LRG_ASYNC_SYNC_WORDS 16  // per slot: 0 branch tiles done, 1 their target, 2 pooled-product blocks done, 3 target, 4 head tiles done, 5 target,
-                                 //           6 inlier tiles, 7 neighbour tiles of the evaluation in flight
+#define LRG_ASYNC_SYNC_WORDS 16  // per slot: 0 branch tiles done, 1 pooled-product blocks done, 2 head tiles done (arrival counters); 4 .. 7 one 16-byte word written by
+                                 //           the front workgroup: the three targets and inlier | neighbour << 16 tiles of the evaluation in flight; 8 a debug stamp
 #define LRG_ASYNC_MAX_SERVED 8   // slots per front workgroup
 #define LRG_TASK_BRANCH 1
 #define LRG_TASK_GEMV 2
@@ -260,10 +260,9 @@ LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
         int last = 0, nt_in = 0, nt_nb = 0;
         if (lane == 0) {
             // (the evaluation's targets and tile counts were written before its tasks were published: fetched beside the arrival, not after it)
-            const int tgt = lrg_ld_coh(&sy[1]);
-            if (A.gemv_units) {
-                nt_in = lrg_ld_coh(&sy[6]); nt_nb = lrg_ld_coh(&sy[7]);
-            }
+            const float4 tq = lrg_ld_coh4(reinterpret_cast<const float *>(sy), 16u);      // (targets and tile counts: one 16-byte word, written as one)
+            const int tgt = __float_as_int(tq.x);
+            nt_in = __float_as_int(tq.w) & 0xFFFF; nt_nb = (int)((unsigned)__float_as_int(tq.w) >> 16);
             const int done = __hip_atomic_fetch_add(&sy[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             last = done == tgt;
             if (LRG_DBG(A)) {
@@ -305,9 +304,10 @@ __device__ __forceinline__ void lrg_async_gemv_arrive(const LrgAsyncArgs &A, con
     if (tid < 64) {
         int last = 0, nt_in = 0, nt_nb = 0;
         if (lane == 0) {
-            const int tgt = lrg_ld_coh(&sy[3]);
-            nt_in = lrg_ld_coh(&sy[6]); nt_nb = lrg_ld_coh(&sy[7]);
-            const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            const float4 tq = lrg_ld_coh4(reinterpret_cast<const float *>(sy), 16u);
+            const int tgt = __float_as_int(tq.y);
+            nt_in = __float_as_int(tq.w) & 0xFFFF; nt_nb = (int)((unsigned)__float_as_int(tq.w) >> 16);
+            const int done = __hip_atomic_fetch_add(&sy[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             last = done == tgt;
             if (LRG_DBG(A)) {
                 const long long now = wall_clock64();
@@ -467,12 +467,12 @@ LRG_ASYNC_ROLE void lrg_async_gemv_unit(lrg_kargs_ptr kp_, int unit_, long long 
             if (lane == 0) {
                 int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
                 if (LRG_DBG(A)) {
-                    const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                    const int done = __hip_atomic_fetch_add(&sy[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
                     const long long now = wall_clock64();
                     lrg_dbg_add(A, 8 + 2 * LRG_TASK_GEMV, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_GEMV, 1);
-                    if (done == lrg_ld_coh(&sy[3])) lrg_dbg_add(A, 3, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+                    if (done == lrg_ld_coh(&sy[5])) lrg_dbg_add(A, 3, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
                 } else {
-                    __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&sy[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -486,8 +486,8 @@ struct LrgWaitPooled {
     int32_t *queue;
     long long t_launch, abort_ticks;
     __device__ __forceinline__ void operator()() const {
-        const int tgt = lrg_ld_coh(&sy[3]);
-        for (unsigned spin = 1; lrg_ld_coh(&sy[2]) < tgt; ++spin) {
+        const int tgt = lrg_ld_coh(&sy[5]);
+        for (unsigned spin = 1; lrg_ld_coh(&sy[1]) < tgt; ++spin) {
             if ((spin & 255u) == 0) {
                 if (lrg_ld_coh(&queue[LRG_AQ_ABORT])) break;
                 if (wall_clock64() - t_launch > abort_ticks) { lrg_st_coh(&queue[LRG_AQ_ABORT], 5); break; }
@@ -530,11 +530,11 @@ LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     lrg_drain_stores();                              // the logits are out before the arrival the front workgroup polls
     team.sync();
     if (tid == 0) {
-        const int done = __hip_atomic_fetch_add(&sy[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
         if (LRG_DBG(A)) {
             const long long now = wall_clock64();
             lrg_dbg_add(A, 8 + 2 * LRG_TASK_HEAD, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_HEAD, 1);
-            if (done == lrg_ld_coh(&sy[5])) lrg_dbg_add(A, 4, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+            if (done == lrg_ld_coh(&sy[6])) lrg_dbg_add(A, 4, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
         }
     }
     return team.target;
@@ -806,7 +806,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
             if (st == 2) continue;
             ++live;
             if (st == 1) {
-                if (tid == 0) C.bc[0] = lrg_ld_coh(&A.sync[(long)s * LRG_ASYNC_SYNC_WORDS + 4]) >= C.tgt[i][2];
+                if (tid == 0) C.bc[0] = lrg_ld_coh(&A.sync[(long)s * LRG_ASYNC_SYNC_WORDS + 2]) >= C.tgt[i][2];
                 __syncthreads();
                 const int ready = C.bc[0];
                 __syncthreads();
@@ -863,8 +863,8 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
             if (tid == 0) {
                 int32_t *sy = A.sync + (long)s * LRG_ASYNC_SYNC_WORDS;
                 C.tgt[i][0] += (nt_in + nt_nb) * A.branch_parts; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb;
-                lrg_st_coh(&sy[1], C.tgt[i][0]); lrg_st_coh(&sy[3], C.tgt[i][1]); lrg_st_coh(&sy[5], C.tgt[i][2]);
-                lrg_st_coh(&sy[6], nt_in); lrg_st_coh(&sy[7], nt_nb);
+                lrg_st_coh4(reinterpret_cast<float *>(sy), 16u, make_float4(__int_as_float(C.tgt[i][0]), __int_as_float(C.tgt[i][1]), __int_as_float(C.tgt[i][2]),
+                                                                      __int_as_float(nt_in | (nt_nb << 16))));      // (one 16-byte store instead of five dwords)
                 if (LRG_DBG(A)) {
                     const long long now = wall_clock64();
                     lrg_st_coh(&sy[8], (int)(unsigned)now);
