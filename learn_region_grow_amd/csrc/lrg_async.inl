@@ -426,9 +426,11 @@ LRG_ASYNC_ROLE void lrg_async_gemv_unit(lrg_kargs_ptr kp_, int unit_, long long 
                 *reinterpret_cast<int4 *>(pl + 4 * j) = m;
             }
         } else {   // the slot's pooled row: one 16-byte load per lane
+#ifndef LRG_EXP_NO_UNIT_LOAD      // (experiment switch, --policy gt only)
             const float *src = g.pooled + (long)slot * P;
             for (int j = tid; j < (P >> 2); j += FTHREADS)
                 *reinterpret_cast<float4 *>(pl + 4 * j) = lrg_ld_coh4(src, (unsigned)j * 16u);
+#endif
         }
         team.sync();
         {
@@ -486,6 +488,9 @@ struct LrgWaitPooled {
     int32_t *queue;
     long long t_launch, abort_ticks;
     __device__ __forceinline__ void operator()() const {
+#ifdef LRG_EXP_NO_WAIT_POOLED      // (experiment switch, --policy gt only: what the head tiles' wait for the pooled product costs a step)
+        return;
+#endif
         const int tgt = lrg_ld_coh(&sy[5]);
         for (unsigned spin = 1; lrg_ld_coh(&sy[1]) < tgt; ++spin) {
             if ((spin & 255u) == 0) {

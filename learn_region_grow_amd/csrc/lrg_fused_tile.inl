@@ -556,10 +556,12 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
                     const int ins = ONE ? inst : run_inst[k];
                     if (ins < 0) continue;
                     int *dst = reinterpret_cast<int *>(P.pool + (long)ins * P.pool_stride);
+#ifndef LRG_EXP_NO_POOL_ATOMICS      // (experiment switch: what the atomics cost, measured under --policy gt where the logits do not steer the growth)
                     for (int c = cb_lo * FBN + tid; c < min(L.N, cb_hi * FBN); c += FTHREADS) {      // (the columns this task ran)
                         const int m = reinterpret_cast<const int *>(act_out)[k * L.N + c];
                         if (m > 0) atomicMax(dst + c, m);
                     }
+#endif
                 }
             }
         }
