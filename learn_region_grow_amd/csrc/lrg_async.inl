@@ -111,7 +111,11 @@ __device__ __forceinline__ void lrg_dbg_add(const LrgAsyncArgs &A, int i, long l
     if (LRG_DBG(A)) atomicAdd(&A.dbg[i], (unsigned long long)v);
 }
 
+#ifdef LRG_EXP_NO_DRAIN      // (experiment switch, --policy gt only: arrivals without waiting for the stores before them -- results may be stale)
+__device__ __forceinline__ void lrg_drain_stores() {}
+#else
 __device__ __forceinline__ void lrg_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 
 // ---- publishing `n` tasks: one reservation, then the entries (lanes 0 .. n-1 of the calling wavefront; n <= 64) ----
 template <class F>

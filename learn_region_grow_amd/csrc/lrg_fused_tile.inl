@@ -17,6 +17,12 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef LRG_TILE_N16
+#define LRG_TILE_N16 0   // 1: the 64 -> 64 layers of single-instance 32-row tiles on v_mfma_f32_16x16x4_f32, all four waves (0: 32 x 32 strips, two waves).
+#endif                   // Bit-identical (tests/test_gpu_free_run.py pass with it, same label checksum) and SLOWER: 804-815 k against 871-873 k instance-steps/s in three
+                         // variants of the operand path (lane exchange by v_permlane32_swap, two ds_read_b128 per k-group, all weights of the pass requested up front):
+                         // the layer's own cycle stamps barely move (5.7 -> 5.3 k, 5.1 -> 4.9 k) and the pooled layer behind it gets 5 % slower
+                         // (profiles/r04_tile_n16.txt).  Off; kept as the measured alternative the round-3 review asked for.
 #define FBN 128      // output columns per pass: 4 waves side by side, each a (32*RT)x32 strip (RT 32x32 MFMA tiles sharing B)
 #define FTHREADS 256 // one wave per SIMD per tile; 2-3 tiles per CU interleave without sharing barriers
 
@@ -175,6 +181,50 @@ __device__ __forceinline__ void tile_mfma_first(f32x16 (&acc)[RT], const float *
     }
 }
 
+// A 64-wide layer of a single 32-row tile on ALL four waves: wave w computes columns 16 w .. 16 w + 15 as two 16 x 16 blocks (rows 0-15, 16-31) with
+// v_mfma_f32_16x16x4_f32.  As 32 x 32 strips only two of the four waves have columns in such a layer (2.7 k of MFMAs + epilogue + barrier = ~5 k cycles per
+// layer, and a branch tile without its two 64 -> 64 layers makes a step 7 us shorter: profiles/r04_knockout_gt.txt).
+// Same bits as tile_mfma: that instruction adds its four products as an FMA chain over its lane groups q = 0 .. 3 (tools/mfma16_probe.hip: 100 % of 131 072 outputs),
+// so with lane group q of instruction j fed k = 8 g + {0, 4, 1, 5 | 2, 6, 3, 7}[4 j + q] an output sees the chain k = 8 g + 0, 4, 1, 5, 2, 6, 3, 7 of the 32 x 32 x 2
+// formulation (lane half h feeds k = 8 g + 4 h + s in instruction s).
+//   A: lane (i = lane % 16, q) reads k half q & 1 of rows i and 16 + i (two ds_read_b128 per k-group) and uses x, z (q < 2) or y, w (q >= 2) of each;
+//   B: the packed image as it is: the lane's float4 of (k half q & 1, column 16 w + i) holds k = 8 g + 4 (q & 1) + 0 .. 3 -- x, z for q < 2, y, w for q >= 2.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int NG, int FD>
+__device__ __forceinline__ void tile_mfma16_n64(f32x4v (&acc)[2], const float *ap, int ld16, const float4 *wp, const float4 *wpn, float4 (&bq)[FD], bool lower) {
+    static_assert(NG >= FD && NG >= 2, "the ring must not be deeper than a pass");
+    // ap: row i = lane % 16, k half q & 1; ap + ld16: the same of row 16 + i.  Two ds_read_b128 per k-group (lane groups q and q ^ 2 read the same words:
+    // broadcast) -- v_permlane32_swap exchanges of one read's halves were measured first and cost ~500 cycles per k-group.
+    // A k-group is 4 x 32 cycles of MFMAs here, not 4 x 64: the ring's FD groups of lead are ~500 cycles, less than a trip to L2 -- the weights of the groups
+    // behind the ring's (FD .. NG - 1) are requested at once, up front, and the ring is refilled for the NEXT pass only.
+    float4 bx[NG - FD];
+#pragma unroll
+    for (int g = FD; g < NG; ++g) bx[g - FD] = wp[g * 64];
+    float4 ar[3][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        ar[0][r] = *reinterpret_cast<const float4 *>(ap + r * ld16);
+        ar[1][r] = *reinterpret_cast<const float4 *>(ap + r * ld16 + 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 2 < NG)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) ar[(g + 2) % 3][r] = *reinterpret_cast<const float4 *>(ap + r * ld16 + 8 * (g + 2));
+        const float4 a0 = ar[g % 3][0], a1 = ar[g % 3][1];
+        const float4 b = g < FD ? bq[g] : bx[g - FD];
+        const float b0 = lower ? b.x : b.y, b1 = lower ? b.z : b.w;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(lower ? a0.x : a0.y, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lower ? a1.x : a1.y, b0, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(lower ? a0.z : a0.w, b1, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lower ? a1.z : a1.w, b1, acc[1], 0, 0, 0);
+        if (g < FD) bq[g] = wpn[g * 64];          // (the next pass's first FD groups, as every pass leaves them)
+        // (nothing moves across a k-group: left to itself the compiler sinks the loads to their uses)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // LDS floats of one tile
 #define LRG_TILE_LDS_FLOATS(CAP0, CAP1, RT, PACKED) ((CAP0) + (CAP1) + 512 + ((PACKED) ? 3 * 32 * (RT) + 8 : 0))
 
@@ -236,16 +286,24 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
     // A 64-wide layer of a 64-row tile is laid out 2x2 (each wave one 32x32 tile) instead of 1x4 strips of which only
     // two would have columns: all four SIMDs stay busy through the narrow layers.
     auto is22 = [&](const LrgFusedLayer &L, int l) { return RT == 2 && L.N == 64 && (L.K == 64 || l == 0); };
-    auto col_of = [&](const LrgFusedLayer &L, int l, int cb) { return is22(L, l) ? (wn & 1) * 32 : cb * FBN + wn * 32; };
+    // ... and a 64 -> 64 layer of a single-instance 32-row tile runs on 16 x 16 x 4 MFMAs, every wave 16 columns (tile_mfma16_n64)
+    auto isn16 = [&](const LrgFusedLayer &L) {
+        return LRG_TILE_N16 && PACKED && ONE && RT == 1 && L.N == 64 && L.K == 64 && (L.flags & (LRG_FL_RELU | LRG_FL_KEEP)) == (LRG_FL_RELU | LRG_FL_KEEP) &&
+               !(L.flags & (LRG_FL_POOL | LRG_FL_INST_BIAS | LRG_FL_INPLACE));
+    };
+    auto col_of = [&](const LrgFusedLayer &L, int l, int cb) { return is22(L, l) ? (wn & 1) * 32 : isn16(L) ? wn * 16 : cb * FBN + wn * 32; };
 
     // this lane's float4 of k-group 0 of the 32-column block starting at column c of layer L (packed image)
     auto wptr = [&](const LrgFusedLayer &L, int c) {
+        if (isn16(L))       // (lane group q reads k half q & 1 of its column 16 wn + lane % 16)
+            return reinterpret_cast<const float4 *>(L.w) + (long)(c >> 5) * L.ng * 64 + ((lane >> 4) & 1) * 32 + ((c + (lane & 15)) & 31);
         return reinterpret_cast<const float4 *>(L.w) + (long)(c >> 5) * L.ng * 64 + lane;
     };
     // bias of column c of layer L for this lane (a per-instance row when the layer carries the hoisted pooled product)
     auto bias_of = [&](const LrgFusedLayer &L, int c) -> float {
         if (!L.bias) return 0.f;
         if (PACKED && (L.flags & LRG_FL_INST_BIAS)) return 0.f;       // added per run of rows in the epilogue
+        if (isn16(L)) return L.bias[c + (lane & 15)];
         return (L.flags & LRG_FL_INST_BIAS) ? L.bias[(long)inst * L.N + c + li] : L.bias[c + li];
     };
     float4 bq[FD], bf[2];
@@ -338,6 +396,9 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
     for (int l = 0; l < nlayers; ++l) {
         const LrgFusedLayer L = Lnext;             // descriptors are fetched one layer ahead (scalar loads off the critical path)
         if (l + 1 < nlayers) Lnext = P.L[l + 1];   // (after the last layer Lnext == L: the ring refill stays in bounds)
+#ifdef LRG_EXP_SKIP_NARROW      // (experiment switch, --policy gt only: a branch tile without its two 64 -> 64 layers)
+        if (ONE && nlayers == 5 && (l == 1 || l == 2)) { prevN = L.N; continue; }
+#endif
         const bool inplace = (L.flags & LRG_FL_INPLACE) != 0;
         const float *act_in = (l & 1) ? buf0 : buf1;
         float *act_out = ((l & 1) != 0) == !inplace ? buf1 : buf0;
@@ -346,7 +407,8 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
         const int rbase = m22 ? (wn >> 1) * 32 : 0;          // first row of this wave's strip within the tile
         const int ntile = m22 ? 1 : RT;
         const float *ap = act_in + (rbase + li) * ld_in + 4 * lh;
-        const int ncb = m22 ? 1 : (L.N + FBN - 1) / FBN;
+        const bool n16 = isn16(L);
+        const int ncb = (m22 || n16) ? 1 : (L.N + FBN - 1) / FBN;
         // (this task's share of the pooled layer's column blocks; every other layer whole)
         const bool shared = ONE && nparts > 1 && (L.flags & LRG_FL_POOL) && !(L.flags & LRG_FL_KEEP);
         const int cb_lo = shared ? part * ncb / nparts : 0, cb_hi = shared ? (part + 1) * ncb / nparts : ncb;
@@ -363,6 +425,25 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             int coln = col_of(Lx, same ? l : l + 1, cb_next);
             if (coln >= Lx.N) coln = 0;
             const float4 *wpn = wptr(Lx, coln);
+
+            if constexpr (PACKED && ONE && RT == 1) {
+                if (n16) {
+                    const float bv = bvn;
+                    bvn = bias_of(Lx, coln);
+                    f32x4v c2[2];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { c2[0][t] = 0.f; c2[1][t] = 0.f; }
+                    const int i16 = lane & 15, q4 = lane >> 4;
+                    tile_mfma16_n64<8, FD>(c2, act_in + i16 * ld_in + 4 * (q4 & 1), 16 * ld_in, wptr(L, col0), wpn, bq, lane < 32);
+                    // the block of rows 16 r .. 16 r + 15: lane (i16, q4) holds rows 16 r + 4 q4 + t of column col0 + i16
+                    float *o = act_out + (4 * q4) * ld_out + col0 + i16;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o[(16 * r + t) * ld_out] = fmaxf(c2[r][t] + bv, 0.f);
+                    continue;
+                }
+            }
 
             f32x16 acc[RT];
 #pragma unroll
