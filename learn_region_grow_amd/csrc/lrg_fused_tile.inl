@@ -254,6 +254,11 @@ __device__ __forceinline__ void tile_mfma16_n64(f32x4v (&acc)[2], const float *a
 // ONE (with PACKED): all rows of the tile belong to ONE instance, `inst`, and all of them are live (the free-running kernel: a slot's
 // rows have a place of their own, padded to whole tiles with copies of its last row) -- no run detection, the centre and the
 // per-instance bias addressed by `inst` directly (no trip through row_inst first).
+#ifdef LRG_EXP_NO_TILE_SYNC      // (experiment switch, --policy gt only: what the LDS barriers INSIDE a tile cost -- a tile's results are garbage without them)
+#define LRG_TILE_SYNC(t) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define LRG_TILE_SYNC(t) (t).sync()
+#endif
 struct LrgNoWait { static constexpr bool late = false; __device__ __forceinline__ void operator()() const {} };
 // before_inst_bias: called by every thread right before the first per-instance bias (the hoisted pooled product of a head) is read --
 // the free-running kernel's head tiles wait there for the pooled product of their slot.  WAIT::late (ONE only): the first pass of that
@@ -386,7 +391,7 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
         }
         if (tid == 0) { const int n = __popcll(m); run_start[n] = FM; *run_count = n; }
     }
-    team.sync();
+    LRG_TILE_SYNC(team);
     TRACE(1);
     const int nruns = (PACKED && !ONE) ? *run_count : 1;
 
@@ -500,7 +505,7 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
                 prefetch_b<FD>(bq, wpn);      // an idle wave still owes the next pass its first weights
             }
             TRACE_PASS(l, cb, 0);
-            if (inplace) team.sync();                // the output overlays this layer's input: everyone must be done reading
+            if (inplace) LRG_TILE_SYNC(team);                // the output overlays this layer's input: everyone must be done reading
             if constexpr (PACKED && ONE && WAIT::late) {
                 if (late_bias) {
                     before_inst_bias();
@@ -621,7 +626,7 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             }
             TRACE_PASS(l, cb, 1);
         }
-        team.sync();                                 // layer boundary: outputs visible, inputs dead
+        LRG_TILE_SYNC(team);                                 // layer boundary: outputs visible, inputs dead
         if constexpr (PACKED) {
             if (ONE && COH && P.pool_rows && (L.flags & LRG_FL_POOL) && !(L.flags & LRG_FL_KEEP)) {
                 // the tile's maxima as one row for whoever takes the maximum over the slot's tiles (the pooled-product units): 16 bytes
