@@ -226,6 +226,14 @@ __device__ __forceinline__ int lrg_uniform(int v) { return __builtin_amdgcn_read
 // tile a flat instruction)
 extern __shared__ __attribute__((aligned(16))) float lrg_async_smem[];
 #define LRG_ASYNC_ROLE __device__ __noinline__
+// The tile tasks are inlined into the worker's loop (round 4).  As functions of their own (round 3) every call saved and restored the callee-saved registers the
+// tile code uses -- 54 / 72 dwords per lane and task through scratch memory: ~0.6 MB of writes and as many reads per evaluation, which is what the write counter of
+// profiles/r03_pmc_free_run.json (13.5 GB per launch) was made of, and 1.3 % of the rate.  One function = one register allocation for branch and head tiles and the
+// loop's few values; the compiler keeps the MFMA loops free of spills (checked in the ISA: scratch traffic only at the worker's own entry and exit, once per launch).
+// The front step stays a function: inlined into the serving loop it reloads ~170 spilled values per step.
+#ifndef LRG_ASYNC_TASK
+#define LRG_ASYNC_TASK __device__ __forceinline__
+#endif
 
 __device__ __forceinline__ LrgLdsTeam lrg_async_team(const LrgAsyncArgs &A, float *sm, int target) {      // sm: the team's part of the LDS
     int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
@@ -238,7 +246,7 @@ __device__ __forceinline__ LrgLdsTeam lrg_async_team(const LrgAsyncArgs &A, floa
 }
 
 // ---- the three task types (each returns the team's barrier count, to be handed to the next one) ----
-LRG_ASYNC_ROLE int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task) {
+LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
@@ -506,7 +514,7 @@ struct LrgWaitPooled {
     }
 };
 
-LRG_ASYNC_ROLE int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task, long long t_launch) {
+LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task, long long t_launch) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;

@@ -159,3 +159,24 @@ def test_fill_in_inside_the_launch_equals_the_fill_in_between_launches(net, monk
         np.testing.assert_array_equal(g.cluster_label, w.cluster_label)
         np.testing.assert_array_equal(g.filled_label, w.filled_label)
         np.testing.assert_array_equal(g.filled_label, grouping_ref.nn1_fill(room['points'], g.cluster_label))
+
+
+@pytest.mark.parametrize('F,lite', [(12, 0), (9, 0), (13, 2)])
+def test_free_run_feature_size_and_lite_variants(cuda_device, F, lite):
+    """The reference's feature-size variants (test_region_grow.py:72-77: the first F of the 13 columns) and lite = 2 through the free-running launches --
+    rows gathered at a 64-byte stride in 16-byte pieces whatever F is (9 .. 16), the host's fill-in kernels where the in-launch one (13 features) does
+    not apply -- against the lock-step iterations."""
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    from learn_region_grow_amd.grow import RegionGrower
+    w = synthetic.make_synthetic_weights(feature_size=F, lite=lite, **WEIGHT_KW)
+    net = LrgNetHIP(1, 1, 512, 512, F, lite, device=cuda_device).load_weights(w)
+    rooms = [dict(r, points=np.ascontiguousarray(r['points'][:, :F])) for r in _rooms()[:4]]
+    kw = dict(rooms_in_flight=4, rng='counter', seed=3, policy='net')
+    want = RegionGrower(net, free_run=False, **kw).run(rooms)
+    gr = RegionGrower(net, free_run=True, **kw)
+    got = gr.run(rooms)
+    assert gr.free_run and gr.fill_in_launch == (F == 13)
+    for g, w_ in zip(got, want):
+        same_regions(g.regions, w_.regions)
+        np.testing.assert_array_equal(g.cluster_label, w_.cluster_label)
+        np.testing.assert_array_equal(g.filled_label, w_.filled_label)
