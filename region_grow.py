@@ -67,8 +67,9 @@ def parse(argv=None):
     ap.add_argument('--room-names', default=None, help='one room name per line, in file order (data/<area>_room_name.txt of the reference)')
     ap.add_argument('--room-list', default=None, help='names of the rooms to process (data/s3dis_sampled.txt); needs --room-names')
     ap.add_argument('--device', default=None, help='default: cuda:<LOCAL_RANK>')
-    ap.add_argument('--gpus', type=int, default=1, help='GPUs of this node, one process each: started by the script itself when it is not already '
-                                                         'running under torch.distributed.run (whose WORLD_SIZE must then agree)')
+    ap.add_argument('--gpus', type=int, default=None, help='GPUs of this node, one process each: started by the script itself when it is not already '
+                                                            'running under torch.distributed.run (whose LOCAL_WORLD_SIZE must agree when both are given; '
+                                                            'without --gpus the launcher decides)')
     ap.add_argument('--lanes', type=int, default=0, help='groups of slots on their own HIP streams (counter stream only); 0 = auto')
     ap.add_argument('--quiet-regions', action='store_true', help='do not print the per-region lines (test_region_grow.py:217)')
     ap.add_argument('--timing', action='store_true',
@@ -149,14 +150,10 @@ def timing_table(buckets):
 
 def main(argv=None):
     args = parse(argv)
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        # not under torch.distributed.run yet: start the ranks (one process per GPU of this node) and become their launcher
-        import socket
-        with socket.socket() as sk:
-            sk.bind(('127.0.0.1', 0))
-            port = sk.getsockname()[1]
-        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
-                                  '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv))
+    if (args.gpus or 1) > 1 and 'WORLD_SIZE' not in os.environ:
+        # the launcher picks a free port itself (--standalone: a port bound and closed here could be taken before the ranks start)
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1', '--nproc-per-node',
+                                  str(args.gpus), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv))
     import torch
     import torch.distributed as dist
     from learn_region_grow_amd import checkpoint, metrics, preprocess, preprocess_gpu, synthetic, dist as lrg_dist
@@ -167,8 +164,9 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit('region_grow.py needs a GPU (the HIP path has no CPU fallback)')
     rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
-        raise SystemExit('region_grow.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+    if args.gpus is not None and local_world != args.gpus:
+        raise SystemExit('region_grow.py: --gpus %d but LOCAL_WORLD_SIZE=%d' % (args.gpus, local_world))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     one_dev = os.environ.get('LRG_BENCH_ONE_DEVICE') == '1'      # testing on a 1-GPU box: every rank on cuda:0, collectives over gloo
     device = torch.device(args.device if args.device else 'cuda:%d' % (0 if one_dev else local))
