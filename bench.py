@@ -87,6 +87,8 @@ def parse():
                     help='room jobs of the fixed-work leg over ALL ranks (0 = skip; default: max(8 jobs per geometry, 4 waves x 8 GPUs x slots per GPU) -- '
                          'SURVEY.md 8e: the same R for every N, and at N = 8 every rank still pushes four waves of rooms through its slots)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-box-seconds', type=float, default=12.0,
+                    help='cpu_baseline.all_cores: the oracle on many rooms at once, one single-threaded process per room, for this long (0 = skip)')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
     ap.add_argument('--p0-rooms', type=int, default=4, help='rooms of the preprocessing (P0) side measurement (0 = skip)')
     return ap.parse_args()
@@ -141,7 +143,7 @@ def _cpu_room(room, weights, seconds, policy, faithful, net_fn, key):
     return count[0], t1 - t0, time.time() - t1
 
 
-def cpu_baseline(rooms, weights, seconds, policy, gpu_room_steps):
+def cpu_baseline(rooms, weights, seconds, policy, gpu_room_steps, box_seconds=0.0):
     """The oracle (faithful NumPy restatement of test_region_grow.py:175-316: per-point Python voxel-set loop, un-hoisted
     1088-wide head) on this box's host cores: the median-size room of the set, grown to the end and filled in when the
     budget allows (rooms/s = 1 / that time), else extrapolated from its step rate and the steps the GPU run took for the same
@@ -170,6 +172,58 @@ def cpu_baseline(rooms, weights, seconds, policy, gpu_room_steps):
     n2, t2, _ = _cpu_room(room, weights, seconds * 0.25, policy, False, _hoisted_numpy_net(weights), 0)
     out['strong'] = dict(value=n2 / t2, unit='instance-steps/s',
                          sample='%d grow steps of the same room, vectorised voxel-set membership + hoisted head (NumPy/BLAS), %.1f s' % (n2, t2))
+    if box_seconds > 0:
+        out['all_cores'] = cpu_baseline_all_cores(rooms, weights, box_seconds, policy, gpu_room_steps)
+    return out
+
+
+def _cpu_pool_worker(job):
+    room, weights, seconds, policy, key = job
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(1)
+    except Exception:
+        pass
+    n, t_grow, t_fill = _cpu_room(room, weights, seconds, policy, True, None, key)
+    return n, t_grow, t_fill
+
+
+def cpu_baseline_all_cores(rooms, weights, seconds, policy, gpu_room_steps):
+    """The same oracle on MANY rooms at once, one single-threaded process per room (the rooms are independent, test_region_grow.py:110-183: what a
+    user of the reference with a many-core host would do): rooms spread evenly over the set's size order, each grown for `seconds` (or to its end).
+    value = all steps / the longest worker's time."""
+    import multiprocessing as mp
+    workers = max(1, min(len(rooms), (os.cpu_count() or 2) - 2, 64))
+    order = np.argsort([len(r['points']) for r in rooms])
+    picks = [int(order[(2 * i + 1) * len(order) // (2 * workers)]) for i in range(workers)]
+    keep = ('points', 'obj_id', 'order')
+    jobs = [({k: rooms[i][k] for k in keep}, weights, seconds, policy, 0) for i in picks]
+    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
+    os.environ.update({k: '1' for k in saved})                    # (the children are spawned: they read these when NumPy loads)
+    t0 = time.time()
+    try:
+        with mp.get_context('spawn').Pool(workers) as pool:
+            res = pool.map(_cpu_pool_worker, jobs, chunksize=1)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    wall = time.time() - t0
+    steps = sum(r[0] for r in res)
+    busy = max(r[1] + (r[2] or 0.0) for r in res)
+    finished = sum(1 for r in res if r[2] is not None)
+    known = [gpu_room_steps[i] for i in picks if gpu_room_steps.get(i)]
+    out = dict(value=steps / busy, unit='instance-steps/s', cores=workers, kind='port', rooms_finished=finished, wall_seconds=wall,
+               per_core=steps / busy / workers)
+    if known:
+        out['rooms_per_sec'] = (steps / busy) / float(np.mean(known))
+        out['rooms_per_sec_extrapolated'] = True
+    out['sample'] = ('%d rooms (evenly over the set\'s sizes: %d .. %d points), one single-threaded process each, oracle.grow_ref (faithful=True, policy=%s) for '
+                     '%.0f s or to the room\'s end: %d steps, longest worker %.1f s, %d rooms grown to the end; rooms/s = step rate / the mean steps the GPU run '
+                     'took for these rooms' % (workers, min(len(rooms[i]['points']) for i in picks), max(len(rooms[i]['points']) for i in picks), policy,
+                                               seconds, steps, busy, finished))
     return out
 
 
@@ -707,7 +761,7 @@ def main():
                     sweep[str(sl)] = {'error': repr(e)[:200]}
             out['steady_more_rooms_in_flight'] = sweep
         if world == 1 and args.cpu_seconds > 0:
-            out['cpu_baseline'] = cpu_baseline(base, weights, args.cpu_seconds, args.policy, room_steps)
+            out['cpu_baseline'] = cpu_baseline(base, weights, args.cpu_seconds, args.policy, room_steps, args.cpu_box_seconds)
         if world == 1 and args.p0_rooms > 0:
             out['preprocessing_p0'] = p0_rates(args.p0_rooms, dev)
         print(json.dumps(out))

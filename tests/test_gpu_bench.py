@@ -27,7 +27,7 @@ def run_bench(argv, env=None, timeout=1200):
 @pytest.mark.parametrize('mode,lanes,graph', [('free', 0, 0), ('lockstep', 1, 0), ('lockstep', 2, 4)])
 def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
     r, lines = run_bench(['--gpus', '1', '--steps', '3', '--warmup', '2', '--iters-per-step', '16', '--step-ms', '2', '--rooms', '6', '--fixed-rooms', '12',
-                          '--best-slots', '3,6', '--steady-slots', '9' if mode == 'free' else '', '--cpu-seconds', '3', '--p0-rooms', '1', '--mode', mode, '--lanes', str(lanes), '--graph', str(graph),
+                          '--best-slots', '3,6', '--steady-slots', '9' if mode == 'free' else '', '--cpu-seconds', '3', '--cpu-box-seconds', '2', '--p0-rooms', '1', '--mode', mode, '--lanes', str(lanes), '--graph', str(graph),
                           '--cache', str(tmp_path / 'cache')])
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1
@@ -60,6 +60,7 @@ def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
     for k in ('value', 'unit', 'cores', 'kind', 'sample', 'rooms_per_sec'):
         assert k in cb, k
     assert cb['kind'] == 'port' and cb['value'] > 0 and cb['strong']['value'] > 0 and cb['rooms_per_sec'] > 0
+    assert cb['all_cores']['value'] > 0 and cb['all_cores']['cores'] >= 1 and cb['all_cores']['kind'] == 'port'
     assert d['preprocessing_p0']['gpu_rooms_per_sec'] > 0
     if mode == 'free':
         assert d['steady_more_rooms_in_flight']['9']['value'] > 0

@@ -138,3 +138,19 @@ def test_reference_goldens_agree_with_torch_conv1d(path):
     w = synthetic.make_synthetic_weights(feature_size=int(g['feature_size']), lite=None if lite < 0 else lite, seed=0, gain=2.0, bias_std=0.2,
                                          add_bias_shift=0.0, rmv_bias_shift=-3.0)
     assert torch_check.check_against_torch(g, w) < 5e-5
+
+
+def test_bench_cpu_baseline_on_all_cores_counts_the_steps_of_every_room():
+    """bench.py's cpu_baseline.all_cores leg: the oracle on several rooms at once, one spawned single-threaded process per room (no GPU involved)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    w = synthetic.make_synthetic_weights(**WEIGHT_KW)
+    rooms = []
+    for name in ('greedy_room100.npz', 'greedy_room101.npz', 'greedy_room100.npz'):
+        g = np.load(os.path.join(GOLDEN, name))
+        rooms.append(dict(points=g['points'], obj_id=g['obj_id'], order=g['order']))
+    before = os.environ.get('OMP_NUM_THREADS')
+    out = bench.cpu_baseline_all_cores(rooms, w, 1.5, 'net', {0: 100, 1: 200, 2: 100})
+    assert out['kind'] == 'port' and out['unit'] == 'instance-steps/s' and 1 <= out['cores'] <= 3
+    assert out['value'] > 0 and out['rooms_per_sec'] > 0 and abs(out['per_core'] * out['cores'] - out['value']) < 1e-6
+    assert os.environ.get('OMP_NUM_THREADS') == before      # (the caller's thread settings come back)
