@@ -458,7 +458,7 @@ typedef struct LrgAsyncBuffers {
     size_t queue_bytes;
     int32_t *sync;              /* [n_slots, 16] arrival counters of the slots (cleared by every call)                     */
     int32_t front_workgroups;   /* workgroups serving the slots (each up to 8 of them), 0 = default                       */
-    int32_t teams;              /* tile teams (four wavefronts) per worker workgroup: 1 .. 3, 0 = default                 */
+    int32_t teams;              /* tile teams (four wavefronts) per worker workgroup: 1 .. 4 (4: two of them run branch tiles only), 0 = default */
     int32_t compute_units;      /* workgroups of the launch in all (front + worker), at most one per CU of the device; 0 = all CUs */
     int32_t poll_sleep;         /* idle tile teams poll the queue every poll_sleep x ~0.25 us; 0 = default                  */
     int32_t branch_parts;       /* tasks per branch tile (1, 2 or 4: they share the four column blocks of its pooled layer and each run the

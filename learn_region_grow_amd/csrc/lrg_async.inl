@@ -56,15 +56,19 @@
 #define LRG_TASK_FILL 4
 #define LRG_ASYNC_SYNC_WORDS 16  // per slot: 0 branch tiles done, 1 pooled-product blocks done, 2 head tiles done (arrival counters); 4 .. 7 one 16-byte word written by
                                  //           the front workgroup: the three targets and inlier | neighbour << 16 tiles of the evaluation in flight; 8 a debug stamp
-#define LRG_ASYNC_MAX_SERVED 8   // slots per front workgroup
+#define LRG_ASYNC_MAX_SERVED 16   // slots per front workgroup
 #define LRG_TASK_BRANCH 1
 #define LRG_TASK_GEMV 2
 #define LRG_TASK_HEAD 3
 #define LRG_TASK(type, slot, side, idx) (((type) << 28) | ((slot) << 8) | ((side) << 7) | (idx))
 
-// LDS of a tile team: the head stack's tile is the larger one
+// LDS of a tile team: [task word, barrier counter (16-byte multiples) (+ the cycle stamps of an LRG_TRACE build)][the tile's buffers].  The head stack's tile is the
+// larger one; a team that only ever runs branch tiles (the first `small_teams` of a workgroup, where four teams share the CU's 160 KB) gets by with the smaller.
 #define LRG_ASYNC_TILE_FLOATS LRG_TILE_LDS_FLOATS(32 * 260, 32 * 68, 1, true)
-#define LRG_ASYNC_TEAM_FLOATS (LRG_ASYNC_TILE_FLOATS + 24 + (LRG_TRACE ? 64 : 0))      // + task word, barrier counter (16-byte multiples) (+ the cycle stamps of an LRG_TRACE build)
+#define LRG_ASYNC_BRANCH_TILE_FLOATS LRG_TILE_LDS_FLOATS(32 * 68, 32 * 132, 1, true)
+#define LRG_ASYNC_CTL_FLOATS (24 + (LRG_TRACE ? 64 : 0))
+#define LRG_ASYNC_TEAM_FLOATS (LRG_ASYNC_TILE_FLOATS + LRG_ASYNC_CTL_FLOATS)
+#define LRG_ASYNC_SMALL_TEAM_FLOATS (LRG_ASYNC_BRANCH_TILE_FLOATS + LRG_ASYNC_CTL_FLOATS)
 
 struct LrgAsyncArgs {
     LrgFusedProb prob[4];        // 0 inlier branch, 1 neighbour branch, 2 add head (neighbour rows), 3 remove head (inlier rows)
@@ -89,6 +93,8 @@ struct LrgAsyncArgs {
     const int32_t *fill_label_base;  // the label arena (LrgRoom.label points into it) and the filled-label arena of the same layout
     int32_t *fill_out_base;
     int fill_wgs;                // the last team of the first fill_wgs worker workgroups serves the fill-in ring only
+    int small_teams;             // the first so many teams of a worker workgroup run branch tiles only, on the smaller LDS region (four teams per workgroup)
+    int small_alt;               // 1: ... and one more of them on the odd workgroups
     int fill_extra;              // 1: ... and that team is one more than the other workgroups have (where LDS and threads allow: up to two tile teams)
     float *pool_rows;            // nullable (with the units): [n_slots][2 sides][16 tiles][P / 2] column maxima by branch tile, instead of atomicMax on the pooled feature
     int pool_rows_stride;        // 2 * 16 * (P / 2)
@@ -235,8 +241,11 @@ extern __shared__ __attribute__((aligned(16))) float lrg_async_smem[];
 #define LRG_ASYNC_TASK __device__ __forceinline__
 #endif
 
+// branch-only teams of worker workgroup wg_no (small_alt: one more on the odd ones -- a step's branch tiles are ~64 % of its tile time, 2.5 of 4 teams)
+__device__ __forceinline__ int lrg_async_small_teams(const LrgAsyncArgs &A, int wg_no) { return A.small_teams + ((wg_no & 1) ? A.small_alt : 0); }
+
 __device__ __forceinline__ LrgLdsTeam lrg_async_team(const LrgAsyncArgs &A, float *sm, int target) {      // sm: the team's part of the LDS
-    int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
+    int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
     LrgLdsTeam team;
     team.cnt = &word[4];
     team.target = target;
@@ -250,12 +259,12 @@ LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
-    float *sm = lrg_async_smem + sm_off;
+    float *sm = lrg_async_smem + sm_off + LRG_ASYNC_CTL_FLOATS;      // (sm_off: the team's region, control words first)
     const LrgLdsTeam team = lrg_async_team(A, sm, target);
     const int tid = team.tid(), lane = tid & 63;
     const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 31, part = (code >> 5) & 3;      // (tile, part of its pooled layer)
     int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
-    int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
+    int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
     const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
     long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;      // (LRG_TRACE build: cycle stamps of the tile's phases)
     lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps,
@@ -340,7 +349,7 @@ LRG_ASYNC_ROLE int lrg_async_task_gemv(lrg_kargs_ptr kp_, int code_, int sm_off_
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
-    float *sm = lrg_async_smem + sm_off;
+    float *sm = lrg_async_smem + sm_off + LRG_ASYNC_CTL_FLOATS;      // (sm_off: the team's region, control words first)
     const LrgLdsTeam team = lrg_async_team(A, sm, target);
     const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
     lrg_async_gemv(A.gemv, slot, side, idx, sm, team);
@@ -518,12 +527,12 @@ LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
-    float *sm = lrg_async_smem + sm_off;
+    float *sm = lrg_async_smem + sm_off + LRG_ASYNC_CTL_FLOATS;      // (sm_off: the team's region, control words first)
     const LrgLdsTeam team = lrg_async_team(A, sm, target);
     const int tid = team.tid();
     const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
     int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
-    int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
+    int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
     const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
     long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;
     // (a head tile shares its CU with a branch tile of another slot and is the shorter of the two: issued first where both want a SIMD --
@@ -610,7 +619,7 @@ LRG_ASYNC_ROLE int lrg_async_task_fill(lrg_kargs_ptr kp_, int code_, int sm_off_
     const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
     const LrgAsyncKArgs &K = LRG_ASYNC_KARGS();
     const LrgAsyncArgs &A = K.A;
-    float *sm = lrg_async_smem + sm_off;
+    float *sm = lrg_async_smem + sm_off + LRG_ASYNC_CTL_FLOATS;      // (sm_off: the team's region, control words first)
     const LrgLdsTeam team = lrg_async_team(A, sm, target);
     const int tid = team.tid();
     const int room = (code >> 10) & 0x3FFFF, chunk = code & 1023;
@@ -627,7 +636,7 @@ LRG_ASYNC_ROLE int lrg_async_task_fill(lrg_kargs_ptr kp_, int code_, int sm_off_
     if (U > 0) lrg_async_fill_chunk<13>(R->points, label_in, list, best, U, n, chunk * LRG_NN1_C, sm, team);
     lrg_drain_stores();                                            // this chunk's atomicMin are out before the arrival
     team.sync();
-    int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);
+    int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
     if (tid == 0) {
         const int done = __hip_atomic_fetch_add(&fs[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
         word[2] = done == fs[2];
@@ -701,12 +710,13 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int sm_off = lrg_uniform(sm_off_);
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
-    float *sm = lrg_async_smem + sm_off;
+    float *sm = lrg_async_smem + sm_off + LRG_ASYNC_CTL_FLOATS;      // (sm_off: the team's region, control words first)
     LrgLdsTeam team = lrg_async_team(A, sm, 0);
     const int tid = team.tid();
-    int *word = reinterpret_cast<int *>(sm + LRG_ASYNC_TILE_FLOATS);       // [0] task of this round
-    const int team_no = sm_off / LRG_ASYNC_TEAM_FLOATS, wg_no = (int)blockIdx.x - A.n_front - A.gemv_units;
-    const bool secondary = A.head_ring == 1 && 2 * team_no + (wg_no & 1) >= A.ring0_halves;
+    int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);       // [0] task of this round
+    const int team_no = lrg_uniform((int)threadIdx.x >> 8), wg_no = (int)blockIdx.x - A.n_front - A.gemv_units;
+    // (small teams have the LDS of a branch tile only: ring 0; beside them every other team runs the rest)
+    const bool secondary = A.head_ring == 1 && (A.small_teams ? team_no >= lrg_async_small_teams(A, wg_no) : 2 * team_no + (wg_no & 1) >= A.ring0_halves);
     const bool filler = A.fill_list && wg_no < A.fill_wgs && team_no == A.teams - 1 + A.fill_extra;      // this team serves the fill-in ring only (fill_extra: a team MORE on these workgroups)
     // (at 68 slots two branch tiles on a CU slow each other: 809 k -> 783 k instance-steps/s with some second teams on ring 0; at 272 slots
     //  with three teams a single branch team per CU is what every slot queues for: 257 us from publishing to the last branch tile)
@@ -930,8 +940,9 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgAs
         // worker workgroup: teams of four consecutive wavefronts (one per SIMD), each on its own part of the LDS
         const int t = tid >> 8;
         if (t >= K.A.teams + (((int)blockIdx.x - K.A.n_front - K.A.gemv_units < K.A.fill_wgs && K.A.fill_list) ? K.A.fill_extra : 0)) return;
-        const int sm_off = t * LRG_ASYNC_TEAM_FLOATS;
-        int *word = reinterpret_cast<int *>(lrg_async_smem + sm_off + LRG_ASYNC_TILE_FLOATS);
+        const int small = lrg_async_small_teams(K.A, (int)blockIdx.x - K.A.n_front - K.A.gemv_units);
+        const int sm_off = t < small ? t * LRG_ASYNC_SMALL_TEAM_FLOATS : small * LRG_ASYNC_SMALL_TEAM_FLOATS + (t - small) * LRG_ASYNC_TEAM_FLOATS;
+        int *word = reinterpret_cast<int *>(lrg_async_smem + sm_off);
         if ((tid & 255) == 0) { word[4] = 0; word[5] = 0; }  // the team's barrier counter, its 'at work' flag
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // the only workgroup-wide barrier of a worker: before any team has started

@@ -1616,11 +1616,12 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // Pooled-product units (lrg_async.inl): sixteen CUs for the LrgNet of the paper (2 heads x 256 columns, 1024 pooled features).
     // Off (-1), or where the slices do not fit / would leave the tile teams fewer than half of the CUs: the teams' 128-column blocks.  Off
     // above 176 slots too: sixteen units take ~1.1 M pooled products a second, and the head tiles that wait for them hold their teams
-    // (136 / 160 / 192 / 272 slots with | without units: 1.13 | 1.03, 1.15 | 1.11, 1.14 | 1.17, 1.06 | 1.11 M instance-steps/s, profiles/r03_slots_sweep.log).
+    // (136 / 160 / 192 / 272 slots with | without units: 1.13 | 1.03, 1.15 | 1.11, 1.14 | 1.17, 1.06 | 1.11 M instance-steps/s, profiles/r03_slots_sweep.log;
+    //  end of round 4, profiles/r04_teams_units_sweep.txt: 136 / 160 / 176 slots 1.15 | 1.09, 1.16 | 1.19, 1.17 | 1.23 M -- off above 148).
     {
         const LrgGemvArgs &g = A.gemv;
         int units = (g.C % LRG_GEMV_UNIT_COLS == 0) ? 2 * g.C / LRG_GEMV_UNIT_COLS : 0;
-        if (ab->gemv_units < 0 || (ab->gemv_units == 0 && n_slots > 176) || (size_t)LRG_GEMV_UNIT_FLOATS(g.P) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
+        if (ab->gemv_units < 0 || (ab->gemv_units == 0 && n_slots > 148) || (size_t)LRG_GEMV_UNIT_FLOATS(g.P) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
             n_front + units > wgs / 2 + wgs / 4 || n_slots >= (1 << 20))
             units = 0;
         A.gemv_units = units;
@@ -1654,7 +1655,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // the head tiles wait inside for the pooled-product units, and at 68 slots the teams are what a step queues for: 1 / 2 / 3 teams
     // 751 / 806 / 771 k instance-steps/s with 34 front workgroups, profiles/r03_units_sweep.log); one while the slots are few (nothing
     // queues, a tile alone is faster: eight scenes 108 k against 97 k); three where hundreds of slots are in flight
-    const int teams = ab->teams > 0 ? min(ab->teams, 3) : n_slots <= 24 ? 1 : n_slots <= 96 ? (A.gemv_units ? 2 : 1) : 3;      // (112 slots: 2 / 3 teams 1.02 / 1.04 M; 96: 1.00 / 0.96 M)
+    const int teams = ab->teams > 0 ? min(ab->teams, 4) : n_slots <= 24 ? 1 : n_slots <= 96 ? (A.gemv_units ? 2 : 1) : n_slots <= (A.gemv_units ? 128 : 200) ? 3 : 4;      // (112 slots: 2 / 3 teams 1.02 / 1.04 M; 96: 1.00 / 0.96 M)
     A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.room_queue = ab->room_queue; A.work = reinterpret_cast<unsigned long long *>(ab->work); A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
     A.qmask = (int)async_ring_entries(n_slots) - 1;
     A.gmask = (int)async_unit_ring_entries(n_slots) - 1;
@@ -1670,7 +1671,11 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     {
         static const int r0_env = getenv("LRG_ASYNC_RING0_HALVES") ? atoi(getenv("LRG_ASYNC_RING0_HALVES")) : 0;
         A.ring0_halves = r0_env > 0 ? r0_env : teams >= 3 ? 3 : 2;
-        A.head_ring = (teams > 1 && r0_env >= 0) ? 1 : 0;      // (LRG_ASYNC_RING0_HALVES=-1: one ring)
+        A.head_ring = (teams > 1 && (r0_env >= 0 || teams == 4)) ? 1 : 0;      // (LRG_ASYNC_RING0_HALVES=-1: one ring)
+        // four teams: 2 x (branch tile: 28 KB) + 2 x (head tile: 44.5 KB) = 145 KB of the CU's 160; the first two run branch tiles only
+        static const int small_env = getenv("LRG_ASYNC_SMALL_TEAMS") ? atoi(getenv("LRG_ASYNC_SMALL_TEAMS")) : 0;      // 2, 3, or 23 = 2 / 3 on even / odd workgroups
+        A.small_teams = teams == 4 ? (small_env == 3 ? 3 : 2) : 0;
+        A.small_alt = (teams == 4 && small_env == 23) ? 1 : 0;
     }
     A.poll_sleep = ab->poll_sleep > 0 ? ab->poll_sleep : 1;
     // few slots, most teams idle: a branch tile as two tasks that share its pooled layer (tile 22.8 -> 18.4 us; eight 100 k-point scenes
@@ -1684,7 +1689,9 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     LRG_HIP_CHECK(hipMemsetAsync(ab->queue, 0, qbytes, st));
     LRG_HIP_CHECK(hipMemsetAsync(ab->sync, 0, (size_t)n_slots * LRG_ASYNC_SYNC_WORDS * sizeof(int32_t), st));
     const size_t front_lds = ((sizeof(LrgFrontShared) + 15) & ~(size_t)15) + sizeof(LrgAsyncFrontCtl);
-    const size_t team_lds = (size_t)(teams + A.fill_extra) * LRG_ASYNC_TEAM_FLOATS * sizeof(float);
+    // (small_alt: the odd workgroups have one small team more and one big team less -- the even ones' layout is the larger)
+    const size_t team_lds = ((size_t)A.small_teams * LRG_ASYNC_SMALL_TEAM_FLOATS + (size_t)(teams - A.small_teams + A.fill_extra) * LRG_ASYNC_TEAM_FLOATS) * sizeof(float);
+    static_assert((2 * LRG_ASYNC_SMALL_TEAM_FLOATS + 2 * LRG_ASYNC_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "four tile teams per CU");
     const size_t unit_lds = A.gemv_units ? (size_t)LRG_GEMV_UNIT_FLOATS(A.gemv.P) * sizeof(float) + 16 : 0;
     const size_t lds = (max(max(front_lds, team_lds), unit_lds) + 15) & ~(size_t)15;
     static bool attr_done[LRG_MAX_DEVICES] = {};
