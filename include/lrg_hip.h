@@ -560,7 +560,7 @@ size_t lrg_nn1_fill_workspace_bytes(int n);
 int lrg_nn1_fill_ws(const float *points, int n, int F, const int32_t *label_in, int32_t *label_out, void *workspace,
                     size_t workspace_bytes, void *stream);
 /* Several rooms at once (the rooms that finish during one free-running launch): the same result as lrg_nn1_fill_ws room by room, three
- * launches per 16 rooms.  `jobs` is host memory; n = 0 rooms are skipped.  workspace: lrg_nn1_fill_batch_workspace_bytes(jobs, n_jobs) bytes. */
+ * launches per 64 rooms.  `jobs` is host memory; n = 0 rooms are skipped.  workspace: lrg_nn1_fill_batch_workspace_bytes(jobs, n_jobs) bytes. */
 typedef struct LrgFillJob {
     const float *points;         /* [n, F] */
     const int32_t *label_in;     /* [n], 0 = unlabeled */

@@ -1026,10 +1026,13 @@ __global__ __launch_bounds__(256) void lrg_nn1_fill_kernel(const float *points, 
 // exactly like "smallest distance, then smallest index" (numpy.argmin's first minimum).  Candidate rows are read once per 64
 // queries instead of once per query.
 #define LRG_NN1_Q 64
+#ifndef LRG_NN1_C
 #define LRG_NN1_C 256
+#endif
+#define LRG_NN1_TARGET_WGS 4096      // workgroups the search grid aims for (256 CUs x 8)
 // Up to LRG_FILL_BATCH rooms per launch (blockIdx.z = the room): the rooms that finish during one free-running launch are filled in
 // together -- three launches for all of them instead of four per room (their gaps and tails were a third of a 13 k-point room's 35 us).
-#define LRG_FILL_BATCH 16
+#define LRG_FILL_BATCH 64
 struct LrgFillBatchArgs {
     const float *points[LRG_FILL_BATCH];
     const int32_t *label_in[LRG_FILL_BATCH];
@@ -1040,12 +1043,28 @@ struct LrgFillBatchArgs {
     int32_t *counts;         // [LRG_FILL_BATCH] unlabeled points of each room (zero before the prep kernel)
 };
 
-__global__ void lrg_nn1_prep_kernel(LrgFillBatchArgs B) {
+__global__ __launch_bounds__(256) void lrg_nn1_prep_kernel(LrgFillBatchArgs B) {
+    // the list of a room's unlabeled points (in any order: every query is searched for on its own) -- ONE atomic per workgroup on the room's counter (one per
+    // point, even aggregated per wavefront, was 70 us for sixteen 45 k-point rooms: the same address 700 times per room)
+    __shared__ int wsum[4], base_sh;
     const int job = blockIdx.z, n = B.n[job];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    B.best[job][i] = ~0ull;
-    if (B.label_in[job][i] == 0) B.list[job][atomicAdd(B.counts + job, 1)] = i;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool un = i < n && B.label_in[job][i] == 0;
+    if (i < n) B.best[job][i] = ~0ull;
+    const unsigned long long m = __ballot(un);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        base_sh = tot ? atomicAdd(B.counts + job, tot) : 0;
+    }
+    __syncthreads();
+    if (un) {
+        int off = base_sh + __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        B.list[job][off] = i;
+    }
 }
 
 __global__ __launch_bounds__(256) void lrg_nn1_search_kernel(LrgFillBatchArgs B, int F) {
@@ -1190,6 +1209,9 @@ __global__ __launch_bounds__(256) void lrg_nn1_search_pairs_kernel(LrgFillBatchA
     }
 }
 
+// (Measured and not kept, profiles/r04_fill_grid_ab.txt: the candidate rows through the scalar cache -- s_load into scalar registers, broadcast operands of the packed
+//  operations, two queries per lane, no LDS at all -- +2 % on the Area-5 set, -28 % on 100 k-point scenes: eight workgroups' chunks are 104 KB against a 16 KB scalar
+//  cache, and a scalar load's result can only be waited for with lgkmcnt(0).)
 __global__ void lrg_nn1_write_kernel(LrgFillBatchArgs B) {
     const int job = blockIdx.z, n = B.n[job];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1862,9 +1884,18 @@ int lrg_nn1_fill_batch(const LrgFillJob *jobs, int n_jobs, int F, void *workspac
             ++nb;
         }
         if (!nb) continue;
-        LRG_HIP_CHECK(hipMemsetAsync(B.counts, 0, 64, st));
+        LRG_HIP_CHECK(hipMemsetAsync(B.counts, 0, LRG_FILL_BATCH * sizeof(int32_t), st));
+        static_assert(LRG_FILL_BATCH * sizeof(int32_t) <= 256 && sizeof(LrgFillBatchArgs) <= 4096, "counters in the workspace's first 256 bytes, arguments in the kernarg segment");
         hipLaunchKernelGGL(lrg_nn1_prep_kernel, dim3((nmax + 255) / 256, 1, nb), dim3(256), 0, st, B);
-        const dim3 grid(min(16, (nmax + LRG_NN1_Q - 1) / LRG_NN1_Q), (nmax + LRG_NN1_C - 1) / LRG_NN1_C, nb);
+        // Query-block columns of the search grid: every column of a chunk's row stages that chunk again, and a workgroup's rounds (64 queries each) share its staging --
+        // as few columns as still fill the chip (16 columns whatever the batch: 0.18 / 0.21 of the fp32 vector peak on the Area-5 set / 100 k-point scenes, 2: 0.23 / 0.27,
+        // profiles/r04_fill_grid_ab.txt).  A lone small room keeps its 16.
+        static const int gx_env = getenv("LRG_NN1_GX") ? atoi(getenv("LRG_NN1_GX")) : 0;            // (A/B switches)
+        static const int wgs_env = getenv("LRG_NN1_WGS") ? atoi(getenv("LRG_NN1_WGS")) : 0;
+        long chunks = 0;
+        for (int k = 0; k < nb; ++k) chunks += (B.n[k] + LRG_NN1_C - 1) / LRG_NN1_C;
+        const int want = (int)(((wgs_env > 0 ? wgs_env : LRG_NN1_TARGET_WGS) + chunks - 1) / chunks);
+        const dim3 grid(min(gx_env > 0 ? gx_env : max(1, min(16, want)), (nmax + LRG_NN1_Q - 1) / LRG_NN1_Q), (nmax + LRG_NN1_C - 1) / LRG_NN1_C, nb);
         // the feature counts of the reference's variants (test_region_grow.py:72-77) are compiled in; any other goes the generic way
         if (F == 13 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<13>, grid, dim3(256), 0, st, B);
         else if (F == 12 && !generic) hipLaunchKernelGGL(lrg_nn1_search_pairs_kernel<12>, grid, dim3(256), 0, st, B);

@@ -463,7 +463,7 @@ class RegionGrower:
                                             self._fill_ws.numel(), _stream_ptr(self.dev)), 'lrg_nn1_fill_ws')
 
     def fill_many(self, rs):
-        """fill(r) for every r of rs, the rooms filled in together (lrg_nn1_fill_batch: three launches per 16 rooms instead of four per
+        """fill(r) for every r of rs, the rooms filled in together (lrg_nn1_fill_batch: three launches per 64 rooms instead of four per
         room; the rooms that finish during one free-running launch)."""
         rs = list(rs)
         if getattr(self, 'free_run', False) and getattr(self, 'fill_cus', 0) > 0 and not getattr(self, '_in_fill_stream', False):
