@@ -79,39 +79,53 @@ __global__ void lrg_group_point_grad_kernel(long total, int n, int c, int m, int
 // onto b x n target rows, and the ball query pads its index lists with copies of the first hit (tf_grouping_g.cu:20-23), so most atomics
 // of a query land on the same few rows and serialise there (203 us for 67 MB of gradients = 0.045 of the HBM peak,
 // profiles/r03_grouping_rates.json; pre-reduced per (batch item, row range) in LDS and flushed with one atomic per target element: 97 us --
-// the flush is still millions of atomics).  Here the workgroup streams its 64-byte slice of every gradient row of the batch item
-// (16 bytes per lane, eight loads in flight), adds it into LDS (ds_add_f32: nothing leaves the CU) and stores its n x 16 sums with plain
+// the flush is still millions of atomics).  Here the workgroup streams its slice (32 bytes since the end of round 4) of every gradient row of the batch item
+// (16 bytes per lane, the next rows' loads in flight), adds it into LDS (ds_add_f32: nothing leaves the CU) and stores its n x 16 sums with plain
 // stores.  Every input byte is read once, every output byte written once; the order of the additions differs from launch to launch as
 // the reference's does (atomicAdd, :61-78).
-#define LRG_GPG_SLICE 16
-__global__ __launch_bounds__(512) void lrg_group_point_grad_lds_kernel(int n, int c, int m_ns, const float *grad_out, const int *idx,
+#ifndef LRG_GPG_SLICE
+#define LRG_GPG_SLICE 8
+#endif
+#ifndef LRG_GPG_U
+#define LRG_GPG_U 2
+#endif
+// SLICE channels per workgroup (16: four 16-byte pieces per gradient row, 8: two).  Harness shape (b = 32, n = 512, m x nsample = 8 192, c = 64; profiles/r04_g4_ab.txt):
+// 16 channels = 128 workgroups on 256 CUs, one buffer of 8 rows per lane: 37 us (0.245 of the HBM peak); two buffers: 32-33 us; 8 channels = 256 workgroups: 22.0 us
+// (0.41; two rows per lane and buffer; 4 / 8 rows: 22.6 / 24.8 us); 4 channels = 512 workgroups: 29-31 us (a wavefront's load touches 64 rows for 16 bytes each).  The workgroups of one batch item sit on ONE XCD (workgroup id -> XCD round robin:
+// id = 8 k + x runs on XCD x), so that the 64-byte sectors of a 256-byte gradient row that its slices fetch come through the same L2.  Two buffers of U rows per
+// lane: the next pass's loads are in flight while this pass's rows are combined and added.
+template <int SLICE, int U>
+__global__ __launch_bounds__(512) void lrg_group_point_grad_lds_kernel(int b, int n, int c, int m_ns, const float *grad_out, const int *idx,
                                                                        float *grad_points, int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) float gp_acc[];      // [n][16]
-    const int tid = threadIdx.x, bi = blockIdx.y, ch0 = blockIdx.x * LRG_GPG_SLICE;
-    const int total = n * LRG_GPG_SLICE;
+    extern __shared__ __attribute__((aligned(16))) float gp_acc[];      // [n][SLICE]
+    constexpr int L = SLICE / 4;                                        // 16-byte pieces (lanes) per row
+    constexpr int WROWS = 64 / L, PASS = 8 * WROWS;                     // rows per wavefront / per workgroup and load
+    const int tid = threadIdx.x;
+    const int nslice = c / SLICE, G = 8 * nslice, id_in = (int)blockIdx.x % G;
+    const int bi = ((int)blockIdx.x / G) * 8 + (id_in & 7), ch0 = (id_in >> 3) * SLICE;
+    if (bi >= b) return;
+    const int total = n * SLICE;
     for (int e = 4 * tid; e < total; e += 4 * 512) *reinterpret_cast<float4 *>(gp_acc + e) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    // 128 rows per pass, four lanes (16 bytes each) per row.  A wavefront holds 16 consecutive rows; lane = 16 * piece + row, so that the
-    // rows of one 16-byte piece are the 16 lanes of a DPP row and "the row before" is a row_shr -- no LDS crossbar trip per shuffle
+    // A wavefront holds WROWS consecutive rows; lane = 16 * g + ri: the 16 lanes of a DPP row are 16 consecutive rows of ONE 16-byte piece (g = piece + L * (row / 16)),
+    // so "the row before" is a row_shr -- no LDS crossbar trip per shuffle
     const int lane = tid & 63;
-    const int ri = lane & 15, l = lane >> 4, rl = (tid >> 6) * 16 + ri;
+    const int ri = lane & 15, g = lane >> 4, l = g % L, rl = (tid >> 6) * WROWS + (g / L) * 16 + ri;
     const float *go = grad_out + (size_t)bi * m_ns * c + ch0 + 4 * l;
     const int *ix = idx + (size_t)bi * m_ns;
-    constexpr int U = 8;
-#define LRG_DPP_SHR(x, d) __builtin_amdgcn_update_dpp(0, (x), 0x110 + (d), 0xf, 0xf, true)
     auto shr_f = [](float x, auto D) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x110 + decltype(D)::value, 0xf, 0xf, true)); };
-    for (int rb = 0; rb < m_ns; rb += U * 128) {
-        float4 v[U];
-        int ii[U];
+    auto load = [&](float4 (&v)[U], int (&ii)[U], int rb) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int r = rb + u * 128 + rl;
+            const int r = rb + u * PASS + rl;
             ii[u] = -1;
             if (r < m_ns) { ii[u] = ix[r]; v[u] = *reinterpret_cast<const float4 *>(go + (size_t)r * c); }
         }
-        // A padded index list repeats one index over its tail: rows of equal index are added up inside the wavefront first (a segmented scan
-        // over the RUNS of equal index among its 16 rows; a later run of the same index adds separately) and one lane per run and piece goes
-        // to LDS.  Sixteen lanes adding to one LDS word are sixteen serialised updates otherwise (176 us against 60).
+    };
+    // A padded index list repeats one index over its tail: rows of equal index are added up inside the wavefront first (a segmented scan
+    // over the RUNS of equal index among its 16 rows; a later run of the same index adds separately) and one lane per run and piece goes
+    // to LDS.  Sixteen lanes adding to one LDS word are sixteen serialised updates otherwise (176 us against 60).
+    auto add = [&](const float4 (&v)[U], const int (&ii)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             int key = ii[u];
@@ -133,17 +147,28 @@ __global__ __launch_bounds__(512) void lrg_group_point_grad_lds_kernel(int n, in
             const int nkey = __builtin_amdgcn_update_dpp(-2, key, 0x100 + 1, 0xf, 0xf, false);      // row_shl:1 -- the next row's index
             const bool last = ri == 15 || nkey != key;
             if (key >= 0 && last) {
-                float *a = gp_acc + key * LRG_GPG_SLICE + 4 * l;
+                float *a = gp_acc + key * SLICE + 4 * l;
                 atomicAdd(a + 0, w.x); atomicAdd(a + 1, w.y); atomicAdd(a + 2, w.z); atomicAdd(a + 3, w.w);
             }
         }
+    };
+    {
+        float4 va[U], vb[U];
+        int ia[U], ib[U];
+        constexpr int STEP = U * PASS;
+        load(va, ia, 0);
+        for (int rb = 0; rb < m_ns; rb += 2 * STEP) {
+            load(vb, ib, rb + STEP);              // (rows past the end: index -1, nothing loaded)
+            add(va, ia);
+            load(va, ia, rb + 2 * STEP);
+            add(vb, ib);
+        }
     }
-#undef LRG_DPP_SHR
     __syncthreads();
     float *gp = grad_points + (size_t)bi * n * c + ch0;
-    for (int e = tid; e < n * 4; e += 512) {             // (point, quarter of the slice): 16 bytes
-        const int p = e >> 2, q = e & 3;
-        float4 sum = *reinterpret_cast<const float4 *>(gp_acc + p * LRG_GPG_SLICE + 4 * q);
+    for (int e = tid; e < n * L; e += 512) {             // (point, 16-byte piece of the slice)
+        const int p = e / L, q = e % L;
+        float4 sum = *reinterpret_cast<const float4 *>(gp_acc + p * SLICE + 4 * q);
         float4 *dst = reinterpret_cast<float4 *>(gp + (size_t)p * c + 4 * q);
         if (accumulate) { const float4 o = *dst; sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w; }      // (the op ADDS into grad_points, which the caller zeroed)
         *dst = sum;
@@ -368,16 +393,17 @@ int lrg_group_point_grad(int b, int n, int c, int m, int nsample, const float *g
     if (total == 0) return 0;
     const size_t lds = (size_t)n * LRG_GPG_SLICE * sizeof(float);
     const long m_ns = (long)m * nsample;
-    if (c % LRG_GPG_SLICE == 0 && c / LRG_GPG_SLICE <= 65535 && lds <= 144 * 1024 && m_ns < (1L << 30) && b <= 65535 &&
+    if (c % LRG_GPG_SLICE == 0 && c / LRG_GPG_SLICE <= 4096 && lds <= 144 * 1024 && m_ns < (1L << 30) && b <= 65535 &&
         ((((uintptr_t)grad_out) | ((uintptr_t)grad_points)) & 15) == 0 && m_ns >= 256) {
+        auto kern = lrg_group_point_grad_lds_kernel<LRG_GPG_SLICE, LRG_GPG_U>;
         static bool attr_done[LRG_MAX_DEVICES] = {};
         const int dev = lrg_current_device();
         if (!attr_done[dev]) {
-            LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_group_point_grad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
             attr_done[dev] = true;
         }
-        hipLaunchKernelGGL(lrg_group_point_grad_lds_kernel, dim3(c / LRG_GPG_SLICE, b), dim3(512), lds, (hipStream_t)stream, n, c, (int)m_ns, grad_out, idx,
-                           grad_points, 1);
+        const int nslice = c / LRG_GPG_SLICE;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(((b + 7) / 8) * 8 * nslice)), dim3(512), lds, (hipStream_t)stream, b, n, c, (int)m_ns, grad_out, idx, grad_points, 1);
         LRG_LAUNCH_CHECK();
         return 0;
     }
