@@ -173,7 +173,11 @@ def cpu_baseline(rooms, weights, seconds, policy, gpu_room_steps, box_seconds=0.
     out['strong'] = dict(value=n2 / t2, unit='instance-steps/s',
                          sample='%d grow steps of the same room, vectorised voxel-set membership + hoisted head (NumPy/BLAS), %.1f s' % (n2, t2))
     if box_seconds > 0:
-        out['all_cores'] = cpu_baseline_all_cores(rooms, weights, box_seconds, policy, gpu_room_steps)
+        # the figure quoted as the baseline: the whole box at work on many rooms; the single room (BLAS threads = cores, one Python thread) stays beside it
+        box = cpu_baseline_all_cores(rooms, weights, box_seconds, policy, gpu_room_steps)
+        box['one_room'] = {k: v for k, v in out.items() if k != 'strong'}
+        box['strong'] = out['strong']
+        return box
     return out
 
 

@@ -60,7 +60,7 @@ def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
     for k in ('value', 'unit', 'cores', 'kind', 'sample', 'rooms_per_sec'):
         assert k in cb, k
     assert cb['kind'] == 'port' and cb['value'] > 0 and cb['strong']['value'] > 0 and cb['rooms_per_sec'] > 0
-    assert cb['all_cores']['value'] > 0 and cb['all_cores']['cores'] >= 1 and cb['all_cores']['kind'] == 'port'
+    assert cb['one_room']['value'] > 0 and cb['one_room']['rooms_per_sec'] > 0 and cb['cores'] >= 1 and cb['per_core'] > 0      # (value: many rooms on many cores)
     assert d['preprocessing_p0']['gpu_rooms_per_sec'] > 0
     if mode == 'free':
         assert d['steady_more_rooms_in_flight']['9']['value'] > 0
