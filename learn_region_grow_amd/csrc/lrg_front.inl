@@ -603,7 +603,9 @@ __device__ __forceinline__ void lrg_front_gather_rows16(int target, const float 
             if (it < nit) {
                 const int side = it >= nit_in ? 1 : 0, l = it - (side ? nit_in : 0);
                 const int j = l >> 2, q = l & 3;
+#ifndef LRG_EXP_NO_GATHER_STORE      // (experiment switch, --policy gt only: what the rows' write-through stores cost the front step)
                 lrg_st_coh4(side ? out_nb : out_in, (unsigned)l * 16u, make_float4(v[u][0], v[u][1], v[u][2], v[u][3]));
+#endif
                 if (q == 0 && j < (side ? rnb : rin))
                     (side ? upd_nb : upd_in)[j] = make_float4(v[u][0], v[u][1], v[u][2], (obj && (side ? ob[u] == target : ob[u] != target)) ? 1.f : 0.f);
             }
