@@ -244,6 +244,24 @@ extern __shared__ __attribute__((aligned(16))) float lrg_async_smem[];
 // branch-only teams of worker workgroup wg_no (small_alt: one more on the odd ones -- a step's branch tiles are ~64 % of its tile time, 2.5 of 4 teams)
 __device__ __forceinline__ int lrg_async_small_teams(const LrgAsyncArgs &A, int wg_no) { return A.small_teams + ((wg_no & 1) ? A.small_alt : 0); }
 
+// (experiment switches: a stage made N x 10 ns longer -- the slope of the step time over N is that stage's weight in the step, queueing included;
+//  the results do not change, so these run under the normal policy: tools/r04_delay.sh)
+__device__ __forceinline__ void lrg_exp_delay(int ticks) {
+    if (ticks > 0) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(1);
+    }
+}
+#ifndef LRG_EXP_DELAY_FRONT
+#define LRG_EXP_DELAY_FRONT 0
+#endif
+#ifndef LRG_EXP_DELAY_BRANCH
+#define LRG_EXP_DELAY_BRANCH 0
+#endif
+#ifndef LRG_EXP_DELAY_HEAD
+#define LRG_EXP_DELAY_HEAD 0
+#endif
+
 __device__ __forceinline__ LrgLdsTeam lrg_async_team(const LrgAsyncArgs &A, float *sm, int target) {      // sm: the team's part of the LDS
     int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
     LrgLdsTeam team;
@@ -275,6 +293,7 @@ LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
         lrg_dbg_add(A, 32, 1);
     }
 #endif
+    lrg_exp_delay(LRG_EXP_DELAY_BRANCH);
     lrg_drain_stores();                              // conv[1] rows and the pooled maxima are out before the arrival
     team.sync();
     if (tid < 64) {
@@ -553,6 +572,7 @@ LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     }
 #endif
     __builtin_amdgcn_s_setprio(0);
+    lrg_exp_delay(LRG_EXP_DELAY_HEAD);
     lrg_drain_stores();                              // the logits are out before the arrival the front workgroup polls
     team.sync();
     if (tid == 0) {
@@ -772,7 +792,9 @@ LRG_ASYNC_ROLE int lrg_async_front_step(lrg_kargs_ptr kp_, int s_) {
     const int s = lrg_uniform(s_);
     const LrgAsyncKArgs &K = LRG_ASYNC_KARGS();
     LrgFrontShared &SH = *reinterpret_cast<LrgFrontShared *>(lrg_async_smem);
-    return lrg_front_greedy_slot<true>(SH, K.slots, K.rooms, K.A.n_slots, K.prm, K.A.front, K.A.big, s);
+    const int r = lrg_front_greedy_slot<true>(SH, K.slots, K.rooms, K.A.n_slots, K.prm, K.A.front, K.A.big, s);
+    lrg_exp_delay(LRG_EXP_DELAY_FRONT);
+    return r;
 }
 
 // ---- a front workgroup: serves the slots f, f + n_front, ... ----

@@ -128,7 +128,7 @@ __device__ __forceinline__ void prefetch_b(float4 (&bq)[FD], const float4 *wp) {
 template <int NG, int RT, int RTT, int FD>
 __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[RT], const float *ap, int ld_in, const float4 *wp,
                                           const float4 *wpn, float4 (&bq)[FD]) {
-    static_assert(NG >= FD && NG >= 2, "the ring must not be deeper than a pass");
+    static_assert(NG >= FD && NG >= 2 && NG % FD == 0, "the ring must not be deeper than a pass, and a pass must leave it where the next one expects its first groups");
     float4 ar[3][RTT];                  // A operands of groups g, g+1, g+2 (explicit rotation: program order = issue order)
 #pragma unroll
     for (int t = 0; t < RTT; ++t) {
@@ -192,7 +192,7 @@ __device__ __forceinline__ void tile_mfma_first(f32x16 (&acc)[RT], const float *
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int NG, int FD>
 __device__ __forceinline__ void tile_mfma16_n64(f32x4v (&acc)[2], const float *ap, int ld16, const float4 *wp, const float4 *wpn, float4 (&bq)[FD], bool lower) {
-    static_assert(NG >= FD && NG >= 2, "the ring must not be deeper than a pass");
+    static_assert(NG >= FD && NG >= 2 && NG % FD == 0, "the ring must not be deeper than a pass, and a pass must leave it where the next one expects its first groups");
     // ap: row i = lane % 16, k half q & 1; ap + ld16: the same of row 16 + i.  Two ds_read_b128 per k-group (lane groups q and q ^ 2 read the same words:
     // broadcast) -- v_permlane32_swap exchanges of one read's halves were measured first and cost ~500 cycles per k-group.
     // A k-group is 4 x 32 cycles of MFMAs here, not 4 x 64: the ring's FD groups of lead are ~500 cycles, less than a trip to L2 -- the weights of the groups
