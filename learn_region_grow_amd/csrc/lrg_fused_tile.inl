@@ -655,7 +655,10 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             // HBM copy of a layer the next one reads from LDS (conv[1] for the heads, :130,:134): whole rows, float4
             const int q = L.N >> 2;
             float *gb = L.gout + r0 * L.N;
-            for (int idx = tid; idx < FM * q; idx += FTHREADS) {
+            // (a single-instance 32-row tile whose NEXT layer is 64 wide keeps two of its four waves busy there: the other two copy, the first two go on --
+            //  the copy reads what the next layer reads; 640 of a branch tile's 52 k cycles, profiles/r04_delay_and_stamps.txt)
+            const bool by_idle = PACKED && ONE && RT == 1 && l + 1 < nlayers && Lnext.N <= 64 && !(Lnext.flags & LRG_FL_INPLACE) && !isn16(Lnext);
+            for (int idx = by_idle ? tid - FTHREADS / 2 : tid; idx < FM * q && idx >= 0; idx += by_idle ? FTHREADS / 2 : FTHREADS) {
                 const int row = idx / q, c4 = idx - row * q;
                 const float4 v = *reinterpret_cast<const float4 *>(act_out + row * ld_out + 4 * c4);
                 if constexpr (COH) lrg_st_coh4(gb, (unsigned)(row * L.N + 4 * c4) * 4u, v);
