@@ -252,6 +252,9 @@ __device__ __forceinline__ void lrg_exp_delay(int ticks) {
         while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(1);
     }
 }
+#ifndef LRG_TICKET_EARLY
+#define LRG_TICKET_EARLY 1
+#endif
 #ifndef LRG_EXP_DELAY_FRONT
 #define LRG_EXP_DELAY_FRONT 0
 #endif
@@ -273,7 +276,7 @@ __device__ __forceinline__ LrgLdsTeam lrg_async_team(const LrgAsyncArgs &A, floa
 }
 
 // ---- the three task types (each returns the team's barrier count, to be handed to the next one) ----
-LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task) {
+LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task, int &next_ticket, int *ticket_word) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
@@ -294,6 +297,9 @@ LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
     }
 #endif
     lrg_exp_delay(LRG_EXP_DELAY_BRANCH);
+    // the team's next ticket is on its way while this task's stores drain (an agent-scope atomic with a result is a round trip of its own: taken at the
+    // loop's head it was ~1 us between a finished tile and the first look at the next task)
+    if (LRG_TICKET_EARLY && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lrg_drain_stores();                              // conv[1] rows and the pooled maxima are out before the arrival
     team.sync();
     if (tid < 64) {
@@ -542,7 +548,7 @@ struct LrgWaitPooled {
     }
 };
 
-LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task, long long t_launch) {
+LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task, long long t_launch, int &next_ticket, int *ticket_word) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
@@ -573,6 +579,7 @@ LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
 #endif
     __builtin_amdgcn_s_setprio(0);
     lrg_exp_delay(LRG_EXP_DELAY_HEAD);
+    if (LRG_TICKET_EARLY && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lrg_drain_stores();                              // the logits are out before the arrival the front workgroup polls
     team.sync();
     if (tid == 0) {
@@ -740,12 +747,15 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
     const bool filler = A.fill_list && wg_no < A.fill_wgs && team_no == A.teams - 1 + A.fill_extra;      // this team serves the fill-in ring only (fill_extra: a team MORE on these workgroups)
     // (at 68 slots two branch tiles on a CU slow each other: 809 k -> 783 k instance-steps/s with some second teams on ring 0; at 272 slots
     //  with three teams a single branch team per CU is what every slot queues for: 257 us from publishing to the last branch tile)
+    const int ring = secondary ? 1 : 0;      // (more than one team per workgroup: the first teams run the branch tiles, the others the rest)
+    int *ticket_word = &A.queue[filler ? LRG_AQ_FHEAD : LRG_AQ_HEAD + ring * LRG_AQ_SECOND];
+    int next_ticket = -1;                    // (thread 0: the ticket a tile task took while its stores drained)
     for (;;) {
         long long t_task = 0;
         if (tid == 0) {
             const long long t_wait = LRG_DBG(A) ? wall_clock64() : 0;
-            const int ring = secondary ? 1 : 0;      // (more than one team per workgroup: the first teams run the branch tiles, the others the rest)
-            const int t = __hip_atomic_fetch_add(&A.queue[filler ? LRG_AQ_FHEAD : LRG_AQ_HEAD + ring * LRG_AQ_SECOND], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int t = next_ticket >= 0 ? next_ticket : __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            next_ticket = -1;
             int *slot = filler ? &A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (A.gmask + 1) + (t & (LRG_ASYNC_FILL_RING - 1))]
                                : &A.queue[LRG_AQ_RING + ring * (A.qmask + 1) + (t & A.qmask)];
             int code = 0;
@@ -772,9 +782,9 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
         if (code < 0) return;                                //  INSIDE this one, which every wavefront reaches after it has read the word)
         const int type = (code >> 28) & 7;
         if (type == LRG_TASK_FILL) team.target = lrg_async_task_fill(kp, code, sm_off, team.target);
-        else if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task);
+        else if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task, next_ticket, ticket_word);
         else if (type == LRG_TASK_GEMV) team.target = lrg_async_task_gemv(kp, code, sm_off, team.target, t_task);
-        else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task, t_launch);
+        else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task, t_launch, next_ticket, ticket_word);
     }
 }
 
