@@ -1702,7 +1702,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     A.poll_sleep = ab->poll_sleep > 0 ? ab->poll_sleep : 1;
     // few slots, most teams idle: a branch tile as two tasks that share its pooled layer (tile 22.8 -> 18.4 us; eight 100 k-point scenes
     // 75.9 k -> 78.1 k instance-steps/s, four tasks 75.0 k; 68 rooms: 559 k -> 505 k, the teams are busy there: profiles/r03_parts_perf.log)
-    A.branch_parts = ab->branch_parts > 0 ? (ab->branch_parts >= 4 ? 4 : ab->branch_parts >= 2 ? 2 : 1) : (n_slots <= 12 ? 2 : 1);
+    A.branch_parts = ab->branch_parts > 0 ? (ab->branch_parts >= 4 ? 4 : ab->branch_parts >= 2 ? 2 : 1) : (n_slots <= 46 ? 2 : 1);      // (end of round 4, profiles/r04_teams_units_sweep.txt: 16 / 24 / 39 / 44 / 52 / 68 slots, 2 against 1 part: +8 / +6 / +2.3 / +1.5 / -2 / -17 %)
     A.max_steps = max_steps;
     A.budget_ticks = budget_us > 0 ? (long long)budget_us * 100 : (1LL << 60);      // wall_clock64: 100 MHz
     A.abort_ticks = (budget_us > 0 ? (long long)budget_us * 100 : 0) + 400000000LL;  // ... + 4 s without an end: something is broken
