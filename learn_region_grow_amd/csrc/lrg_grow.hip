@@ -1686,7 +1686,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         const int workers = wgs - n_front - A.gemv_units;
         // (16 / 32 / 64 / 103 such workgroups at 68 rooms in flight: 852 / 858 / 857 / 857 k instance-steps/s, 6: 804 k -- a big room's ~170 tasks queue for
         //  them; without the in-launch fill-in 852 k: profiles/r04_fill_in_launch_ab.txt)
-        A.fill_wgs = ab->fill_wgs > 0 ? min(ab->fill_wgs, workers / 2) : min(32, workers / 4);
+        A.fill_wgs = ab->fill_wgs > 0 ? min(ab->fill_wgs, workers / 2) : min(64, workers / 3);      // (end of round 4, 2 176 rooms: 32 / 64 / 96 such workgroups 581 / 587 / 587 rooms/s at 68 slots, 839 / 856 / 844 at 272)
         if (A.fill_wgs < 1) { A.fill_list = nullptr; a.fill_in_launch = 0; }      // (too few workgroups: the host fills in)
         A.fill_extra = (A.fill_list && teams <= 2) ? 1 : 0;
     }
