@@ -220,6 +220,83 @@ __global__ __launch_bounds__(256) void lrg_selection_sort_kernel(long rows, int 
 //                  written: the b x m x n matrix never exists.
 // The reference scans t = s+1 .. n-1 keeping `min` while dist[t] < dist[min] (strict): the FIRST minimum, NaNs never
 // preferred, and a NaN at position s stays put.
+// Wave-wide minimum through DPP (the row's 16 lanes by quad_perm / mirrors, rows by row_bcast:15 / :31; the result is read from lane 63: uniform, a scalar).
+__device__ __forceinline__ float lrg_wave_min_f32(float x) {      // x must not be NaN
+    // v_min_f32 with the DPP modifier on its first operand: one instruction per step (through the builtins: a copy, a DPP move, a canonicalising maximum and the
+    // minimum); a VGPR written by the previous vector instruction needs two wait states before a DPP read.  Lanes of masked-out rows keep x.
+    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(x));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+// The search of lrg_rowselect_passes for the first position >= s holding `best`, and the exchange.  R = the first register of the chunk looked at (four compares
+// whose lane masks are scalars, one branch per chunk: a branch per register was sixteen dependent vector-to-scalar round trips per pass on average), RS = the
+// register of position s.  The exchange is written in the block that knows its register (an index computed at run time would send the whole row to scratch
+// memory; measured alternatives, profiles/r04_rowselect_ab.txt: a masked move per register 649 us, a branch per chunk after a scalar-only search 561 us,
+// this 486 us before the fused DPP minimum).
+template <int R, int RS, int NR>
+__device__ __forceinline__ void lrg_rowselect_exchange(float (&v)[NR], unsigned short *orig, unsigned long long m, float best, float vs, int s, int ls, int L) {
+    const int lp = __builtin_ctzll(m), p = R * 64 + lp;
+    asm volatile("; exchange with register %0" :: "n"(R));      // (keeps the NR copies of this block apart: merged, they would index v at run time)
+    if (p != s) {
+        v[R] = L == lp ? vs : v[R];
+        if (L == ls) v[RS] = best;
+        if (L == 0) { const unsigned short t0 = orig[p]; orig[p] = orig[s]; orig[s] = t0; }
+    }
+}
+template <int R, int RS, int NR>
+__device__ __forceinline__ void lrg_rowselect_hit(float (&v)[NR], unsigned short *orig, float best, float vs, int s, int ls, int L) {
+    if constexpr (R < NR) {
+        constexpr int CH = 4;
+        unsigned long long m[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            m[j] = (R + j < NR) ? __ballot(v[(R + j < NR) ? R + j : R] == best) : 0ull;
+            if (R + j == RS) m[j] &= ~0ull << ls;                   // (positions below s are out)
+        }
+        if (m[0] | m[1] | m[2] | m[3]) {
+            if (m[0]) lrg_rowselect_exchange<R, RS, NR>(v, orig, m[0], best, vs, s, ls, L);
+            else if (m[1]) lrg_rowselect_exchange<(R + 1 < NR ? R + 1 : R), RS, NR>(v, orig, m[1], best, vs, s, ls, L);
+            else if (m[2]) lrg_rowselect_exchange<(R + 2 < NR ? R + 2 : R), RS, NR>(v, orig, m[2], best, vs, s, ls, L);
+            else lrg_rowselect_exchange<(R + 3 < NR ? R + 3 : R), RS, NR>(v, orig, m[3], best, vs, s, ls, L);
+            return;
+        }
+        lrg_rowselect_hit<R + CH, RS, NR>(v, orig, best, vs, s, ls, L);
+    }
+}
+
+#define LRG_ROWSELECT_MAX_RS 8      // register rows that can hold selected positions: k <= 512 (larger k: the memory-resident kernel)
+template <int RS, int NR>
+__device__ __forceinline__ void lrg_rowselect_passes(float (&v)[NR], unsigned short *orig, int kk, int L) {
+    if constexpr (RS < NR && RS < LRG_ROWSELECT_MAX_RS) {
+        constexpr int rs = RS;
+        if (rs * 64 >= kk) return;
+        for (int ls = 0; ls < 64; ++ls) {
+            const int s = rs * 64 + ls;
+            if (s >= kk) break;
+            const float vs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[rs]), ls));      // the value at position s (a scalar)
+            // The minimum VALUE first (v_min3 over the registers, a DPP reduction over the lanes; NaNs ignored as by the reference's strict compare) -- a
+            // (value, position) pair carried through the scan and the wave reduction was three instructions per register and ten per reduction step.
+            float mv = L >= ls ? v[rs] : INFINITY;
+            if (!(mv == mv)) mv = INFINITY;
+#pragma unroll
+            for (int r = rs + 1; r < NR; ++r) mv = fminf(mv, v[r]);
+            const float best = lrg_wave_min_f32(mv);
+            // nothing below +inf (all remaining +inf / NaN), or a NaN at s (nothing compares below it): position s stays
+            if (!(best < INFINITY) || vs != vs) continue;
+            // ... then the first POSITION that holds it: registers in ascending order, one compare each whose lane mask is a scalar; the first register
+            // with a hit ends the search, its lowest lane is the position -- and the exchange is written there, in code that knows its register (an
+            // index computed at run time would send the whole row to scratch memory)
+            lrg_rowselect_hit<RS, RS, NR>(v, orig, best, vs, s, ls, L);
+        }
+        lrg_rowselect_passes<RS + 1, NR>(v, orig, kk, L);
+    }
+}
+
 template <int NR, bool FUSED>
 __global__ __launch_bounds__(256) void lrg_rowselect_kernel(long rows, int n, int m, int c, int k, const float *dist, const float *xyz1,
                                                              const float *xyz2, int *outi, float *out) {
@@ -254,36 +331,9 @@ __global__ __launch_bounds__(256) void lrg_rowselect_kernel(long rows, int n, in
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     const int kk = min(k, n);
-#pragma unroll
-    for (int rs = 0; rs < NR; ++rs) {
-        if (rs * 64 >= kk) break;
-        for (int ls = 0; ls < 64; ++ls) {
-            const int s = rs * 64 + ls;
-            if (s >= kk) break;
-            const float vs = __shfl(v[rs], ls);                      // the value at position s
-            // first minimum over the positions >= s held by this lane (registers ascend with the position)
-            float best = INFINITY; int bt = INT_MAX;
-            if (L >= ls && v[rs] < best) { best = v[rs]; bt = rs * 64 + L; }
-#pragma unroll
-            for (int r = rs + 1; r < NR; ++r)
-                if (v[r] < best) { best = v[r]; bt = r * 64 + L; }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ov = __shfl_xor(best, off); const int ot = __shfl_xor(bt, off);
-                if (ot != INT_MAX && (bt == INT_MAX || ov < best || (ov == best && ot < bt))) { best = ov; bt = ot; }
-            }
-            // nothing below +inf (all remaining +inf / NaN), or a NaN at s (nothing compares below it): position s stays
-            const int p = (bt == INT_MAX || vs != vs) ? s : bt;
-            if (p != s) {
-                if (L == ls) v[rs] = best;
-                const int lp = p & 63, rp = p >> 6;
-#pragma unroll
-                for (int r = rs; r < NR; ++r)
-                    if (r == rp && L == lp) v[r] = vs;
-                if (L == 0) { const unsigned short t0 = orig[w][p]; orig[w][p] = orig[w][s]; orig[w][s] = t0; }
-            }
-        }
-    }
+    // the passes over the positions 64 rs .. 64 rs + 63, one instantiation per rs (v[rs] must be a register, not an indexed array: the loop over rs is
+    // unrolled by the template, not left to the unroller's size limits -- with it not unrolled the whole row went to scratch memory)
+    lrg_rowselect_passes<0, NR>(v, orig[w], kk, L);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (FUSED) {
@@ -305,6 +355,7 @@ template <bool FUSED>
 static int launch_rowselect(long rows, int n, int m, int c, int k, const float *dist, const float *xyz1, const float *xyz2, int *outi,
                             float *out, hipStream_t st) {
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (k > 64 * LRG_ROWSELECT_MAX_RS) return 1;      // (more selected positions than the register formulation is instantiated for)
     if (n <= 512) hipLaunchKernelGGL((lrg_rowselect_kernel<8, FUSED>), grid, block, 0, st, rows, n, m, c, k, dist, xyz1, xyz2, outi, out);
     else if (n <= 1024) hipLaunchKernelGGL((lrg_rowselect_kernel<16, FUSED>), grid, block, 0, st, rows, n, m, c, k, dist, xyz1, xyz2, outi, out);
     else if (n <= 2048) hipLaunchKernelGGL((lrg_rowselect_kernel<32, FUSED>), grid, block, 0, st, rows, n, m, c, k, dist, xyz1, xyz2, outi, out);
