@@ -589,7 +589,7 @@ int lrg_group_point_grad(int b, int n, int c, int m, int nsample, const float *g
                          float *grad_points, void *stream);
 /* knn_point (tf_grouping.py:48-73) in one kernel: val [b,m,k], idx [b,m,k] = the first k entries of selectionSortLauncher applied
  * to the distance matrix sum_c (xyz1[b,n,c]-xyz2[b,m,c])^2, bit for bit (same swap sequence, so the same order among equal
- * distances), without the b x m x n matrix ever existing.  n <= 4096 (a row lives in registers), k <= n. */
+ * distances), without the b x m x n matrix ever existing.  n <= 4096 (a row lives in registers), k <= min(n, 512); LRG_EINVAL - 2 beyond. */
 int lrg_knn_topk(int b, int n, int m, int c, int k, const float *xyz1, const float *xyz2, float *val, int *idx, void *stream);
 /* dist[b,m,n] = sum_c (xyz1[b,n,c]-xyz2[b,m,c])^2 -- the matrix knn_point builds at tf_grouping.py:62-65 */
 int lrg_pairwise_sqdist(int b, int n, int m, int c, const float *xyz1, const float *xyz2, float *dist, void *stream);

@@ -412,7 +412,7 @@ int lrg_selection_sort(int b, int n, int m, int k, const float *dist, int *outi,
 
 int lrg_knn_topk(int b, int n, int m, int c, int k, const float *xyz1, const float *xyz2, float *val, int *idx, void *stream) {
     if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || !xyz1 || !xyz2 || !val || !idx) return LRG_EINVAL - 1;
-    if (n > 4096) return LRG_EINVAL - 2;          // larger rows: lrg_pairwise_sqdist + lrg_selection_sort
+    if (n > 4096 || k > 64 * LRG_ROWSELECT_MAX_RS) return LRG_EINVAL - 2;          // larger rows or more neighbours: lrg_pairwise_sqdist + lrg_selection_sort
     long rows = (long)b * m;
     if (rows == 0) return 0;
     const int rc = launch_rowselect<true>(rows, n, m, c, k, nullptr, xyz1, xyz2, idx, val, (hipStream_t)stream);

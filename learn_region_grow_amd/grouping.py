@@ -77,7 +77,7 @@ def group_point_grad(points, idx, grad_out):
 def knn_point(k, xyz1, xyz2, fused=None):
     """xyz1 (b,n,c) dataset, xyz2 (b,m,c) queries -> val (b,m,k) squared L2, idx (b,m,k) int32
     (tf_grouping.py:48-73: distance matrix + select_top_k + slice).  fused=None: lrg_knn_topk (distances and the selection in
-    registers, no b x m x n matrix) whenever n <= 4096, else the reference's three steps; fused=False forces those."""
+    registers, no b x m x n matrix) whenever n <= 4096 and k <= 512, else the reference's three steps; fused=False forces those."""
     xyz1 = _chk(xyz1, 3, torch.float32, 'xyz1')
     xyz2 = _chk(xyz2, 3, torch.float32, 'xyz2')
     b, n, c = xyz1.shape
@@ -85,7 +85,7 @@ def knn_point(k, xyz1, xyz2, fused=None):
     if xyz2.shape[0] != b or xyz2.shape[2] != c or not 0 < k <= n:
         raise ValueError('knn_point expects (b,n,c) and (b,m,c) with 0 < k <= n')
     if fused is None:
-        fused = n <= 4096
+        fused = n <= 4096 and k <= 512      # (lrg_rowselect_kernel keeps the row in registers and is instantiated for k <= 512)
     if fused:
         val = torch.empty((b, m, k), dtype=torch.float32, device=xyz1.device)
         idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
