@@ -246,65 +246,78 @@ __device__ __forceinline__ float lrg_wave_min_f32(float x) {      // x must not 
                  "s_nop 1" : "+v"(x));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
-// The search of lrg_rowselect_passes for the first position >= s holding `best`, and the exchange.  R = the first register of the chunk looked at (four compares
-// whose lane masks are scalars, one branch per chunk: a branch per register was sixteen dependent vector-to-scalar round trips per pass on average), RS = the
-// register of position s.  The exchange is written in the block that knows its register (an index computed at run time would send the whole row to scratch
-// memory; measured alternatives, profiles/r04_rowselect_ab.txt: a masked move per register 649 us, a branch per chunk after a scalar-only search 561 us,
-// this 486 us before the fused DPP minimum).
-template <int R, int RS, int NR>
-__device__ __forceinline__ void lrg_rowselect_exchange(float (&v)[NR], unsigned short *orig, unsigned long long m, float best, float vs, int s, int ls, int L) {
-    const int lp = __builtin_ctzll(m), p = R * 64 + lp;
-    asm volatile("; exchange with register %0" :: "n"(R));      // (keeps the NR copies of this block apart: merged, they would index v at run time)
-    if (p != s) {
-        v[R] = L == lp ? vs : v[R];
-        if (L == ls) v[RS] = best;
-        if (L == 0) { const unsigned short t0 = orig[p]; orig[p] = orig[s]; orig[s] = t0; }
+// The row as ONE vector value (32 registers at most: a VGPR tuple; 64 registers = two of them): elements are read with constant indices everywhere, and the one
+// write whose register is known only at run time -- as a scalar -- compiles to s_set_gpr_idx_on + a move (an array indexed like that goes to scratch memory; a
+// block per register that writes "its" element makes the compiler carry the whole row through copies at the 32-way merge: profiles/r04_rowselect_ab.txt).
+template <int NR>
+struct LrgRow {
+    static constexpr int H = NR > 32 ? 32 : NR;
+    typedef float V __attribute__((ext_vector_type(H)));
+    V lo, hi;      // (hi: registers 32 .. 63 of a 64-register row)
+    __device__ __forceinline__ float get(int r) const { return (NR > 32 && r >= 32) ? hi[r >= 32 ? r - 32 : 0] : lo[r < H ? r : 0]; }      // r: a constant after unrolling
+    __device__ __forceinline__ void set(int r, float x) {
+        if (NR > 32 && r >= 32) hi[r >= 32 ? r - 32 : 0] = x;
+        else lo[r < H ? r : 0] = x;
     }
-}
+    // lane `mine` of register rp (a scalar) takes val
+    __device__ __forceinline__ void put(int rp, bool mine, float val) {
+        if (NR > 32 && rp >= 32) { const float o = hi[rp - 32]; hi[rp - 32] = mine ? val : o; }
+        else { const float o = lo[rp]; lo[rp] = mine ? val : o; }
+    }
+};
+
+// The search of lrg_rowselect_passes for the first position >= s holding `best`: R = the first register of the chunk looked at (four compares whose lane masks
+// are scalars, one branch per chunk: a branch per register was sixteen dependent vector-to-scalar round trips per pass on average), RS = the register of
+// position s.  Scalars only.
 template <int R, int RS, int NR>
-__device__ __forceinline__ void lrg_rowselect_hit(float (&v)[NR], unsigned short *orig, float best, float vs, int s, int ls, int L) {
+__device__ __forceinline__ int lrg_rowselect_find(const LrgRow<NR> &v, float best, int ls) {
     if constexpr (R < NR) {
         constexpr int CH = 4;
         unsigned long long m[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            m[j] = (R + j < NR) ? __ballot(v[(R + j < NR) ? R + j : R] == best) : 0ull;
+            m[j] = (R + j < NR) ? __ballot(v.get(R + j < NR ? R + j : R) == best) : 0ull;
             if (R + j == RS) m[j] &= ~0ull << ls;                   // (positions below s are out)
         }
         if (m[0] | m[1] | m[2] | m[3]) {
-            if (m[0]) lrg_rowselect_exchange<R, RS, NR>(v, orig, m[0], best, vs, s, ls, L);
-            else if (m[1]) lrg_rowselect_exchange<(R + 1 < NR ? R + 1 : R), RS, NR>(v, orig, m[1], best, vs, s, ls, L);
-            else if (m[2]) lrg_rowselect_exchange<(R + 2 < NR ? R + 2 : R), RS, NR>(v, orig, m[2], best, vs, s, ls, L);
-            else lrg_rowselect_exchange<(R + 3 < NR ? R + 3 : R), RS, NR>(v, orig, m[3], best, vs, s, ls, L);
-            return;
+            if (m[0]) return R * 64 + __builtin_ctzll(m[0]);
+            if (m[1]) return (R + 1) * 64 + __builtin_ctzll(m[1]);
+            if (m[2]) return (R + 2) * 64 + __builtin_ctzll(m[2]);
+            return (R + 3) * 64 + __builtin_ctzll(m[3]);
         }
-        lrg_rowselect_hit<R + CH, RS, NR>(v, orig, best, vs, s, ls, L);
+        return lrg_rowselect_find<R + CH, RS, NR>(v, best, ls);
+    } else {
+        return -1;
     }
 }
 
 #define LRG_ROWSELECT_MAX_RS 8      // register rows that can hold selected positions: k <= 512 (larger k: the memory-resident kernel)
 template <int RS, int NR>
-__device__ __forceinline__ void lrg_rowselect_passes(float (&v)[NR], unsigned short *orig, int kk, int L) {
+__device__ __forceinline__ void lrg_rowselect_passes(LrgRow<NR> &v, unsigned short *orig, int kk, int L) {
     if constexpr (RS < NR && RS < LRG_ROWSELECT_MAX_RS) {
         constexpr int rs = RS;
         if (rs * 64 >= kk) return;
         for (int ls = 0; ls < 64; ++ls) {
             const int s = rs * 64 + ls;
             if (s >= kk) break;
-            const float vs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[rs]), ls));      // the value at position s (a scalar)
+            const float vrs = v.get(rs);
+            const float vs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vrs), ls));      // the value at position s (a scalar)
             // The minimum VALUE first (v_min3 over the registers, a DPP reduction over the lanes; NaNs ignored as by the reference's strict compare) -- a
             // (value, position) pair carried through the scan and the wave reduction was three instructions per register and ten per reduction step.
-            float mv = L >= ls ? v[rs] : INFINITY;
+            float mv = L >= ls ? vrs : INFINITY;
             if (!(mv == mv)) mv = INFINITY;
 #pragma unroll
-            for (int r = rs + 1; r < NR; ++r) mv = fminf(mv, v[r]);
+            for (int r = rs + 1; r < NR; ++r) mv = fminf(mv, v.get(r));
             const float best = lrg_wave_min_f32(mv);
             // nothing below +inf (all remaining +inf / NaN), or a NaN at s (nothing compares below it): position s stays
             if (!(best < INFINITY) || vs != vs) continue;
-            // ... then the first POSITION that holds it: registers in ascending order, one compare each whose lane mask is a scalar; the first register
-            // with a hit ends the search, its lowest lane is the position -- and the exchange is written there, in code that knows its register (an
-            // index computed at run time would send the whole row to scratch memory)
-            lrg_rowselect_hit<RS, RS, NR>(v, orig, best, vs, s, ls, L);
+            // ... then the first POSITION that holds it, from ballot masks in register order, and the exchange
+            const int p = lrg_rowselect_find<RS, RS, NR>(v, best, ls);
+            if (p >= 0 && p != s) {
+                v.put(p >> 6, L == (p & 63), vs);
+                v.set(rs, L == ls ? best : v.get(rs));
+                if (L == 0) { const unsigned short t0 = orig[p]; orig[p] = orig[s]; orig[s] = t0; }
+            }
         }
         lrg_rowselect_passes<RS + 1, NR>(v, orig, kk, L);
     }
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256) void lrg_rowselect_kernel(long rows, int n, in
     const int w = threadIdx.x >> 6, L = lrg_lane();
     const long q = (long)blockIdx.x * 4 + w;
     if (q >= rows) return;
-    float v[NR];
+    LrgRow<NR> v;
     if (FUSED) {
         const long bi = q / m;
         const float *p1 = xyz1 + bi * n * c, *p2 = xyz2 + q * c;
@@ -332,20 +345,19 @@ __global__ __launch_bounds__(256) void lrg_rowselect_kernel(long rows, int n, in
                     acc = l == 0 ? sq : __fadd_rn(acc, sq);
                 }
             }
-            v[r] = acc;
+            v.set(r, acc);
         }
     } else {
         const float *d = dist + q * n;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) { const int t = r * 64 + L; v[r] = t < n ? d[t] : INFINITY; }
+        for (int r = 0; r < NR; ++r) { const int t = r * 64 + L; v.set(r, t < n ? d[t] : INFINITY); }
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) orig[w][r * 64 + L] = (unsigned short)(r * 64 + L);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     const int kk = min(k, n);
-    // the passes over the positions 64 rs .. 64 rs + 63, one instantiation per rs (v[rs] must be a register, not an indexed array: the loop over rs is
-    // unrolled by the template, not left to the unroller's size limits -- with it not unrolled the whole row went to scratch memory)
+    // the passes over the positions 64 rs .. 64 rs + 63, one instantiation per rs (unrolled by the template, not left to the unroller's size limits)
     lrg_rowselect_passes<0, NR>(v, orig[w], kk, L);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -353,13 +365,13 @@ __global__ __launch_bounds__(256) void lrg_rowselect_kernel(long rows, int n, in
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int t = r * 64 + L;
-            if (t < kk) { out[q * k + t] = v[r]; outi[q * k + t] = orig[w][t]; }
+            if (t < kk) { out[q * k + t] = v.get(r); outi[q * k + t] = orig[w][t]; }
         }
     } else {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int t = r * 64 + L;
-            if (t < n) { out[q * n + t] = v[r]; outi[q * n + t] = orig[w][t]; }
+            if (t < n) { out[q * n + t] = v.get(r); outi[q * n + t] = orig[w][t]; }
         }
     }
 }
