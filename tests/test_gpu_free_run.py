@@ -27,11 +27,13 @@ def _rooms():
 
 @pytest.mark.parametrize('steps,fronts,teams,in_flight,units', [(1, 0, 0, 5, 0), (7, 0, 0, 5, 0), (64, 1, 1, 3, 0), (64, 5, 3, 5, 0), (16, 2, 2, 2, 0), (64, 0, 0, 9, 0),
                                                                  (64, 3, 1, 5, -1), (16, 2, 2, 4, -1),
-                                                                 (64, 0, 0, 30, 0), (64, 0, 0, 100, 0), (64, 0, 0, 200, 0)])
+                                                                 (64, 0, 0, 30, 0), (64, 0, 0, 100, 0), (64, 0, 0, 200, 0),
+                                                                 (64, 0, 4, 9, 0), (64, 0, 4, 9, -1), (64, 0, 0, 140, 0), (64, 0, 0, 260, 0)])
 def test_free_run_equals_lock_step(net, steps, fronts, teams, in_flight, units):
     """units: 0 = the pooled-product units (the heads' pooled kernels in the LDS of workgroups of their own, head tiles started beside them),
     -1 = the pooled product as 128-column blocks of the tile teams.  in_flight 5 / 30 / 100 / 200: the shapes a launch takes by its
-    slot count (one front workgroup per slot and one team per CU | units and two teams | units and three teams | no units, three teams)."""
+    slot count (one front workgroup per slot and one team per CU | units and two teams | units and three teams | no units, three teams); 140 / 260:
+    units and four teams | no units and four teams (two branch-only teams on the smaller LDS region), also forced at 9 slots."""
     from learn_region_grow_amd.grow import RegionGrower
     rooms = _rooms()
     kw = dict(rooms_in_flight=in_flight, rng='counter', seed=123, policy='net')
