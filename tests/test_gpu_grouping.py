@@ -56,7 +56,7 @@ def test_selection_sort_known_answer_and_ties(cuda_device):
 
 
 @pytest.mark.parametrize('b,n,m,c,k', [(2, 500, 40, 3, 8), (3, 2048, 33, 3, 128), (1, 64, 5, 3, 64), (2, 1300, 17, 6, 40), (1, 4096, 9, 3, 70),
-                                        (2, 70, 64, 1, 1)])
+                                        (2, 70, 64, 1, 1), (1, 2048, 5, 3, 300), (1, 1024, 4, 3, 512)])
 def test_knn_point_fused_and_unfused(cuda_device, b, n, m, c, k):
     """knn_point (tf_grouping.py:48-73): the fused lrg_knn_topk (distances + selection in registers) and the reference's three steps
     (distance matrix, select_top_k, slice) against the C oracle's selection sort -- same swap sequence, so the same order among
@@ -76,6 +76,25 @@ def test_knn_point_fused_and_unfused(cuda_device, b, n, m, c, k):
         val, idx = grouping.knn_point(k, dev(x1, cuda_device), dev(x2, cuda_device), fused=fused)
         np.testing.assert_array_equal(idx.cpu().numpy(), wi[:, :, :k], err_msg='fused=%s' % fused)
         np.testing.assert_array_equal(val.cpu().numpy(), wo[:, :, :k], err_msg='fused=%s' % fused)
+
+
+def test_more_neighbours_than_the_register_selection_holds(cuda_device):
+    """k > 512: the selection with the row in registers is instantiated for the first eight register rows -- select_top_k takes the memory-resident
+    kernel, knn_point the reference's three steps, lrg_knn_topk itself says so."""
+    from learn_region_grow_amd import grouping, _lib
+    rs = np.random.RandomState(11)
+    x1 = rs.randn(1, 1024, 3).astype(np.float32)
+    x2 = rs.randn(1, 3, 3).astype(np.float32)
+    dist = G.knn_dist(x1, x2)
+    wi, wo = G.selection_sort(600, dist)
+    oi, o = grouping.select_top_k(600, dev(dist, cuda_device))
+    np.testing.assert_array_equal(oi.cpu().numpy(), wi)
+    np.testing.assert_array_equal(o.cpu().numpy(), wo)
+    val, idx = grouping.knn_point(600, dev(x1, cuda_device), dev(x2, cuda_device))
+    np.testing.assert_array_equal(idx.cpu().numpy(), wi[:, :, :600])
+    np.testing.assert_array_equal(val.cpu().numpy(), wo[:, :, :600])
+    with pytest.raises(_lib.LrgHipError):
+        grouping.knn_point(600, dev(x1, cuda_device), dev(x2, cuda_device), fused=True)
 
 
 def test_selection_sort_full_rows_large(cuda_device):
