@@ -78,6 +78,25 @@ def test_knn_point_fused_and_unfused(cuda_device, b, n, m, c, k):
         np.testing.assert_array_equal(val.cpu().numpy(), wo[:, :, :k], err_msg='fused=%s' % fused)
 
 
+@pytest.mark.parametrize('b,n,m,ns,c', [(5, 300, 40, 16, 16), (9, 512, 33, 32, 24), (2, 512, 128, 64, 64), (3, 100, 20, 16, 8), (1, 2000, 64, 8, 40)])
+def test_group_point_grad_workgroup_owned_slices(cuda_device, b, n, m, ns, c):
+    """The gradient's LDS formulation (c a multiple of 8, m x nsample >= 256: a workgroup owns 8 channels of a batch item, the workgroups of an item on one XCD;
+    batch sizes that are no multiple of 8) against the C oracle, with index lists padded by copies of their first entry as the ball query pads them
+    (tf_grouping_g.cu:20-23) and with the op's accumulate-into semantics (the caller's zeroed buffer)."""
+    from learn_region_grow_amd import grouping
+    rs = np.random.RandomState(b * 1000 + c)
+    pts = rs.rand(b, n, c).astype(np.float32)
+    idx = rs.randint(0, n, (b, m, ns)).astype(np.int32)
+    keep = rs.randint(1, ns + 1, (b, m))
+    for bi in range(b):
+        for j in range(m):
+            idx[bi, j, keep[bi, j]:] = idx[bi, j, 0]
+    go = rs.randn(b, m, ns, c).astype(np.float32)
+    gp = grouping.group_point_grad(dev(pts, cuda_device), dev(idx, cuda_device), dev(go, cuda_device))
+    want = G.group_point_grad(go, idx, n)
+    np.testing.assert_allclose(gp.cpu().numpy(), want, rtol=2e-5, atol=2e-5 * ns)      # (sums of up to m x nsample terms in another order)
+
+
 def test_more_neighbours_than_the_register_selection_holds(cuda_device):
     """k > 512: the selection with the row in registers is instantiated for the first eight register rows -- select_top_k takes the memory-resident
     kernel, knn_point the reference's three steps, lrg_knn_topk itself says so."""
