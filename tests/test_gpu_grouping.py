@@ -213,7 +213,7 @@ def test_nn1_fill_tiled_on_a_room(cuda_device, hip_lib):
 
 
 def test_nn1_fill_batch_equals_room_by_room(cuda_device, hip_lib):
-    """lrg_nn1_fill_batch over 19 rooms of different sizes (two groups of launches; an empty room, a room without unlabeled points, a room
+    """lrg_nn1_fill_batch over 70 rooms of different sizes (two groups of launches; an empty room, a room without unlabeled points, a room
     without labeled points among them) = lrg_nn1_fill_ws room by room."""
     import ctypes
     import torch
@@ -221,11 +221,12 @@ def test_nn1_fill_batch_equals_room_by_room(cuda_device, hip_lib):
     from learn_region_grow_amd.lrgnet import _ptr, _stream_ptr
     rs = np.random.RandomState(5)
     F = 13
-    sizes = [3000, 64, 1, 0, 777, 5000, 257, 256, 255, 1200, 90, 4100, 33, 2048, 600, 17, 999, 1500, 320]
+    base = [3000, 64, 1, 0, 777, 5000, 257, 256, 255, 1200, 90, 4100, 33, 2048, 600, 17, 999, 1500, 320]
+    sizes = base + [s + 5 * j if s else 0 for j in (1, 2, 3) for s in base[:17]]      # 70 rooms: two groups of launches (64 rooms per group)
     P, L, O, R = [], [], [], []
     for k, n in enumerate(sizes):
         pts = (rs.randn(max(n, 1), F) * 10 ** rs.uniform(-1, 1, (max(n, 1), F))).astype(np.float32)[:n]
-        lab = ((rs.rand(n) < (0.0 if k == 4 else 1.0 if k == 6 else 0.4)) * rs.randint(1, 9, n)).astype(np.int32)
+        lab = ((rs.rand(n) < (0.0 if k % 19 == 4 else 1.0 if k % 19 == 6 else 0.4)) * rs.randint(1, 9, n)).astype(np.int32)
         P.append(dev(pts.reshape(n, F) if n else np.zeros((1, F), np.float32), cuda_device)); L.append(dev(lab if n else np.zeros(1, np.int32), cuda_device))
         O.append(torch.full((max(n, 1),), -7, dtype=torch.int32, device=cuda_device)); R.append(torch.full((max(n, 1),), -7, dtype=torch.int32, device=cuda_device))
     jobs = (_lib.LrgFillJob * len(sizes))()
