@@ -13,7 +13,8 @@ def dev(a, cuda_device):
 
 
 @pytest.mark.parametrize('b,n,m,radius,ns', [(2, 200, 50, 0.2, 16), (3, 1024, 256, 0.1, 32), (1, 64, 16, 0.8, 32),
-                                              (2, 70, 33, 0.01, 8), (32, 512, 128, 0.1, 64)])
+                                              (2, 70, 33, 0.01, 8), (32, 512, 128, 0.1, 64),
+                                              (2, 1000, 20, 0.5, 100), (1, 1000, 20, 0.5, 300), (1, 300, 9, 0.45, 64)])      # (lists that fill up inside / behind a round of four chunks)
 def test_query_ball_point(cuda_device, b, n, m, radius, ns):
     from learn_region_grow_amd import grouping
     rs = np.random.RandomState(n)
