@@ -134,12 +134,14 @@ def test_selection_sort_full_rows_large(cuda_device):
     np.testing.assert_array_equal(o.cpu().numpy(), wo)
 
 
-def test_group_point_wide_rows(cuda_device):
-    """c a multiple of 4: the 16-byte path (the harness shape of tf_ops/grouping/test/query_ball_point.cpp: c = 64)."""
+@pytest.mark.parametrize('b,n,m,ns,c', [(4, 512, 128, 64, 64), (3, 100, 7, 5, 12), (1, 33, 1, 1, 4), (2, 257, 13, 9, 20)])
+def test_group_point_wide_rows(cuda_device, b, n, m, ns, c):
+    """c a multiple of 4: the 16-byte path (the harness shape of tf_ops/grouping/test/query_ball_point.cpp: c = 64; sizes that end inside a
+    workgroup's two pieces per thread)."""
     from learn_region_grow_amd import grouping
     rs = np.random.RandomState(3)
-    pts = rs.rand(4, 512, 64).astype(np.float32)
-    idx = rs.randint(0, 512, (4, 128, 64)).astype(np.int32)
+    pts = rs.rand(b, n, c).astype(np.float32)
+    idx = rs.randint(0, n, (b, m, ns)).astype(np.int32)
     out = grouping.group_point(dev(pts, cuda_device), dev(idx, cuda_device))
     np.testing.assert_array_equal(out.cpu().numpy(), G.group_point(pts, idx))
 
