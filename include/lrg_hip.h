@@ -484,7 +484,7 @@ typedef struct LrgAsyncBuffers {
     const int32_t *fill_label_base;
     int32_t *fill_out_base;     /* the filled labels (label_out of lrg_nn1_fill), same layout                                            */
     int32_t fill_rooms;         /* rooms in the LrgRoom array                                                                            */
-    int32_t fill_wgs;           /* worker workgroups with a team for the fill-in ring (one more than the others have, up to two tile teams;
+    int32_t fill_wgs;           /* worker workgroups with a team for the fill-in ring (one more than the others have, up to three tile teams;
                                    else their last team); 0 = default (64)                                                                */
     int32_t rows16;             /* 1: buffers->x_in / x_nb hold row_cap x 16 floats (16-byte aligned): lrg_grow_async gathers its rows at a 64-byte stride
                                    in 16-byte pieces (9 .. 16 features); 0: row_cap x feature_size floats, one element per store (ABI 8)            */

@@ -69,6 +69,9 @@
 #define LRG_ASYNC_CTL_FLOATS (24 + (LRG_TRACE ? 64 : 0))
 #define LRG_ASYNC_TEAM_FLOATS (LRG_ASYNC_TILE_FLOATS + LRG_ASYNC_CTL_FLOATS)
 #define LRG_ASYNC_SMALL_TEAM_FLOATS (LRG_ASYNC_BRANCH_TILE_FLOATS + LRG_ASYNC_CTL_FLOATS)
+// ... and a team that only serves the fill-in ring (the EXTRA team of a fill workgroup, always its last) with a chunk's rows, label flags and partial minima
+// (lrg_async_fill_chunk: 256 x 13 + 256 + 4 x 64 x 2 floats): three tile teams and it are 150 KB
+#define LRG_ASYNC_FILL_TEAM_FLOATS (LRG_NN1_C * 13 + LRG_NN1_C + 4 * 64 * 2 + 8 + LRG_ASYNC_CTL_FLOATS)
 
 struct LrgAsyncArgs {
     LrgFusedProb prob[4];        // 0 inlier branch, 1 neighbour branch, 2 add head (neighbour rows), 3 remove head (inlier rows)

@@ -1688,7 +1688,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         //  them; without the in-launch fill-in 852 k: profiles/r04_fill_in_launch_ab.txt)
         A.fill_wgs = ab->fill_wgs > 0 ? min(ab->fill_wgs, workers / 2) : min(64, workers / 3);      // (end of round 4, 2 176 rooms: 32 / 64 / 96 such workgroups 581 / 587 / 587 rooms/s at 68 slots, 839 / 856 / 844 at 272)
         if (A.fill_wgs < 1) { A.fill_list = nullptr; a.fill_in_launch = 0; }      // (too few workgroups: the host fills in)
-        A.fill_extra = (A.fill_list && teams <= 2) ? 1 : 0;
+        A.fill_extra = (A.fill_list && teams <= 3) ? 1 : 0;      // (a fourth team of 256 threads beside three tile teams; its LDS region is 16 KB)
     }
     {
         static const int r0_env = getenv("LRG_ASYNC_RING0_HALVES") ? atoi(getenv("LRG_ASYNC_RING0_HALVES")) : 0;
@@ -1712,7 +1712,9 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     LRG_HIP_CHECK(hipMemsetAsync(ab->sync, 0, (size_t)n_slots * LRG_ASYNC_SYNC_WORDS * sizeof(int32_t), st));
     const size_t front_lds = ((sizeof(LrgFrontShared) + 15) & ~(size_t)15) + sizeof(LrgAsyncFrontCtl);
     // (small_alt: the odd workgroups have one small team more and one big team less -- the even ones' layout is the larger)
-    const size_t team_lds = ((size_t)A.small_teams * LRG_ASYNC_SMALL_TEAM_FLOATS + (size_t)(teams - A.small_teams + A.fill_extra) * LRG_ASYNC_TEAM_FLOATS) * sizeof(float);
+    const size_t team_lds = ((size_t)A.small_teams * LRG_ASYNC_SMALL_TEAM_FLOATS + (size_t)(teams - A.small_teams) * LRG_ASYNC_TEAM_FLOATS +
+                             (size_t)A.fill_extra * LRG_ASYNC_FILL_TEAM_FLOATS) * sizeof(float);
+    static_assert((3 * LRG_ASYNC_TEAM_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "three tile teams and a fill team per CU");
     static_assert((2 * LRG_ASYNC_SMALL_TEAM_FLOATS + 2 * LRG_ASYNC_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "four tile teams per CU");
     const size_t unit_lds = A.gemv_units ? (size_t)LRG_GEMV_UNIT_FLOATS(A.gemv.P) * sizeof(float) + 16 : 0;
     const size_t lds = (max(max(front_lds, team_lds), unit_lds) + 15) & ~(size_t)15;
