@@ -98,7 +98,7 @@ struct LrgAsyncArgs {
     int fill_wgs;                // the last team of the first fill_wgs worker workgroups serves the fill-in ring only
     int small_teams;             // the first so many teams of a worker workgroup run branch tiles only, on the smaller LDS region (four teams per workgroup)
     int small_alt;               // 1: ... and one more of them on the odd workgroups
-    int fill_extra;              // 1: ... and that team is one more than the other workgroups have (where LDS and threads allow: up to two tile teams)
+    int fill_extra;              // 1: ... and that team is one more than the other workgroups have (where LDS and threads allow: up to three tile teams)
     float *pool_rows;            // nullable (with the units): [n_slots][2 sides][16 tiles][P / 2] column maxima by branch tile, instead of atomicMax on the pooled feature
     int pool_rows_stride;        // 2 * 16 * (P / 2)
     int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
