@@ -416,7 +416,12 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
         const int ncb = (m22 || n16) ? 1 : (L.N + FBN - 1) / FBN;
         // (this task's share of the pooled layer's column blocks; every other layer whole)
         const bool shared = ONE && nparts > 1 && (L.flags & LRG_FL_POOL) && !(L.flags & LRG_FL_KEEP);
+#ifdef LRG_EXP_HALF_POOL      // (experiment switch, --policy gt only: a branch tile without the second half of its pooled layer's column blocks)
+        const int cb_lo = shared ? part * ncb / nparts : 0,
+                  cb_hi = (ONE && nlayers == 5 && (L.flags & LRG_FL_POOL) && !(L.flags & LRG_FL_KEEP) && !shared) ? ncb / 2 : shared ? (part + 1) * ncb / nparts : ncb;
+#else
         const int cb_lo = shared ? part * ncb / nparts : 0, cb_hi = shared ? (part + 1) * ncb / nparts : ncb;
+#endif
         TRACE(2 + 2 * l);
         for (int cb = cb_lo; cb < cb_hi; ++cb) {
             const int col0 = col_of(L, l, cb);
