@@ -259,12 +259,9 @@ def p0_rates(n_rooms, dev):
 
 def _respawn_under_torchrun(args):
     """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks (one per GPU) and become their launcher."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # (--standalone: the launcher finds a free port itself; one picked and closed here could be taken before the ranks start)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           os.path.abspath(__file__)] + sys.argv[1:]
     os.execv(sys.executable, cmd)
 
 
