@@ -89,6 +89,9 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cpu-box-seconds', type=float, default=12.0,
                     help='cpu_baseline.all_cores: the oracle on many rooms at once, one single-threaded process per room, for this long (0 = skip)')
+    ap.add_argument('--one-rank-collective', type=int, default=1,
+                    help='--gpus 1: 1 = a one-rank RCCL process group is brought up and the fixed-work leg\'s label gather goes through its all_gather '
+                         '(the nccl branch of learn_region_grow_amd/dist.py executed on the device); 0 = the single-rank short cut')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
     ap.add_argument('--p0-rooms', type=int, default=4, help='rooms of the preprocessing (P0) side measurement (0 = skip)')
     return ap.parse_args()
@@ -197,17 +200,23 @@ def cpu_baseline_all_cores(rooms, weights, seconds, policy, gpu_room_steps):
     user of the reference with a many-core host would do): rooms spread evenly over the set's size order, each grown for `seconds` (or to its end).
     value = all steps / the longest worker's time."""
     import multiprocessing as mp
-    workers = max(1, min(len(rooms), (os.cpu_count() or 2) - 2, 64))
+    cores = max(1, min(len(rooms), (os.cpu_count() or 2) - 2, 64))
     order = np.argsort([len(r['points']) for r in rooms])
+    # ... and beside them the SMALLEST rooms of the set grown to the end and filled in (up to four windows each), so that rooms/s is also MEASURED on
+    # whole rooms, not only extrapolated from a step rate: eight rooms where the box has 32+ cores
+    n_small = min(8, cores // 4, len(rooms))
+    workers = cores - n_small
     picks = [int(order[(2 * i + 1) * len(order) // (2 * workers)]) for i in range(workers)]
+    small = [int(i) for i in order[:n_small]]
     keep = ('points', 'obj_id', 'order')
     jobs = [({k: rooms[i][k] for k in keep}, weights, seconds, policy, 0) for i in picks]
+    jobs += [({k: rooms[i][k] for k in keep}, weights, 4.0 * seconds, policy, 0) for i in small]
     saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
     os.environ.update({k: '1' for k in saved})                    # (the children are spawned: they read these when NumPy loads)
     t0 = time.time()
     try:
-        with mp.get_context('spawn').Pool(workers) as pool:
-            res = pool.map(_cpu_pool_worker, jobs, chunksize=1)
+        with mp.get_context('spawn').Pool(workers + n_small) as pool:
+            res_all = pool.map(_cpu_pool_worker, jobs, chunksize=1)
     finally:
         for k, v in saved.items():
             if v is None:
@@ -215,15 +224,28 @@ def cpu_baseline_all_cores(rooms, weights, seconds, policy, gpu_room_steps):
             else:
                 os.environ[k] = v
     wall = time.time() - t0
+    res, res_small = res_all[:workers], res_all[workers:]
     steps = sum(r[0] for r in res)
     busy = max(r[1] + (r[2] or 0.0) for r in res)
     finished = sum(1 for r in res if r[2] is not None)
     known = [gpu_room_steps[i] for i in picks if gpu_room_steps.get(i)]
-    out = dict(value=steps / busy, unit='instance-steps/s', cores=workers, kind='port', rooms_finished=finished, wall_seconds=wall,
+    out = dict(value=steps / busy, unit='instance-steps/s', cores=workers, cores_busy=workers + n_small, kind='port', rooms_finished=finished, wall_seconds=wall,
                per_core=steps / busy / workers)
     if known:
         out['rooms_per_sec'] = (steps / busy) / float(np.mean(known))
         out['rooms_per_sec_extrapolated'] = True
+    done_small = [(i, r) for i, r in zip(small, res_small) if r[2] is not None]
+    if done_small:
+        # measured, on whole rooms: every one of these was grown to its end and filled in by one core; rooms/s of the box = cores / mean seconds per room.
+        # (The smallest rooms of the set: fewer steps, and cheaper ones -- the reference's mask update is a Python loop over all N points per step -- than
+        #  the set's mean room; an upper bound for the set, next to the extrapolated figure above.)
+        secs = [r[1] + r[2] for _, r in done_small]
+        out['measured_small_rooms'] = dict(rooms_finished=len(done_small), rooms_started=n_small, points=[len(rooms[i]['points']) for i, _ in done_small],
+                                           steps=[r[0] for _, r in done_small], seconds_each=secs, cores_used=len(done_small),
+                                           rooms_per_sec_per_core=len(secs) / float(np.sum(secs)), rooms_per_sec_box=(workers + n_small) * len(secs) / float(np.sum(secs)),
+                                           what='the %d smallest rooms of the set, each grown to its end and filled in by one single-threaded process: '
+                                                'rooms/s per core = rooms / the sum of their seconds; x the %d cores in use = the box' % (n_small, workers + n_small))
+        out['rooms_finished'] = finished + len(done_small)
     out['sample'] = ('%d rooms (evenly over the set\'s sizes: %d .. %d points), one single-threaded process each, oracle.grow_ref (faithful=True, policy=%s) for '
                      '%.0f s or to the room\'s end: %d steps, longest worker %.1f s, %d rooms grown to the end; rooms/s = step rate / the mean steps the GPU run '
                      'took for these rooms' % (workers, min(len(rooms[i]['points']) for i in picks), max(len(rooms[i]['points']) for i in picks), policy,
@@ -381,6 +403,24 @@ def main():
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         backend = dist.get_backend()
+    force_coll = False
+    collective_error = None
+    if world == 1 and args.one_rank_collective and not dist.is_initialized():
+        # One GPU: the exchange of the N > 1 path (learn_region_grow_amd/dist.py: all_gather of the label buffers, all_reduce of the counts) still
+        # runs, over a one-rank RCCL communicator -- so that the code an 8-GPU run takes has executed on the device in every record of this
+        # script.  Nothing depends on it: if RCCL cannot be brought up the single-rank short cut is taken and the line says why.
+        try:
+            import socket
+            sck = socket.socket()
+            sck.bind(('127.0.0.1', 0))
+            port = sck.getsockname()[1]
+            sck.close()
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
+            backend = dist.get_backend()
+            force_coll = True
+        except Exception as e:      # noqa: BLE001 -- reported in the line
+            collective_error = '%s: %s' % (type(e).__name__, e)
+            backend = None
 
     weights = synthetic.load_trained_weights() if args.weights == 'trained' else synthetic.make_synthetic_weights(seed=0)
     resolution = 0.1
@@ -590,9 +630,10 @@ def main():
     # HBM traffic / matrix-pipe occupancy of the loop's kernel: PMC passes of their own (tools/pmc_free_run.sh), quoted from the committed
     # file only when it was measured on this ABI and formulation
     roof['traffic'] = None
-    tpath = os.path.join(REPO, 'profiles', 'r04_pmc_free_run.json' if leg.free else 'r02_traffic_loop.json')
-    if leg.free and not os.path.exists(tpath):
-        tpath = os.path.join(REPO, 'profiles', 'r03_pmc_free_run.json')
+    tpath = os.path.join(REPO, 'profiles', 'r05_pmc_free_run.json' if leg.free else 'r02_traffic_loop.json')
+    for older in ('r04_pmc_free_run.json', 'r03_pmc_free_run.json'):
+        if leg.free and not os.path.exists(tpath):
+            tpath = os.path.join(REPO, 'profiles', older)
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if leg.free and tj.get('abi') == _lib.load().lrg_abi_version():
@@ -627,12 +668,12 @@ def main():
         flat, order, lens = fl.labels()
         ids = [mine[i] for i in order]
         tg0 = time.perf_counter()
-        gathered = lrg_dist.gather_flat_labels(ids, lens, flat, R, device=coll_dev)
+        gathered = lrg_dist.gather_flat_labels(ids, lens, flat, R, device=coll_dev, force_collective=force_coll)
         barrier()
         tf1 = time.perf_counter()
-        el = lrg_dist.allreduce_max(tf1 - tf0, device=coll_dev)
+        el = lrg_dist.allreduce_max(tf1 - tf0, device=coll_dev, force_collective=force_coll)
         st = fl.stats()
-        f_steps, f_rooms = lrg_dist.allreduce_sum([float(st[2]), float(len(my_jobs))], device=coll_dev)
+        f_steps, f_rooms = lrg_dist.allreduce_sum([float(st[2]), float(len(my_jobs))], device=coll_dev, force_collective=force_coll)
         ok = all(gathered[j] is not None and len(gathered[j]) == sizes[j] and int(gathered[j].min()) > 0 for j in range(R))
         crc = 0
         for j in range(R):                                  # one checksum over every room's final labels, in job order
@@ -643,7 +684,8 @@ def main():
                'scaling': 'strong', 'slots_per_gpu': fl.slots, 'waves_per_rank': R / float(world) / max(fl.slots, 1),
                'waves_per_rank_at_8_gpus': R / 8.0 / max(n_slots, 1), 'formulation': 'free-running launches' if fl.free else 'lock-step iterations',
                'lanes': fl.lanes, 'grow_seconds_rank0': tf_grow, 'gather_seconds_rank0': tf1 - tg0, 'rccl_ranks': world,
-               'collective_backend': backend, 'all_rooms_labeled_after_gather': bool(ok), 'labels_crc32': int(crc), 'given_up': int(st[3]),
+               'collective_backend': backend, 'collective_executed': bool(world > 1 or force_coll), 'collective_error': collective_error,
+               'all_rooms_labeled_after_gather': bool(ok), 'labels_crc32': int(crc), 'given_up': int(st[3]),
                'what': '%d room jobs = the %d geometries x %d random-stream keys, LPT-sharded by point count over %d rank(s), reset -> grow -> '
                        '1-NN fill-in -> all_gather of the labels' % (R, len(base), (R + len(base) - 1) // len(base), world)}
         if measure_fill and fl.free and rank == 0:
@@ -768,6 +810,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

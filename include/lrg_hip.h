@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define LRG_ABI_VERSION 8
+#define LRG_ABI_VERSION 9
 #define LRG_EINVAL (-1000)
 #define LRG_ERESIDENCY (-1100)  /* lrg_grow_async: the launch's workgroups cannot all be resident at once on this stream / device (see there) */
 
@@ -488,7 +488,9 @@ typedef struct LrgAsyncBuffers {
                                    else their last team); 0 = default (64)                                                                */
     int32_t rows16;             /* 1: buffers->x_in / x_nb hold row_cap x 16 floats (16-byte aligned): lrg_grow_async gathers its rows at a 64-byte stride
                                    in 16-byte pieces (9 .. 16 features); 0: row_cap x feature_size floats, one element per store (ABI 8)            */
-    int32_t reserved;
+    int32_t start_wait_us;      /* the launch's start rendezvous (all its workgroups must be running at once): how long the front workgroups wait for the
+                                   others before the launch gives up with reason 6; 0 = default: the launch budget + 20 ms (a kernel of another stream that
+                                   holds CUs for up to one budget is waited out, something that never leaves is reported)  (ABI 9; was `reserved`) */
     float *pool_rows;           /* nullable: lrg_grow_async_pool_rows_bytes(weights, n_slots) bytes, 16-byte aligned -- with the pooled-product units a
                                    branch tile leaves the column maxima of its rows as one row here (16-byte stores) and the units take the maximum
                                    over a slot's tiles; NULL: one atomicMax per column and tile on the pooled feature (ABI 8)              */

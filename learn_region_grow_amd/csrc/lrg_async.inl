@@ -104,6 +104,7 @@ struct LrgAsyncArgs {
     int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
     int branch_parts;            // tasks per branch tile (1, 2, 4): they share the column blocks of the pooled layer (lrg_fused_tile)
     int max_steps;               // evaluations per slot in this launch
+    long long start_ticks;       // ... the front workgroups wait at most this long for all workgroups of the launch to have started (reason 6)
     long long budget_ticks;      // wall_clock64 ticks (100 MHz) after which no new evaluation is started
     long long abort_ticks;       // ... after which a waiting workgroup gives up
     unsigned long long *work;    // nullable: [4] evaluations, distinct inlier rows, distinct neighbour rows, 32-row tiles (x 2 stacks) of this buffer's launches
@@ -691,7 +692,7 @@ LRG_ASYNC_ROLE int lrg_async_task_fill(lrg_kargs_ptr kp_, int code_, int sm_off_
 }
 
 // the front workgroup (all its threads) that has just finished `room`: list of the unlabeled points, release, tasks
-__device__ __noinline__ void lrg_async_fill_publish(lrg_kargs_ptr kp_, int room_) {
+__device__ __noinline__ void lrg_async_fill_publish(lrg_kargs_ptr kp_, int room_, long long t_launch) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int room = lrg_uniform(room_);
     const LrgAsyncKArgs &K = LRG_ASYNC_KARGS();
@@ -714,6 +715,7 @@ __device__ __noinline__ void lrg_async_fill_publish(lrg_kargs_ptr kp_, int room_
     __syncthreads();
     const int chunks = (n + LRG_NN1_C - 1) / LRG_NN1_C;
     if (tid == 0) { fs[0] = *cnt; fs[1] = 0; fs[2] = chunks; fs[3] = 0; }
+    lrg_drain_stores();                                            // (this wavefront's list / best stores have reached the L2: the barrier alone does not wait for them)
     __syncthreads();                                               // every wavefront's stores are issued ...
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // ... and written back (labels, visited marks of this room included)
@@ -726,7 +728,20 @@ __device__ __noinline__ void lrg_async_fill_publish(lrg_kargs_ptr kp_, int room_
         for (int c0 = 0; c0 < chunks; c0 += 64) {
             const int m = min(64, chunks - c0);
             int base = 0;
-            if (lane == 0) base = __hip_atomic_fetch_add(&A.queue[LRG_AQ_FTAIL], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                // Back-pressure: the ring has a fixed number of entries and rooms may finish faster than their tasks are taken (large scenes, few
+                // fill teams).  An entry may be overwritten only when the one a ring's length before it has been taken AND zeroed by its team;
+                // tickets are handed out in order and a team zeroes its entry right after reading it, so with at most HALF a ring outstanding
+                // (reserved - tickets handed out) that holds with thousands of tasks to spare.  The fill teams depend on nobody: waiting here
+                // cannot deadlock, and it is bounded like every other wait of this kernel.
+                for (unsigned spin = 1;; ++spin) {
+                    const int out = lrg_ld_coh(&A.queue[LRG_AQ_FTAIL]) - lrg_ld_coh(&A.queue[LRG_AQ_FHEAD]);
+                    if (out + m <= LRG_ASYNC_FILL_RING / 2 || lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) break;
+                    if ((spin & 1023u) == 0 && wall_clock64() - t_launch > A.abort_ticks) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 7); break; }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                base = __hip_atomic_fetch_add(&A.queue[LRG_AQ_FTAIL], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             base = __shfl(base, 0);
             if (lane < m) lrg_st_coh(&ring[(base + lane) & fmask], (LRG_TASK_FILL << 28) | (room << 10) | (c0 + lane));
         }
@@ -766,7 +781,14 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
                 code = lrg_ld_coh(slot);
                 if (code) break;
                 if ((spin & 7) == 7) {
-                    if (lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front || lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) { code = -1; break; }
+                    if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) { code = -1; break; }
+                    if (lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front) {
+                        // Every front workgroup has left, so nothing more is published.  A tile team's entries are all taken by then (the front
+                        // workgroups waited for their results); nobody waits for a fill-in, so a filler leaves only when its ticket lies beyond the
+                        // FINAL reservation count -- an entry reserved before the last front workgroup left is written (write-through, drained before
+                        // FRONTS_DONE was raised) and is waited for here instead of being given up on a stale look at the slot.
+                        if (!filler || t - lrg_ld_coh(&A.queue[LRG_AQ_FTAIL]) >= 0) { code = -1; break; }
+                    }
                     if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) {
                         lrg_st_coh(&A.queue[LRG_AQ_ABORT], 2);
                         code = -1;
@@ -835,13 +857,14 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
     lrg_drain_stores();
     // Start rendezvous: front workgroups, units and tile teams wait for each other, so every workgroup of the launch must be running
     // (one per CU).  On a chip the launch has to itself they all start within a microsecond; when something else holds CUs (another
-    // process, a kernel of another stream) some never start while these wait -- found out here within 20 ms and reported (reason 6),
-    // not by the hand-overs' bounds seconds later.
+    // process, a kernel of another stream) some never start while these wait -- found out here within the launch budget + 20 ms
+    // (LrgAsyncBuffers.start_wait_us: a kernel that leaves within a budget is waited out) and reported (reason 6), not by the hand-overs'
+    // bounds seconds later.
     if (tid == 0) {
         const int all = (int)gridDim.x;
         for (unsigned spin = 0; lrg_ld_coh(&A.queue[LRG_AQ_ARRIVED]) < all; ++spin) {
             if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) break;
-            if ((spin & 15) == 15 && wall_clock64() - t_launch > LRG_ASYNC_START_TICKS) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 6); break; }
+            if ((spin & 15) == 15 && wall_clock64() - t_launch > A.start_ticks) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 6); break; }
             __builtin_amdgcn_s_sleep(8);
         }
     }
@@ -895,7 +918,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 // looking for a seed (-> served again at once)
                 __syncthreads();
                 if (A.fill_list && slots[s].room >= 0 && slots[s].status == LRG_DONE) {      // (uniform: plain loads of the slot this workgroup owns)
-                    lrg_async_fill_publish(kp, slots[s].room);       // the room is finished: its fill-in as tasks of this launch
+                    lrg_async_fill_publish(kp, slots[s].room, t_launch);       // the room is finished: its fill-in as tasks of this launch
                     if (tid == 0) slots[s].status = LRG_IDLE;
                     __syncthreads();
                 }

@@ -1706,6 +1706,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     A.max_steps = max_steps;
     A.budget_ticks = budget_us > 0 ? (long long)budget_us * 100 : (1LL << 60);      // wall_clock64: 100 MHz
     A.abort_ticks = (budget_us > 0 ? (long long)budget_us * 100 : 0) + 400000000LL;  // ... + 4 s without an end: something is broken
+    A.start_ticks = ab->start_wait_us > 0 ? (long long)ab->start_wait_us * 100 : (budget_us > 0 ? (long long)budget_us * 100 : 0) + LRG_ASYNC_START_TICKS;
     static_assert(sizeof(LrgAsyncKArgs) <= 4096, "kernel arguments");
     hipStream_t st = (hipStream_t)stream;
     LRG_HIP_CHECK(hipMemsetAsync(ab->queue, 0, qbytes, st));

@@ -21,12 +21,19 @@ def shard_rooms_lpt(sizes, world_size):
     return [sorted(s) for s in shards]
 
 
-def gather_room_labels(local_ids, local_labels, n_rooms, device=None, group=None):
+def _short_cut(world, force_collective):
+    """A single rank needs no exchange -- unless the caller wants the collectives of an initialised process group executed
+    all the same (`force_collective`: the one-rank RCCL run of tests/test_gpu_dist.py and of bench.py at --gpus 1, which is
+    the only way the nccl branch can be exercised on a one-GPU box)."""
+    return world == 1 and not (force_collective and dist.is_initialized())
+
+
+def gather_room_labels(local_ids, local_labels, n_rooms, device=None, group=None, force_collective=False):
     """All ranks end up with the labels of all rooms: one all_gather of (room id, size) tables and one
     all_gather of a flat int32 label buffer padded to the largest shard.  `local_labels[i]` is the int array of
     room `local_ids[i]`.  Returns a list of n_rooms arrays (None for rooms nobody owned)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if _short_cut(world, force_collective):
         out = [None] * n_rooms
         for i, lab in zip(local_ids, local_labels):
             out[i] = np.asarray(lab, dtype=np.int32)
@@ -57,12 +64,12 @@ def gather_room_labels(local_ids, local_labels, n_rooms, device=None, group=None
     return out
 
 
-def gather_flat_labels(local_ids, local_lens, flat, n_rooms, device=None, group=None):
+def gather_flat_labels(local_ids, local_lens, flat, n_rooms, device=None, group=None, force_collective=False):
     """gather_room_labels for labels that are still on the GPU: `flat` is one int32 tensor holding the labels of rooms
     `local_ids` back to back (`local_lens` points each).  With the nccl backend the flat buffer goes into the all_gather as
     it is (device to device over xGMI); gloo stages it through the host.  Returns a list of n_rooms arrays."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if _short_cut(world, force_collective):
         host = flat.cpu().numpy()
         out, o = [None] * n_rooms, 0
         for i, n in zip(local_ids, local_lens):
@@ -97,9 +104,9 @@ def gather_flat_labels(local_ids, local_lens, flat, n_rooms, device=None, group=
     return out
 
 
-def allreduce_sum(values, device=None, group=None):
+def allreduce_sum(values, device=None, group=None, force_collective=False):
     """Sum a small list of numbers over ranks (throughput accounting)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or _short_cut(dist.get_world_size(group), force_collective):
         return list(values)
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
@@ -108,8 +115,8 @@ def allreduce_sum(values, device=None, group=None):
     return t.cpu().tolist()
 
 
-def allreduce_max(value, device=None, group=None):
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+def allreduce_max(value, device=None, group=None, force_collective=False):
+    if not dist.is_initialized() or _short_cut(dist.get_world_size(group), force_collective):
         return value
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')

@@ -119,6 +119,30 @@ class RegionGrower:
         self._rooms_loaded = False
 
     # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def free_run_applies(net, rooms, rooms_in_flight, restarts=1, group_size=None, rng='counter', resolution=0.1, packed=None, free_run=None,
+                         skip_duplicate_rows=True, **_):
+        """Whether a RegionGrower built with these arguments would grow `rooms` with free-running launches (the decision load_rooms takes
+        once it has the rooms on the device), from the host arrays alone -- so that a caller who builds its growers around that answer
+        (LanedRegionGrower: one free-running lane, or several lock-step lanes) need not build them twice."""
+        if free_run is False or rng != 'counter' or net.mode != 'fused' or not skip_duplicate_rows or packed is False or not rooms:
+            return False
+        G = int(restarts if group_size is None else group_size)
+        ns = [int(len(r['points'])) for r in rooms]
+        if G != 1 or int(restarts) != 1 or max(net.num_inlier_points, net.num_neighbor_points) > 512 or getattr(net, 'lite', 0) == 1:
+            return False
+        if max(ns) > (_lib.LRG_PACKED_MAX_POINTS if packed else _lib.LRG_PACKED_AUTO_POINTS):
+            return False
+        for r in rooms:      # packed voxel words: every room within 2048 x 2048 x 1024 voxels (lrg_voxelize: rint(x / resolution) in float32)
+            if len(r['points']):
+                v = np.rint(np.asarray(r['points'], dtype=np.float32)[:, :3] / np.float32(resolution))
+                if ((v.max(axis=0) - v.min(axis=0)) > np.array([2047, 2047, 1023])).any():
+                    return False
+        if free_run:
+            return True
+        return (int(rooms_in_flight) * G <= _lib.LRG_FREE_RUN_AUTO_SLOTS and max(ns) <= _lib.LRG_FREE_RUN_AUTO_POINTS and
+                os.environ.get('LRG_FREE_RUN', '1') != '0')
+
     def load_rooms(self, rooms):
         """rooms: list of dicts with points [n,F] float32, obj_id [n], order [n] (= argsort(curvatures),
         test_region_grow.py:183) and optional room_id.  Uploads them, voxelises (:175) and builds the
@@ -627,8 +651,8 @@ class RegionGrower:
         if int(st[3]):
             raise _lib.LrgHipError('lrg_grow_async gave up on a hand-over between workgroups (%d front workgroups; sum of their reasons %d -- 1 launch '
                                    'past its time limit, 2 a team waited too long for a task, 3 a team lost a wavefront at a barrier, 4 / 5 a pooled-product '
-                                   'unit / a head tile waited too long, 6 not all workgroups of the launch were resident within 20 ms: something else holds '
-                                   'compute units of this device): results are invalid'
+                                   'unit / a head tile waited too long, 6 not all workgroups of the launch were resident within its budget + 20 ms: something else holds '
+                                   'compute units of this device, 7 the fill-in ring stayed full): results are invalid'
                                    % (int(st[3]) & 0xFFFFFFFF, int(st[3]) >> 32))
         return out
 
@@ -659,6 +683,23 @@ class RegionGrower:
         self.set_room_queue(list(range(first, self.n_rooms)))
         self.rooms_finished = 0
 
+    def verify_fills_in_launch(self):
+        """A room the done ring reported as filled in by its launch (bit 31) must have its 'filled' word set by the last fill task
+        (LrgAsyncBuffers.fill_sync[room][3]); a room whose tasks did not complete is filled in here, by the host-launched kernels --
+        never left with stale labels.  Returns the rooms that needed it (normally none)."""
+        rooms = sorted(set(getattr(self, '_filled_in_launch', [])))
+        self._filled_in_launch = []
+        if not rooms or not getattr(self, 'fill_in_launch', False):
+            return []
+        torch.cuda.current_stream(self.dev).synchronize()
+        flags = self.a_fill_sync[:, 3].cpu().numpy()
+        missing = [r for r in rooms if flags[r] != 1]
+        if missing:
+            self.fill_many(missing)
+            torch.cuda.current_stream(self.dev).synchronize()
+        self.fills_redone = getattr(self, 'fills_redone', 0) + len(missing)
+        return missing
+
     def free_run_step(self, fill=True, steps=None, budget_us=None, wait=False):
         """One launch, then the fill-in (test_region_grow.py:308-316) of the rooms reported finished since the last call; returns
         how many those were."""
@@ -672,6 +713,9 @@ class RegionGrower:
             self._in_fill_stream = True
         if fill:
             self.fill_many([r for r, f in zip(self.done_rooms, self.done_filled) if not f])
+            if not hasattr(self, '_filled_in_launch'):
+                self._filled_in_launch = []
+            self._filled_in_launch.extend(r for r, f in zip(self.done_rooms, self.done_filled) if f)
         if last:
             self._in_fill_stream = False
         self.rooms_finished += n
@@ -690,6 +734,8 @@ class RegionGrower:
             self.free_run_step(fill)
         torch.cuda.current_stream(self.dev).synchronize()
         self.wait_fills()
+        if fill:
+            self.verify_fills_in_launch()
         self.async_buffers.room_queue = None
         return self.n_rooms
 
@@ -1017,23 +1063,32 @@ class LanedRegionGrower:
         if kw.get('rng', 'counter') != 'counter':
             raise ValueError("lanes need rng='counter' (the legacy stream is replayed on the host, one iteration at a time)")
         self.net = net
-        self._rebuild = None
+        self._build(rooms_in_flight, lanes, cu_partition, kw)
+
+    def _build(self, rooms_in_flight, lanes, cu_partition, kw):
+        """Lane count: given, or automatic (decided per room set in load_rooms; until rooms are seen: a single free-running lane where the
+        arguments allow one, else auto_lanes)."""
+        self._auto = None
         if lanes is None or int(lanes) <= 0:
-            lanes = auto_lanes(int(rooms_in_flight) * int(kw.get('restarts', 1)))
-            lockstep_lanes = lanes
-            # free-running launches (RegionGrower's choice up to 96 greedy slots) fill the chip by themselves: one lane
+            lockstep_lanes = auto_lanes(int(rooms_in_flight) * int(kw.get('restarts', 1)))
+            lanes = lockstep_lanes
+            # free-running launches (RegionGrower's choice up to LRG_FREE_RUN_AUTO_SLOTS greedy slots) fill the chip by themselves: one lane
             if (kw.get('free_run', None) is not False and int(kw.get('restarts', 1)) == 1 and int(rooms_in_flight) <= _lib.LRG_FREE_RUN_AUTO_SLOTS and
                     kw.get('packed', None) is not False and os.environ.get('LRG_FREE_RUN', '1') != '0'):
                 lanes = 1
                 if lockstep_lanes > 1:
-                    # RegionGrower decides on free-running launches only when it sees the rooms (load_rooms: packed voxel words, point
-                    # counts, lite); if it falls back to lock-step iterations the lanes are rebuilt as auto_lanes would have them
-                    self._rebuild = dict(rooms_in_flight=rooms_in_flight, lanes=lockstep_lanes, cu_partition=cu_partition, kw=dict(kw, free_run=False))
+                    self._auto = dict(rooms_in_flight=rooms_in_flight, lockstep_lanes=lockstep_lanes, cu_partition=cu_partition, kw=dict(kw))
+        self._build_lanes(rooms_in_flight, lanes, cu_partition, kw)
+
+    def _build_lanes(self, rooms_in_flight, lanes, cu_partition, kw):
+        net = self.net
         lanes = max(1, min(int(lanes), int(rooms_in_flight)))
-        if lanes > 1 and kw.get('free_run', None) is None:
-            # lanes are lock-step growers side by side; a free-running launch wants every CU for itself (two of them on two streams take
-            # turns CU by CU as the other's workgroups leave: correct, but neither is ever whole)
-            kw = dict(kw, free_run=False)
+        if lanes > 1 and kw.get('free_run', None):
+            # a free-running launch needs ALL its workgroups resident at once (one per CU: they wait for each other); a second one on another
+            # stream finds the CUs taken and gives up at its start rendezvous (reason 6) -- refused here instead
+            raise ValueError('free_run=True needs lanes=1: a free-running launch occupies every compute unit of the device (DESIGN.md section 4)')
+        if lanes > 1:
+            kw = dict(kw, free_run=False)      # lanes are lock-step growers side by side
         share = [rooms_in_flight // lanes + (1 if k < rooms_in_flight % lanes else 0) for k in range(lanes)]
         self.streams = lane_streams(net.device, lanes, cu_partition)
         self.growers = []
@@ -1043,6 +1098,19 @@ class LanedRegionGrower:
         self.where = []          # original room index -> (lane, index within the lane)
 
     def load_rooms(self, rooms):
+        if self._auto is not None and rooms:
+            # lanes chosen automatically: ONE free-running lane where free-running launches apply to these rooms, else lock-step lanes as
+            # auto_lanes has them -- decided from the room list (RegionGrower.free_run_applies) BEFORE any grower is built or loaded, and
+            # decided again for every room set
+            a = self._auto
+            free = RegionGrower.free_run_applies(self.net, rooms, a['rooms_in_flight'], **a['kw'])
+            want = 1 if free else a['lockstep_lanes']
+            if want != len(self.growers) or (not free and any(g.want_free_run is not False for g in self.growers)):
+                for gr in self.growers:
+                    gr._release_graph()
+                self.growers = []
+                torch.cuda.empty_cache()
+                self._build_lanes(a['rooms_in_flight'], want, a['cu_partition'], a['kw'] if free else dict(a['kw'], free_run=False))
         L = len(self.growers)
         order = sorted(range(len(rooms)), key=lambda i: -len(rooms[i]['points']))     # largest first, dealt round the lanes
         parts = [[] for _ in range(L)]
@@ -1053,15 +1121,10 @@ class LanedRegionGrower:
             room = dict(rooms[i])
             room.setdefault('room_id', i)
             parts[k].append(room)
-        if self._rebuild is not None and L == 1 and rooms:
-            # one lane was chosen in the expectation of free-running launches: the grower decides when it sees the rooms
+        if L == 1 and rooms:
             gr = self.growers[0]
             with torch.cuda.stream(self.streams[0]):
                 gr.load_rooms(parts[0])
-            if not gr.free_run:
-                rb, self._rebuild = self._rebuild, None
-                self.__init__(self.net, rooms_in_flight=rb['rooms_in_flight'], lanes=rb['lanes'], cu_partition=rb['cu_partition'], **rb['kw'])
-                return self.load_rooms(rooms)
             gr.room_index = list(order)
             torch.cuda.synchronize()
             return

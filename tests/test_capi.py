@@ -33,7 +33,7 @@ def test_abi_and_struct_layout(hip_lib):
     assert quoted and all(q == header for q in quoted), 'INTEGRATION.md asserts ABI %s, the header says %d' % (quoted, header)
     assert hip_lib.lrg_target_arch() == b'gfx950'
     for which, st in enumerate((_lib.LrgWeights, _lib.LrgRoom, _lib.LrgSlot, _lib.LrgGrowParams, _lib.LrgStepBuffers,
-                               _lib.LrgPackedBuffers, _lib.LrgBeamGroup, _lib.LrgAsyncBuffers)):
+                               _lib.LrgPackedBuffers, _lib.LrgBeamGroup, _lib.LrgAsyncBuffers, _lib.LrgFillJob)):
         assert hip_lib.lrg_struct_size(which) == ctypes.sizeof(st)
 
 

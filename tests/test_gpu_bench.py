@@ -53,6 +53,8 @@ def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
         assert rf['launches'] == 3 and 'lrg_grow_async_kernel' in rf['kernel']
     fw = d['fixed_work']
     assert fw['rooms'] == 12 and fw['rooms_per_sec'] > 0 and fw['all_rooms_labeled_after_gather'] and fw['rccl_ranks'] == 1 and fw['given_up'] == 0
+    # one rank: the label gather and the count reductions still went through RCCL (a one-rank communicator on the device)
+    assert fw['collective_backend'] == 'nccl' and fw['collective_executed'] and fw['collective_error'] is None
     assert d['rooms_per_sec'] == fw['rooms_per_sec']
     fb = d['fixed_work_best']
     assert fb['all_rooms_labeled_after_gather'] and fb['rooms_per_sec'] >= fw['rooms_per_sec'] and set(fb['sweep']) == {'3', '6'}

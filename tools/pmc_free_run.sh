@@ -3,7 +3,7 @@
 # rocprofv3 --pmc passes of their own (FETCH_SIZE | WRITE_SIZE | SQ counters), the byte counters corrected on a 256 MiB copy as
 # MI355X_MICROARCH.md prescribes (tools/pmc_calib.py), the launch duration from a --kernel-trace pass of the same command.
 #   usage (GPU box): tools/pmc_free_run.sh <commit> [out.json]
-R=$GRAFT_REPO_ROOT; COMMIT=${1:-unknown}; OUT=${2:-gpurun_out/r04_pmc_free_run.json}
+R=$GRAFT_REPO_ROOT; COMMIT=${1:-unknown}; OUT=${2:-gpurun_out/r05_pmc_free_run.json}
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pmcf && mkdir -p /tmp/pmcf
 B="python $R/bench.py --gpus 1 --steps 6 --warmup 4 --cpu-seconds 0 --p0-rooms 0 --fixed-rooms 0 --steady-slots="
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pmcf/kt -o kt --output-format csv -- $B > /tmp/pmcf/kt.log 2>&1
