@@ -372,6 +372,11 @@ def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         _respawn_under_torchrun(args)
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner through C stdio when a communicator is
+    # created, flushed at exit -- after the line): everything but the line goes to stderr; the line is written to the real stdout at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from learn_region_grow_amd import _lib, synthetic, workloads, dist as lrg_dist
@@ -807,7 +812,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(base, weights, args.cpu_seconds, args.policy, room_steps, args.cpu_box_seconds)
         if world == 1 and args.p0_rooms > 0:
             out['preprocessing_p0'] = p0_rates(args.p0_rooms, dev)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if world > 1:
         dist.barrier()
     if dist.is_initialized():

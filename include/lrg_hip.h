@@ -142,8 +142,11 @@ enum {
     LRG_STOP_EMPTY = 5,      /* mask became empty; the reference raises at :292 -- defined as a stop here  */
     LRG_STOP_MAXSTEPS = 6,   /* optional safety cap (off when max_region_steps <= 0)                        */
     LRG_DONE = 7,            /* the slot's room has no unvisited seed left                                  */
-    LRG_WAIT = 8             /* finished its restarts, waiting for its group; also the state a host binds a
+    LRG_WAIT = 8,            /* finished its restarts, waiting for its group; also the state a host binds a
                                 fresh group in (with seed = -1) so that lrg_advance picks the first seed    */
+    LRG_PENDING = 9          /* lrg_grow_async with LrgAsyncBuffers.speculate > 1: the slot's region has stopped growing
+                                (last_reason says why) and waits for the regions of the room's earlier seeds to be
+                                committed first (test_region_grow.py:186-188 visits the seeds one after the other)    */
 };
 
 #define LRG_LOG_WORDS 8
@@ -220,6 +223,9 @@ typedef struct LrgSlot {
     int32_t acc_rmv;         /* likewise for the remove head (:180)                                                     */
     double ml_score;         /* --scoring ml: log-likelihood of the masks sampled in the restart in progress (restart :251-271) */
     double ml_best;          /* ... of the banked restart                                                                */
+    int32_t spec_pos;        /* speculation (ABI 9): position of the slot's seed in the room's seed order, INT32_MAX = no region in progress */
+    int32_t spec_flags;      /* bit 0: the region in progress is void -- a region committed before it took a point inside a box it
+                                had queried (:222-228 would have seen that point as visited); it is dropped and grown again         */
 } LrgSlot;
 
 #define LRG_SCAN_CHUNK 4096  /* points per workgroup of the chunked mask scans */
@@ -471,9 +477,10 @@ typedef struct LrgAsyncBuffers {
                                    the queue), [1] rooms queued, [2 + k] = room index | reset << 30 (reset: clear visited / labels /
                                    cursor first, as lrg_bind_group does).  A slot whose room is finished (or that has none) takes the
                                    next one inside the launch; finished rooms appear in the stats ring as slot | room << 32      */
-    uint64_t *work;             /* nullable: [4] running totals (never cleared by the library) of what the launches evaluated: LrgNet
+    uint64_t *work;             /* nullable: [8] running totals (never cleared by the library) of what the launches evaluated: LrgNet
                                    evaluations, distinct inlier rows, distinct neighbour rows, 32-row tiles per stack (branch = head) --
-                                   the algorithmic FLOPs of the launches follow from these                                        */
+                                   the algorithmic FLOPs of the launches follow from these; [4] regions voided and grown again under
+                                   `speculate`, [5] the evaluations those regions had taken (ABI 9: 8 words, was 4)                  */
     /* In-launch fill-in (ABI 8; all five non-NULL, 13 features): a room that finishes during the launch gets its 1-NN fill-in
        (test_region_grow.py:308-316) from tile teams of the same launch instead of from lrg_nn1_fill_batch between launches; such rooms
        carry bit 31 in the slot word of their done-ring entry.  The arenas are laid out like the label arena the rooms' LrgRoom.label
@@ -488,6 +495,13 @@ typedef struct LrgAsyncBuffers {
                                    else their last team); 0 = default (64)                                                                */
     int32_t rows16;             /* 1: buffers->x_in / x_nb hold row_cap x 16 floats (16-byte aligned): lrg_grow_async gathers its rows at a 64-byte stride
                                    in 16-byte pieces (9 .. 16 features); 0: row_cap x feature_size floats, one element per store (ABI 8)            */
+    int32_t speculate;          /* K > 1 (ABI 9): the slots are groups of K (slots g K .. g K + K - 1, one front workgroup per group), all bound to the SAME room:
+                                   the regions of the room's next K unvisited seeds grow side by side and are committed in seed order; a region is dropped and
+                                   grown again when a region committed before it contains a point inside any dilated box it has queried -- otherwise its
+                                   queries saw exactly what the sequential loop (:186-188,:210-217,:227-228) would have shown them.  Same regions, same labels;
+                                   for the few-rooms corner (one room or scene per GPU), where a room's chain of dependent steps leaves the chip idle.
+                                   n_slots must be a multiple of K; the caller binds whole groups (lrg_bind_group with group_size K); 0 / 1 = off           */
+    int32_t reserved2;
     int32_t start_wait_us;      /* the launch's start rendezvous (all its workgroups must be running at once): how long the front workgroups wait for the
                                    others before the launch gives up with reason 6; 0 = default: the launch budget + 20 ms (a kernel of another stream that
                                    holds CUs for up to one budget is waited out, something that never leaves is reported)  (ABI 9; was `reserved`) */

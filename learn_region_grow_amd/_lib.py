@@ -23,7 +23,7 @@ LRG_FWD_KEEP_ACTS = 4
 LRG_FWD_POOL_ZEROED = 8
 
 (LRG_IDLE, LRG_ACTIVE, LRG_STOP_NONEIGHBOR, LRG_STOP_NOEXPAND, LRG_STOP_STUCK, LRG_STOP_EMPTY, LRG_STOP_MAXSTEPS,
- LRG_DONE, LRG_WAIT) = range(9)
+ LRG_DONE, LRG_WAIT, LRG_PENDING) = range(10)
 REASON_NAMES = {LRG_STOP_NONEIGHBOR: 'noneighbor', LRG_STOP_NOEXPAND: 'noexpand', LRG_STOP_STUCK: 'stuck',
                 LRG_STOP_EMPTY: 'empty', LRG_STOP_MAXSTEPS: 'maxsteps'}
 
@@ -61,7 +61,8 @@ class LrgSlot(ctypes.Structure):
                 ('seq_mn', ctypes.c_int32 * 3), ('seq_mx', ctypes.c_int32 * 3),
                 ('target', ctypes.c_int32), ('pad', ctypes.c_int32), ('chunk_cnt', _fp), ('scan_cnt', ctypes.c_int32),
                 ('scan_mn', ctypes.c_int32 * 3), ('scan_mx', ctypes.c_int32 * 3), ('query', ctypes.c_int32),
-                ('acc_add', ctypes.c_int32), ('acc_rmv', ctypes.c_int32), ('ml_score', ctypes.c_double), ('ml_best', ctypes.c_double)]
+                ('acc_add', ctypes.c_int32), ('acc_rmv', ctypes.c_int32), ('ml_score', ctypes.c_double), ('ml_best', ctypes.c_double),
+                ('spec_pos', ctypes.c_int32), ('spec_flags', ctypes.c_int32)]
 
 
 LRG_SCAN_CHUNK = 4096
@@ -90,7 +91,7 @@ class LrgPackedBuffers(ctypes.Structure):
 class LrgAsyncBuffers(ctypes.Structure):
     _fields_ = [('queue', _fp), ('queue_bytes', ctypes.c_size_t), ('sync', _fp), ('front_workgroups', ctypes.c_int32), ('teams', ctypes.c_int32),
                 ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('branch_parts', ctypes.c_int32), ('gemv_units', ctypes.c_int32), ('room_queue', _fp), ('work', _fp),
-                ('fill_list', _fp), ('fill_best', _fp), ('fill_sync', _fp), ('fill_label_base', _fp), ('fill_out_base', _fp), ('fill_rooms', ctypes.c_int32), ('fill_wgs', ctypes.c_int32), ('rows16', ctypes.c_int32), ('start_wait_us', ctypes.c_int32),
+                ('fill_list', _fp), ('fill_best', _fp), ('fill_sync', _fp), ('fill_label_base', _fp), ('fill_out_base', _fp), ('fill_rooms', ctypes.c_int32), ('fill_wgs', ctypes.c_int32), ('rows16', ctypes.c_int32), ('speculate', ctypes.c_int32), ('reserved2', ctypes.c_int32), ('start_wait_us', ctypes.c_int32),
                 ('pool_rows', _fp), ('pool_rows_bytes', ctypes.c_size_t), ('debug_ticks', _fp)]
 
 

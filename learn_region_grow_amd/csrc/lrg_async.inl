@@ -814,7 +814,9 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
 }
 
 struct LrgAsyncFrontCtl {
-    int state[LRG_ASYNC_MAX_SERVED];     // 0 to be served, 1 evaluation in flight, 2 finished for this launch
+    int state[LRG_ASYNC_MAX_SERVED];     // 0 to be served, 1 evaluation in flight, 2 finished for this launch; speculation: 3 no seed left for the slot while the
+                                         // group's room is not finished (parked until the group is rebound), 4 region pending (served when it is the room's
+                                         // earliest in flight, or voided)
     int steps[LRG_ASYNC_MAX_SERVED];
     int tgt[LRG_ASYNC_MAX_SERVED][3];    // running targets of the slot's three arrival counters
     int bc[4];                           // broadcasts of thread 0
@@ -842,13 +844,15 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
     const int tid = threadIdx.x, lane = tid & 63;
     LrgAsyncFrontCtl &C = *reinterpret_cast<LrgAsyncFrontCtl *>(reinterpret_cast<char *>(smem) + ((sizeof(LrgFrontShared) + 15) & ~(size_t)15));
     const int f = blockIdx.x;
-    const int n_served = (A.n_slots - f + A.n_front - 1) / A.n_front;          // slots f, f + n_front, ...
+    const int spec_k = A.front.spec_k > 1 ? A.front.spec_k : 0;                // speculation: this workgroup serves the group f K .. f K + K - 1 (one room)
+    const int n_served = spec_k ? spec_k : (A.n_slots - f + A.n_front - 1) / A.n_front;          // else the slots f, f + n_front, ...
+    const int s_first = spec_k ? f * spec_k : f, s_step = spec_k ? 1 : A.n_front;
     const int row_stride = A.front.row_stride;
     const int n_gemv = A.gemv_units ? A.gemv_units : 2 * ((A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS);
     if (tid < LRG_ASYNC_MAX_SERVED) { C.state[tid] = tid < n_served ? 0 : 2; C.steps[tid] = 0; C.tgt[tid][0] = C.tgt[tid][1] = C.tgt[tid][2] = 0; }
     // a slot's rows have a fixed place in the row arrays: their tags are written once per launch
     for (int i = 0; i < n_served; ++i) {
-        const int s = f + i * A.n_front;
+        const int s = s_first + i * s_step;
         for (int j = tid; j < row_stride; j += LRG_FRONT_THREADS) {
             lrg_st_coh(&A.front.row_slot_in[(long)s * row_stride + j], s);
             lrg_st_coh(&A.front.row_slot_nb[(long)s * row_stride + j], s);
@@ -886,10 +890,32 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
         }
         int live = 0;
         for (int i = 0; i < n_served; ++i) {
-            const int s = f + i * A.n_front;
+            const int s = s_first + i * s_step;
             int st = C.state[i];
-            if (st == 2) continue;
-            ++live;
+            if (st == 2 || st == 3) continue;
+            if (st == 4) {
+                // a pending region: its turn has come when no slot of the group holds an earlier seed position, or it was voided; given up for this
+                // launch with the budget, or when nobody is left who could commit before it (every other slot finished for this launch)
+                if (tid == 0) {
+                    int others = 0;
+                    for (int k = 0; k < n_served; ++k) others += (C.state[k] == 0 || C.state[k] == 1) ? 1 : 0;
+                    const int my = slots[s].spec_pos;
+                    bool head = true;
+                    for (int k = 0; k < n_served; ++k)
+                        if (k != i && slots[s_first + k].spec_pos < my) head = false;
+                    C.bc[0] = (head || (slots[s].spec_flags & 1)) ? 1 : (others == 0 || wall_clock64() - t_launch > A.budget_ticks) ? 2 : 0;
+                }
+                __syncthreads();
+                const int turn = C.bc[0];
+                __syncthreads();
+                if (turn == 2) { if (tid == 0) C.state[i] = 2; continue; }
+                ++live;
+                if (turn == 0) continue;
+                if (tid == 0) C.state[i] = 0;
+                st = 0;
+            } else {
+                ++live;
+            }
             if (st == 1) {
                 if (tid == 0) C.bc[0] = lrg_ld_coh(&A.sync[(long)s * LRG_ASYNC_SYNC_WORDS + 2]) >= C.tgt[i][2];
                 __syncthreads();
@@ -924,7 +950,11 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 }
                 if (tid == 0) {
                     const int status = slots[s].status;
-                    const bool idle = slots[s].room < 0 || status == LRG_DONE || status == LRG_IDLE;
+                    // (speculation: a slot without a seed left is parked while the group's room is unfinished -- IDLE with the room bound; the slot that
+                    //  finishes the room went through DONE above and is IDLE with the others now: the group takes its next room as a whole)
+                    const bool parked = spec_k && status == LRG_IDLE && slots[s].room >= 0 && !rooms[slots[s].room].done;
+                    const bool pending = spec_k && status == LRG_PENDING;
+                    const bool idle = !parked && (slots[s].room < 0 || status == LRG_DONE || status == LRG_IDLE);
                     int next = -1;
                     if (idle && A.room_queue) {      // the slot's room is finished (or it has none): the next room of the queue, if any is left
                         if (lrg_ld_coh(&A.room_queue[0]) < A.room_queue[1]) {
@@ -933,11 +963,13 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                         }
                     }
                     C.bc[3] = next;
-                    C.state[i] = (idle && next < 0) ? 2 : 0;
+                    C.state[i] = parked ? 3 : pending ? 4 : (idle && next < 0) ? 2 : 0;
+                    if (spec_k && idle)              // the whole group: bound to the next room together, or finished for this launch together
+                        for (int k = 0; k < n_served; ++k) C.state[k] = next < 0 ? 2 : 0;
                 }
                 __syncthreads();
                 const int next = C.bc[3];
-                if (next >= 0) lrg_bind_group_device(slots, rooms, s, 1, next & 0x3FFFFFFF, next >> 30, 1);
+                if (next >= 0) lrg_bind_group_device(slots, rooms, spec_k ? s_first : s, spec_k ? spec_k : 1, next & 0x3FFFFFFF, next >> 30, 1);
                 __syncthreads();
                 continue;
             }

@@ -45,6 +45,9 @@ struct LrgFrontArgs {
     int row_stride;          // free-running kernel: slot s owns the rows [s * row_stride, (s + 1) * row_stride) of the row arrays
     int rows16;              // free-running kernel: 1 = the gathered rows are written at a 64-byte stride (16 floats, zero-padded) in 16-byte pieces
     int fill_in_launch;      // free-running kernel: finished rooms are filled in (:308-316) by tile teams of the same launch -- flagged in the done ring (bit 31 of the slot word)
+    unsigned long long *spec_stats;      // nullable: [0] regions voided by an earlier commit, [1] evaluations those regions had taken (LrgAsyncBuffers.work + 4)
+    int spec_k;              // free-running kernel: K > 1 = speculation -- the slots g K .. g K + K - 1 grow the regions of the next K unvisited seeds of ONE room
+                             // side by side (LrgAsyncBuffers.speculate; see "speculation" below); 0 / 1 = one slot, one room
 };
 
 // ---- (1) mask update of the evaluation just finished + count / bounding box of the new mask + stop decision ----
@@ -766,6 +769,116 @@ struct LrgFrontShared {
     int off[2];
 };
 
+// ---- speculation (LrgFrontArgs.spec_k = K > 1): several regions of ONE room in flight ----
+// The reference grows a room's regions one after the other: the seeds are visited in curvature order, a visited point is no seed and no
+// candidate (test_region_grow.py:186-188,:227-228), and a region marks its points visited when it stops (:210-217).  A room is a chain of
+// dependent steps, and a GPU that holds one room (BASELINE configs 3 and 5: one room or scene per GPU) runs one such chain.  Here the K slots of
+// a group, all served by ONE front workgroup, grow the regions of the room's next K unvisited seeds side by side:
+//   * seeds are handed out in order (R->seed_cursor), so the positions in flight are consecutive unvisited positions of the order;
+//   * regions are COMMITTED in seed order: a region that has stopped waits (LRG_PENDING, its members kept in its index list) until no
+//     slot of the group holds an earlier position;
+//   * a commit voids every later region in flight that could have seen one of the committed points as a candidate: every box query of a
+//     region lies inside [seq_mn - 1, seq_mx + 1] (its running bounding box, dilated: :222-225,:302-303), so a committed point inside that
+//     box of slot t sets t's void flag; t drops its region (at its next turn: an evaluation in flight cannot be recalled) and grows again
+//     from the same seed if that is still unvisited, else from the next seed handed out.  A region that was not voided saw, in every
+//     query, exactly the visited flags the sequential loop would have shown it: committed points outside its boxes never were candidates, and
+//     its own members cannot have been committed by another region (a member was a candidate first: inside a box).
+// The random stream is keyed by (room, seed point, step), not by slot or order of execution, so the regions, their order in the log and the
+// cluster ids (assigned at commit) are those of the sequential loop: identical labels (tests/test_gpu_speculation.py).
+#ifdef LRG_SPEC_TRACE      // (debug build: events of the speculation protocol into LrgAsyncBuffers.work + 8: [0] count, then 4 words per event -- tools/spec_debug.py allocates 4 x 65536)
+#define LRG_SPEC_EV(a, type, slot, v0, v1, v2) do { if ((a).spec_stats) { const unsigned long long e_ = atomicAdd(&(a).spec_stats[4], 1ULL); if (e_ < 65536) { \
+    unsigned long long *p_ = (a).spec_stats + 5 + 4 * e_; p_[0] = ((unsigned long long)(type) << 32) | (unsigned)(slot); p_[1] = (unsigned long long)(long long)(v0); \
+    p_[2] = (unsigned long long)(long long)(v1); p_[3] = (unsigned long long)(long long)(v2); } } } while (0)
+#else
+#define LRG_SPEC_EV(a, type, slot, v0, v1, v2) do {} while (0)
+#endif
+// Every decision of the protocol that all wavefronts must take alike is taken by THREAD 0 from loads of its own (past the L1) and handed to the others through LDS:
+// a "uniform" global load is not uniform in time -- wavefronts that read a word while another thread's store to it is on its way see different values, take
+// different branches and meet at different barriers (seen: the inlier half's sampling one phase behind the rest).
+__device__ __forceinline__ bool lrg_spec_is_head(LrgFrontShared &SH, const LrgSlot *slots, int g0, int K, int s, int my_pos) {
+    __syncthreads();                             // (SH.i[7] may still be read from the last broadcast)
+    if (threadIdx.x == 0) {
+        bool head = true;
+        for (int t = g0; t < g0 + K; ++t)
+            if (t != s && lrg_ld_coh(&slots[t].spec_pos) < my_pos) head = false;
+        SH.i[7] = head ? 1 : 0;
+    }
+    __syncthreads();
+    return SH.i[7] != 0;
+}
+
+// Commit of the region slot s holds in its index list (entries that are no longer members -- removed by the last update -- are skipped):
+// :210-217, the log entry, and the void flags of the later regions in flight.  All threads; ends with a barrier.
+__device__ __noinline__ void lrg_spec_commit(LrgFrontShared &SH, LrgSlot *slots, LrgRoom *R, int g0, int K, int s, const LrgGrowParams &prm, const LrgFrontArgs &a,
+                                             int nlist, int count) {
+    const int tid = threadIdx.x;
+    LrgSlot *S = &slots[s];
+    int *sh_box = SH.tabc;                    // [K - 1 <= 15][6] dilated running boxes of the later regions in flight, [96 + b] their slots (LDS free between two phases of the front)
+    int *sh_hit = SH.i + 7;                   // bit t: slot g0 + t is void
+    const int labeled = count > prm.cluster_threshold;                                       // :213   (nlist, count: in registers from the caller)
+    const int cid = R->next_cluster_id;
+    uint8_t *cur = S->cur, *visited = R->visited;
+    int32_t *label = R->label;
+    const int32_t *cur_idx = S->cur_idx;
+    const int32_t *vox = R->voxels;
+    // the dilated running boxes of the other regions in flight, through LDS (thread 0 reads them past the L1)
+    if (tid == 0) {
+        int k = 0;
+        for (int t = g0; t < g0 + K; ++t) {
+            if (t == s || lrg_ld_coh(&slots[t].spec_pos) == INT_MAX) continue;
+            const LrgSlot *T = &slots[t];
+            for (int d = 0; d < 3; ++d) { sh_box[6 * k + d] = lrg_ld_coh(&T->seq_mn[d]) - 1; sh_box[6 * k + 3 + d] = lrg_ld_coh(&T->seq_mx[d]) + 1; }
+            sh_box[96 + k] = t - g0;
+            ++k;
+        }
+        sh_box[120] = k;
+        *sh_hit = 0;
+    }
+    __syncthreads();
+    const int nb = sh_box[120];
+    int hit = 0;
+    for (int i = tid; i < nlist; i += LRG_FRONT_THREADS) {
+        const int id = lrg_ld_coh(&cur_idx[i]);                                              // (the list may have been written a moment ago, by other wavefronts)
+        if (!cur[id]) continue;
+        visited[id] = 1; if (labeled) label[id] = cid; cur[id] = 0;                          // :212,:214 + reset
+        if (nb) {
+            const int x = vox[3 * (long)id], y = vox[3 * (long)id + 1], z = vox[3 * (long)id + 2];
+            for (int b = 0; b < nb; ++b)
+                if (x >= sh_box[6 * b] && x <= sh_box[6 * b + 3] && y >= sh_box[6 * b + 1] && y <= sh_box[6 * b + 4] && z >= sh_box[6 * b + 2] && z <= sh_box[6 * b + 5])
+                    hit |= 1 << sh_box[96 + b];
+        }
+    }
+    if (hit) atomicOr(sh_hit, hit);
+    // (__syncthreads() does not wait for global stores -- `s_waitcnt lgkmcnt(0); s_barrier` -- and the other wavefronts read these flags right behind the barrier:
+    //  the seed search that follows must see this region's points as visited)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+#ifdef LRG_SPEC_VOID_ALL      // (debug switch: every commit voids every other region in flight -- speculation without any benefit, and without the box test)
+        int h = 0;
+        for (int t = 0; t < K; ++t) if (g0 + t != s && slots[g0 + t].spec_pos != INT_MAX) h |= 1 << t;
+#else
+        const int h = *sh_hit;
+#endif
+        for (int t = 0; t < K; ++t)
+            if (h >> t & 1) slots[g0 + t].spec_flags |= 1;
+        int32_t *log = R->region_log + LRG_LOG_WORDS * (long)R->n_regions;
+        log[0] = S->seed; log[1] = S->steps_total; log[2] = count; log[3] = S->last_reason; log[4] = labeled; log[5] = 0;
+        log[6] = S->acc_add; log[7] = S->acc_rmv;
+        R->n_regions += 1;
+        if (labeled) R->next_cluster_id = cid + 1;                                           // :215
+        if (a.stats) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[0]), 1ULL);
+        }
+        if (h && a.spec_stats) atomicAdd(&a.spec_stats[0], (unsigned long long)__popc(h));
+        LRG_SPEC_EV(a, 3, s, S->seed, (count << 8) | S->last_reason, h);
+        S->spec_pos = INT_MAX;
+        S->status = LRG_WAIT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
 // One slot's front: returns 0 when no evaluation was prepared (slot idle / room finished / seed search to be continued), else
 // (distinct inlier rows << 16) | distinct neighbour rows.
 // ASYNC (the free-running kernel, lrg_async.inl): the slot's rows live at the fixed offset s * a.row_stride of the row arrays,
@@ -834,6 +947,37 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     VI.ox = ox; VI.oy = oy; VI.oz = oz;
     VI.hkeys = R->hash_keys; VI.hvals = R->hash_vals; VI.hmask = R->hash_mask;
     const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
+    const int K = ASYNC ? a.spec_k : 1;
+    const bool spec = ASYNC && K > 1;                    // several regions of this room in flight (see "speculation" above)
+    const int g0 = spec ? (s / K) * K : s;
+    int list_n = nc0, list_count = 0;            // the pending region's list length and member count, carried in registers through this call
+    int spec_void = 0, my_pos = INT_MAX, cursor = 0;
+    if (spec) {
+        // the slot's and the room's words that steer this call, read once by thread 0 (see lrg_spec_is_head) and broadcast
+        if (tid == 0) {
+            sh_tabe[0] = lrg_ld_coh(&S->status); sh_tabe[1] = lrg_ld_coh(&S->count); sh_tabe[2] = lrg_ld_coh(&S->spec_flags);
+            sh_tabe[3] = lrg_ld_coh(&S->spec_pos); sh_tabe[4] = lrg_ld_coh(&R->seed_cursor); sh_tabe[5] = lrg_ld_coh(&S->nc);
+        }
+        __syncthreads();
+        status = sh_tabe[0]; list_count = sh_tabe[1]; spec_void = sh_tabe[2] & 1; my_pos = sh_tabe[3]; cursor = sh_tabe[4]; list_n = sh_tabe[5];
+        __syncthreads();
+    }
+    if (spec && spec_void) {
+        // the region in progress was voided by a commit of an earlier region: dropped here, at the slot's first turn since (the evaluation that was
+        // in flight is ignored); its list holds every member of the mask (all of it after a box query, a superset while pending)
+        if (status == LRG_ACTIVE || status == LRG_PENDING || lrg_is_stop(status)) {
+            for (int i = tid; i < list_n; i += LRG_FRONT_THREADS) cur[lrg_ld_coh(&cur_idx[i])] = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the mask is read again by other wavefronts behind the barrier below)
+            if (tid == 0) {
+                if (a.spec_stats) atomicAdd(&a.spec_stats[1], (unsigned long long)(steps_total0 + (status == LRG_ACTIVE ? 1 : 0)));      // (+ the evaluation that was in flight)
+                LRG_SPEC_EV(a, 4, s, seed0, status, nc0);
+                S->status = LRG_WAIT;                    // (spec_pos stays: the seed search below starts there)
+            }
+            status = LRG_WAIT;
+        }
+        if (tid == 0) { S->spec_flags = 0; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __syncthreads();
+    }
     const int entry_status = status;
     TRACE2(s, 0);
     long long t_phase = (ASYNC && LRG_ASYNC_DEBUG && a.phase_dbg) ? wall_clock64() : 0;
@@ -850,7 +994,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     if (status == LRG_ACTIVE) {
         if (tid == 0) { sh_i[0] = 0; sh_i[1] = 0; sh_i[5] = 0; sh_i[6] = 0; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) id0[k] = cur_idx[min(tid + k * LRG_FRONT_THREADS, nc0 - 1)];
+        for (int k = 0; k < 4; ++k) id0[k] = spec ? lrg_ld_coh(&cur_idx[min(tid + k * LRG_FRONT_THREADS, nc0 - 1)]) : cur_idx[min(tid + k * LRG_FRONT_THREADS, nc0 - 1)];
         const int nside = half ? nc0 : ne0, Nside = half ? Ni : Nn;
         if (mine && nside < Nside)
             sj = (int)lrg_sample_position((uint32_t)j, (uint32_t)nside, (uint32_t)Nside, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
@@ -876,6 +1020,9 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
                 else take = lrg_uniform01(lrg_rng_word((uint32_t)j, half ? LRG_PURPOSE_RMV : LRG_PURPOSE_ADD, (uint32_t)seed0,
                                                        (uint32_t)restart0, (uint32_t)step0, k0, k1)) < conf;   // :266-267
             }
+#ifdef LRG_SPEC_TRACE
+            if (spec && j == 0) LRG_SPEC_EV(a, 5 + half, s, seed0, ((long long)__float_as_uint(lg[0]) << 32) | __float_as_uint(lg[1]), ((long long)take << 40) | ((long long)(row & 0xFFFFF) << 20) | (srow & 0xFFFFF));
+#endif
             if (take) {
                 // the rows are stored uncentred: (x - c) + c in float32, as the reference centres (:243,:246) and un-centres
                 // (:271,:275) the row -- not x itself
@@ -974,6 +1121,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
                 }
             }
             if (st != LRG_ACTIVE) { S->status = st; S->last_reason = st; }
+            if (spec) LRG_SPEC_EV(a, 2, s, seed0, (cnt << 16) | (sh_i[1] << 4) | st, (nc0 << 16) | ne0);
             sh_i[2] = st;
             sh_box[6] = cnt;
         }
@@ -984,6 +1132,149 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     TRACE2(s, 1); phase(1);
 
     // =========================== (2) commit (:210-217), next seed (:186-188), reset (:197-204) ===========================
+    if (spec) {
+        if (lrg_is_stop(status)) {
+            // the region has stopped; it is committed in its turn (lrg_spec_commit) from its index list: after an update the old entries (those
+            // the update removed are skipped there) + the points this step switched on; after a stop taken by the box query the list as it is
+            if (entry_status == LRG_ACTIVE) {
+                const int nadd = sh_i[1];
+                for (int k = tid; k < nadd; k += LRG_FRONT_THREADS) cur_idx[nc0 + k] = sh_src[0][k];
+                if (tid == 0) S->nc = nc0 + nadd;
+                list_n = nc0 + nadd;
+                list_count = sh_box[6];
+            }
+            if (tid == 0) S->status = LRG_PENDING;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (list and length are read by the commit, by every wavefront)
+            __syncthreads();
+            status = LRG_PENDING;
+        }
+        const int32_t *order = R->order;
+        // (what this call itself changes is carried in registers, not read back: a barrier does not wait for thread 0's global stores)
+        for (int round = 0; status == LRG_PENDING || status == LRG_WAIT; ++round) {
+            if (status == LRG_PENDING) {
+                if (!lrg_spec_is_head(SH, slots, g0, K, s, my_pos)) {      // an earlier seed's region is still in flight: wait
+                    if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
+                    return 0;
+                }
+                lrg_spec_commit(SH, slots, R, g0, K, s, prm, a, list_n, list_count);
+                status = LRG_WAIT;
+                my_pos = INT_MAX;
+            }
+            if (round >= LRG_SEED_TRIES) {          // (a run of one-point regions: the next turn goes on)
+                if (tid == 0) { a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0; }
+                return 0;
+            }
+            // the next seed: a voided region's own, while unvisited; else the next unvisited position of the order that no slot holds (:186-188)
+            const int own = my_pos;
+            int found = -1;
+            if (own != INT_MAX) {                // (the voided region's own seed: still unvisited? -- thread 0's look, broadcast)
+                __syncthreads();
+                if (tid == 0) sh_i[3] = __hip_atomic_load(&visited[order[own]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 1;
+                __syncthreads();
+                if (sh_i[3]) found = own;
+                __syncthreads();
+            }
+            if (found < 0) {
+                while (cursor < n) {
+                    const int pos = cursor + tid;
+                    int cand = INT_MAX;
+                    if (pos < n && !visited[order[pos]]) cand = pos;
+                    if (tid == 0) sh_i[3] = INT_MAX;
+                    __syncthreads();
+                    if (cand != INT_MAX) atomicMin(&sh_i[3], cand);
+                    __syncthreads();
+                    const int best = sh_i[3];
+                    __syncthreads();
+                    if (best != INT_MAX) { found = best; break; }
+                    cursor += LRG_FRONT_THREADS;
+                }
+                if (found >= 0) cursor = found + 1;
+                if (tid == 0) R->seed_cursor = found >= 0 ? cursor : n;
+            }
+            if (found < 0) {
+                // no seed left for this slot.  The room is finished when that holds for every slot of the group: the last one reports it.
+                if (tid == 0) {
+                    bool all = true;
+                    for (int t = g0; t < g0 + K; ++t)
+                        if (t != s && slots[t].status != LRG_IDLE) all = false;
+                    S->spec_pos = INT_MAX; S->seed = -1; S->count = -1;
+                    if (all) {
+                        R->done = 1;
+                        S->status = LRG_DONE;
+                        if (a.stats) {
+                            unsigned long long k = atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[1]), 1ULL);
+                            a.stats[4 + (k % LRG_DONE_RING)] = (int64_t)s | (a.fill_in_launch ? (int64_t)1 << 31 : 0) | ((int64_t)room << 32);
+                        }
+                    } else {
+                        S->status = LRG_IDLE;                // (room still bound: the group is rebound as a whole)
+                    }
+                    a.slot_rows[4 * s + 0] = 0; a.slot_rows[4 * s + 1] = 0; big[2 * s] = 0;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the serving loop reads the status right behind this call)
+                }
+                __syncthreads();
+                return 0;
+            }
+            const int sd = order[found];
+            if (tid < 64) {
+                int idx = -1;
+                if (tid < 27 && tid != 13) {
+                    const int dx = tid / 9 - 1, dy = (tid / 3) % 3 - 1, dz = tid % 3 - 1;
+                    const int32_t *v = R->voxels + 3 * (long)sd;
+                    idx = lrg_voxel_index(VI, v[0] + dx, v[1] + dy, v[2] + dz);
+                    if (idx >= 0 && (visited[idx] || idx == sd)) idx = -1;
+                }
+                int rank = 0, total = 0;
+                for (int l = 0; l < 27; ++l) {
+                    const int o = __shfl(idx, l);
+                    if (o >= 0) { ++total; if (idx >= 0 && o < idx) ++rank; }
+                }
+                if (idx >= 0) sh_list[rank] = idx;
+                if (tid == 0) sh_i[4] = total;
+            }
+            __syncthreads();
+            const int total = sh_i[4];
+            __syncthreads();
+            if ((int)tid < total) cand_idx[tid] = sh_list[tid];
+            if (tid == 0) {
+                // (the slot's mask is all zero here: a commit and a drop both clear their members)
+                cur[sd] = 1;                                                                  // :197-198
+                cur_idx[0] = sd;
+                S->seed = sd; S->restart = 0; S->step = 0; S->stuck = 0; S->updated = -1;
+                S->nc = 1; S->ne = total; S->count = 1;
+                for (int d = 0; d < 3; ++d) {
+                    const int v = R->voxels[3 * sd + d];
+                    S->mn[d] = v; S->mx[d] = v; S->seq_mn[d] = v; S->seq_mx[d] = v;          // :199-202
+                }
+                const int tg = obj ? obj[sd] : 0;
+                S->target = tg;
+                sh_box[7] = tg;
+                S->pad = 1;
+                S->scan_cnt = 0;
+                S->scan_mn[0] = S->scan_mn[1] = S->scan_mn[2] = INT_MAX;
+                S->scan_mx[0] = S->scan_mx[1] = S->scan_mx[2] = INT_MIN;
+                S->steps_total = 0; S->best_count = -1; S->best_restart = INT_MAX;
+                S->acc_add = -1; S->acc_rmv = -1;
+                S->spec_pos = found;
+                LRG_SPEC_EV(a, 1, s, sd, found, (total << 16) | (total > 0 ? (sh_list[0] & 0xFFFF) : 0xFFFF));
+                // a seed without an unvisited neighbour is a region of its own, 'noneighbor' before any step (:233-235): committed in its turn like every other
+                S->last_reason = total > 0 ? 0 : LRG_STOP_NONEIGHBOR;
+                S->status = total > 0 ? LRG_ACTIVE : LRG_PENDING;
+            }
+            my_pos = found;
+            list_n = 1; list_count = 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (mask, lists and slot fields are read by other wavefronts behind this barrier: the sampling, the medians, a commit)
+            __syncthreads();
+            if (total > 0) {
+                q_nc = 1; q_ne = total;
+                cur_seed = sd; cur_restart = 0; cur_step = 0;
+                lists_ready = true;
+                status = LRG_ACTIVE;
+                cur_target = sh_box[7];
+            } else {
+                status = LRG_PENDING;
+            }
+        }
+    } else {
     if (lrg_is_stop(status)) {
         // members of the finished region: after an update, the survivors found above; after a stop taken by the box query
         // ('noneighbor', step cap), the list that query compacted (every entry a member)
@@ -1126,6 +1417,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         status = LRG_ACTIVE;
         cur_target = sh_box[7];
     }
+    }      // (not speculating)
     TRACE2(s, 2); phase(2);
     const long long tick1 = a.phase_ticks ? wall_clock64() : 0;
     if (a.phase_ticks && tid == 0) a.phase_ticks[2 * s + 0] += tick1 - tick0;
@@ -1326,7 +1618,8 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         if (j < min(nn, kk)) {
             const int pos = nn < kk ? j : (int)lrg_sample_position((uint32_t)j, (uint32_t)nn, (uint32_t)kk, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
                                                                    (uint32_t)cur_seed, (uint32_t)cur_restart, (uint32_t)cur_step, k0, k1);
-            sh_src[half ? 0 : 1][j] = (half ? cur_idx : cand_idx)[pos];
+            // (a fresh seed: the lists were stored a moment ago by other threads -- the seed and its neighbours are still at hand in a register / in LDS)
+            sh_src[half ? 0 : 1][j] = lists_ready ? (half ? cur_seed : sh_list[pos]) : (half ? cur_idx : cand_idx)[pos];
         }
     }
     if (tid == 0) {
@@ -1364,7 +1657,8 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         const int ch = lrg_centred_channel(wave, F);
         if (ch >= 0) {
             const LrgChanSrc cs = lrg_chan_src(R, wave, ch, F);
-            const float m = nc <= 256 ? lrg_median_wave_r<4>(cs.base, cur_idx, cs.stride, nc)
+            const float m = lists_ready ? cs.base[(long)cur_seed * cs.stride]                  // (a fresh seed: the median of one point is that point, :241)
+                          : nc <= 256 ? lrg_median_wave_r<4>(cs.base, cur_idx, cs.stride, nc)
                           : nc <= 1024 ? lrg_median_wave_r<16>(cs.base, cur_idx, cs.stride, nc)
                                        : lrg_median_wave_r64(cs.base, cur_idx, cs.stride, nc);
             if (lane == 0) sh_c[ch] = m;
@@ -1377,6 +1671,9 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     __syncthreads();
     TRACE2(s, 5); phase(5);
     // the branch kernels and the next update centre with it (:243-247,:271,:275)
+#ifdef LRG_SPEC_TRACE
+    if (spec && tid == 0) LRG_SPEC_EV(a, 7, s, cur_seed, ((long long)sh_src[0][0] << 32) | (unsigned)sh_src[1][0], ((long long)__float_as_uint(sh_c[0]) << 32) | __float_as_uint(sh_c[1]));
+#endif
     if constexpr (ASYNC) { if (tid < 4) lrg_st_coh4(a.center + s * 16, (unsigned)tid * 16u, *reinterpret_cast<const float4 *>(sh_c + 4 * tid)); }
     else if (tid < 16) a.center[s * 16 + tid] = sh_c[tid];
     TRACE2(s, 6);

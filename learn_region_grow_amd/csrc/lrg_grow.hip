@@ -87,6 +87,7 @@ __device__ __noinline__ void lrg_bind_group_device(LrgSlot *slots, LrgRoom *room
             for (int i = tid; i < n; i += blockDim.x) S->cur[i] = 0;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0)
         for (int s = first_slot; s < first_slot + group_size; ++s) {
@@ -99,7 +100,11 @@ __device__ __noinline__ void lrg_bind_group_device(LrgSlot *slots, LrgRoom *room
             S->acc_add = -1; S->acc_rmv = -1; S->ml_score = 0.0; S->ml_best = 0.0;
             S->scan_cnt = 0; S->query = 0;
             for (int d = 0; d < 3; ++d) { S->scan_mn[d] = INT_MAX; S->scan_mx[d] = INT_MIN; }
+            S->spec_pos = INT_MAX; S->spec_flags = 0;
         }
+    // (the free-running kernel serves these slots right behind this barrier, every wavefront reading the fields thread 0 has just stored: __syncthreads()
+    //  waits for LDS traffic only -- `s_waitcnt lgkmcnt(0); s_barrier` -- so the stores are waited for explicitly)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
 
@@ -1635,6 +1640,16 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     n_front = max(n_front, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED);
     n_front = min(n_front, wgs / 2);                         // (at least half of the CUs for the tile teams)
     if (n_front < (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED) return LRG_EINVAL - 8;      // more slots than the front workgroups can serve
+    // Speculation (LrgAsyncBuffers.speculate = K > 1): groups of K slots on one room each, one front workgroup per group (a group's shared state -- the
+    // room's visited flags, labels, seed cursor, the other slots' boxes -- stays on one CU and needs no hand-over)
+    a.spec_k = 0;
+    a.spec_stats = nullptr;
+    if (ab->speculate > 1) {
+        if (ab->speculate > LRG_ASYNC_MAX_SERVED || n_slots % ab->speculate != 0 || n_slots / ab->speculate > wgs / 2) return LRG_EINVAL - 8;
+        a.spec_k = ab->speculate;
+        n_front = n_slots / ab->speculate;
+        if (ab->work) a.spec_stats = reinterpret_cast<unsigned long long *>(ab->work) + 4;
+    }
     // Pooled-product units (lrg_async.inl): sixteen CUs for the LrgNet of the paper (2 heads x 256 columns, 1024 pooled features).
     // Off (-1), or where the slices do not fit / would leave the tile teams fewer than half of the CUs: the teams' 128-column blocks.  Off
     // above 176 slots too: sixteen units take ~1.1 M pooled products a second, and the head tiles that wait for them hold their teams

@@ -53,7 +53,8 @@ class RegionGrower:
     def __init__(self, net, rooms_in_flight=64, restarts=1, group_size=None, rng='counter', seed=0, policy='net',
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
                  skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np', free_run=None,
-                 free_run_steps=1 << 20, free_run_budget_us=5000, free_run_fronts=0, free_run_teams=0, free_run_fill_cus=None, free_run_units=0):
+                 free_run_steps=1 << 20, free_run_budget_us=5000, free_run_fronts=0, free_run_teams=0, free_run_fill_cus=None, free_run_units=0,
+                 speculate=0):
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
         graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*).
@@ -65,7 +66,20 @@ class RegionGrower:
         the first stream of fill_streams(device, free_run_fill_cus) (grower.main_stream), the fill-ins go to the second by themselves.
         None = LRG_FREE_RUN_FILL_CUS, else 0 (fill-ins on the launches' stream).  Measured at 68 rooms in flight: 8 CUs 838-843 k against
         836 k instance-steps/s, 541 against 547 rooms/s fixed work; 6 CUs cannot keep up (728 k), 12 cost more than the fill-ins
-        (profiles/r03_units_sweep.log) -- an option, off by default."""
+        (profiles/r03_units_sweep.log) -- an option, off by default.
+        speculate: K > 1 = K slots per room in flight (free-running launches only): the regions of a room's next K unvisited seeds grow side by
+        side and are committed in seed order; a region that an earlier commit could have influenced (a committed point inside a box it had
+        queried) is dropped and grown again -- identical regions and labels (LrgAsyncBuffers.speculate, csrc/lrg_front.inl).  `rooms_in_flight`
+        stays the number of ROOMS in flight; K x that many slots.  For few rooms per GPU (one room or scene per GPU: a single chain of dependent
+        steps otherwise)."""
+        self.speculate = int(speculate) if speculate and int(speculate) > 1 else 0
+        if self.speculate:
+            if restarts != 1 or rng != 'counter' or (group_size not in (None, 1)) or free_run is False:
+                raise ValueError('speculate needs greedy growing (restarts = 1), the counter stream and free-running launches')
+            if self.speculate > 16:
+                raise ValueError('speculate: at most 16 slots per room')
+            group_size = self.speculate      # the host's slot groups: K slots, one room
+            free_run = True
         self.lib = _lib.load()
         self.net = net
         self.dev = net.device
@@ -89,7 +103,7 @@ class RegionGrower:
         p.n_neighbor = net.num_neighbor_points
         p.cluster_threshold = cluster_threshold
         p.restarts = restarts
-        p.group_size = self.G
+        p.group_size = 1 if self.speculate else self.G      # (speculation: greedy slots; their grouping is the launcher's: LrgAsyncBuffers.speculate)
         p.max_region_steps = max_region_steps
         p.rng_seed = seed & 0xFFFFFFFF
         p.policy = POLICIES[policy]
@@ -347,7 +361,7 @@ class RegionGrower:
             pb.rooms_have_pvox = 1 if self.have_pvox else 0
             self.packed_buffers = pb
             # free-running launches (lrg_grow_async): greedy growing through the single-launch front, lite 0 / 2
-            can_free = (self.G == 1 and self.params.restarts == 1 and self.have_pvox and max(Ni, Nn) <= 512 and
+            can_free = ((self.G == 1 or self.speculate) and self.params.restarts == 1 and self.have_pvox and max(Ni, Nn) <= 512 and
                         getattr(self.net, 'lite', 0) != 1)
             if self.want_free_run and not can_free:
                 raise ValueError('free-running launches need greedy growing (restarts = group_size = 1), rooms with packed voxel words, '
@@ -395,7 +409,8 @@ class RegionGrower:
                     ab.fill_label_base, ab.fill_out_base = self.d_label.data_ptr(), self.d_filled.data_ptr()
                     ab.fill_rooms = len(rooms)
                     ab.fill_wgs = int(os.environ.get('LRG_FREE_RUN_FILL_WGS', '0'))
-                self.a_work = torch.zeros(4, dtype=torch.int64, device=dev)      # evaluations, inlier rows, neighbour rows, tiles
+                self.a_work = torch.zeros(8, dtype=torch.int64, device=dev)      # evaluations, inlier rows, neighbour rows, tiles; speculation: regions voided, their evaluations
+                ab.speculate = self.speculate if self.speculate > 1 else 0
                 ab.work = self.a_work.data_ptr()
                 if os.environ.get('LRG_FREE_RUN_DEBUG') == '1':          # stage-by-stage tick accumulators (tools/free_run_perf.py)
                     self.a_dbg = torch.zeros(64, dtype=torch.int64, device=dev)
@@ -456,6 +471,7 @@ class RegionGrower:
             sl.pad = 0
             sl.scan_cnt = 0
             sl.query = 0
+            sl.spec_pos, sl.spec_flags = 2147483647, 0
             for d in range(3):
                 sl.scan_mn[d], sl.scan_mx[d] = 2147483647, -2147483648
         a, b = group * self.G, (group + 1) * self.G
@@ -1049,6 +1065,14 @@ def lane_streams(device, lanes, cu_partition=False):
                 raw.append(h)
                 streams.append(torch.cuda.ExternalStream(h.value, device=device))
     return streams[:lanes]
+
+
+def auto_speculate(rooms_in_flight):
+    """Regions of one room in flight (RegionGrower(speculate=K)) by the number of rooms this GPU holds at a time.  A room is a chain of dependent
+    steps (test_region_grow.py:186-188); with few rooms the chip idles through it, and a front workgroup (one per room) serves ~3 slots before its own
+    ~25 us per step become the bound.  Measured (profiles/r05_speculation.txt): see DESIGN.md section 3.0."""
+    n = int(rooms_in_flight)
+    return 4 if n <= 8 else 3 if n <= 16 else 2 if n <= 32 else 0
 
 
 class LanedRegionGrower:

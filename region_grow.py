@@ -70,6 +70,10 @@ def parse(argv=None):
     ap.add_argument('--gpus', type=int, default=None, help='GPUs of this node, one process each: started by the script itself when it is not already '
                                                             'running under torch.distributed.run (whose LOCAL_WORLD_SIZE must agree when both are given; '
                                                             'without --gpus the launcher decides)')
+    ap.add_argument('--speculate', type=int, default=-1,
+                    help='regions of ONE room grown side by side (committed in seed order, voided and grown again on a conflict: identical labels); '
+                         '-1 = automatic: learn_region_grow_amd.grow.auto_speculate(rooms in flight) -- several per room while the rooms on this GPU are '
+                         'few (one room or scene per GPU is a single chain of dependent steps otherwise), 0 / 1 = off')
     ap.add_argument('--lanes', type=int, default=0, help='groups of slots on their own HIP streams (counter stream only); 0 = auto')
     ap.add_argument('--quiet-regions', action='store_true', help='do not print the per-region lines (test_region_grow.py:217)')
     ap.add_argument('--timing', action='store_true',
@@ -232,6 +236,8 @@ def main(argv=None):
                   resolution=args.resolution)
         if args.scoring == 'ml':
             kw['scoring'] = 'ml'
+        from learn_region_grow_amd.grow import auto_speculate
+        spec_k = auto_speculate(in_flight) if args.speculate < 0 else args.speculate
         t0 = time.time()
         buckets = None
         if not rooms:
@@ -246,6 +252,8 @@ def main(argv=None):
         elif args.shared_stream:
             kw['rooms_in_flight'] = 1
             results = RegionGrower(net, **kw).run(rooms, legacy_shared_seed=args.seed)
+        elif args.rng == 'counter' and max(1, args.restarts) == 1 and spec_k > 1 and RegionGrower.free_run_applies(net, rooms, in_flight * spec_k, **kw):
+            results = RegionGrower(net, speculate=spec_k, **kw).run(rooms)
         elif args.rng == 'counter' and args.lanes != 1:
             results = LanedRegionGrower(net, lanes=args.lanes, **kw).run(rooms)
         else:
