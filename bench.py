@@ -89,6 +89,10 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cpu-box-seconds', type=float, default=12.0,
                     help='cpu_baseline.all_cores: the oracle on many rooms at once, one single-threaded process per room, for this long (0 = skip)')
+    ap.add_argument('--speculate', type=int, default=0,
+                    help='regions of ONE room grown side by side in the steady and fixed-work legs (RegionGrower(speculate=K): committed in seed order, voided and grown '
+                         'again on a conflict, identical labels); 0 = off (the legs keep `--rooms` rooms in flight, one slot each)')
+    ap.add_argument('--one-room-ks', default='1,2,3,4,6', help='one_room_per_gpu: the speculation depths tried on ONE room on the chip (empty = skip)')
     ap.add_argument('--one-rank-collective', type=int, default=1,
                     help='--gpus 1: 1 = a one-rank RCCL process group is brought up and the fixed-work leg\'s label gather goes through its all_gather '
                          '(the nccl branch of learn_region_grow_amd/dist.py executed on the device); 0 = the single-rank short cut')
@@ -279,6 +283,55 @@ def p0_rates(n_rooms, dev):
     return out
 
 
+def one_room_corner(net, rooms, picks, ks, grow_kw, dev, step_us):
+    """BASELINE configs 3 and 5 as they are named: ONE room (or scene) on the chip.  A room is a chain of dependent steps (test_region_grow.py:186-188: the next
+    seed is the next point the regions so far have left unvisited), so one slot per room leaves a 256-CU part on a single ~70 us chain; with speculation
+    (RegionGrower(speculate=K)) the regions of the next K seeds grow side by side and are committed in order.  Per room and K: seconds from reset to final labels
+    (grow + fill-in), committed steps/s, what was thrown away, and whether the labels equal the K = 1 run's (they must)."""
+    import torch
+    from learn_region_grow_amd.grow import RegionGrower
+    out = {}
+    kw = {k: v for k, v in grow_kw.items() if k != 'graph_iterations'}
+    for name, idx in picks:
+        room = dict(rooms[idx], room_id=424242 + idx)
+        per_k, ref = {}, None
+        for K in ks:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                gr = RegionGrower(net, rooms_in_flight=1, seed=0, free_run=True, free_run_budget_us=int(step_us), speculate=K if K > 1 else 0, **kw)
+                gr.load_rooms([room])
+                torch.cuda.synchronize()
+                best = None
+                for rep in range(2):          # (the second pass: module and allocator warm)
+                    gr.reset_room(0)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    gr.grow_loaded(fill=True)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None else min(best, dt)
+                lab = gr.d_filled[:gr.room_n[0]].cpu().numpy()
+                rr = gr._read_rooms()[0]
+                rl = gr.d_rlog.cpu().numpy().reshape(-1, 8)[:rr.n_regions]
+                work = gr.a_work.cpu().numpy()
+            committed = int(rl[:, 1].sum())
+            if ref is None:
+                ref = lab
+            per_k[str(K)] = {'seconds_per_room': best, 'committed_steps': committed, 'committed_steps_per_sec': committed / best, 'regions': int(rr.n_regions),
+                             'evaluations_executed_two_passes': int(work[0]), 'regions_voided_two_passes': int(work[4]), 'evaluations_voided_two_passes': int(work[5]),
+                             'labels_equal_k1': bool(np.array_equal(lab, ref))}
+            gr._release_graph()
+            del gr
+            torch.cuda.empty_cache()
+        k1 = per_k[str(ks[0])]['seconds_per_room']
+        bestk = min(per_k, key=lambda k: per_k[k]['seconds_per_room'])
+        out[name] = {'points': int(len(room['points'])), 'by_speculation_depth': per_k, 'best_depth': int(bestk), 'speedup_over_one_chain': k1 / per_k[bestk]['seconds_per_room'],
+                     'all_labels_equal': all(v['labels_equal_k1'] for v in per_k.values())}
+    out['what'] = ('ONE room in flight on the whole GPU, free-running launches; depth K = regions of that room grown side by side (1 = the single dependent chain), '
+                   'reset -> grow -> fill-in, best of two passes')
+    return out
+
+
 def _respawn_under_torchrun(args):
     """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks (one per GPU) and become their launcher."""
     # (--standalone: the launcher finds a free port itself; one picked and closed here could be taken before the ranks start)
@@ -310,7 +363,8 @@ class _Leg:
             self.stream = fill_streams(dev, fill_cus)[0] if fill_cus > 0 else torch.cuda.Stream(device=dev)
             with torch.cuda.stream(self.stream):
                 self.gr = RegionGrower(net, rooms_in_flight=slots, seed=seed, free_run=True, free_run_budget_us=int(step_budget_us),
-                                       free_run_fill_cus=fill_cus, **{k: v for k, v in grow_kw.items() if k != 'graph_iterations'})
+                                       free_run_fill_cus=fill_cus, speculate=int(getattr(args, 'speculate', 0)),
+                                       **{k: v for k, v in grow_kw.items() if k != 'graph_iterations'})
                 self.gr.load_rooms(jobs)
             self.growers = [self.gr]
             self.lanes = 1
@@ -544,7 +598,9 @@ def main():
     if dbg0 is not None and rank == 0:
         print(json.dumps(leg.gr.free_run_breakdown(since=dbg0)), file=sys.stderr)
     elapsed = lrg_dist.allreduce_max(t1 - t0, device=coll_dev)
-    inst_steps, rooms_cycled, seeds = lrg_dist.allreduce_sum([float(s1[2] - s0[2]), float(s1[1] - s0[1]), float(s1[0] - s0[0])], device=coll_dev)
+    # (speculation: the device's step counter also holds the steps of regions that were voided and grown again -- `value` counts the steps regions KEEP)
+    voided_steps = float(w1[6] - w0[6]) if (leg.free and args.speculate > 1) else 0.0
+    inst_steps, rooms_cycled, seeds = lrg_dist.allreduce_sum([float(s1[2] - s0[2]) - voided_steps, float(s1[1] - s0[1]), float(s1[0] - s0[0])], device=coll_dev)
     if int(s1[3]):
         raise SystemExit('bench.py: lrg_grow_async gave up on a hand-over (%d): the numbers would be invalid' % int(s1[3]))
 
@@ -571,6 +627,9 @@ def main():
                                          'copies that pad a set to 512 rows and the copies that pad a slot\'s rows to whole 32-row tiles are NOT counted',
                      'evaluations': dw[0], 'rows_evaluated': [dw[1], dw[2]], 'rows_evaluated_fraction': (dw[1] + dw[2]) / max(dw[0] * 1024.0, 1.0),
                      'tiles_run_per_stack': dw[3], 'rows_in_tiles_fraction': (dw[1] + dw[2]) / max(dw[3] * 32.0, 1.0),
+                     'speculation': ({'depth': args.speculate, 'regions_voided': dw[4], 'evaluations_voided': dw[5], 'steps_voided': dw[6],
+                                      'note': 'algorithmic_flops_in_loop counts every evaluation executed, voided ones included (work done, not work kept); '
+                                              '`value` counts kept steps only'} if args.speculate > 1 else None),
                      'reproduce': 'rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps %d --warmup %d  (profiles/r04_bench_kernel_stats.csv)'
                                   % (args.steps, args.warmup)})
     else:
@@ -808,6 +867,14 @@ def main():
                 except Exception as e:      # (informational leg: never fails the line)
                     sweep[str(sl)] = {'error': repr(e)[:200]}
             out['steady_more_rooms_in_flight'] = sweep
+        if world == 1 and args.one_room_ks and args.restarts == 1 and packed:
+            ks = [int(x) for x in args.one_room_ks.split(',') if x.strip()]
+            by_size = sorted(range(len(base)), key=lambda i: len(base[i]['points']))
+            picks = [('scene_0', 0)] if args.workload == 'kitti' else [('median_room', by_size[len(by_size) // 2]), ('largest_room', by_size[-1])]
+            try:
+                out['one_room_per_gpu'] = one_room_corner(net, base, picks, ks, grow_kw, dev, step_us)
+            except Exception as e:      # noqa: BLE001 -- a side measurement must not take the line down
+                out['one_room_per_gpu'] = {'error': repr(e)[:300]}
         if world == 1 and args.cpu_seconds > 0:
             out['cpu_baseline'] = cpu_baseline(base, weights, args.cpu_seconds, args.policy, room_steps, args.cpu_box_seconds)
         if world == 1 and args.p0_rooms > 0:

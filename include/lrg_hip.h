@@ -480,7 +480,8 @@ typedef struct LrgAsyncBuffers {
     uint64_t *work;             /* nullable: [8] running totals (never cleared by the library) of what the launches evaluated: LrgNet
                                    evaluations, distinct inlier rows, distinct neighbour rows, 32-row tiles per stack (branch = head) --
                                    the algorithmic FLOPs of the launches follow from these; [4] regions voided and grown again under
-                                   `speculate`, [5] the evaluations those regions had taken (ABI 9: 8 words, was 4)                  */
+                                   `speculate`, [5] the evaluations those regions had taken, [6] of these: steps counted in stats[2]
+                                   (ABI 9: 8 words, was 4)                                                                          */
     /* In-launch fill-in (ABI 8; all five non-NULL, 13 features): a room that finishes during the launch gets its 1-NN fill-in
        (test_region_grow.py:308-316) from tile teams of the same launch instead of from lrg_nn1_fill_batch between launches; such rooms
        carry bit 31 in the slot word of their done-ring entry.  The arenas are laid out like the label arena the rooms' LrgRoom.label
@@ -511,9 +512,19 @@ typedef struct LrgAsyncBuffers {
     size_t pool_rows_bytes;
     uint64_t *debug_ticks;      /* nullable: [64] accumulators (never cleared by the library) of wall-clock ticks by stage of the
                                    launch, for tools/free_run_perf.py (layout: csrc/lrg_async.inl, LrgAsyncArgs.dbg)            */
+    /* Shared tail tiles (ABI 9; tail_ctl non-NULL, tail_rows > 0, rows16): a slot's rows beyond its last full 32-row tile (16 of ~91 rows per side on
+       average: as padded tiles of the slot's own they were 18 % of all tile rows) go to `tail_rows` rows per side that ALL slots share -- rows
+       [n_slots * row_stride, + tail_rows) of the row arrays (buffers->row_cap and the workspace must cover them) -- so that the tails of several slots fill one
+       branch tile.  Same results bit for bit (the shared tile is lrg_forward_packed's tile: runs of rows, per-run max-pool).  When a launch runs out of
+       shared rows the slots pad tiles of their own again.                                                                                        */
+    int32_t *tail_ctl;          /* lrg_grow_async_tail_bytes(n_slots, tail_rows) bytes, 64-byte aligned (cleared by every call)                    */
+    int32_t tail_rows;          /* a multiple of 32                                                                                                */
+    int32_t tail_close_us;      /* a slot closes its last shared tile (the rest of its rows stay empty) when nobody has filled it up that long after the
+                                   slot's rows went out; 0 = default (2 us), -1 = at once                                                          */
 } LrgAsyncBuffers;
 
 size_t lrg_grow_async_queue_bytes(int n_slots);
+size_t lrg_grow_async_tail_bytes(int n_slots, int tail_rows);
 size_t lrg_grow_async_pool_rows_bytes(const LrgWeights *weights, int n_slots);
 
 /* One free-running launch: every slot takes up to max_steps evaluations (grow steps), and starts no new one once budget_us

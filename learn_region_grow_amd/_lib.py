@@ -92,7 +92,8 @@ class LrgAsyncBuffers(ctypes.Structure):
     _fields_ = [('queue', _fp), ('queue_bytes', ctypes.c_size_t), ('sync', _fp), ('front_workgroups', ctypes.c_int32), ('teams', ctypes.c_int32),
                 ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('branch_parts', ctypes.c_int32), ('gemv_units', ctypes.c_int32), ('room_queue', _fp), ('work', _fp),
                 ('fill_list', _fp), ('fill_best', _fp), ('fill_sync', _fp), ('fill_label_base', _fp), ('fill_out_base', _fp), ('fill_rooms', ctypes.c_int32), ('fill_wgs', ctypes.c_int32), ('rows16', ctypes.c_int32), ('speculate', ctypes.c_int32), ('reserved2', ctypes.c_int32), ('start_wait_us', ctypes.c_int32),
-                ('pool_rows', _fp), ('pool_rows_bytes', ctypes.c_size_t), ('debug_ticks', _fp)]
+                ('pool_rows', _fp), ('pool_rows_bytes', ctypes.c_size_t), ('debug_ticks', _fp),
+                ('tail_ctl', _fp), ('tail_rows', ctypes.c_int32), ('tail_close_us', ctypes.c_int32)]
 
 
 class LrgFillJob(ctypes.Structure):
@@ -213,6 +214,7 @@ _SIGS = {
     'lrg_grow_step_packed': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),
                                             ctypes.POINTER(LrgWeights), ctypes.POINTER(LrgPackedBuffers), _fp]),
     'lrg_grow_async_queue_bytes': (ctypes.c_size_t, [ctypes.c_int]),
+    'lrg_grow_async_tail_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'lrg_grow_async': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams), ctypes.POINTER(LrgWeights),
                                       ctypes.POINTER(LrgPackedBuffers), ctypes.POINTER(LrgAsyncBuffers), ctypes.c_int, ctypes.c_int, _fp]),
     'lrg_front_step': (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LrgGrowParams),

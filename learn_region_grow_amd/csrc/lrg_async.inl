@@ -99,6 +99,15 @@ struct LrgAsyncArgs {
     int small_teams;             // the first so many teams of a worker workgroup run branch tiles only, on the smaller LDS region (four teams per workgroup)
     int small_alt;               // 1: ... and one more of them on the odd workgroups
     int fill_extra;              // 1: ... and that team is one more than the other workgroups have (where LDS and threads allow: up to three tile teams)
+    // Shared tail tiles (nullable: tail == nullptr -> every slot pads its own last tile).  A slot's rows beyond its last full 32-row tile -- 16 of 91 rows per side
+    // on average: 18 % of all tile rows were such padding -- are reserved from a cursor per side in rows that all slots share (LrgFrontArgs.tail_*), so that the
+    // tails of several slots fill one BRANCH tile: the tile code's packed form (runs of rows of one slot each: per-run max-pool, lrg_forward_packed's arithmetic bit
+    // for bit).  A tile is published by whoever brings its count of written rows to 32; a slot whose last tile stays open longer than tail_ticks closes it (the
+    // cursor is moved to the tile's end, the missing rows count as dead).  The HEAD stack of a tail stays a tile of the slot's own: it reads the slot's conv[1] rows
+    // where the shared tile left them and stores the logits of the slot's rows only (lrg_fused_tile: nrows_out).
+    int32_t *tail;               // [0] / [16] the sides' row cursors (= LrgFrontArgs.tail_cur); [32 + 2 * (side * tail_tiles + tile)] rows written, [.. + 1] dead rows
+    int tail_tiles;              // shared tiles per side
+    long long tail_ticks;        // (wall_clock64: 100 MHz)
     float *pool_rows;            // nullable (with the units): [n_slots][2 sides][16 tiles][P / 2] column maxima by branch tile, instead of atomicMax on the pooled feature
     int pool_rows_stride;        // 2 * 16 * (P / 2)
     int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
@@ -134,6 +143,17 @@ __device__ __forceinline__ void lrg_async_push(const LrgAsyncArgs &A, int ring, 
     if (lane == 0) base = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL + ring * LRG_AQ_SECOND], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     base = __shfl(base, 0);
     if (lane < n) lrg_st_coh(&A.queue[LRG_AQ_RING + ring * (A.qmask + 1) + ((base + lane) & A.qmask)], code_of(lane));
+}
+
+// the head tiles of a slot whose pooled feature is complete: head 0 = add on the neighbour rows, head 1 = remove on the inlier rows; w_in / w_nb = the side's tiles
+// of the slot's own | bit 12: its tail lies in the shared rows and gets a head tile of its own there (index 16)
+__device__ __forceinline__ void lrg_async_push_heads(const LrgAsyncArgs &A, int slot, int w_in, int w_nb, int lane) {
+    const int nt_in = w_in & 0xFFF, nt_nb = w_nb & 0xFFF, sh_in = (w_in >> 12) & 1, sh_nb = (w_nb >> 12) & 1;
+    lrg_async_push(A, A.head_ring, nt_nb + nt_in + sh_nb + sh_in, lane, [&](int i) {
+        if (i < nt_nb) return LRG_TASK(LRG_TASK_HEAD, slot, 0, i);
+        if (i < nt_nb + nt_in) return LRG_TASK(LRG_TASK_HEAD, slot, 1, i - nt_nb);
+        return (i == nt_nb + nt_in && sh_nb) ? LRG_TASK(LRG_TASK_HEAD, slot, 0, 16) : LRG_TASK(LRG_TASK_HEAD, slot, 1, 16);
+    });
 }
 
 // ---- pooled product of a head's first layer for ONE slot and 128 columns by a team of four wavefronts, in the summation order of
@@ -279,6 +299,34 @@ __device__ __forceinline__ LrgLdsTeam lrg_async_team(const LrgAsyncArgs &A, floa
     return team;
 }
 
+// ---- shared tail tiles: accounting of written rows, by ONE thread ----
+__device__ __forceinline__ int32_t *lrg_tail_words(const LrgAsyncArgs &A, int side, int tile) { return A.tail + 32 + 2 * ((long)side * A.tail_tiles + tile); }
+// `cnt` more rows of shared tile (side, tile) are written and drained (`dead` of them: rows nobody will write); the one who completes the tile publishes it
+__device__ __forceinline__ bool lrg_tail_account(const LrgAsyncArgs &A, int side, int tile, int cnt, int dead) {
+    int32_t *w = lrg_tail_words(A, side, tile);
+    if (dead) {      // (recorded before the count that may complete the tile: the atomic's result is waited for)
+        const int d0 = __hip_atomic_fetch_add(&w[1], dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" :: "v"(d0));
+    }
+    const int f = __hip_atomic_fetch_add(&w[0], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + cnt;
+    if (f == 32) {
+        const int e = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lrg_st_coh(&A.queue[LRG_AQ_RING + (e & A.qmask)], LRG_TASK(LRG_TASK_BRANCH, tile, side, 16));      // (ring 0; idx 16 = a shared tile, the slot field its number)
+        if (A.work) atomicAdd(&A.work[3], 1ULL);
+    }
+    return f >= 32;
+}
+// the slot's last shared tile on `side` has been open for too long: closed if the cursor still stands inside it.  1: nothing left to do for this slot, 0: try again
+__device__ __forceinline__ int lrg_tail_close(const LrgAsyncArgs &A, int side, int tile) {
+    if (lrg_ld_coh(&lrg_tail_words(A, side, tile)[0]) >= 32) return 1;
+    int c = lrg_ld_coh(&A.tail[16 * side]);
+    if ((c >> 5) != tile) return 1;              // (every row of the tile is reserved: whoever writes the last one publishes it)
+    if (!__hip_atomic_compare_exchange_strong(&A.tail[16 * side], &c, (tile + 1) * 32, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;
+    const int dead = (tile + 1) * 32 - c;
+    lrg_tail_account(A, side, tile, dead, dead);
+    return 1;
+}
+
 // ---- the three task types (each returns the team's barrier count, to be handed to the next one) ----
 LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task, int &next_ticket, int *ticket_word) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
@@ -288,12 +336,20 @@ LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
     const LrgLdsTeam team = lrg_async_team(A, sm, target);
     const int tid = team.tid(), lane = tid & 63;
     const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 31, part = (code >> 5) & 3;      // (tile, part of its pooled layer)
-    int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
     int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
-    const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
     long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;      // (LRG_TRACE build: cycle stamps of the tile's phases)
-    lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps,
-                                                                                            LrgNoWait(), part, A.branch_parts);
+    const bool shared = idx == 16;               // a shared tail tile: `slot` is its number; rows of several slots, the runs of its 32 rows (lrg_tail_account)
+    int nruns = 1;
+    if (shared) {
+        const int dead = lrg_ld_coh(&lrg_tail_words(A, side, slot)[1]);
+        const long r0 = (long)A.front.tail_row0 + (long)slot * 32;
+        nruns = lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, false>(A.prob[side], r0, 0, 0, 0x7fffffff, (int)(r0 + 32 - dead), sm, team,
+                                                                                                       stamps, LrgNoWait(), 0, 1);
+    } else {
+        const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
+        lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps,
+                                                                                                LrgNoWait(), part, A.branch_parts);
+    }
 #if LRG_TRACE == 2176
     if (tid == 0 && LRG_DBG(A)) {      // cycles since the tile began, at every stamp (tools/free_run_perf.py prints their means)
         for (int i = 1; i < 21; ++i) if (stamps[i] > stamps[0]) lrg_dbg_add(A, 32 + i, stamps[i] - stamps[0]);
@@ -306,7 +362,14 @@ LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
     if (LRG_TICKET_EARLY && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lrg_drain_stores();                              // conv[1] rows and the pooled maxima are out before the arrival
     team.sync();
+    // (a shared tile arrives for every slot that has rows in it: the runs the tile found, lrg_fused_tile's LDS layout)
+    const int *run_inst = reinterpret_cast<const int *>(sm + 32 * 68 + 32 * 132 + 512) + 33;
+    for (int run = 0; run < nruns; ++run) {
+    const int aslot = shared ? run_inst[run] : slot;
+    if (aslot < 0) continue;
+    int32_t *sy = A.sync + (long)aslot * LRG_ASYNC_SYNC_WORDS;
     if (tid < 64) {
+        const int slot = aslot;
         int last = 0, nt_in = 0, nt_nb = 0;
         if (lane == 0) {
             // (the evaluation's targets and tile counts were written before its tasks were published: fetched beside the arrival, not after it)
@@ -317,7 +380,7 @@ LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
             last = done == tgt;
             if (LRG_DBG(A)) {
                 const long long now = wall_clock64();
-                lrg_dbg_add(A, 8 + 2 * LRG_TASK_BRANCH, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_BRANCH, 1);
+                if (run == 0) { lrg_dbg_add(A, 8 + 2 * LRG_TASK_BRANCH, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_BRANCH, 1); }
                 if (last) lrg_dbg_add(A, 2, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
             }
         }
@@ -329,18 +392,17 @@ LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
                     // (entry: generation tag | tiles per side - 1, four bits each | slot -- the units take the maximum over the slot's tile rows)
                     const int i = __hip_atomic_fetch_add(&A.queue[LRG_AQ_GTAIL], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     lrg_st_coh(&A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (i & A.gmask)],
-                               (lrg_gemv_ring_tag(i, A.gmask) << 20) | (((nt_in - 1) & 15) << 16) | (((nt_nb - 1) & 15) << 12) | slot);
+                               (lrg_gemv_ring_tag(i, A.gmask) << 20) | ((((nt_in & 0xFFF) - 1) & 15) << 16) | ((((nt_nb & 0xFFF) - 1) & 15) << 12) | slot);
                 }
                 nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
-                lrg_async_push(A, A.head_ring, nt_nb + nt_in, lane, [&](int i) {
-                    return i < nt_nb ? LRG_TASK(LRG_TASK_HEAD, slot, 0, i) : LRG_TASK(LRG_TASK_HEAD, slot, 1, i - nt_nb);
-                });
+                lrg_async_push_heads(A, slot, nt_in, nt_nb, lane);
             } else {
                 const int nb = (A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS;
                 lrg_async_push(A, A.head_ring, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
             }
         }
     }
+    }      // (runs of a shared tile)
     return team.target;
 }
 
@@ -367,9 +429,7 @@ __device__ __forceinline__ void lrg_async_gemv_arrive(const LrgAsyncArgs &A, con
         }
         if (__shfl(last, 0)) {                       // head 0 = add on the neighbour rows, head 1 = remove on the inlier rows
             nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
-            lrg_async_push(A, A.head_ring, nt_nb + nt_in, lane, [&](int i) {
-                return i < nt_nb ? LRG_TASK(LRG_TASK_HEAD, slot, 0, i) : LRG_TASK(LRG_TASK_HEAD, slot, 1, i - nt_nb);
-            });
+            lrg_async_push_heads(A, slot, nt_in, nt_nb, lane);
         }
     }
 }
@@ -562,7 +622,10 @@ LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
     int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
     int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
-    const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
+    // (index 16: the head tile of the slot's TAIL rows, where the shared branch tile(s) left their conv[1] rows; the rows behind them are other slots')
+    const bool tail = idx == 16;
+    const long r0 = tail ? (long)A.front.tail_row0 + lrg_ld_coh(&sy[side ? 9 : 10]) : (long)slot * A.front.row_stride + (long)idx * 32;
+    const int rows_out = tail ? ((lrg_ld_coh(&sy[11]) >> (side ? 0 : 16)) & 0xFFFF) : 32;
     long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;
     // (a head tile shares its CU with a branch tile of another slot and is the shorter of the two: issued first where both want a SIMD --
     //  852 -> 856 k instance-steps/s at 68 rooms in flight; the branch tiles first: 847 k)
@@ -570,10 +633,11 @@ LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     if (A.gemv_units) {
         LrgWaitPooled wait;
         wait.sy = sy; wait.queue = A.queue; wait.t_launch = t_launch; wait.abort_ticks = A.abort_ticks;
-        lrg_fused_tile<32 * 260, 32 * 68, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true, LrgWaitPooled>(A.prob[2 + side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm,
-                                                                                                               team, stamps, wait);
+        lrg_fused_tile<32 * 260, 32 * 68, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true, LrgWaitPooled>(A.prob[2 + side], r0, slot, tail ? 0 : idx, 0x7fffffff, 0x7fffffff, sm,
+                                                                                                               team, stamps, wait, 0, 1, rows_out);
     } else {
-        lrg_fused_tile<32 * 260, 32 * 68, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[2 + side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps);
+        lrg_fused_tile<32 * 260, 32 * 68, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[2 + side], r0, slot, tail ? 0 : idx, 0x7fffffff, 0x7fffffff, sm, team, stamps,
+                                                                                                LrgNoWait(), 0, 1, rows_out);
     }
 #if LRG_TRACE == 8320
     if (tid == 0 && LRG_DBG(A)) {
@@ -820,6 +884,8 @@ struct LrgAsyncFrontCtl {
     int steps[LRG_ASYNC_MAX_SERVED];
     int tgt[LRG_ASYNC_MAX_SERVED][3];    // running targets of the slot's three arrival counters
     int bc[4];                           // broadcasts of thread 0
+    int open_tile[LRG_ASYNC_MAX_SERVED][2];      // shared tail tiles: the side's last shared tile of the evaluation in flight while it is unpublished, else -1
+    long long open_since[LRG_ASYNC_MAX_SERVED];
 };
 
 // ---- one slot's front step, a function of its own: the register allocation of lrg_front_greedy_kernel (no spills) instead of the
@@ -849,7 +915,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
     const int s_first = spec_k ? f * spec_k : f, s_step = spec_k ? 1 : A.n_front;
     const int row_stride = A.front.row_stride;
     const int n_gemv = A.gemv_units ? A.gemv_units : 2 * ((A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS);
-    if (tid < LRG_ASYNC_MAX_SERVED) { C.state[tid] = tid < n_served ? 0 : 2; C.steps[tid] = 0; C.tgt[tid][0] = C.tgt[tid][1] = C.tgt[tid][2] = 0; }
+    if (tid < LRG_ASYNC_MAX_SERVED) { C.state[tid] = tid < n_served ? 0 : 2; C.steps[tid] = 0; C.tgt[tid][0] = C.tgt[tid][1] = C.tgt[tid][2] = 0; C.open_tile[tid][0] = C.open_tile[tid][1] = -1; }
     // a slot's rows have a fixed place in the row arrays: their tags are written once per launch
     for (int i = 0; i < n_served; ++i) {
         const int s = s_first + i * s_step;
@@ -889,7 +955,47 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
             break;
         }
         int live = 0;
-        for (int i = 0; i < n_served; ++i) {
+        int chosen = -1;
+        if (spec_k) {
+            // Speculation: ONE slot per pass, the ready one with the earliest seed position -- the room's earliest region in flight is what every later one waits
+            // for (in-order commit), so its steps come first; the slots that only speculate take the front workgroup's time that is left.
+            if (tid == 0) {
+                int first = -1, first_pos = INT_MAX;
+                for (int k = 0; k < n_served; ++k) {
+                    const int p = slots[s_first + k].spec_pos;
+                    if (p < first_pos) { first = k; first_pos = p; }
+                }
+                const bool over = wall_clock64() - t_launch > A.budget_ticks;
+                int best = -1, best_pos = 0, nlive = 0;
+                for (int k = 0; k < n_served; ++k) {
+                    const int stk = C.state[k];
+                    if (stk == 2 || stk == 3) continue;
+                    ++nlive;
+                    bool ready = stk == 0;
+                    if (stk == 1) {
+                        ready = lrg_ld_coh(&A.sync[(long)(s_first + k) * LRG_ASYNC_SYNC_WORDS + 2]) >= C.tgt[k][2];
+                        if (!ready && A.tail && (C.open_tile[k][0] >= 0 || C.open_tile[k][1] >= 0) && wall_clock64() - C.open_since[k] > A.tail_ticks)
+                            for (int side = 0; side < 2; ++side)
+                                if (C.open_tile[k][side] >= 0 && lrg_tail_close(A, side, C.open_tile[k][side])) C.open_tile[k][side] = -1;
+                    }
+                    if (stk == 4) ready = k == first || (slots[s_first + k].spec_flags & 1) || over || (first >= 0 && C.state[first] == 2);
+                    const int p = slots[s_first + k].spec_pos;
+                    if (ready && (best < 0 || p < best_pos)) { best = k; best_pos = p; }
+                }
+                C.bc[0] = best; C.bc[1] = nlive;
+            }
+            __syncthreads();
+            chosen = C.bc[0];
+            live = C.bc[1];
+            __syncthreads();
+            if (chosen < 0) {
+                if (!live) break;
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+        }
+        for (int ii = 0; ii < (spec_k ? 1 : n_served); ++ii) {
+            const int i = spec_k ? chosen : ii;
             const int s = s_first + i * s_step;
             int st = C.state[i];
             if (st == 2 || st == 3) continue;
@@ -897,13 +1003,16 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 // a pending region: its turn has come when no slot of the group holds an earlier seed position, or it was voided; given up for this
                 // launch with the budget, or when nobody is left who could commit before it (every other slot finished for this launch)
                 if (tid == 0) {
-                    int others = 0;
-                    for (int k = 0; k < n_served; ++k) others += (C.state[k] == 0 || C.state[k] == 1) ? 1 : 0;
+                    // (the slot that holds the room's earliest seed position: it is what this one waits for -- if THAT slot is finished for this launch,
+                    //  so is this one; a test for "anybody still at work" gave up while the earliest region's slot was itself pending, a moment before its
+                    //  turn, and blocked everything behind it until the next launch)
                     const int my = slots[s].spec_pos;
-                    bool head = true;
-                    for (int k = 0; k < n_served; ++k)
-                        if (k != i && slots[s_first + k].spec_pos < my) head = false;
-                    C.bc[0] = (head || (slots[s].spec_flags & 1)) ? 1 : (others == 0 || wall_clock64() - t_launch > A.budget_ticks) ? 2 : 0;
+                    int first = i, first_pos = my;
+                    for (int k = 0; k < n_served; ++k) {
+                        const int p = slots[s_first + k].spec_pos;
+                        if (k != i && p < first_pos) { first = k; first_pos = p; }
+                    }
+                    C.bc[0] = (first == i || (slots[s].spec_flags & 1)) ? 1 : (C.state[first] == 2 || wall_clock64() - t_launch > A.budget_ticks) ? 2 : 0;
                 }
                 __syncthreads();
                 const int turn = C.bc[0];
@@ -917,6 +1026,10 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 ++live;
             }
             if (st == 1) {
+                if (tid == 0 && A.tail && (C.open_tile[i][0] >= 0 || C.open_tile[i][1] >= 0) && wall_clock64() - C.open_since[i] > A.tail_ticks) {
+                    for (int side = 0; side < 2; ++side)
+                        if (C.open_tile[i][side] >= 0 && lrg_tail_close(A, side, C.open_tile[i][side])) C.open_tile[i][side] = -1;
+                }
                 if (tid == 0) C.bc[0] = lrg_ld_coh(&A.sync[(long)s * LRG_ASYNC_SYNC_WORDS + 2]) >= C.tgt[i][2];
                 __syncthreads();
                 const int ready = C.bc[0];
@@ -976,12 +1089,20 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
             // The evaluation's targets and the reservation of its queue entries go out with the rows (one trip, not three in a row);
             // rows, centre, the zeroed pooled feature and the targets are out (write-through) once every wavefront has drained; only
             // then the entries are written -- a consumer waits for its entry, not for the reservation.
-            const int nt_in = ((r >> 16) + 31) >> 5, nt_nb = ((r & 0xFFFF) + 31) >> 5;
+            // (shared tail tiles: a side whose tail went to the shared rows has tiles of its own for its FULL tiles only; its tail is in one or two shared branch
+            //  tiles, which arrive on the slot's counter like its own, and in one head tile of the slot's own on those rows)
+            const LrgFrontShared &SHr = *reinterpret_cast<const LrgFrontShared *>(smem);
+            const int rin = r >> 16, rnb = r & 0xFFFF;
+            const int tb_in = A.tail ? SHr.tail[0] : -1, tb_nb = A.tail ? SHr.tail[1] : -1;
+            const int nt_in = tb_in >= 0 ? rin >> 5 : (rin + 31) >> 5, nt_nb = tb_nb >= 0 ? rnb >> 5 : (rnb + 31) >> 5;
+            const int sh_in = tb_in >= 0 ? 1 : 0, sh_nb = tb_nb >= 0 ? 1 : 0;
+            const int nsh = (sh_in ? 1 + ((((tb_in + (rin & 31) - 1) >> 5) != (tb_in >> 5)) ? 1 : 0) : 0) + (sh_nb ? 1 + ((((tb_nb + (rnb & 31) - 1) >> 5) != (tb_nb >> 5)) ? 1 : 0) : 0);
             if (tid == 0) {
                 int32_t *sy = A.sync + (long)s * LRG_ASYNC_SYNC_WORDS;
-                C.tgt[i][0] += (nt_in + nt_nb) * A.branch_parts; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb;
+                C.tgt[i][0] += (nt_in + nt_nb) * A.branch_parts + nsh; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb + sh_in + sh_nb;
+                if (A.tail) { lrg_st_coh(&sy[9], tb_in); lrg_st_coh(&sy[10], tb_nb); lrg_st_coh(&sy[11], (rin & 31) | ((rnb & 31) << 16)); }
                 lrg_st_coh4(reinterpret_cast<float *>(sy), 16u, make_float4(__int_as_float(C.tgt[i][0]), __int_as_float(C.tgt[i][1]), __int_as_float(C.tgt[i][2]),
-                                                                      __int_as_float(nt_in | (nt_nb << 16))));      // (one 16-byte store instead of five dwords)
+                                                                      __int_as_float((nt_in | (sh_in << 12)) | ((nt_nb | (sh_nb << 12)) << 16))));      // (one 16-byte store instead of five dwords)
                 if (LRG_DBG(A)) {
                     const long long now = wall_clock64();
                     lrg_st_coh(&sy[8], (int)(unsigned)now);
@@ -1002,6 +1123,24 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 if (tid < nt * A.branch_parts)
                     lrg_st_coh(&A.queue[LRG_AQ_RING + ((C.bc[3] + tid) & A.qmask)],      // (ring 0)
                                (t < nt_in ? LRG_TASK(LRG_TASK_BRANCH, s, 0, t) : LRG_TASK(LRG_TASK_BRANCH, s, 1, t - nt_in)) | (part << 5));
+            }
+            if (A.tail && tid == 0) {
+                // the tail rows are out (drained above): counted into their shared tiles -- whoever completes a tile publishes it; the side's last tile, if
+                // still open, is watched by this workgroup's polls (closed after tail_ticks)
+                const long long now = wall_clock64();
+                for (int side = 0; side < 2; ++side) {
+                    const int tb = side ? tb_nb : tb_in, tl = (side ? rnb : rin) & 31;
+                    C.open_tile[i][side] = -1;
+                    if (tb >= 0) {
+                        const int ta = tb >> 5, tz = (tb + tl - 1) >> 5, ca = min(32 - (tb & 31), tl);
+                        bool full = lrg_tail_account(A, side, ta, ca, 0);
+                        if (tz != ta) full = lrg_tail_account(A, side, tz, tl - ca, 0);
+                        if (!full) C.open_tile[i][side] = tz;
+                    }
+                    const int dead = SHr.tail[2 + side];
+                    if (dead) lrg_tail_account(A, side, A.tail_tiles - 1, dead, dead);      // (a reservation that fell off the end of the shared rows)
+                }
+                C.open_since[i] = now;
             }
             __syncthreads();
         }

@@ -45,7 +45,14 @@ struct LrgFrontArgs {
     int row_stride;          // free-running kernel: slot s owns the rows [s * row_stride, (s + 1) * row_stride) of the row arrays
     int rows16;              // free-running kernel: 1 = the gathered rows are written at a 64-byte stride (16 floats, zero-padded) in 16-byte pieces
     int fill_in_launch;      // free-running kernel: finished rooms are filled in (:308-316) by tile teams of the same launch -- flagged in the done ring (bit 31 of the slot word)
-    unsigned long long *spec_stats;      // nullable: [0] regions voided by an earlier commit, [1] evaluations those regions had taken (LrgAsyncBuffers.work + 4)
+    // free-running kernel, shared tail tiles (lrg_async.inl): a slot's rows beyond its last FULL 32-row tile go to rows that the slots share, reserved from a cursor
+    // per side -- several slots' tails fill one tile instead of each padding a tile of its own.  nullable (then every slot pads its own tail, as before).
+    int32_t *tail_cur;       // [0] / [16]: rows reserved so far on the inlier / neighbour side (one 64-byte line each)
+    int32_t *tail_base;      // [n_slots][2]: where the slot's tail rows of its evaluation in flight start in the shared rows (-1: in its own place)
+    int tail_rows;           // shared rows per side (a multiple of 32)
+    int tail_row0;           // first shared row in the row arrays (= n_slots * row_stride)
+    unsigned long long *spec_stats;      // nullable: [0] regions voided by an earlier commit, [1] evaluations those regions had taken, [2] of them: mask updates done, i.e. steps the
+                                         // device's step counter holds that no committed region keeps (LrgAsyncBuffers.work + 4)
     int spec_k;              // free-running kernel: K > 1 = speculation -- the slots g K .. g K + K - 1 grow the regions of the next K unvisited seeds of ONE room
                              // side by side (LrgAsyncBuffers.speculate; see "speculation" below); 0 / 1 = one slot, one room
 };
@@ -581,9 +588,11 @@ __device__ __forceinline__ void lrg_front_gather_rows(int target, const float *p
 template <int U, int PAD>
 __device__ __forceinline__ void lrg_front_gather_rows16(int target, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
                                                         const LrgFrontArgs &a, const int (*sh_src)[512], int rin, int rnb, int offi, int offn,
-                                                        int tid, int bd) {
-    const int rin_p = LRG_PAD_ROWS_TO(rin, PAD), rnb_p = LRG_PAD_ROWS_TO(rnb, PAD);      // (rows past the set: copies of its last row)
+                                                        int tid, int bd, int tbi = -1, int tbn = -1) {
+    // (tbi / tbn >= 0: the side's rows beyond its last full tile go to the shared rows from there, unpadded; else the side is padded to whole tiles in its own place)
+    const int rin_p = tbi >= 0 ? rin : LRG_PAD_ROWS_TO(rin, PAD), rnb_p = tbn >= 0 ? rnb : LRG_PAD_ROWS_TO(rnb, PAD);      // (rows past the set: copies of its last row)
     const int nit_in = rin_p * 4, nit = nit_in + rnb_p * 4;
+    const int fi = tbi >= 0 ? (rin & ~31) : INT_MAX, fn = tbn >= 0 ? (rnb & ~31) : INT_MAX;      // first row of the tail
     float *out_in = a.x_in + (long)offi * 16, *out_nb = a.x_nb + (long)offn * 16;
     float4 *upd_in = a.upd_in + (long)s * ni, *upd_nb = a.upd_nb + (long)s * nn;
     for (int i0 = tid; i0 < nit; i0 += U * bd) {
@@ -607,6 +616,11 @@ __device__ __forceinline__ void lrg_front_gather_rows16(int target, const float 
                 const int side = it >= nit_in ? 1 : 0, l = it - (side ? nit_in : 0);
                 const int j = l >> 2, q = l & 3;
 #ifndef LRG_EXP_NO_GATHER_STORE      // (experiment switch, --policy gt only: what the rows' write-through stores cost the front step)
+                if (j >= (side ? fn : fi)) {      // a tail row: to the shared rows, with its tag (the shared tile finds its runs of rows by them)
+                    const long row = (long)a.tail_row0 + (side ? tbn : tbi) + (j - (side ? fn : fi));
+                    lrg_st_coh4((side ? a.x_nb : a.x_in) + row * 16, (unsigned)q * 16u, make_float4(v[u][0], v[u][1], v[u][2], v[u][3]));
+                    if (q == 0) lrg_st_coh(&(side ? a.row_slot_nb : a.row_slot_in)[row], s);
+                } else
                 lrg_st_coh4(side ? out_nb : out_in, (unsigned)l * 16u, make_float4(v[u][0], v[u][1], v[u][2], v[u][3]));
 #endif
                 if (q == 0 && j < (side ? rnb : rin))
@@ -619,7 +633,7 @@ __device__ __forceinline__ void lrg_front_gather_rows16(int target, const float 
 template <int PAD, bool COH>
 __device__ __forceinline__ void lrg_front_gather(int target, const float *points, const int32_t *obj, int s, int F, int ni, int nn,
                                                  const LrgFrontArgs &a, const int (*sh_src)[512], int rin,
-                                                 int rnb, int offi, int offn, int first, int nthreads) {
+                                                 int rnb, int offi, int offn, int first, int nthreads, int tbi = -1, int tbn = -1) {
     const int tid = (int)threadIdx.x - first, bd = nthreads;
     if (tid < 0 || tid >= nthreads) return;
     if constexpr (!COH) {         // (the free-running kernel: a slot's rows have a fixed place, the tags were written once)
@@ -629,9 +643,9 @@ __device__ __forceinline__ void lrg_front_gather(int target, const float *points
     if constexpr (COH) {
         if (a.rows16) {
             const int nit = (LRG_PAD_ROWS_TO(rin, PAD) + LRG_PAD_ROWS_TO(rnb, PAD)) * 4;
-            if (nit <= bd) lrg_front_gather_rows16<1, PAD>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
-            else if (nit <= 2 * bd) lrg_front_gather_rows16<2, PAD>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
-            else lrg_front_gather_rows16<4, PAD>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd);
+            if (nit <= bd) lrg_front_gather_rows16<1, PAD>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd, tbi, tbn);
+            else if (nit <= 2 * bd) lrg_front_gather_rows16<2, PAD>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd, tbi, tbn);
+            else lrg_front_gather_rows16<4, PAD>(target, points, obj, s, F, ni, nn, a, sh_src, rin, rnb, offi, offn, tid, bd, tbi, tbn);
             return;
         }
     }
@@ -767,6 +781,8 @@ struct LrgFrontShared {
     int wt_c[16], wt_e[16];  // (the grid query scans over all 16 wavefronts)
     int box[8];              // bounding box of the mask (S->mn, S->mx) for the box query, [6] count, [7] target
     int off[2];
+    int tail[4];             // shared tail tiles: [0] / [1] first shared row of the inlier / neighbour tail (-1: none), [2] / [3] rows of a failed reservation that lie
+                             // inside the shared rows (dead rows of the last shared tile, for the serving loop to account)
 };
 
 // ---- speculation (LrgFrontArgs.spec_k = K > 1): several regions of ONE room in flight ----
@@ -909,6 +925,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     uint8_t *cur = S->cur;
     int32_t *cur_idx = S->cur_idx, *cand_idx = S->cand_idx;
     const int rows_off_in = a.slot_rows[4 * s + 2], rows_off_nb = a.slot_rows[4 * s + 3];
+    const int tail_b_in = (ASYNC && a.tail_base) ? a.tail_base[2 * s] : -1, tail_b_nb = (ASYNC && a.tail_base) ? a.tail_base[2 * s + 1] : -1;
     // (free-running: the centre went out write-through -- read it the way other workgroups do, not through a line of this CU's L1)
     const float c0 = ASYNC ? lrg_ld_coh(a.center + s * 16 + 0) : a.center[s * 16 + 0], c1 = ASYNC ? lrg_ld_coh(a.center + s * 16 + 1) : a.center[s * 16 + 1];
     const int half = tid >> 9, j = tid & 511;                    // first half: add slot j, second half: remove slot j
@@ -969,7 +986,10 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
             for (int i = tid; i < list_n; i += LRG_FRONT_THREADS) cur[lrg_ld_coh(&cur_idx[i])] = 0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the mask is read again by other wavefronts behind the barrier below)
             if (tid == 0) {
-                if (a.spec_stats) atomicAdd(&a.spec_stats[1], (unsigned long long)(steps_total0 + (status == LRG_ACTIVE ? 1 : 0)));      // (+ the evaluation that was in flight)
+                if (a.spec_stats) {
+                    atomicAdd(&a.spec_stats[1], (unsigned long long)(steps_total0 + (status == LRG_ACTIVE ? 1 : 0)));      // (+ the evaluation that was in flight)
+                    atomicAdd(&a.spec_stats[2], (unsigned long long)steps_total0);                                         // (steps counted in stats[2] that no region keeps)
+                }
                 LRG_SPEC_EV(a, 4, s, seed0, status, nc0);
                 S->status = LRG_WAIT;                    // (spec_pos stays: the seed search below starts there)
             }
@@ -1000,7 +1020,11 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
             sj = (int)lrg_sample_position((uint32_t)j, (uint32_t)nside, (uint32_t)Nside, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
                                           (uint32_t)seed0, (uint32_t)restart0, (uint32_t)step0, k0, k1);
         const int srow = nside < Nside ? sj : j;                                              // a padded slot reads its source row
-        const long row = (half ? rows_off_in : rows_off_nb) + srow;
+        long row = (half ? rows_off_in : rows_off_nb) + srow;
+        if constexpr (ASYNC) {      // (a row of the side's tail: in the shared rows, where the evaluation's gather put it)
+            const int tb = half ? tail_b_in : tail_b_nb, first_tail = min(nside, Nside) & ~31;
+            if (tb >= 0 && srow >= first_tail) row = (long)a.tail_row0 + tb + (srow - first_tail);
+        }
         int idx = -1;
         int correct = 0;
         if (mine) {
@@ -1605,7 +1629,23 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     const bool is_big = nc > small_max;
     int oi = 0, on = 0;
     if (tid == 0) {                                      // requested here, needed after the sampling arithmetic
-        if constexpr (ASYNC) { oi = s * a.row_stride; on = s * a.row_stride; }
+        if constexpr (ASYNC) {
+            oi = s * a.row_stride; on = s * a.row_stride;
+            int tb[2] = {-1, -1}, dead[2] = {0, 0};
+            if (a.tail_cur && a.rows16) {
+                // the rows beyond the side's last full tile: reserved in the shared rows (the next slots' tails follow: one tile for several of them).  Out of
+                // shared rows (a launch longer than they were sized for): the side pads a tile of its own, as without them.
+                const int tl[2] = {rin & 31, rnb & 31};
+                for (int side = 0; side < 2; ++side)
+                    if (tl[side]) {
+                        const int b = __hip_atomic_fetch_add(&a.tail_cur[16 * side], tl[side], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (b + tl[side] <= a.tail_rows) tb[side] = b;
+                        else if (b < a.tail_rows) dead[side] = a.tail_rows - b;      // (the reservation fell off the end: what lies inside is nobody's)
+                    }
+            }
+            SH.tail[0] = tb[0]; SH.tail[1] = tb[1]; SH.tail[2] = dead[0]; SH.tail[3] = dead[1];
+            if (a.tail_base) { a.tail_base[2 * s] = tb[0]; a.tail_base[2 * s + 1] = tb[1]; }
+        }
         else {
             oi = atomicAdd(&a.counters[0], LRG_PAD_ROWS(rin));
             on = atomicAdd(&a.counters[1], LRG_PAD_ROWS(rnb));
@@ -1635,7 +1675,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         // the nine medians of such a region come from lrg_front_big_kernel (one workgroup per channel) or from the median
         // workgroups of this launch; nothing here waits for them: the rows go out uncentred
         if (tid < 16 && !(ASYNC && a.own_medians)) a.center[s * 16 + tid] = 0.f;
-        lrg_front_gather<PAD, ASYNC>(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS);
+        lrg_front_gather<PAD, ASYNC>(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 0, LRG_FRONT_THREADS, ASYNC ? SH.tail[0] : -1, ASYNC ? SH.tail[1] : -1);
         TRACE2(s, 5); phase(5);
         if constexpr (ASYNC) if (a.own_medians) {   // the region's medians by this workgroup (no launch of the (slot, channel) medians)
             __syncthreads();
@@ -1665,7 +1705,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         }
         if constexpr (ASYNC && LRG_ASYNC_DEBUG) if (a.phase_dbg && tid == 0) atomicAdd(&a.phase_dbg[0], (unsigned long long)(wall_clock64() - t_small));      // (one median)
     } else {
-        lrg_front_gather<PAD, ASYNC>(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64);
+        lrg_front_gather<PAD, ASYNC>(cur_target, points, obj, s, F, Ni, Nn, a, sh_src, rin, rnb, sh_off[0], sh_off[1], 9 * 64, LRG_FRONT_THREADS - 9 * 64, ASYNC ? SH.tail[0] : -1, ASYNC ? SH.tail[1] : -1);
         if constexpr (ASYNC && LRG_ASYNC_DEBUG) if (a.phase_dbg && tid == 9 * 64) atomicAdd(&a.phase_dbg[7], (unsigned long long)(wall_clock64() - t_small));  // (the gather)
     }
     __syncthreads();

@@ -264,13 +264,15 @@ struct LrgNoWait { static constexpr bool late = false; __device__ __forceinline_
 // the free-running kernel's head tiles wait there for the pooled product of their slot.  WAIT::late (ONE only): the first pass of that
 // layer runs its MFMAs first and waits (and fetches its bias values) in front of its epilogue -- a tile that was started before the
 // pooled product is complete has the staging and a pass of MFMAs to do meanwhile.
+// nrows_out (COH heads): only the logits of the tile's first nrows_out rows are stored -- a slot's TAIL rows (fewer than 32) sit in rows that slots share
+// (lrg_async.inl, "shared tail tiles"); the rows behind them are other slots', whose logits this tile must not touch.
 // part / nparts (ONE only, nparts 1, 2 or 4): the column blocks of the POOLED layer -- 128 -> 512: four passes, more than half of a branch
 // tile's time -- are shared among nparts tasks that each run the layers before it again (a quarter of the FLOPs); the column maxima
 // are independent of each other, part 0 alone stores conv[1].  A tile's latency for its work, where teams are idle anyway.
 template <int CAP0, int CAP1, int RT, int FD, bool DIRECT, bool PACKED, bool COH, class TEAM, bool ONE = false, class WAIT = LrgNoWait>
 __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, int inst, int tile, int nvalid, int nrows_packed,
                                               float *smem, const TEAM &team, long long *trace_sh, const WAIT &before_inst_bias = WAIT(),
-                                              int part = 0, int nparts = 1) {
+                                              int part = 0, int nparts = 1, int nrows_out = 32 * RT) {
     constexpr int FM = 32 * RT;      // rows (points) per tile
     static_assert(!PACKED || RT == 1, "packed rows use 32-row tiles");
     float *buf0 = smem;                       // outputs of even layers
@@ -707,7 +709,10 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             // two rows' logits per 16-byte write-through store: the lane of the even row takes the odd row's pair from its neighbour LPR lanes on
             const float t0 = s0 + P.fb[0], t1 = s1 + P.fb[1];
             const float u0 = __shfl_down(t0, LPR), u1 = __shfl_down(t1, LPR);
-            if (q == 0 && !(row & 1)) lrg_st_coh4(P.fout + r0 * 2, (unsigned)row * 8u, make_float4(t0, t1, u0, u1));
+            if (q == 0 && !(row & 1)) {
+                if (row + 1 < nrows_out) lrg_st_coh4(P.fout + r0 * 2, (unsigned)row * 8u, make_float4(t0, t1, u0, u1));
+                else if (row < nrows_out) lrg_st_coh2(P.fout + (r0 + row) * 2, t0, t1);
+            }
         } else if (q == 0) {
             if constexpr (COH) lrg_st_coh2(P.fout + (r0 + row) * 2, s0 + P.fb[0], s1 + P.fb[1]);
             else *reinterpret_cast<float2 *>(P.fout + (r0 + row) * 2) = make_float2(s0 + P.fb[0], s1 + P.fb[1]);

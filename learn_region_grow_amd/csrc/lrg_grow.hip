@@ -1563,6 +1563,12 @@ size_t lrg_grow_async_queue_bytes(int n_slots) {
     return (LRG_AQ_RING + 2 * async_ring_entries(n_slots) + async_unit_ring_entries(n_slots) + LRG_ASYNC_FILL_RING) * sizeof(int32_t);
 }
 
+size_t lrg_grow_async_tail_bytes(int n_slots, int tail_rows) {
+    if (n_slots <= 0 || tail_rows <= 0 || (tail_rows & 31)) return 0;
+    // (the two row cursors on a 64-byte line each, two words per shared tile and side, the slots' tail bases)
+    return (size_t)(32 + 4 * (size_t)(tail_rows / 32) + 2 * (size_t)n_slots) * sizeof(int32_t);
+}
+
 size_t lrg_grow_async_pool_rows_bytes(const LrgWeights *weights, int n_slots) {
     if (!weights || n_slots <= 0 || weights->n_conv < 1) return 0;
     return (size_t)n_slots * 2 * 16 * (size_t)weights->conv_ch[weights->n_conv - 1] * sizeof(float);      // [slot][side][tile][columns of the pooled layer]
@@ -1676,6 +1682,19 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         A.fill_list = ab->fill_list; A.fill_best = reinterpret_cast<unsigned long long *>(ab->fill_best); A.fill_sync = ab->fill_sync;
         A.fill_label_base = ab->fill_label_base; A.fill_out_base = ab->fill_out_base;
         a.fill_in_launch = 1;
+    }
+    // Shared tail tiles: the caller's row arrays continue behind the slots' own rows
+    A.tail = nullptr; A.tail_tiles = 0; A.tail_ticks = 0;
+    a.tail_cur = nullptr; a.tail_base = nullptr; a.tail_rows = 0; a.tail_row0 = 0;
+    if (ab->tail_ctl && ab->tail_rows > 0 && a.rows16 && !ab->pool_rows) {
+        if ((ab->tail_rows & 31) || ((uintptr_t)ab->tail_ctl & 63) || (long)b->row_cap < (long)n_slots * row_stride + ab->tail_rows || n_slots >= (1 << 20) ||
+            ab->tail_rows / 32 >= (1 << 20))
+            return LRG_EINVAL - 9;
+        A.tail = ab->tail_ctl; A.tail_tiles = ab->tail_rows / 32;
+        A.tail_ticks = ab->tail_close_us < 0 ? 0 : ab->tail_close_us > 0 ? (long long)ab->tail_close_us * 100 : 200;
+        a.tail_cur = ab->tail_ctl; a.tail_rows = ab->tail_rows; a.tail_row0 = n_slots * row_stride;
+        a.tail_base = ab->tail_ctl + 32 + 4 * (size_t)A.tail_tiles;
+        LRG_HIP_CHECK(hipMemsetAsync(ab->tail_ctl, 0, (32 + 4 * (size_t)A.tail_tiles) * sizeof(int32_t), (hipStream_t)stream));
     }
     A.pool_rows = nullptr; A.pool_rows_stride = 0;
     if (A.gemv_units && ab->pool_rows && row_stride <= 512 && n_slots <= 4096) {

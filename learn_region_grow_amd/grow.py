@@ -54,7 +54,7 @@ class RegionGrower:
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
                  skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np', free_run=None,
                  free_run_steps=1 << 20, free_run_budget_us=5000, free_run_fronts=0, free_run_teams=0, free_run_fill_cus=None, free_run_units=0,
-                 speculate=0):
+                 speculate=0, free_run_tail_rows=None):
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
         graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*).
@@ -129,6 +129,7 @@ class RegionGrower:
         self.free_run_teams = int(free_run_teams)
         self.free_run_fill_cus = free_run_fill_cus
         self.free_run_units = int(free_run_units)      # 0 = pooled-product units where they fit, -1 = the tile teams' 128-column blocks
+        self.free_run_tail_rows = free_run_tail_rows   # shared tail tiles: rows per side (None = by the slot count, 0 = off)
         self.debug_hook = None      # tests: called once per active slot per legacy iteration with the step's data
         self._rooms_loaded = False
 
@@ -331,6 +332,16 @@ class RegionGrower:
         if self.packed:
             cap_rows = S * ((max(Ni, Nn) + 31) // 32 * 32)     # (a slot's rows are allocated in multiples of 8 -- or, free-running, have
                                                                  #  a place of their own of whole 32-row tiles)
+            # Shared tail tiles of the free-running launches (LrgAsyncBuffers.tail_ctl): rows behind the slots' own that the slots' tails share, so that the rows
+            # beyond a slot's last full tile fill tiles together.  Sized for a 25 ms launch at the rate the slot count sustains (~32 k evaluations x 2 x 16 rows:
+            # when a launch runs out of them, the slots pad tiles of their own again); on from 96 slots -- below, a step is a chain of latencies and a tile that waits
+            # for a second slot's tail only lengthens it.  LRG_FREE_RUN_TAIL_ROWS: 0 = off, n = that many rows per side.
+            self.tail_rows = 0
+            if self.want_free_run is not False and F >= 9 and F <= 16:
+                env = os.environ.get('LRG_FREE_RUN_TAIL_ROWS', '')
+                want = int(env) if env else (self.free_run_tail_rows if self.free_run_tail_rows is not None else (min(1 << 20, 4096 * S) if S >= 96 else 0))
+                self.tail_rows = max(0, want) // 32 * 32
+            cap_rows += self.tail_rows
             self.row_cap = cap_rows
             # (room for rows at a 64-byte stride: the free-running kernel gathers and stages its rows in 16-byte pieces, LrgAsyncBuffers.rows16; the
             #  lock-step launches use the first cap_rows x F floats of the same arrays)
@@ -409,6 +420,12 @@ class RegionGrower:
                     ab.fill_label_base, ab.fill_out_base = self.d_label.data_ptr(), self.d_filled.data_ptr()
                     ab.fill_rooms = len(rooms)
                     ab.fill_wgs = int(os.environ.get('LRG_FREE_RUN_FILL_WGS', '0'))
+                if self.tail_rows and ab.rows16:
+                    tb = self.lib.lrg_grow_async_tail_bytes(S, self.tail_rows)
+                    self.a_tail = torch.zeros(tb // 4 + 16, dtype=torch.int32, device=dev)
+                    ab.tail_ctl = (self.a_tail.data_ptr() + 63) // 64 * 64
+                    ab.tail_rows = self.tail_rows
+                    ab.tail_close_us = int(os.environ.get('LRG_FREE_RUN_TAIL_US', '0'))
                 self.a_work = torch.zeros(8, dtype=torch.int64, device=dev)      # evaluations, inlier rows, neighbour rows, tiles; speculation: regions voided, their evaluations
                 ab.speculate = self.speculate if self.speculate > 1 else 0
                 ab.work = self.a_work.data_ptr()

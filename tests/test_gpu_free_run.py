@@ -182,3 +182,37 @@ def test_free_run_feature_size_and_lite_variants(cuda_device, F, lite):
         same_regions(g.regions, w_.regions)
         np.testing.assert_array_equal(g.cluster_label, w_.cluster_label)
         np.testing.assert_array_equal(g.filled_label, w_.filled_label)
+
+
+@pytest.mark.parametrize('in_flight,tail_rows,close_us,units,teams', [(5, 4096, 0, 0, 0), (9, 4096, -1, 0, 0), (9, 256, 0, 0, 0), (30, 8192, 30, 0, 0), (100, 16384, 0, 0, 0),
+                                                                       (200, 32768, 0, 0, 0), (30, 8192, 0, -1, 0), (9, 4096, 0, 0, 4), (64, 64, 0, 0, 0)])
+def test_shared_tail_tiles_equal_lock_step(net, monkeypatch, in_flight, tail_rows, close_us, units, teams):
+    """Shared tail tiles (LrgAsyncBuffers.tail_ctl): the rows beyond a slot's last full 32-row tile share branch tiles with other slots' tails (the packed tile
+    form: runs of rows, per-run max-pool), the head stack of a tail is a tile of the slot's own that stores only the slot's rows.  Same regions and labels as the
+    lock-step iterations -- with tiles that fill up by themselves (many slots), tiles closed at once (close_us -1) or after a long wait (30 us), 256 / 64 shared
+    rows (the launches run out of them and fall back to padded tiles of the slots' own), the pooled product by the units or as blocks of the tile teams, four teams."""
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = _rooms()
+    kw = dict(rooms_in_flight=in_flight, rng='counter', seed=123, policy='net')
+    want = RegionGrower(net, free_run=False, **kw).run(rooms)
+    monkeypatch.setenv('LRG_FREE_RUN_TAIL_US', str(close_us))
+    gr = RegionGrower(net, free_run=True, free_run_tail_rows=tail_rows, free_run_units=units, free_run_teams=teams, **kw)
+    got = gr.run(rooms)
+    assert gr.free_run and gr.tail_rows == tail_rows and gr.async_buffers.tail_ctl
+    for g, w in zip(got, want):
+        same_regions(g.regions, w.regions)
+        np.testing.assert_array_equal(g.cluster_label, w.cluster_label)
+        np.testing.assert_array_equal(g.filled_label, w.filled_label)
+    work = gr.a_work.cpu().numpy()
+    assert work[3] * 32 >= work[1] + work[2]          # (tiles run x 32 rows cover the rows evaluated)
+
+
+def test_shared_tail_tiles_with_speculation(net, monkeypatch):
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = _rooms()
+    kw = dict(rooms_in_flight=3, rng='counter', seed=123, policy='net')
+    want = RegionGrower(net, free_run=True, **kw).run(rooms)
+    got = RegionGrower(net, speculate=3, free_run_tail_rows=4096, **kw).run(rooms)
+    for g, w in zip(got, want):
+        same_regions(g.regions, w.regions)
+        np.testing.assert_array_equal(g.filled_label, w.filled_label)

@@ -159,3 +159,32 @@ def test_kitti_scenes_as_benchmarked_match_the_oracle(cuda_device):
         np.testing.assert_array_equal(np.where(got.cluster_label <= ids, got.cluster_label, 0), want.cluster_label)
         check_invariants(sc, got)
         np.testing.assert_array_equal(got.filled_label, grouping_ref.nn1_fill(sc['points'], got.cluster_label))
+
+
+def test_a_complete_kitti_shaped_scene_matches_the_oracle(cuda_device):
+    """The prefix test above stops the oracle after ~4 % of a 100 k-point scene.  Here a WHOLE scene of the same shape (the same generator at the same 0.3 m
+    resolution, 20 k points) meets the oracle from the first seed to the last label: every region record, the cluster labels and the filled labels
+    (test_region_grow.py:186-316), under the trained weights and the Bernoulli policy -- once with one slot on the scene, once with three regions
+    of the scene in flight (RegionGrower(speculate=3): the configuration `one scan per GPU` of BASELINE.json configs[4] runs in)."""
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    from learn_region_grow_amd.grow import RegionGrower
+    net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=cuda_device).load_weights(synthetic.load_trained_weights())
+    scene = workloads.kitti_scenes(1, seed_base=5200, points=20000)[0]
+
+    def net_fn(xi, xn):
+        _, add, _, rmv, _ = net.run(xi, xn)
+        return add, rmv
+
+    def oracle(seed):
+        return [grow_ref.grow_room(scene['points'], scene['obj_id'], scene['order'], None, rng_ref.CounterStream(seed, scene['room_id']), net_fn=net_fn,
+                                   policy='net', resolution=0.3)]
+    seed, (want,) = seed_without_near_tie(oracle, range(3, 9), 5e-7)
+    key = lambda r: (r['seed'], r['steps'], r['points'], r['reason'], r['labeled'])
+    for K in (0, 3):
+        gr = RegionGrower(net, rooms_in_flight=1, rng='counter', seed=seed, policy='net', resolution=0.3, speculate=K)
+        got = gr.run([scene])[0]
+        assert gr.free_run
+        assert [key(r) for r in got.regions] == [key(r) for r in want.regions]
+        np.testing.assert_array_equal(got.cluster_label, want.cluster_label)
+        np.testing.assert_array_equal(got.filled_label, want.filled_label)
+        assert int((got.filled_label > 0).sum()) == len(scene['points'])

@@ -60,6 +60,7 @@ def test_speculation_gives_the_sequential_result(net, K, in_flight, steps, polic
     # the closet voids regions for every K; what was thrown away is accounted for: executed = committed + voided evaluations
     assert work[4] > 0 and work[5] > 0
     assert int(work[0]) == committed + int(work[5])
+    assert gr.instance_steps == committed + int(work[6])          # the device's step counter = kept steps + the voided regions' steps
 
 
 def test_speculation_matches_the_oracle(net):
