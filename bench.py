@@ -89,9 +89,10 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cpu-box-seconds', type=float, default=12.0,
                     help='cpu_baseline.all_cores: the oracle on many rooms at once, one single-threaded process per room, for this long (0 = skip)')
-    ap.add_argument('--speculate', type=int, default=0,
+    ap.add_argument('--speculate', type=int, default=-1,
                     help='regions of ONE room grown side by side in the steady and fixed-work legs (RegionGrower(speculate=K): committed in seed order, voided and grown '
-                         'again on a conflict, identical labels); 0 = off (the legs keep `--rooms` rooms in flight, one slot each)')
+                         'again on a conflict, identical labels); -1 = grow.auto_speculate(rooms in flight): 3 up to 16 rooms, 2 up to 32, off above (the 68-room line); '
+                         '0 = off')
     ap.add_argument('--one-room-ks', default='1,2,3,4,6', help='one_room_per_gpu: the speculation depths tried on ONE room on the chip (empty = skip)')
     ap.add_argument('--one-rank-collective', type=int, default=1,
                     help='--gpus 1: 1 = a one-rank RCCL process group is brought up and the fixed-work leg\'s label gather goes through its all_gather '
@@ -491,6 +492,9 @@ def main():
     else:
         base = workloads.area5_rooms(min(args.rooms, 68), seed_base=1000, cache_dir=args.cache)
     slots = min(args.rooms, 8) if args.workload == 'kitti' else args.rooms
+    if args.speculate < 0:
+        from learn_region_grow_amd.grow import auto_speculate
+        args.speculate = auto_speculate(slots) if (args.restarts == 1 and args.mode != 'lockstep') else 0
     net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, mode=args.net_mode).load_weights(weights)
     packed = bool(args.packed) and args.net_mode == 'fused' and max(len(r['points']) for r in base) <= (
         _lib.LRG_PACKED_MAX_POINTS if args.packed > 1 else _lib.LRG_PACKED_AUTO_POINTS)      # --packed 2 forces it up to 131072 points
@@ -817,7 +821,8 @@ def main():
                                    (', greedy test_region_grow.py loop' if args.restarts == 1 else
                                     ', test_random_restart.py loop with %d restarts per seed batched per launch' % args.restarts),
                        'step': step_what, 'formulation': 'free-running launches (lrg_grow_async)' if free_steady else 'lock-step iterations (lrg_grow_step_packed)' if packed else 'lrg_grow_step',
-                       'rooms_in_flight_per_gpu': S, 'slots_per_gpu': S * args.restarts, 'lanes': 1 if free_steady else n_lanes, 'policy': args.policy,
+                       'rooms_in_flight_per_gpu': S, 'slots_per_gpu': S * args.restarts * (args.speculate if (free_steady and args.speculate > 1) else 1),
+                       'speculation_depth': args.speculate if (free_steady and args.speculate > 1) else 0, 'lanes': 1 if free_steady else n_lanes, 'policy': args.policy,
                        'compute_units_left_to_the_fill_ins': (int(os.environ.get('LRG_FREE_RUN_FILL_CUS', args.fill_cus)) if free_steady else 0),
                        'restarts': args.restarts, 'points': '512 inlier + 512 neighbour x 13 features', 'rng': 'counter (Philox) stream',
                        'weights': ('trained on synthetic Area-5-shaped rooms by train_region_grow.py (learn_region_grow_amd/weights)'

@@ -105,7 +105,7 @@ struct LrgAsyncArgs {
     // for bit).  A tile is published by whoever brings its count of written rows to 32; a slot whose last tile stays open longer than tail_ticks closes it (the
     // cursor is moved to the tile's end, the missing rows count as dead).  The HEAD stack of a tail stays a tile of the slot's own: it reads the slot's conv[1] rows
     // where the shared tile left them and stores the logits of the slot's rows only (lrg_fused_tile: nrows_out).
-    int32_t *tail;               // [0] / [16] the sides' row cursors (= LrgFrontArgs.tail_cur); [32 + 2 * (side * tail_tiles + tile)] rows written, [.. + 1] dead rows
+    int32_t *tail;               // [0] / [16] the sides' row cursors (= LrgFrontArgs.tail_cur); [32 + side * tail_tiles + tile] rows accounted for | dead rows << 16
     int tail_tiles;              // shared tiles per side
     long long tail_ticks;        // (wall_clock64: 100 MHz)
     float *pool_rows;            // nullable (with the units): [n_slots][2 sides][16 tiles][P / 2] column maxima by branch tile, instead of atomicMax on the pooled feature
@@ -299,35 +299,76 @@ __device__ __forceinline__ LrgLdsTeam lrg_async_team(const LrgAsyncArgs &A, floa
     return team;
 }
 
-// ---- shared tail tiles: accounting of written rows, by ONE thread ----
-__device__ __forceinline__ int32_t *lrg_tail_words(const LrgAsyncArgs &A, int side, int tile) { return A.tail + 32 + 2 * ((long)side * A.tail_tiles + tile); }
-// `cnt` more rows of shared tile (side, tile) are written and drained (`dead` of them: rows nobody will write); the one who completes the tile publishes it
-__device__ __forceinline__ bool lrg_tail_account(const LrgAsyncArgs &A, int side, int tile, int cnt, int dead) {
-    int32_t *w = lrg_tail_words(A, side, tile);
-    if (dead) {      // (recorded before the count that may complete the tile: the atomic's result is waited for)
-        const int d0 = __hip_atomic_fetch_add(&w[1], dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" :: "v"(d0));
-    }
-    const int f = __hip_atomic_fetch_add(&w[0], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + cnt;
-    if (f == 32) {
-        const int e = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lrg_st_coh(&A.queue[LRG_AQ_RING + (e & A.qmask)], LRG_TASK(LRG_TASK_BRANCH, tile, side, 16));      // (ring 0; idx 16 = a shared tile, the slot field its number)
-        if (A.work) atomicAdd(&A.work[3], 1ULL);
-    }
-    return f >= 32;
+// ---- shared tail tiles ----
+// One word per shared tile and side: rows accounted for (written, or dead) | dead rows << 16.  The slot whose reservation takes a tile's FIRST row publishes the
+// tile's task together with its own tiles (no round trip of its own); every slot adds its rows when they are out (an atomic nobody waits for); the team that takes
+// the task waits for the 32nd row -- and closes the tile (moves the side's cursor to its end: the rest are dead rows) when that takes longer than tail_ticks.
+__device__ __forceinline__ int32_t *lrg_tail_word(const LrgAsyncArgs &A, int side, int tile) { return A.tail + 32 + ((long)side * A.tail_tiles + tile); }
+__device__ __forceinline__ void lrg_tail_account(const LrgAsyncArgs &A, int side, int tile, int cnt, int dead) {
+    __hip_atomic_fetch_add(lrg_tail_word(A, side, tile), cnt | (dead << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (result unused: no wait)
 }
-// the slot's last shared tile on `side` has been open for too long: closed if the cursor still stands inside it.  1: nothing left to do for this slot, 0: try again
-__device__ __forceinline__ int lrg_tail_close(const LrgAsyncArgs &A, int side, int tile) {
-    if (lrg_ld_coh(&lrg_tail_words(A, side, tile)[0]) >= 32) return 1;
-    int c = lrg_ld_coh(&A.tail[16 * side]);
-    if ((c >> 5) != tile) return 1;              // (every row of the tile is reserved: whoever writes the last one publishes it)
-    if (!__hip_atomic_compare_exchange_strong(&A.tail[16 * side], &c, (tile + 1) * 32, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;
-    const int dead = (tile + 1) * 32 - c;
-    lrg_tail_account(A, side, tile, dead, dead);
-    return 1;
+// by ONE thread of the team that runs shared tile (side, tile): returns its dead rows once all 32 are accounted for (-1: given up)
+__device__ __forceinline__ int lrg_tail_wait(const LrgAsyncArgs &A, int side, int tile, long long t_launch) {
+    const int32_t *w = lrg_tail_word(A, side, tile);
+    const long long t0 = wall_clock64();
+    bool closed = false;
+    for (unsigned spin = 1;; ++spin) {
+        const int v = lrg_ld_coh(w);
+        if ((v & 0xFFFF) >= 32) return v >> 16;
+        if (!closed && wall_clock64() - t0 > A.tail_ticks) {
+            int c = lrg_ld_coh(&A.tail[16 * side]);
+            if ((c >> 5) != tile) closed = true;      // (every row of the tile is reserved: their slots are writing them)
+            else if (__hip_atomic_compare_exchange_strong(&A.tail[16 * side], &c, (tile + 1) * 32, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                const int dead = (tile + 1) * 32 - c;
+                lrg_tail_account(A, side, tile, dead, dead);
+                closed = true;
+            }
+        }
+        if ((spin & 255u) == 0) {
+            if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) return -1;
+            if (wall_clock64() - t_launch > A.abort_ticks) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 8); return -1; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
 }
 
 // ---- the three task types (each returns the team's barrier count, to be handed to the next one) ----
+// a branch tile that has rows of `slot` is done (wavefront 0 of the team): the last one to arrive for the slot's evaluation publishes its pooled product and head tiles
+__device__ __forceinline__ void lrg_async_branch_arrive(const LrgAsyncArgs &A, int slot, int lane, long long t_task, bool count_task) {
+    int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
+    int last = 0, nt_in = 0, nt_nb = 0;
+    if (lane == 0) {
+        // (the evaluation's targets and tile counts were written before its tasks were published: fetched beside the arrival, not after it)
+        const float4 tq = lrg_ld_coh4(reinterpret_cast<const float *>(sy), 16u);      // (targets and tile counts: one 16-byte word, written as one)
+        const int tgt = __float_as_int(tq.x);
+        nt_in = __float_as_int(tq.w) & 0xFFFF; nt_nb = (int)((unsigned)__float_as_int(tq.w) >> 16);
+        const int done = __hip_atomic_fetch_add(&sy[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        last = done == tgt;
+        if (LRG_DBG(A)) {
+            const long long now = wall_clock64();
+            if (count_task) { lrg_dbg_add(A, 8 + 2 * LRG_TASK_BRANCH, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_BRANCH, 1); }
+            if (last) lrg_dbg_add(A, 2, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+        }
+    }
+    if (__shfl(last, 0)) {                       // the slot's pooled feature is complete: its product with the heads' first layers
+        if (A.gemv_units) {
+            // one entry for all units; and the head tiles at once -- they stage their rows and run the first pass of MFMAs while the
+            // units work, and wait for the product in front of that pass's epilogue (LrgWaitPooled)
+            if (lane == 0) {
+                // (entry: generation tag | tiles per side - 1, four bits each | slot -- the units take the maximum over the slot's tile rows)
+                const int i = __hip_atomic_fetch_add(&A.queue[LRG_AQ_GTAIL], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lrg_st_coh(&A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (i & A.gmask)],
+                           (lrg_gemv_ring_tag(i, A.gmask) << 20) | ((((nt_in & 0xFFF) - 1) & 15) << 16) | ((((nt_nb & 0xFFF) - 1) & 15) << 12) | slot);
+            }
+            nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
+            lrg_async_push_heads(A, slot, nt_in, nt_nb, lane);
+        } else {
+            const int nb = (A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS;
+            lrg_async_push(A, A.head_ring, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
+        }
+    }
+}
+
 LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task, int &next_ticket, int *ticket_word) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
@@ -337,19 +378,10 @@ LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
     const int tid = team.tid(), lane = tid & 63;
     const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 31, part = (code >> 5) & 3;      // (tile, part of its pooled layer)
     int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
+    const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
     long long *stamps = LRG_TRACE ? reinterpret_cast<long long *>(word + 8) : nullptr;      // (LRG_TRACE build: cycle stamps of the tile's phases)
-    const bool shared = idx == 16;               // a shared tail tile: `slot` is its number; rows of several slots, the runs of its 32 rows (lrg_tail_account)
-    int nruns = 1;
-    if (shared) {
-        const int dead = lrg_ld_coh(&lrg_tail_words(A, side, slot)[1]);
-        const long r0 = (long)A.front.tail_row0 + (long)slot * 32;
-        nruns = lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, false>(A.prob[side], r0, 0, 0, 0x7fffffff, (int)(r0 + 32 - dead), sm, team,
-                                                                                                       stamps, LrgNoWait(), 0, 1);
-    } else {
-        const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
-        lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps,
-                                                                                                LrgNoWait(), part, A.branch_parts);
-    }
+    lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, true>(A.prob[side], r0, slot, idx, 0x7fffffff, 0x7fffffff, sm, team, stamps,
+                                                                                            LrgNoWait(), part, A.branch_parts);
 #if LRG_TRACE == 2176
     if (tid == 0 && LRG_DBG(A)) {      // cycles since the tile began, at every stamp (tools/free_run_perf.py prints their means)
         for (int i = 1; i < 21; ++i) if (stamps[i] > stamps[0]) lrg_dbg_add(A, 32 + i, stamps[i] - stamps[0]);
@@ -362,47 +394,37 @@ LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
     if (LRG_TICKET_EARLY && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lrg_drain_stores();                              // conv[1] rows and the pooled maxima are out before the arrival
     team.sync();
-    // (a shared tile arrives for every slot that has rows in it: the runs the tile found, lrg_fused_tile's LDS layout)
+    if (tid < 64) lrg_async_branch_arrive(A, slot, lane, t_task, true);
+    return team.target;
+}
+
+// A SHARED tail tile (task index 16; the slot field = the tile's number): rows of several slots, the runs of its 32 rows.  A function of its own (like the pooled
+// blocks and the fill-in): inlined beside the two single-slot tiles it cost the worker's loop 150 spill instructions, some inside the tiles' passes.
+LRG_ASYNC_ROLE int lrg_async_task_branch_shared(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task, long long t_launch) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    float *sm = lrg_async_smem + sm_off + LRG_ASYNC_CTL_FLOATS;
+    const LrgLdsTeam team = lrg_async_team(A, sm, target);
+    const int tid = team.tid(), lane = tid & 63;
+    const int tile = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1;
+    int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
+    if (tid == 0) word[3] = lrg_tail_wait(A, side, tile, t_launch);      // (the tile was published when its first row was reserved: its rows may still be on their way)
+    team.sync();
+    const int dead = max(word[3], 0);
+    const long r0 = (long)A.front.tail_row0 + (long)tile * 32;
+    const int nruns = lrg_fused_tile<32 * 68, 32 * 132, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, false>(A.prob[side], r0, 0, 0, 0x7fffffff, (int)(r0 + 32 - dead), sm, team,
+                                                                                                             nullptr, LrgNoWait(), 0, 1);
+    lrg_drain_stores();                              // conv[1] rows and the pooled maxima are out before the arrivals
+    team.sync();
+    // (it arrives for every slot that has rows in it: the runs the tile found, lrg_fused_tile's LDS layout)
     const int *run_inst = reinterpret_cast<const int *>(sm + 32 * 68 + 32 * 132 + 512) + 33;
-    for (int run = 0; run < nruns; ++run) {
-    const int aslot = shared ? run_inst[run] : slot;
-    if (aslot < 0) continue;
-    int32_t *sy = A.sync + (long)aslot * LRG_ASYNC_SYNC_WORDS;
-    if (tid < 64) {
-        const int slot = aslot;
-        int last = 0, nt_in = 0, nt_nb = 0;
-        if (lane == 0) {
-            // (the evaluation's targets and tile counts were written before its tasks were published: fetched beside the arrival, not after it)
-            const float4 tq = lrg_ld_coh4(reinterpret_cast<const float *>(sy), 16u);      // (targets and tile counts: one 16-byte word, written as one)
-            const int tgt = __float_as_int(tq.x);
-            nt_in = __float_as_int(tq.w) & 0xFFFF; nt_nb = (int)((unsigned)__float_as_int(tq.w) >> 16);
-            const int done = __hip_atomic_fetch_add(&sy[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-            last = done == tgt;
-            if (LRG_DBG(A)) {
-                const long long now = wall_clock64();
-                if (run == 0) { lrg_dbg_add(A, 8 + 2 * LRG_TASK_BRANCH, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_BRANCH, 1); }
-                if (last) lrg_dbg_add(A, 2, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
-            }
+    if (tid < 64)
+        for (int run = 0; run < nruns; ++run) {
+            const int slot = run_inst[run];
+            if (slot >= 0) lrg_async_branch_arrive(A, slot, lane, t_task, run == 0);
         }
-        if (__shfl(last, 0)) {                       // the slot's pooled feature is complete: its product with the heads' first layers
-            if (A.gemv_units) {
-                // one entry for all units; and the head tiles at once -- they stage their rows and run the first pass of MFMAs while the
-                // units work, and wait for the product in front of that pass's epilogue (LrgWaitPooled)
-                if (lane == 0) {
-                    // (entry: generation tag | tiles per side - 1, four bits each | slot -- the units take the maximum over the slot's tile rows)
-                    const int i = __hip_atomic_fetch_add(&A.queue[LRG_AQ_GTAIL], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    lrg_st_coh(&A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (i & A.gmask)],
-                               (lrg_gemv_ring_tag(i, A.gmask) << 20) | ((((nt_in & 0xFFF) - 1) & 15) << 16) | ((((nt_nb & 0xFFF) - 1) & 15) << 12) | slot);
-                }
-                nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
-                lrg_async_push_heads(A, slot, nt_in, nt_nb, lane);
-            } else {
-                const int nb = (A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS;
-                lrg_async_push(A, A.head_ring, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
-            }
-        }
-    }
-    }      // (runs of a shared tile)
+    team.sync();
     return team.target;
 }
 
@@ -871,6 +893,7 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
         if (code < 0) return;                                //  INSIDE this one, which every wavefront reaches after it has read the word)
         const int type = (code >> 28) & 7;
         if (type == LRG_TASK_FILL) team.target = lrg_async_task_fill(kp, code, sm_off, team.target);
+        else if (type == LRG_TASK_BRANCH && (code & 31) == 16) team.target = lrg_async_task_branch_shared(kp, code, sm_off, team.target, t_task, t_launch);
         else if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task, next_ticket, ticket_word);
         else if (type == LRG_TASK_GEMV) team.target = lrg_async_task_gemv(kp, code, sm_off, team.target, t_task);
         else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task, t_launch, next_ticket, ticket_word);
@@ -884,19 +907,24 @@ struct LrgAsyncFrontCtl {
     int steps[LRG_ASYNC_MAX_SERVED];
     int tgt[LRG_ASYNC_MAX_SERVED][3];    // running targets of the slot's three arrival counters
     int bc[4];                           // broadcasts of thread 0
-    int open_tile[LRG_ASYNC_MAX_SERVED][2];      // shared tail tiles: the side's last shared tile of the evaluation in flight while it is unpublished, else -1
-    long long open_since[LRG_ASYNC_MAX_SERVED];
 };
 
 // ---- one slot's front step, a function of its own: the register allocation of lrg_front_greedy_kernel (no spills) instead of the
 //      ~230 spill instructions it had inlined into the serving loop below, for ~100 saved / restored registers per step ----
+template <bool SPEC>
 LRG_ASYNC_ROLE int lrg_async_front_step(lrg_kargs_ptr kp_, int s_) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
     const int s = lrg_uniform(s_);
     const LrgAsyncKArgs &K = LRG_ASYNC_KARGS();
     LrgFrontShared &SH = *reinterpret_cast<LrgFrontShared *>(lrg_async_smem);
-    const int r = lrg_front_greedy_slot<true>(SH, K.slots, K.rooms, K.A.n_slots, K.prm, K.A.front, K.A.big, s);
+    const int r = lrg_front_greedy_slot<true, SPEC>(SH, K.slots, K.rooms, K.A.n_slots, K.prm, K.A.front, K.A.big, s);
     lrg_exp_delay(LRG_EXP_DELAY_FRONT);
+    // Every wavefront's stores of this turn are performed before anybody goes on: the slot's next turn -- and the serving loop right behind this call -- start with
+    // loads of the slot's words by EVERY wavefront (status, list sizes, ...), and a word whose store is still on its way is read as old by some wavefronts and as
+    // new by others: they take different branches and meet at different barriers (round 5: seen as a label checksum that differed in 2 of 16 runs).  A barrier
+    // alone does not wait for global stores (`s_waitcnt lgkmcnt(0); s_barrier`).
+    lrg_drain_stores();
+    __syncthreads();
     return r;
 }
 
@@ -915,7 +943,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
     const int s_first = spec_k ? f * spec_k : f, s_step = spec_k ? 1 : A.n_front;
     const int row_stride = A.front.row_stride;
     const int n_gemv = A.gemv_units ? A.gemv_units : 2 * ((A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS);
-    if (tid < LRG_ASYNC_MAX_SERVED) { C.state[tid] = tid < n_served ? 0 : 2; C.steps[tid] = 0; C.tgt[tid][0] = C.tgt[tid][1] = C.tgt[tid][2] = 0; C.open_tile[tid][0] = C.open_tile[tid][1] = -1; }
+    if (tid < LRG_ASYNC_MAX_SERVED) { C.state[tid] = tid < n_served ? 0 : 2; C.steps[tid] = 0; C.tgt[tid][0] = C.tgt[tid][1] = C.tgt[tid][2] = 0; }
     // a slot's rows have a fixed place in the row arrays: their tags are written once per launch
     for (int i = 0; i < n_served; ++i) {
         const int s = s_first + i * s_step;
@@ -972,12 +1000,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                     if (stk == 2 || stk == 3) continue;
                     ++nlive;
                     bool ready = stk == 0;
-                    if (stk == 1) {
-                        ready = lrg_ld_coh(&A.sync[(long)(s_first + k) * LRG_ASYNC_SYNC_WORDS + 2]) >= C.tgt[k][2];
-                        if (!ready && A.tail && (C.open_tile[k][0] >= 0 || C.open_tile[k][1] >= 0) && wall_clock64() - C.open_since[k] > A.tail_ticks)
-                            for (int side = 0; side < 2; ++side)
-                                if (C.open_tile[k][side] >= 0 && lrg_tail_close(A, side, C.open_tile[k][side])) C.open_tile[k][side] = -1;
-                    }
+                    if (stk == 1) ready = lrg_ld_coh(&A.sync[(long)(s_first + k) * LRG_ASYNC_SYNC_WORDS + 2]) >= C.tgt[k][2];
                     if (stk == 4) ready = k == first || (slots[s_first + k].spec_flags & 1) || over || (first >= 0 && C.state[first] == 2);
                     const int p = slots[s_first + k].spec_pos;
                     if (ready && (best < 0 || p < best_pos)) { best = k; best_pos = p; }
@@ -1026,10 +1049,6 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 ++live;
             }
             if (st == 1) {
-                if (tid == 0 && A.tail && (C.open_tile[i][0] >= 0 || C.open_tile[i][1] >= 0) && wall_clock64() - C.open_since[i] > A.tail_ticks) {
-                    for (int side = 0; side < 2; ++side)
-                        if (C.open_tile[i][side] >= 0 && lrg_tail_close(A, side, C.open_tile[i][side])) C.open_tile[i][side] = -1;
-                }
                 if (tid == 0) C.bc[0] = lrg_ld_coh(&A.sync[(long)s * LRG_ASYNC_SYNC_WORDS + 2]) >= C.tgt[i][2];
                 __syncthreads();
                 const int ready = C.bc[0];
@@ -1051,7 +1070,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
             __syncthreads();
             if (stop) { if (tid == 0) C.state[i] = 2; continue; }
             const long long t_front = LRG_DBG(A) ? wall_clock64() : 0;
-            const int r = __builtin_amdgcn_readfirstlane(lrg_async_front_step(kp, s));
+            const int r = __builtin_amdgcn_readfirstlane(spec_k ? lrg_async_front_step<true>(kp, s) : lrg_async_front_step<false>(kp, s));
             if (r == 0) {
                 // no evaluation: the slot is idle / its room finished (-> finished for this launch), or it stopped a region / goes on
                 // looking for a seed (-> served again at once)
@@ -1097,6 +1116,10 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
             const int nt_in = tb_in >= 0 ? rin >> 5 : (rin + 31) >> 5, nt_nb = tb_nb >= 0 ? rnb >> 5 : (rnb + 31) >> 5;
             const int sh_in = tb_in >= 0 ? 1 : 0, sh_nb = tb_nb >= 0 ? 1 : 0;
             const int nsh = (sh_in ? 1 + ((((tb_in + (rin & 31) - 1) >> 5) != (tb_in >> 5)) ? 1 : 0) : 0) + (sh_nb ? 1 + ((((tb_nb + (rnb & 31) - 1) >> 5) != (tb_nb >> 5)) ? 1 : 0) : 0);
+            // the shared tile whose FIRST row this reservation took (at most one per side): its task goes out with the slot's own
+            const int op_in = !sh_in ? -1 : (tb_in & 31) == 0 ? tb_in >> 5 : (((tb_in + (rin & 31) - 1) >> 5) != (tb_in >> 5)) ? (tb_in >> 5) + 1 : -1;
+            const int op_nb = !sh_nb ? -1 : (tb_nb & 31) == 0 ? tb_nb >> 5 : (((tb_nb + (rnb & 31) - 1) >> 5) != (tb_nb >> 5)) ? (tb_nb >> 5) + 1 : -1;
+            const int n_open = (op_in >= 0 ? 1 : 0) + (op_nb >= 0 ? 1 : 0);
             if (tid == 0) {
                 int32_t *sy = A.sync + (long)s * LRG_ASYNC_SYNC_WORDS;
                 C.tgt[i][0] += (nt_in + nt_nb) * A.branch_parts + nsh; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb + sh_in + sh_nb;
@@ -1110,11 +1133,12 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 }
                 if (A.work) {
                     atomicAdd(&A.work[0], 1ULL); atomicAdd(&A.work[1], (unsigned long long)(r >> 16));
-                    atomicAdd(&A.work[2], (unsigned long long)(r & 0xFFFF)); atomicAdd(&A.work[3], (unsigned long long)(nt_in + nt_nb));
+                    atomicAdd(&A.work[2], (unsigned long long)(r & 0xFFFF)); atomicAdd(&A.work[3], (unsigned long long)(nt_in + nt_nb + n_open));
+                    atomicAdd(&A.work[7], (unsigned long long)(nt_in + nt_nb + sh_in + sh_nb));      // (head tiles: a tail's head tile is the slot's own)
                 }
                 C.state[i] = 1;
                 C.steps[i] += 1;
-                C.bc[3] = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL], (nt_in + nt_nb) * A.branch_parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                C.bc[3] = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL], (nt_in + nt_nb) * A.branch_parts + n_open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             lrg_drain_stores();
             __syncthreads();
@@ -1124,23 +1148,22 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                     lrg_st_coh(&A.queue[LRG_AQ_RING + ((C.bc[3] + tid) & A.qmask)],      // (ring 0)
                                (t < nt_in ? LRG_TASK(LRG_TASK_BRANCH, s, 0, t) : LRG_TASK(LRG_TASK_BRANCH, s, 1, t - nt_in)) | (part << 5));
             }
-            if (A.tail && tid == 0) {
-                // the tail rows are out (drained above): counted into their shared tiles -- whoever completes a tile publishes it; the side's last tile, if
-                // still open, is watched by this workgroup's polls (closed after tail_ticks)
-                const long long now = wall_clock64();
-                for (int side = 0; side < 2; ++side) {
-                    const int tb = side ? tb_nb : tb_in, tl = (side ? rnb : rin) & 31;
-                    C.open_tile[i][side] = -1;
-                    if (tb >= 0) {
-                        const int ta = tb >> 5, tz = (tb + tl - 1) >> 5, ca = min(32 - (tb & 31), tl);
-                        bool full = lrg_tail_account(A, side, ta, ca, 0);
-                        if (tz != ta) full = lrg_tail_account(A, side, tz, tl - ca, 0);
-                        if (!full) C.open_tile[i][side] = tz;
-                    }
+            if (A.tail && tid >= 128 && tid < 132) {
+                // the tail rows are out (drained above): counted into their shared tiles by atomics nobody waits for (lanes 0 / 1: the inlier side's first / second
+                // tile, 2 / 3: the neighbour side's); the tasks of the tiles this slot opened, behind its own in the ring
+                const int side = (tid - 128) >> 1, second = (tid - 128) & 1;
+                const int tb = side ? tb_nb : tb_in, tl = (side ? rnb : rin) & 31;
+                if (tb >= 0) {
+                    const int ta = tb >> 5, tz = (tb + tl - 1) >> 5, ca = min(32 - (tb & 31), tl);
+                    if (!second) lrg_tail_account(A, side, ta, ca, 0);
+                    else if (tz != ta) lrg_tail_account(A, side, tz, tl - ca, 0);
+                } else if (!second) {
                     const int dead = SHr.tail[2 + side];
                     if (dead) lrg_tail_account(A, side, A.tail_tiles - 1, dead, dead);      // (a reservation that fell off the end of the shared rows)
                 }
-                C.open_since[i] = now;
+                const int op = side ? op_nb : op_in;
+                if (!second && op >= 0)
+                    lrg_st_coh(&A.queue[LRG_AQ_RING + ((C.bc[3] + (nt_in + nt_nb) * A.branch_parts + (side && op_in >= 0 ? 1 : 0)) & A.qmask)], LRG_TASK(LRG_TASK_BRANCH, op, side, 16));
             }
             __syncthreads();
         }

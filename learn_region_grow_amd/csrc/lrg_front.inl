@@ -900,7 +900,9 @@ __device__ __noinline__ void lrg_spec_commit(LrgFrontShared &SH, LrgSlot *slots,
 // ASYNC (the free-running kernel, lrg_async.inl): the slot's rows live at the fixed offset s * a.row_stride of the row arrays,
 // padded to whole 32-row tiles; what other workgroups of the same launch read (rows, centre, the zeroed pooled feature) goes out
 // write-through, what they wrote (the logits) is read past the L1 (lrg_fused_tile.inl, COH).
-template <bool ASYNC>
+// SPEC (ASYNC only): the speculation protocol compiled in -- an instantiation of its own, so that the one-slot-per-room step keeps the register allocation it had
+// without it (with both in one function the step saved and restored 32 instead of 21 registers per call).
+template <bool ASYNC, bool SPEC = false>
 __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot *slots, LrgRoom *rooms, int n_slots, const LrgGrowParams &prm,
                                                      const LrgFrontArgs &a, int32_t *big, const int s) {
     uint8_t *sh_flags = SH.flags;
@@ -964,8 +966,8 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     VI.ox = ox; VI.oy = oy; VI.oz = oz;
     VI.hkeys = R->hash_keys; VI.hvals = R->hash_vals; VI.hmask = R->hash_mask;
     const uint32_t k0 = prm.rng_seed, k1 = (uint32_t)R->room_id;
-    const int K = ASYNC ? a.spec_k : 1;
-    const bool spec = ASYNC && K > 1;                    // several regions of this room in flight (see "speculation" above)
+    const int K = (ASYNC && SPEC) ? a.spec_k : 1;
+    constexpr bool spec = ASYNC && SPEC;                 // several regions of this room in flight (see "speculation" above)
     const int g0 = spec ? (s / K) * K : s;
     int list_n = nc0, list_count = 0;            // the pending region's list length and member count, carried in registers through this call
     int spec_void = 0, my_pos = INT_MAX, cursor = 0;
@@ -1628,23 +1630,24 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     const int rin = min(nc, Ni), rnb = min(ne, Nn);
     const bool is_big = nc > small_max;
     int oi = 0, on = 0;
+    if constexpr (ASYNC) {
+        if (tid < 2) {                                   // (lane 0: the inlier side, lane 1: the neighbour side -- one round trip for both)
+            // the rows beyond the side's last full tile: reserved in the shared rows (the next slots' tails follow: one tile for several of them).  Out of
+            // shared rows (a launch longer than they were sized for): the side pads a tile of its own, as without them.
+            int tb = -1, dead = 0;
+            const int tl = (tid ? rnb : rin) & 31;
+            if (a.tail_cur && a.rows16 && tl) {
+                const int b = __hip_atomic_fetch_add(&a.tail_cur[16 * tid], tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (b + tl <= a.tail_rows) tb = b;
+                else if (b < a.tail_rows) dead = a.tail_rows - b;      // (the reservation fell off the end: what lies inside is nobody's)
+            }
+            SH.tail[tid] = tb; SH.tail[2 + tid] = dead;
+            if (a.tail_base) a.tail_base[2 * s + tid] = tb;
+        }
+    }
     if (tid == 0) {                                      // requested here, needed after the sampling arithmetic
         if constexpr (ASYNC) {
             oi = s * a.row_stride; on = s * a.row_stride;
-            int tb[2] = {-1, -1}, dead[2] = {0, 0};
-            if (a.tail_cur && a.rows16) {
-                // the rows beyond the side's last full tile: reserved in the shared rows (the next slots' tails follow: one tile for several of them).  Out of
-                // shared rows (a launch longer than they were sized for): the side pads a tile of its own, as without them.
-                const int tl[2] = {rin & 31, rnb & 31};
-                for (int side = 0; side < 2; ++side)
-                    if (tl[side]) {
-                        const int b = __hip_atomic_fetch_add(&a.tail_cur[16 * side], tl[side], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (b + tl[side] <= a.tail_rows) tb[side] = b;
-                        else if (b < a.tail_rows) dead[side] = a.tail_rows - b;      // (the reservation fell off the end: what lies inside is nobody's)
-                    }
-            }
-            SH.tail[0] = tb[0]; SH.tail[1] = tb[1]; SH.tail[2] = dead[0]; SH.tail[3] = dead[1];
-            if (a.tail_base) { a.tail_base[2 * s] = tb[0]; a.tail_base[2 * s + 1] = tb[1]; }
         }
         else {
             oi = atomicAdd(&a.counters[0], LRG_PAD_ROWS(rin));

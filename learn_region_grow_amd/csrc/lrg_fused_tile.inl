@@ -350,6 +350,20 @@ __device__ __forceinline__ int lrg_fused_tile(const LrgFusedProb &P, long r0, in
             const float4 cv = lrg_ld_coh4(P.center + (long)inst * 16, (unsigned)(4 * c4) * 4u);
             *reinterpret_cast<float4 *>(&buf1[row * ld_x + 4 * c4]) = make_float4(__fsub_rn(xv.x, cv.x), __fsub_rn(xv.y, cv.y), __fsub_rn(xv.z, cv.z), __fsub_rn(xv.w, cv.w));
         }
+    } else if (PACKED && !ONE && COH && P.center && P.ldx == 16 && Kp == 16) {
+        // a shared tile of the free-running kernel (rows at a 64-byte stride, of several slots): the row's tag first, then its centre -- two round trips for
+        // the tile instead of three per element of the general form below
+        for (int idx = tid; idx < FM * 4; idx += FTHREADS) {
+            const int row = idx >> 2, c4 = idx & 3;
+            const float4 xv = lrg_ld_coh4(P.x + r0 * 16, (unsigned)(row * 16 + 4 * c4) * 4u);
+            const int ins = (r0 + row < nrows_packed) ? lrg_ld_coh(P.row_inst + r0 + row) : -1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ins >= 0) {
+                const float4 cv = lrg_ld_coh4(P.center + (long)ins * 16, (unsigned)(4 * c4) * 4u);
+                v = make_float4(__fsub_rn(xv.x, cv.x), __fsub_rn(xv.y, cv.y), __fsub_rn(xv.z, cv.z), __fsub_rn(xv.w, cv.w));
+            }
+            *reinterpret_cast<float4 *>(&buf1[row * ld_x + 4 * c4]) = v;
+        }
     } else if (PACKED && P.center) {
         // uncentred rows: subtract the owning instance's centre while staging (same float32 subtraction the gather would do)
         for (int idx = tid; idx < FM * Kp; idx += FTHREADS) {

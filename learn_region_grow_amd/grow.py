@@ -1089,7 +1089,9 @@ def auto_speculate(rooms_in_flight):
     steps (test_region_grow.py:186-188); with few rooms the chip idles through it, and a front workgroup (one per room) serves ~3 slots before its own
     ~25 us per step become the bound.  Measured (profiles/r05_speculation.txt): see DESIGN.md section 3.0."""
     n = int(rooms_in_flight)
-    return 4 if n <= 8 else 3 if n <= 16 else 2 if n <= 32 else 0
+    # (profiles/r05_speculation.txt: one 100 k-point scene 1.60 x at K = 3 (2 / 4 / 6: 1.51 / 1.56 / 1.42), eight scenes 127 k -> 181 / 193 / 189 k kept steps/s at
+    #  K = 2 / 3 / 4; 16 Area-5-shaped rooms 285 -> 340 k at K = 3; 68 rooms: K = 2 loses 7 % -- the chip is busy there without it)
+    return 3 if n <= 16 else 2 if n <= 32 else 0
 
 
 class LanedRegionGrower:
