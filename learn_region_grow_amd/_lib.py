@@ -116,9 +116,9 @@ LRG_PACKED_AUTO_POINTS = 32 * 4096     # ... chosen by default up to its limit (
                                        # policy now: packed 88 k against 69 k instance-steps/s, profiles/r03_kitti_*.json)
 LRG_FREE_RUN_AUTO_POINTS = 32 * 4096   # free-running launches by default up to the packed limit too: eight 100 k-point scenes, one front workgroup per
                                        # scene, one team per CU: 108 k instance-steps/s against 88 k lock-step (profiles/r03_kitti2_*.json)
-LRG_FREE_RUN_AUTO_SLOTS = 300           # ... and up to this many slots in flight.  Fixed work of 2 176 rooms, rooms/s free-running | lock-step (end of round 4, four tile
-                                       # teams per worker above 200 slots: profiles/r04_teams_units_sweep.txt): 136: 722, 240: 828-845, 272: 836-857 | 834,
-                                       # 320: 845-863 | 865, 400: 834-853 | 899, 544: -- | 930 (round 3: the crossover was at 240, profiles/r03_slots_sweep.log)
+LRG_FREE_RUN_AUTO_SLOTS = 360           # ... and up to this many slots in flight.  Fixed work of 2 176 rooms, rooms/s free-running | lock-step (round 5, shared tail tiles
+                                       # and 44 front workgroups from 224 slots on: profiles/r05_tail_fronts*.txt; lock-step: profiles/r04_teams_units_sweep.txt):
+                                       # 136: 721, 272: 872 | 834, 320: 886 | 865, 400: 882 | 899, 480: 881, 544: 877 | 930 (round 4: 836-857 at 272, the crossover at 300)
 LRG_VGRID_MAX_CELLS = 1 << 26          # dense voxel grid of a room (LrgRoom.vgrid): at most 64 M cells (256 MB) per room ...
 LRG_VGRID_TOTAL_CELLS = 1 << 31        # ... and 8 GB for the rooms of one grower
 LRG_DONE_RING = 1020

@@ -1641,7 +1641,10 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // ... and never more than an eighth of the CUs (+ 2: 34 of 256) by default: a front step takes ~24 us whatever the number of slots, so
     // ~1 M steps/s keep ~25 front workgroups busy, and every CU beyond that is a CU without tile teams (192 slots: 24 / 28 / 34 / 48 front
     // workgroups 0.92 / 1.06 / 1.17 / 1.11 M instance-steps/s; 272 slots: 34 / 40 / 48 / 64 / 96: 1.11 / 1.07 / 1.02 / 0.94 / 0.76 M)
-    int n_front = ab->front_workgroups > 0 ? ab->front_workgroups : n_slots <= 24 ? n_slots : min((n_slots + 1) / 2, wgs / 8 + 2);
+    // (with shared tail tiles -- a sixth fewer branch tiles -- the tile teams need fewer CUs and the slots more: 272 slots 34 / 40 / 46 / 52 front workgroups
+    //  828 (without them) / 872 / 871 / 858 rooms/s, 320 slots 40 / 44 / 48: 876 / 886 / 881, profiles/r05_tail_fronts*.txt)
+    const bool tails_on = ab->tail_ctl && ab->tail_rows > 0 && ab->rows16 && !ab->pool_rows;
+    int n_front = ab->front_workgroups > 0 ? ab->front_workgroups : n_slots <= 24 ? n_slots : min((n_slots + 1) / 2, tails_on ? wgs * 11 / 64 : wgs / 8 + 2);
     n_front = min(n_front, n_slots);
     n_front = max(n_front, (n_slots + LRG_ASYNC_MAX_SERVED - 1) / LRG_ASYNC_MAX_SERVED);
     n_front = min(n_front, wgs / 2);                         // (at least half of the CUs for the tile teams)

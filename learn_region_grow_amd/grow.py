@@ -334,12 +334,14 @@ class RegionGrower:
                                                                  #  a place of their own of whole 32-row tiles)
             # Shared tail tiles of the free-running launches (LrgAsyncBuffers.tail_ctl): rows behind the slots' own that the slots' tails share, so that the rows
             # beyond a slot's last full tile fill tiles together.  Sized for a 25 ms launch at the rate the slot count sustains (~32 k evaluations x 2 x 16 rows:
-            # when a launch runs out of them, the slots pad tiles of their own again); on from 96 slots -- below, a step is a chain of latencies and a tile that waits
-            # for a second slot's tail only lengthens it.  LRG_FREE_RUN_TAIL_ROWS: 0 = off, n = that many rows per side.
+            # when a launch runs out of them, the slots pad tiles of their own again).  On from 224 slots, where the tile teams are what the launch is bound by and
+            # the CUs they save can serve slots instead (44 front workgroups instead of 34: lrg_grow_async): 2 176 room jobs at 272 slots 828 -> 872 rooms/s, 320: ->
+            # 886; below, a step is a chain of latencies and a tile that waits for a second slot's tail only lengthens it (68 slots: 868 -> 714 k instance-steps/s,
+            # 136: 1.14 -> 1.07 M; profiles/r05_tail_sweep_v2.txt, r05_tail_fronts*.txt).  LRG_FREE_RUN_TAIL_ROWS: 0 = off, n = that many rows per side.
             self.tail_rows = 0
             if self.want_free_run is not False and F >= 9 and F <= 16:
                 env = os.environ.get('LRG_FREE_RUN_TAIL_ROWS', '')
-                want = int(env) if env else (self.free_run_tail_rows if self.free_run_tail_rows is not None else (min(1 << 20, 4096 * S) if S >= 96 else 0))
+                want = int(env) if env else (self.free_run_tail_rows if self.free_run_tail_rows is not None else (min(1 << 20, 4096 * S) if (S >= 224 and not self.speculate) else 0))
                 self.tail_rows = max(0, want) // 32 * 32
             cap_rows += self.tail_rows
             self.row_cap = cap_rows
