@@ -63,7 +63,7 @@ def parse():
     ap.add_argument('--iters-per-step', type=int, default=512, help='lock-step iterations per (macro-)step')
     ap.add_argument('--fill-cus', type=int, default=0, help='free-running launches: CUs left out of the launches for the fill-ins of finished rooms (0: fill-ins between two launches)')
     ap.add_argument('--steady-slots', default='192', help='the steady leg again with this many rooms in flight, reported as steady_more_rooms_in_flight (empty = skip)')
-    ap.add_argument('--best-slots', default='68,136,192,272,400,544', help='slot counts of the fixed_work_best sweep (empty = skip)')
+    ap.add_argument('--best-slots', default='68,136,192,272,320,400,544', help='slot counts of the fixed_work_best sweep (empty = skip)')
     ap.add_argument('--rooms', type=int, default=68, help='rooms in flight per GPU (the Area-5 set has 68)')
     ap.add_argument('--restarts', type=int, default=1)
     ap.add_argument('--workload', default='area5', choices=['area5', 'kitti', 'scannet'],

@@ -83,6 +83,9 @@ struct LrgAsyncArgs {
     int32_t *room_queue;         // nullable: [0] rooms handed out so far, [1] rooms queued, [2 + k] = room index | reset << 30
     int qmask;                   // ring entries - 1 (power of two)
     int gmask;                   // entries of the pooled-product units' ring - 1 (power of two, at least 2 n_slots)
+    int gemv_batch;              // > 1 (without the units): pooled products in batches of up to so many slots (LRG_GEMV_BATCH) -- the slots whose branch tiles are all in
+                                 // queue up in the (otherwise unused) units' ring; a batch's blocks stream the kernels' 128 columns ONCE for all its slots
+    long long gemv_batch_ticks;  // a batch that is not full that long after its leader task was taken is closed with the slots it has
     int gemv_units;              // workgroups n_front .. n_front + gemv_units - 1 hold 32 columns each of the heads' pooled kernels in LDS (0: the
                                  // pooled product is a task of the tile teams, 128 columns each)
     int n_slots, n_front, teams;
@@ -164,6 +167,10 @@ __device__ __forceinline__ void lrg_async_push_heads(const LrgAsyncArgs &A, int 
 // groups of a wavefront on four ranges -- with sixteen rows in flight per lane.  (With one column per lane and the loop left to the
 // compiler two loads were in flight: 34 us per block of 64 columns, profiles/r03_free3_perf.log.)
 #define LRG_GEMV_TASK_COLS 128
+#ifndef LRG_GEMV_BATCH
+#define LRG_GEMV_BATCH 8           // slots per batch of pooled products ("batched pooled products" below)
+#endif
+#define LRG_GEMV_NOBODY 0xFFFFF     // a ring position of a closed batch that no slot took
 template <class TEAM>
 __device__ __forceinline__ void lrg_async_gemv(const LrgGemvArgs &g, int slot, int z, int cb, float *sm, const TEAM &team) {
     const int tid = team.tid(), lane = tid & 63, wave = tid >> 6;
@@ -362,6 +369,16 @@ __device__ __forceinline__ void lrg_async_branch_arrive(const LrgAsyncArgs &A, i
             }
             nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
             lrg_async_push_heads(A, slot, nt_in, nt_nb, lane);
+        } else if (A.gemv_batch > 1) {
+            // batched pooled products: the slot queues up; whoever opens a batch (its first entry) publishes the batch's leader task
+            if (lane == 0) {
+                const int i = __hip_atomic_fetch_add(&A.queue[LRG_AQ_GTAIL], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lrg_st_coh(&A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (i & A.gmask)], (lrg_gemv_ring_tag(i, A.gmask) << 20) | slot);
+                if ((i % LRG_GEMV_BATCH) == 0) {
+                    const int e = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL + A.head_ring * LRG_AQ_SECOND], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    lrg_st_coh(&A.queue[LRG_AQ_RING + A.head_ring * (A.qmask + 1) + (e & A.qmask)], LRG_TASK(LRG_TASK_GEMV, (i / LRG_GEMV_BATCH) & 0xFFFFF, 0, 64));
+                }
+            }
         } else {
             const int nb = (A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS;
             lrg_async_push(A, A.head_ring, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, slot, i / nb, i % nb); });
@@ -428,6 +445,67 @@ LRG_ASYNC_ROLE int lrg_async_task_branch_shared(lrg_kargs_ptr kp_, int code_, in
     return team.target;
 }
 
+// ---- batched pooled products (no units): one trip of a 128-column block of the heads' pooled kernels (512 KB from L2) for up to LRG_GEMV_BATCH slots ----
+// With hundreds of slots in flight every slot's pooled product streamed the kernels' 2 MB from L2 by itself: 2.4 TB/s of L2 reads at 1.2 M evaluations a second, 23 us
+// per block (7.7 alone) and 17 % of the tile teams' time (profiles/r05_bench_debug_320.log) -- the lock-step iterations do it as ONE GEMM.  Here the slots whose branch
+// tiles are all in queue up (the units' ring, unused without units): the first of every LRG_GEMV_BATCH ring positions publishes a LEADER task, whose team waits until
+// the batch's entries are written -- or closes it after gemv_batch_ticks (the ring's tail is moved to the batch's end, the unused positions marked) -- and then publishes
+// the batch's 2 x 4 block tasks.  A block task computes its 128 columns for every slot of the batch with the arithmetic of lrg_async_gemv, row by row: the same sums in
+// the same order, bit for bit.
+template <class TEAM>
+__device__ __forceinline__ void lrg_async_gemv_rows(const LrgGemvArgs &g, const int *slots_of, int n, int z, int cb, float *sm, const TEAM &team) {
+    const int tid = team.tid(), lane = tid & 63, wave = tid >> 6;
+    float *pl = sm, *part = sm + LRG_GEMV_BATCH * g.P;          // [n][P] pooled rows, [8][128] partial sums
+    for (int j = 0; j < n; ++j)
+        for (int i = 2 * tid; i < g.P; i += 2 * FTHREADS) {
+            const float2 v = lrg_ld_coh2(g.pooled + (long)slots_of[j] * g.P + i);
+            pl[j * g.P + i] = v.x; pl[j * g.P + i + 1] = v.y;
+        }
+    team.sync();
+    const int kq = g.P >> 3;
+    const int half = wave >> 1, r = 4 * (wave & 1) + (lane >> 4), cl = half * 64 + 4 * (lane & 15);
+    const int c = cb * LRG_GEMV_TASK_COLS + cl;
+    float4 acc[LRG_GEMV_BATCH];
+#pragma unroll
+    for (int j = 0; j < LRG_GEMV_BATCH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < g.C) {
+        const float *w = g.w[z] + c + (long)(r * kq) * g.ldw;
+        const float *p = pl + r * kq;
+        for (int kb = 0; kb < kq; kb += 16) {
+            float4 wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = *reinterpret_cast<const float4 *>(w + (long)(kb + u) * g.ldw);
+#pragma unroll
+            for (int j = 0; j < LRG_GEMV_BATCH; ++j) {
+                if (j < n) {
+#pragma unroll
+                    for (int uu = 0; uu < 16; ++uu) {
+                        const int u = (uu & 8) | ((uu & 1) << 2) | ((uu >> 1) & 3);      // k = 8g + 0, 4, 1, 5, 2, 6, 3, 7: the order of the MFMA formulation (lrg_async_gemv)
+                        const float pk = p[j * g.P + kb + u];
+                        acc[j].x = fmaf(pk, wv[u].x, acc[j].x); acc[j].y = fmaf(pk, wv[u].y, acc[j].y);
+                        acc[j].z = fmaf(pk, wv[u].z, acc[j].z); acc[j].w = fmaf(pk, wv[u].w, acc[j].w);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LRG_GEMV_BATCH; ++j) {
+        if (j < n) {
+            if (c < g.C) *reinterpret_cast<float4 *>(part + r * LRG_GEMV_TASK_COLS + cl) = acc[j];
+            team.sync();
+            if (tid < LRG_GEMV_TASK_COLS && cb * LRG_GEMV_TASK_COLS + tid < g.C) {
+                const int col = cb * LRG_GEMV_TASK_COLS + tid;
+                float sum = part[tid];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) sum += part[q * LRG_GEMV_TASK_COLS + tid];
+                lrg_st_coh(g.hb[z] + (long)slots_of[j] * g.C + col, sum + (g.bias[z] ? g.bias[z][col] : 0.f));
+            }
+            team.sync();
+        }
+    }
+}
+
 // a block of a slot's pooled product is out: the last one publishes the slot's head tiles
 template <class TEAM>
 __device__ __forceinline__ void lrg_async_gemv_arrive(const LrgAsyncArgs &A, const TEAM &team, int slot, long long t_task) {
@@ -465,6 +543,91 @@ LRG_ASYNC_ROLE int lrg_async_task_gemv(lrg_kargs_ptr kp_, int code_, int sm_off_
     const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
     lrg_async_gemv(A.gemv, slot, side, idx, sm, team);
     lrg_async_gemv_arrive(A, team, slot, t_task);
+    return team.target;
+}
+
+// a batch's leader (index 64: waits for / closes the batch, publishes its block tasks) or one of its block tasks (index 32 | block): the slot field = the batch's number
+LRG_ASYNC_ROLE int lrg_async_task_gemv_batch(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task, long long t_launch) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    float *sm = lrg_async_smem + sm_off + LRG_ASYNC_CTL_FLOATS;
+    const LrgLdsTeam team = lrg_async_team(A, sm, target);
+    const int tid = team.tid(), lane = tid & 63;
+    const int batch = (code >> 8) & 0xFFFFF, z = (code >> 7) & 1, idx = code & 127;
+    const int i0 = batch * LRG_GEMV_BATCH;
+    int32_t *ring = A.queue + LRG_AQ_RING + 2 * (A.qmask + 1);
+    int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);      // [8 .. 15]: the batch's slots (LRG_GEMV_NOBODY: an unused position), [3] how many
+    if (idx & 64) {
+        if (tid == 0) {
+            const long long t0 = wall_clock64();
+            bool closed = false;
+            for (int k = 0; k < LRG_GEMV_BATCH; ++k) {
+                const int tag = lrg_gemv_ring_tag(i0 + k, A.gmask);
+                for (unsigned spin = 1;; ++spin) {
+                    if ((lrg_ld_coh(&ring[(i0 + k) & A.gmask]) >> 20) == tag) break;
+                    if (!closed && wall_clock64() - t0 > A.gemv_batch_ticks) {
+                        int c = lrg_ld_coh(&A.queue[LRG_AQ_GTAIL]);
+                        if (c - i0 >= LRG_GEMV_BATCH) closed = true;      // (every position is taken: their slots are on the way)
+                        else if (__hip_atomic_compare_exchange_strong(&A.queue[LRG_AQ_GTAIL], &c, i0 + LRG_GEMV_BATCH, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            for (int q = c; q < i0 + LRG_GEMV_BATCH; ++q) lrg_st_coh(&ring[q & A.gmask], (lrg_gemv_ring_tag(q, A.gmask) << 20) | LRG_GEMV_NOBODY);
+                            closed = true;
+                        }
+                    }
+                    if ((spin & 255u) == 0) {
+                        if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) { k = LRG_GEMV_BATCH; break; }
+                        if (wall_clock64() - t_launch > A.abort_ticks) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 9); k = LRG_GEMV_BATCH; break; }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the marks of a closed batch are out before its block tasks)
+        }
+        team.sync();
+        if (tid < 64) {
+            const int nb = (A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS;
+            lrg_async_push(A, A.head_ring, 2 * nb, lane, [&](int i) { return LRG_TASK(LRG_TASK_GEMV, batch, i / nb, 32 | (i % nb)); });
+        }
+        team.sync();
+        return team.target;
+    }
+    // a block task: the batch's entries are final
+    if (tid < LRG_GEMV_BATCH) word[8 + tid] = lrg_ld_coh(&ring[(i0 + tid) & A.gmask]) & 0xFFFFF;
+    team.sync();
+    int members[LRG_GEMV_BATCH], n = 0;
+#pragma unroll
+    for (int k = 0; k < LRG_GEMV_BATCH; ++k) {
+        const int m = word[8 + k];
+        if (m != LRG_GEMV_NOBODY) members[n++] = m;
+    }
+    team.sync();
+    if (tid < LRG_GEMV_BATCH) word[8 + tid] = tid < n ? members[tid] : 0;      // (compacted: the rows of the product)
+    team.sync();
+    lrg_async_gemv_rows(A.gemv, word + 8, n, z, idx & 31, sm, team);
+    lrg_drain_stores();
+    team.sync();
+    if (tid < 64)
+        for (int k = 0; k < n; ++k) {
+            const int slot = word[8 + k];
+            int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
+            int last = 0, nt_in = 0, nt_nb = 0;
+            if (lane == 0) {
+                const float4 tq = lrg_ld_coh4(reinterpret_cast<const float *>(sy), 16u);
+                nt_in = __float_as_int(tq.w) & 0xFFFF; nt_nb = (int)((unsigned)__float_as_int(tq.w) >> 16);
+                const int done = __hip_atomic_fetch_add(&sy[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                last = done == __float_as_int(tq.y);
+                if (LRG_DBG(A)) {
+                    const long long now = wall_clock64();
+                    if (k == 0) { lrg_dbg_add(A, 8 + 2 * LRG_TASK_GEMV, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_GEMV, 1); }
+                    if (last) lrg_dbg_add(A, 3, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+                }
+            }
+            if (__shfl(last, 0)) {
+                nt_in = __shfl(nt_in, 0); nt_nb = __shfl(nt_nb, 0);
+                lrg_async_push_heads(A, slot, nt_in, nt_nb, lane);
+            }
+        }
+    team.sync();
     return team.target;
 }
 
@@ -895,6 +1058,7 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
         if (type == LRG_TASK_FILL) team.target = lrg_async_task_fill(kp, code, sm_off, team.target);
         else if (type == LRG_TASK_BRANCH && (code & 31) == 16) team.target = lrg_async_task_branch_shared(kp, code, sm_off, team.target, t_task, t_launch);
         else if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task, next_ticket, ticket_word);
+        else if (type == LRG_TASK_GEMV && (code & 96)) team.target = lrg_async_task_gemv_batch(kp, code, sm_off, team.target, t_task, t_launch);
         else if (type == LRG_TASK_GEMV) team.target = lrg_async_task_gemv(kp, code, sm_off, team.target, t_task);
         else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task, t_launch, next_ticket, ticket_word);
     }

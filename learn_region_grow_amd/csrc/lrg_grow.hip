@@ -1671,6 +1671,16 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
             n_front + units > wgs / 2 + wgs / 4 || n_slots >= (1 << 20))
             units = 0;
         A.gemv_units = units;
+        // without the units: the pooled products in batches (lrg_async.inl, LRG_GEMV_BATCH) where slots become ready faster than a batch's patience --
+        // LRG_ASYNC_GEMV_BATCH=0 / =1: off / on whatever the slot count; LRG_ASYNC_GEMV_BATCH_US: the patience
+        const int batch_env = getenv("LRG_ASYNC_GEMV_BATCH") ? atoi(getenv("LRG_ASYNC_GEMV_BATCH")) : -1;
+        const int batch_us10 = getenv("LRG_ASYNC_GEMV_BATCH_US") ? (int)(10.0 * atof(getenv("LRG_ASYNC_GEMV_BATCH_US"))) : 15;
+        const bool fits = (size_t)(LRG_GEMV_BATCH * g.P + 8 * LRG_GEMV_TASK_COLS) <= (size_t)LRG_ASYNC_TILE_FLOATS && (g.P & 127) == 0 && n_slots < LRG_GEMV_NOBODY;
+        // (2 176 room jobs, rooms/s without | with: 200 slots 771 | 731, 272: 873 | 800, 320: 888 | 850, 400: 880 | 896 -- a block takes 68 us for ~7.7 slots instead
+        //  of 23 us for one, 35 instead of 93 team-us per evaluation, but the pooled stage of a slot's step grows from 71 to 108 us and below ~400 slots the launch is
+        //  bound by that latency, not by its teams: profiles/r05_gemv_batch_v1.txt, r05_bench_debug_batch.log)
+        A.gemv_batch = (units == 0 && fits && (batch_env > 0 || (batch_env < 0 && n_slots >= 384))) ? LRG_GEMV_BATCH : 0;
+        A.gemv_batch_ticks = (long long)batch_us10 * 10;
     }
     // With the units, a branch tile leaves its column maxima of the pooled layer as one row of 16-byte stores (pool_rows) and the units take
     // the maximum over a slot's tiles while loading: no atomicMax per column (7 k atomics = write transactions per evaluation, each to

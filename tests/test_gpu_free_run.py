@@ -216,3 +216,23 @@ def test_shared_tail_tiles_with_speculation(net, monkeypatch):
     for g, w in zip(got, want):
         same_regions(g.regions, w.regions)
         np.testing.assert_array_equal(g.filled_label, w.filled_label)
+
+
+@pytest.mark.parametrize('in_flight,patience_us,teams,tail_rows', [(5, 1.5, 0, 0), (9, 0.1, 0, 0), (30, 5, 0, 0), (100, 1.5, 0, 0), (200, 1.5, 0, 0), (260, 1.5, 0, 32768), (9, 1.5, 4, 4096)])
+def test_batched_pooled_products_equal_lock_step(net, monkeypatch, in_flight, patience_us, teams, tail_rows):
+    """Without the pooled-product units the slots whose branch tiles are in queue up and the heads' pooled products are computed for up to eight of them per trip of
+    the kernels' columns from L2 (lrg_async.inl, LRG_GEMV_BATCH) -- the same sums in the same order as one slot at a time: same regions and labels as the lock-step
+    iterations, with batches that fill up (many slots), batches closed after 0.1 us (mostly single slots) or 5 us, with shared tail tiles, with four teams."""
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = _rooms()
+    kw = dict(rooms_in_flight=in_flight, rng='counter', seed=123, policy='net')
+    want = RegionGrower(net, free_run=False, **kw).run(rooms)
+    monkeypatch.setenv('LRG_ASYNC_GEMV_BATCH', '1')
+    monkeypatch.setenv('LRG_ASYNC_GEMV_BATCH_US', str(patience_us))
+    gr = RegionGrower(net, free_run=True, free_run_units=-1, free_run_teams=teams, free_run_tail_rows=tail_rows, **kw)
+    got = gr.run(rooms)
+    assert gr.free_run
+    for g, w in zip(got, want):
+        same_regions(g.regions, w.regions)
+        np.testing.assert_array_equal(g.cluster_label, w.cluster_label)
+        np.testing.assert_array_equal(g.filled_label, w.filled_label)
