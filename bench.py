@@ -741,7 +741,9 @@ def main():
         tf1 = time.perf_counter()
         el = lrg_dist.allreduce_max(tf1 - tf0, device=coll_dev, force_collective=force_coll)
         st = fl.stats()
-        f_steps, f_rooms = lrg_dist.allreduce_sum([float(st[2]), float(len(my_jobs))], device=coll_dev, force_collective=force_coll)
+        wk = fl.work()
+        kept = float(st[2]) - (float(wk[6]) if (wk is not None and args.speculate > 1) else 0.0)      # (speculation: the steps of voided regions are not the rooms')
+        f_steps, f_rooms = lrg_dist.allreduce_sum([kept, float(len(my_jobs))], device=coll_dev, force_collective=force_coll)
         ok = all(gathered[j] is not None and len(gathered[j]) == sizes[j] and int(gathered[j].min()) > 0 for j in range(R))
         crc = 0
         for j in range(R):                                  # one checksum over every room's final labels, in job order

@@ -252,7 +252,7 @@ def main(argv=None):
         elif args.shared_stream:
             kw['rooms_in_flight'] = 1
             results = RegionGrower(net, **kw).run(rooms, legacy_shared_seed=args.seed)
-        elif args.rng == 'counter' and max(1, args.restarts) == 1 and spec_k > 1 and RegionGrower.free_run_applies(net, rooms, in_flight * spec_k, **kw):
+        elif args.rng == 'counter' and max(1, args.restarts) == 1 and spec_k > 1 and RegionGrower.free_run_applies(net, rooms, in_flight * spec_k, **{k: v for k, v in kw.items() if k != 'rooms_in_flight'}):
             results = RegionGrower(net, speculate=spec_k, **kw).run(rooms)
         elif args.rng == 'counter' and args.lanes != 1:
             results = LanedRegionGrower(net, lanes=args.lanes, **kw).run(rooms)

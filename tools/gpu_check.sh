@@ -19,6 +19,6 @@ print('bench: %.0f %s (%s), %.0f rooms/s fixed work (best %.0f at %s slots), %.1
     d.get('cpu_baseline', {}).get('value', float('nan'))))
 PY
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt_d
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_d -o kt --output-format csv -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --p0-rooms 0 --best-slots "" --steady-slots "" > /tmp/kt_d.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_d -o kt --output-format csv -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --p0-rooms 0 --best-slots "" --steady-slots "" --one-room-ks= > /tmp/kt_d.log 2>&1
 cp $(ls /tmp/kt_d/*/*kernel_stats.csv /tmp/kt_d/*kernel_stats.csv 2>/dev/null | head -1) $R/gpurun_out/r05_bench_kernel_stats.csv
 head -7 $R/gpurun_out/r05_bench_kernel_stats.csv | cut -c1-160

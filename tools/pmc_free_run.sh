@@ -5,7 +5,7 @@
 #   usage (GPU box): tools/pmc_free_run.sh <commit> [out.json]
 R=$GRAFT_REPO_ROOT; COMMIT=${1:-unknown}; OUT=${2:-gpurun_out/r05_pmc_free_run.json}
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pmcf && mkdir -p /tmp/pmcf
-B="python $R/bench.py --gpus 1 --steps 6 --warmup 4 --cpu-seconds 0 --p0-rooms 0 --fixed-rooms 0 --steady-slots="
+B="python $R/bench.py --gpus 1 --steps 6 --warmup 4 --cpu-seconds 0 --p0-rooms 0 --fixed-rooms 0 --one-room-ks= --steady-slots="
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pmcf/kt -o kt --output-format csv -- $B > /tmp/pmcf/kt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmcf/fetch -o f --output-format csv -- $B > /tmp/pmcf/f.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmcf/write -o w --output-format csv -- $B > /tmp/pmcf/w.log 2>&1
