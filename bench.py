@@ -631,6 +631,9 @@ def main():
                                          'copies that pad a set to 512 rows and the copies that pad a slot\'s rows to whole 32-row tiles are NOT counted',
                      'evaluations': dw[0], 'rows_evaluated': [dw[1], dw[2]], 'rows_evaluated_fraction': (dw[1] + dw[2]) / max(dw[0] * 1024.0, 1.0),
                      'tiles_run_per_stack': dw[3], 'rows_in_tiles_fraction': (dw[1] + dw[2]) / max(dw[3] * 32.0, 1.0),
+                     'head_tiles_run': dw[7], 'head_rows_in_tiles_fraction': (dw[1] + dw[2]) / max(dw[7] * 32.0, 1.0),
+                     'tiles_note': 'tiles_run_per_stack / rows_in_tiles_fraction: the BRANCH stack (with shared tail tiles the rows beyond a slot\'s last full tile share '
+                                   'tiles: fewer of them); the head stack keeps a tile of the slot\'s own for its tail: head_tiles_run / head_rows_in_tiles_fraction',
                      'speculation': ({'depth': args.speculate, 'regions_voided': dw[4], 'evaluations_voided': dw[5], 'steps_voided': dw[6],
                                       'note': 'algorithmic_flops_in_loop counts every evaluation executed, voided ones included (work done, not work kept); '
                                               '`value` counts kept steps only'} if args.speculate > 1 else None),
