@@ -605,6 +605,12 @@ int lrg_nn1_fill_batch(const LrgFillJob *jobs, int n_jobs, int F, void *workspac
 /* queryBallPointLauncher (tf_grouping_g.cu:125; kernel :3-36).  Rows with no hit are zero-filled. */
 int lrg_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
                          int *idx, int *pts_cnt, void *stream);
+/* query_ball_point + group_point(xyz, idx) + group_point(points, idx) as the reference chains them in sample_and_group (train_pointnet.py:113-121), in ONE launch:
+ * idx [b,m,nsample], pts_cnt [b,m] as lrg_query_ball_point; grouped_xyz [b,m,nsample,3] = xyz1 rows at idx (minus the query's coordinates when subtract_center: the
+ * float32 subtraction of :117); grouped_points [b,m,nsample,c] = points rows at idx (points and grouped_points both NULL: skipped).  nsample <= 4096.  (ABI 9) */
+int lrg_query_ball_group(int b, int n, int m, int c, float radius, int nsample, const float *xyz1, const float *xyz2, const float *points, int *idx,
+                         int *pts_cnt, float *grouped_xyz, float *grouped_points, int subtract_center, void *stream);
+
 /* selectionSortLauncher (tf_grouping_g.cu:129; kernel :83-123): full [b,m,n] outputs, first k sorted. */
 int lrg_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream);
 /* groupPointLauncher (tf_grouping_g.cu:133; kernel :40-57) */

@@ -236,6 +236,7 @@ _SIGS = {
     'lrg_nn1_fill_batch': (ctypes.c_int, [ctypes.POINTER(LrgFillJob), ctypes.c_int, ctypes.c_int, _fp, ctypes.c_size_t, _fp]),
     'lrg_query_ball_point': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _fp,
                                             _fp, _fp, _fp, _fp]),
+    'lrg_query_ball_group': (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, _fp]),
     'lrg_selection_sort': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
     'lrg_group_point': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp,
                                        _fp, _fp]),

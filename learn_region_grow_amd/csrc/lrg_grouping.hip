@@ -439,6 +439,97 @@ int lrg_query_ball_point(int b, int n, int m, float radius, int nsample, const f
     return 0;
 }
 
+// ---- ball query + the two gathers of sample_and_group (train_pointnet.py:113-121: query_ball_point, group_point(xyz), group_point(points)) in ONE launch ----
+// The ball query at the reference's harness shape is a 5.8 us kernel on a 1.3 MB problem: bound by its launch and one trip to memory, not by bytes -- and the reference
+// never calls it alone: the two group_point launches that follow read the index list it has just written.  Here the wavefront that scanned a query keeps the list in LDS
+// and gathers both row sets itself: the same idx / pts_cnt, the same gathered values (optionally with the query's coordinates subtracted from the gathered xyz, the
+// "translation normalization" of :117, a float32 subtraction).
+__global__ __launch_bounds__(256) void lrg_ball_group_kernel(int b, int n, int m, int c, float radius, int nsample, const float *xyz1, const float *xyz2,
+                                                             const float *points, int *idx, int *pts_cnt, float *gxyz, float *gpts, int subtract_center) {
+    extern __shared__ int lrg_bg_list[];                              // [4 wavefronts][nsample]
+    const int wave = threadIdx.x >> 6, lane = lrg_lane();
+    const long q = (long)blockIdx.x * 4 + wave;
+    if (q >= (long)b * m) return;
+    int *list = lrg_bg_list + wave * nsample;
+    const long bi = q / m;
+    const float *p1 = xyz1 + bi * n * 3;
+    const float x2 = xyz2[q * 3 + 0], y2 = xyz2[q * 3 + 1], z2 = xyz2[q * 3 + 2];
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    int cnt = 0, first = -1;
+    constexpr int UN = 4;
+    for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64 * UN) {      // (lrg_query_ball_kernel's scan: the FIRST nsample points inside the radius, tf_grouping_g.cu:3-36)
+        float px[UN], py[UN], pz[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = min(k0 + 64 * u + lane, n - 1);
+            px[u] = p1[k * 3 + 0]; py[u] = p1[k * 3 + 1]; pz[u] = p1[k * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = k0 + 64 * u + lane;
+            if (k0 + 64 * u >= n || cnt >= nsample) break;
+            bool hit = false;
+            if (k < n) {
+                float dx = __fsub_rn(x2, px[u]), dy = __fsub_rn(y2, py[u]), dz = __fsub_rn(z2, pz[u]);
+                float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                float d = fmaxf(__fsqrt_rn(d2), 1e-20f);
+                hit = d < radius;
+            }
+            unsigned long long mask = __ballot(hit);
+            if (mask) {
+                if (first < 0) first = k0 + 64 * u + (int)__ffsll((long long)mask) - 1;
+                int pos = cnt + __popcll(mask & lt);
+                if (hit && pos < nsample) list[pos] = k;
+                cnt += __popcll(mask);
+            }
+        }
+    }
+    if (cnt > nsample) cnt = nsample;
+    for (int l = cnt + lane; l < nsample; l += 64) list[l] = first < 0 ? 0 : first;      // (:26-29)
+    if (lane == 0) pts_cnt[q] = cnt;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int *out = idx + q * nsample;
+    for (int l = lane; l < nsample; l += 64) out[l] = list[l];
+    // group_point(xyz, idx) (:116) -- three floats per sample, consecutive lanes on consecutive floats
+    float *ox = gxyz + q * nsample * 3;
+    const float cen[3] = {subtract_center ? x2 : 0.f, subtract_center ? y2 : 0.f, subtract_center ? z2 : 0.f};
+    for (int e = lane; e < nsample * 3; e += 64) {
+        const int l = e / 3, d = e - 3 * l;
+        const float v = p1[(long)list[l] * 3 + d];
+        ox[e] = subtract_center ? __fsub_rn(v, cen[d]) : v;
+    }
+    // group_point(points, idx) (:119)
+    if (points && gpts) {
+        const float *pp = points + bi * n * c;
+        float *op = gpts + q * nsample * c;
+        if ((c & 3) == 0 && ((((uintptr_t)points | (uintptr_t)gpts) & 15) == 0)) {
+            const int c4 = c >> 2;
+            for (int e = lane; e < nsample * c4; e += 64) {
+                const int l = e / c4, k = e - l * c4;
+                reinterpret_cast<float4 *>(op)[e] = reinterpret_cast<const float4 *>(pp + (long)list[l] * c)[k];
+            }
+        } else {
+            for (int e = lane; e < nsample * c; e += 64) {
+                const int l = e / c, k = e - l * c;
+                op[e] = pp[(long)list[l] * c + k];
+            }
+        }
+    }
+}
+
+int lrg_query_ball_group(int b, int n, int m, int c, float radius, int nsample, const float *xyz1, const float *xyz2, const float *points, int *idx,
+                         int *pts_cnt, float *grouped_xyz, float *grouped_points, int subtract_center, void *stream) {
+    if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || c < 0 || !xyz1 || !xyz2 || !idx || !pts_cnt || !grouped_xyz) return LRG_EINVAL - 1;
+    if ((points != nullptr) != (grouped_points != nullptr) || (points && c <= 0) || nsample > 4096) return LRG_EINVAL - 2;
+    long q = (long)b * m;
+    if (q == 0) return 0;
+    hipLaunchKernelGGL(lrg_ball_group_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), (size_t)4 * nsample * sizeof(int), (hipStream_t)stream, b, n, m, c, radius,
+                       nsample, xyz1, xyz2, points, idx, pts_cnt, grouped_xyz, grouped_points, subtract_center);
+    LRG_LAUNCH_CHECK();
+    return 0;
+}
+
 int lrg_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream) {
     if (b < 0 || n <= 0 || m < 0 || k < 0 || !dist || !outi || !out) return LRG_EINVAL - 1;
     long rows = (long)b * m;

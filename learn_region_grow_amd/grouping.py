@@ -36,6 +36,31 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     return idx, cnt
 
 
+def query_ball_group(radius, nsample, xyz1, xyz2, points=None, subtract_center=False):
+    """query_ball_point + group_point(xyz1, idx) + group_point(points, idx) in one launch -- the chain of sample_and_group (train_pointnet.py:113-121).
+    -> idx (b,m,nsample), pts_cnt (b,m), grouped_xyz (b,m,nsample,3) (minus xyz2[:, :, None] when subtract_center, :117), grouped_points (b,m,nsample,c) or None."""
+    xyz1 = _chk(xyz1, 3, torch.float32, 'xyz1')
+    xyz2 = _chk(xyz2, 3, torch.float32, 'xyz2')
+    if xyz1.shape[2] != 3 or xyz2.shape[2] != 3 or xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError('QueryBallPoint expects (batch_size, ndataset, 3) and (batch_size, npoint, 3)')
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    c = 0
+    if points is not None:
+        points = _chk(points, 3, torch.float32, 'points')
+        if points.shape[0] != b or points.shape[1] != n:
+            raise ValueError('GroupPoint expects points (batch_size, ndataset, channel)')
+        c = points.shape[2]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    gx = torch.empty((b, m, nsample, 3), dtype=torch.float32, device=xyz1.device)
+    gp = torch.empty((b, m, nsample, c), dtype=torch.float32, device=xyz1.device) if points is not None else None
+    _lib.check(_lib.load().lrg_query_ball_group(b, n, m, c, ctypes.c_float(radius), nsample, _ptr(xyz1), _ptr(xyz2), _ptr(points) if points is not None else None,
+                                                _ptr(idx), _ptr(cnt), _ptr(gx), _ptr(gp) if gp is not None else None, 1 if subtract_center else 0, _stream_ptr()),
+               'lrg_query_ball_group')
+    return idx, cnt, gx, gp
+
+
 def select_top_k(k, dist):
     """dist (b,m,n) -> (idx (b,m,n) int32, dist_out (b,m,n)); the first k along n are the k smallest."""
     dist = _chk(dist, 3, torch.float32, 'dist')

@@ -244,3 +244,33 @@ def test_nn1_fill_batch_equals_room_by_room(cuda_device, hip_lib):
             _lib.check(hip_lib.lrg_nn1_fill_ws(_ptr(P[k]), n, F, _ptr(L[k]), _ptr(R[k]), _ptr(ws1), ws1.numel(), _stream_ptr()), 'ws')
             np.testing.assert_array_equal(O[k].cpu().numpy()[:n], R[k].cpu().numpy()[:n])
     assert hip_lib.lrg_nn1_fill_batch(jobs, len(sizes), F, _ptr(ws), 64, _stream_ptr()) <= -1000
+
+
+@pytest.mark.parametrize('b,n,m,radius,ns,c', [(2, 200, 50, 0.2, 16, 7), (3, 1024, 256, 0.1, 32, 64), (1, 64, 16, 0.8, 32, 4), (2, 70, 33, 0.01, 8, 0),
+                                                (32, 512, 128, 0.1, 64, 64), (1, 1000, 20, 0.5, 300, 12), (1, 300, 9, 0.45, 64, 3)])
+def test_query_ball_group_equals_the_three_ops(cuda_device, b, n, m, radius, ns, c):
+    """lrg_query_ball_group = query_ball_point + group_point(xyz) + group_point(points) of sample_and_group (train_pointnet.py:113-121) in one launch: the index
+    lists and counts of the C oracle (= the reference's C++), the gathered rows bit for bit, the translation normalization (:117) as a float32 subtraction."""
+    from learn_region_grow_amd import grouping
+    rs = np.random.RandomState(n + c)
+    x1 = rs.rand(b, n, 3).astype(np.float32)
+    x2 = rs.rand(b, m, 3).astype(np.float32)
+    pts = rs.rand(b, n, c).astype(np.float32) if c else None
+    d1, d2 = dev(x1, cuda_device), dev(x2, cuda_device)
+    dp = dev(pts, cuda_device) if c else None
+    widx, wcnt = G.query_ball_point(radius, ns, x1, x2)
+    for sub in (False, True):
+        idx, cnt, gx, gp = grouping.query_ball_group(radius, ns, d1, d2, dp, subtract_center=sub)
+        np.testing.assert_array_equal(cnt.cpu().numpy(), wcnt)
+        np.testing.assert_array_equal(idx.cpu().numpy(), widx)
+        want_x = G.group_point(x1, widx)
+        if sub:
+            want_x = want_x - x2[:, :, None, :]
+        np.testing.assert_array_equal(gx.cpu().numpy(), want_x)
+        if c:
+            np.testing.assert_array_equal(gp.cpu().numpy(), G.group_point(pts, widx))
+            np.testing.assert_array_equal(gp.cpu().numpy(), grouping.group_point(dp, idx).cpu().numpy())
+        else:
+            assert gp is None
+    with pytest.raises(ValueError):
+        grouping.query_ball_group(radius, ns, d1, d2, dev(np.zeros((b, n + 1, 4), np.float32), cuda_device))

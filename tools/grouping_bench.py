@@ -72,6 +72,43 @@ def grouping_rates(device='cuda:0', cpu=True, reps=100):
     rows.append(('G4 group_point_grad', _time_gpu(lambda: grouping.group_point_grad(dp, idx, go), reps),
                  b * m * ns * c * 4 + b * m * ns * 4 + b * n * c * 4,      # grad_out + the indices + grad_points once
                  lambda k: G.group_point_grad(go.cpu().numpy()[:k], idx.cpu().numpy()[:k], n, use_reference=True)))
+    # ---- the chain as the reference calls it (sample_and_group, train_pointnet.py:113-121): three launches, or the fused lrg_query_ball_group ----
+    def chain():
+        i_, _ = grouping.query_ball_point(radius, ns, d1, d2)
+        grouping.group_point(d1, i_)
+        grouping.group_point(dp, i_)
+    t_chain = _time_gpu(chain, reps)
+    t_fusedq = _time_gpu(lambda: grouping.query_ball_group(radius, ns, d1, d2, dp), reps)
+    bytes_chain = b * (n + m) * 12 + b * n * c * 4 + b * m * (ns + 1) * 4 + b * m * ns * (3 + c) * 4
+    out['sample_and_group chain (query_ball_point + 2 x group_point)'] = dict(
+        three_launches_us=t_chain * 1e6, fused_us=t_fusedq * 1e6, algorithmic_bytes=bytes_chain, fused_GBps=bytes_chain / t_fusedq / 1e9,
+        fused_frac_of_hbm_peak=bytes_chain / t_fusedq / HBM, three_launches_frac_of_hbm_peak=bytes_chain / t_chain / HBM,
+        note='Python wrapper calls incl. their output allocations, back to back; the fused launch keeps the index list in the scanning wavefront\'s LDS')
+    # ---- G3 / G4 again with ROTATING buffers beyond the 256 MiB Infinity Cache: the back-to-back figures above re-read a 72 MB working set that fits it ----
+    nrot = 12                                   # 12 x (67 MB out + 4 MB src + 1 MB idx) = 860 MB in flight
+    rot_pts = [torch.rand((b, n, c), device=dev) for _ in range(nrot)]
+    rot_idx = [idx.clone() for _ in range(nrot)]
+    rot_go = [torch.rand((b, m, ns, c), device=dev) for _ in range(nrot)]
+    rot_out = [torch.empty((b, m, ns, c), device=dev) for _ in range(nrot)]
+    rot_gp = [torch.zeros((b, n, c), device=dev) for _ in range(nrot)]
+    from learn_region_grow_amd import _lib as _l
+    from learn_region_grow_amd.lrgnet import _ptr as _p, _stream_ptr as _s
+    lib_ = _l.load()
+    state = {'i': 0}
+
+    def g3_rot():
+        i = state['i'] = (state['i'] + 1) % nrot
+        _l.check(lib_.lrg_group_point(b, n, c, m, ns, _p(rot_pts[i]), _p(rot_idx[i]), _p(rot_out[i]), _s()), 'g3')
+
+    def g4_rot():
+        i = state['i'] = (state['i'] + 1) % nrot
+        _l.check(lib_.lrg_group_point_grad(b, n, c, m, ns, _p(rot_go[i]), _p(rot_idx[i]), _p(rot_gp[i]), _s()), 'g4')
+    for name, fn, nbytes in (('G3 group_point, rotating buffers (860 MB working set)', g3_rot, b * m * ns * c * 4 + b * n * c * 4 + b * m * ns * 4),
+                             ('G4 group_point_grad, rotating buffers (860 MB working set)', g4_rot, b * m * ns * c * 4 + b * m * ns * 4 + b * n * c * 4)):
+        t = _time_gpu(fn, max(reps, 10 * nrot))
+        out[name] = dict(gpu_us=t * 1e6, algorithmic_bytes=nbytes, GBps=nbytes / t / 1e9, frac_of_hbm_peak=nbytes / t / HBM,
+                         note='C entry point called directly on %d sets of buffers in turn: every launch reads and writes memory the Infinity Cache no longer holds' % nrot)
+    del rot_pts, rot_idx, rot_go, rot_out, rot_gp
     shape1 = dict(b=b, n=n, m=m, nsample=ns, c=c, radius=radius)
     for name, t, nbytes, cpu_fn in rows:
         e = dict(gpu_us=t * 1e6, algorithmic_bytes=nbytes, GBps=nbytes / t / 1e9, frac_of_hbm_peak=nbytes / t / HBM, shape=shape1)
