@@ -116,9 +116,10 @@ LRG_PACKED_AUTO_POINTS = 32 * 4096     # ... chosen by default up to its limit (
                                        # policy now: packed 88 k against 69 k instance-steps/s, profiles/r03_kitti_*.json)
 LRG_FREE_RUN_AUTO_POINTS = 32 * 4096   # free-running launches by default up to the packed limit too: eight 100 k-point scenes, one front workgroup per
                                        # scene, one team per CU: 108 k instance-steps/s against 88 k lock-step (profiles/r03_kitti2_*.json)
-LRG_FREE_RUN_AUTO_SLOTS = 360           # ... and up to this many slots in flight.  Fixed work of 2 176 rooms, rooms/s free-running | lock-step (round 5, shared tail tiles
-                                       # and 44 front workgroups from 224 slots on: profiles/r05_tail_fronts*.txt; lock-step: profiles/r04_teams_units_sweep.txt):
-                                       # 136: 721, 272: 872 | 834, 320: 886 | 865, 400: 882 | 899, 480: 881, 544: 877 | 930 (round 4: 836-857 at 272, the crossover at 300)
+LRG_FREE_RUN_AUTO_SLOTS = 480           # ... and up to this many slots in flight.  Fixed work of 2 176 rooms, rooms/s free-running | lock-step (round 5, shared tail tiles --
+                                       # branch and head stacks -- and 44 front workgroups from 224 slots on: profiles/r05_tail_heads*.txt; lock-step:
+                                       # profiles/r04_teams_units_sweep.txt, r05_b_bench_default.json): 136: 721, 272: 864-882 | 834, 320: 898 | 865, 400: 884-911 | 894-899,
+                                       # 480: 898-903, 544: 906-911 | 926-934 (round 4: 836-857 at 272, the crossover at 300)
 LRG_VGRID_MAX_CELLS = 1 << 26          # dense voxel grid of a room (LrgRoom.vgrid): at most 64 M cells (256 MB) per room ...
 LRG_VGRID_TOTAL_CELLS = 1 << 31        # ... and 8 GB for the rooms of one grower
 LRG_DONE_RING = 1020

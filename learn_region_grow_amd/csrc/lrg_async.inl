@@ -110,6 +110,9 @@ struct LrgAsyncArgs {
     // where the shared tile left them and stores the logits of the slot's rows only (lrg_fused_tile: nrows_out).
     int32_t *tail;               // [0] / [16] the sides' row cursors (= LrgFrontArgs.tail_cur); [32 + side * tail_tiles + tile] rows accounted for | dead rows << 16
     int tail_tiles;              // shared tiles per side
+    int tail_heads;              // 1 (without the units): the HEAD stacks of the tails run on the shared tiles too -- a shared tile's head task is published when the
+                                 // pooled products of ALL slots with rows in it are complete ([32 + 2 * tail_tiles + side * tail_tiles + tile]: slots ready | the
+                                 // tile's slots << 16); 0: a head tile of the slot's own per tail, storing its rows only
     long long tail_ticks;        // (wall_clock64: 100 MHz)
     float *pool_rows;            // nullable (with the units): [n_slots][2 sides][16 tiles][P / 2] column maxima by branch tile, instead of atomicMax on the pooled feature
     int pool_rows_stride;        // 2 * 16 * (P / 2)
@@ -150,8 +153,32 @@ __device__ __forceinline__ void lrg_async_push(const LrgAsyncArgs &A, int ring, 
 
 // the head tiles of a slot whose pooled feature is complete: head 0 = add on the neighbour rows, head 1 = remove on the inlier rows; w_in / w_nb = the side's tiles
 // of the slot's own | bit 12: its tail lies in the shared rows and gets a head tile of its own there (index 16)
+__device__ __forceinline__ int32_t *lrg_tail_head_word(const LrgAsyncArgs &A, int side, int tile) { return A.tail + 32 + 2 * (long)A.tail_tiles + ((long)side * A.tail_tiles + tile); }
 __device__ __forceinline__ void lrg_async_push_heads(const LrgAsyncArgs &A, int slot, int w_in, int w_nb, int lane) {
-    const int nt_in = w_in & 0xFFF, nt_nb = w_nb & 0xFFF, sh_in = (w_in >> 12) & 1, sh_nb = (w_nb >> 12) & 1;
+    const int nt_in = w_in & 0xFFF, nt_nb = w_nb & 0xFFF;
+    int sh_in = (w_in >> 12) & 1, sh_nb = (w_nb >> 12) & 1;
+    if (A.tail_heads && (sh_in | sh_nb)) {
+        // the slot is ready for its heads: counted into the shared tiles its tails lie in (lanes 0 / 1: the inlier side's first / second tile, 2 / 3: the neighbour
+        // side's); whoever completes a tile's count publishes its head task (head 1 = remove on the inlier rows, head 0 = add on the neighbour rows)
+        const int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
+        if (lane < 4) {
+            const int side = lane >> 1, second = lane & 1;
+            if (side ? sh_nb : sh_in) {
+                const int tb = lrg_ld_coh(&sy[9 + side]), tl = (lrg_ld_coh(&sy[11]) >> (16 * side)) & 0xFFFF;
+                const int ta = tb >> 5, tz = (tb + tl - 1) >> 5;
+                if (!second || tz != ta) {
+                    const int tile = second ? tz : ta;
+                    const int old = __hip_atomic_fetch_add(lrg_tail_head_word(A, side, tile), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((old & 0xFFFF) + 1 == (int)((unsigned)old >> 16)) {
+                        const int e = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL + A.head_ring * LRG_AQ_SECOND], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lrg_st_coh(&A.queue[LRG_AQ_RING + A.head_ring * (A.qmask + 1) + (e & A.qmask)], LRG_TASK(LRG_TASK_HEAD, tile, side ? 0 : 1, 17));
+                        if (A.work) atomicAdd(&A.work[7], 1ULL);
+                    }
+                }
+            }
+        }
+        sh_in = sh_nb = 0;
+    }
     lrg_async_push(A, A.head_ring, nt_nb + nt_in + sh_nb + sh_in, lane, [&](int i) {
         if (i < nt_nb) return LRG_TASK(LRG_TASK_HEAD, slot, 0, i);
         if (i < nt_nb + nt_in) return LRG_TASK(LRG_TASK_HEAD, slot, 1, i - nt_nb);
@@ -436,6 +463,13 @@ LRG_ASYNC_ROLE int lrg_async_task_branch_shared(lrg_kargs_ptr kp_, int code_, in
     team.sync();
     // (it arrives for every slot that has rows in it: the runs the tile found, lrg_fused_tile's LDS layout)
     const int *run_inst = reinterpret_cast<const int *>(sm + 32 * 68 + 32 * 132 + 512) + 33;
+    if (A.tail_heads && tid == 0) {      // how many slots the tile's HEAD task waits for: known before any of them can be ready (they arrive below)
+        int live = 0;
+        for (int run = 0; run < nruns; ++run) live += run_inst[run] >= 0 ? 1 : 0;
+        const int old = __hip_atomic_fetch_add(lrg_tail_head_word(A, side, tile), live << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" :: "v"(old));      // (performed before the arrivals: the result is waited for)
+    }
+    team.sync();
     if (tid < 64)
         for (int run = 0; run < nruns; ++run) {
             const int slot = run_inst[run];
@@ -452,56 +486,82 @@ LRG_ASYNC_ROLE int lrg_async_task_branch_shared(lrg_kargs_ptr kp_, int code_, in
 // the batch's entries are written -- or closes it after gemv_batch_ticks (the ring's tail is moved to the batch's end, the unused positions marked) -- and then publishes
 // the batch's 2 x 4 block tasks.  A block task computes its 128 columns for every slot of the batch with the arithmetic of lrg_async_gemv, row by row: the same sums in
 // the same order, bit for bit.
+// The block for all the batch's slots on the matrix cores: lrg_head_gemm_kernel's arithmetic (lrg_net.hip) -- a 32-row x 32-column tile per wavefront (rows = the
+// batch's slots, the rest copies of the last one), eight K ranges of P / 8, each a chain of v_mfma_f32_32x32x2_f32 over its k-groups (lane half h feeds k = 8g + 4h + s),
+// the eight partial tiles added in order, the bias last: the sums lrg_async_gemv and lrg_head_gemv_kernel compute with FMA chains in that order, bit for bit.  The
+// pooled rows come from LDS (staged once, row stride P + 4: conflict-free ds_read_b128), the kernels' columns from L2, half a K range (eight k-groups) ahead of the matrix cores.
 template <class TEAM>
 __device__ __forceinline__ void lrg_async_gemv_rows(const LrgGemvArgs &g, const int *slots_of, int n, int z, int cb, float *sm, const TEAM &team) {
-    const int tid = team.tid(), lane = tid & 63, wave = tid >> 6;
-    float *pl = sm, *part = sm + LRG_GEMV_BATCH * g.P;          // [n][P] pooled rows, [8][128] partial sums
+    const int tid = team.tid(), lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int ldp = g.P + 4;
+    float *pl = sm;                                             // [n][P + 4] pooled rows
     for (int j = 0; j < n; ++j)
         for (int i = 2 * tid; i < g.P; i += 2 * FTHREADS) {
             const float2 v = lrg_ld_coh2(g.pooled + (long)slots_of[j] * g.P + i);
-            pl[j * g.P + i] = v.x; pl[j * g.P + i + 1] = v.y;
+            pl[j * ldp + i] = v.x; pl[j * ldp + i + 1] = v.y;
         }
     team.sync();
-    const int kq = g.P >> 3;
-    const int half = wave >> 1, r = 4 * (wave & 1) + (lane >> 4), cl = half * 64 + 4 * (lane & 15);
-    const int c = cb * LRG_GEMV_TASK_COLS + cl;
-    float4 acc[LRG_GEMV_BATCH];
+    const int c0 = cb * LRG_GEMV_TASK_COLS + 32 * wave;
+    if (c0 < g.C) {
+        const int kq = g.P >> 3;                                // k per range (a multiple of 32: checked by lrg_grow_async)
+        const float *arow = pl + min(li, n - 1) * ldp + 4 * lh;
+        // The kernels' columns are requested HALF A RANGE ahead: while the 32 MFMAs of one half run, the other half's 32 dwords per lane are on their way (with
+        // four k-groups requested at a time and nothing in flight during the MFMAs a block was 32 dependent trips to L2: 200-400 slots lost 40 %).
+        f32x16 sum;
+        const int hg = kq / 16;                                  // k-groups per half range (8 for P = 1024)
+        auto wptr = [&](int half_index) { return g.w[z] + (long)((half_index >> 1) * kq + (half_index & 1) * 8 * hg + 4 * lh) * g.ldw + c0 + li; };
+        float w0[8][4], w1[8][4];
+        {
+            const float *wp = wptr(0);
 #pragma unroll
-    for (int j = 0; j < LRG_GEMV_BATCH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < g.C) {
-        const float *w = g.w[z] + c + (long)(r * kq) * g.ldw;
-        const float *p = pl + r * kq;
-        for (int kb = 0; kb < kq; kb += 16) {
-            float4 wv[16];
+            for (int u = 0; u < 8; ++u) { const float *q = wp + (long)(8 * u) * g.ldw; w0[u][0] = q[0]; w0[u][1] = q[g.ldw]; w0[u][2] = q[2 * (long)g.ldw]; w0[u][3] = q[3 * (long)g.ldw]; }
+        }
+        f32x16 acc;
+        for (int r = 0; r < 8; ++r) {
+            const float *ap = arow + r * kq;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) wv[u] = *reinterpret_cast<const float4 *>(w + (long)(kb + u) * g.ldw);
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            {   // second half of this range on its way, first half on the matrix cores
+                const float *wp = wptr(2 * r + 1);
 #pragma unroll
-            for (int j = 0; j < LRG_GEMV_BATCH; ++j) {
-                if (j < n) {
+                for (int u = 0; u < 8; ++u) { const float *q = wp + (long)(8 * u) * g.ldw; w1[u][0] = q[0]; w1[u][1] = q[g.ldw]; w1[u][2] = q[2 * (long)g.ldw]; w1[u][3] = q[3 * (long)g.ldw]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int uu = 0; uu < 16; ++uu) {
-                        const int u = (uu & 8) | ((uu & 1) << 2) | ((uu >> 1) & 3);      // k = 8g + 0, 4, 1, 5, 2, 6, 3, 7: the order of the MFMA formulation (lrg_async_gemv)
-                        const float pk = p[j * g.P + kb + u];
-                        acc[j].x = fmaf(pk, wv[u].x, acc[j].x); acc[j].y = fmaf(pk, wv[u].y, acc[j].y);
-                        acc[j].z = fmaf(pk, wv[u].z, acc[j].z); acc[j].w = fmaf(pk, wv[u].w, acc[j].w);
-                    }
-                }
+            for (int u = 0; u < 8; ++u) {
+                const float4 av = *reinterpret_cast<const float4 *>(ap + 8 * u);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w0[u][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w0[u][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w0[u][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w0[u][3], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (r < 7) {   // first half of the next range on its way, second half of this one on the matrix cores
+                const float *wp = wptr(2 * r + 2);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const float *q = wp + (long)(8 * u) * g.ldw; w0[u][0] = q[0]; w0[u][1] = q[g.ldw]; w0[u][2] = q[2 * (long)g.ldw]; w0[u][3] = q[3 * (long)g.ldw]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 av = *reinterpret_cast<const float4 *>(ap + 8 * (hg + u));
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w1[u][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w1[u][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w1[u][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w1[u][3], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (r == 0) sum = acc;
+            else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sum[i] = sum[i] + acc[i];      // (part[0] + part[1] + ... in order: lrg_head_gemm_kernel's reduction)
             }
         }
-    }
+        const float bias = g.bias[z] ? g.bias[z][c0 + li] : 0.f;
 #pragma unroll
-    for (int j = 0; j < LRG_GEMV_BATCH; ++j) {
-        if (j < n) {
-            if (c < g.C) *reinterpret_cast<float4 *>(part + r * LRG_GEMV_TASK_COLS + cl) = acc[j];
-            team.sync();
-            if (tid < LRG_GEMV_TASK_COLS && cb * LRG_GEMV_TASK_COLS + tid < g.C) {
-                const int col = cb * LRG_GEMV_TASK_COLS + tid;
-                float sum = part[tid];
-#pragma unroll
-                for (int q = 1; q < 8; ++q) sum += part[q * LRG_GEMV_TASK_COLS + tid];
-                lrg_st_coh(g.hb[z] + (long)slots_of[j] * g.C + col, sum + (g.bias[z] ? g.bias[z][col] : 0.f));
-            }
-            team.sync();
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            if (row < n) lrg_st_coh(g.hb[z] + (long)slots_of[row] * g.C + c0 + li, sum[rr] + bias);
         }
     }
 }
@@ -846,6 +906,42 @@ LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
     return team.target;
 }
 
+// The head stack on a SHARED tail tile (task index 17; the slot field = the tile's number, `side` = the head): the rows the shared branch tile left their conv[1]
+// rows in, every run with its own slot's pooled product as bias (the packed tile form); it arrives for every slot with a run in it.
+LRG_ASYNC_ROLE int lrg_async_task_head_shared(lrg_kargs_ptr kp_, int code_, int sm_off_, int target_, long long t_task) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int code = lrg_uniform(code_), sm_off = lrg_uniform(sm_off_), target = lrg_uniform(target_);
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    float *sm = lrg_async_smem + sm_off + LRG_ASYNC_CTL_FLOATS;
+    const LrgLdsTeam team = lrg_async_team(A, sm, target);
+    const int tid = team.tid();
+    const int tile = (code >> 8) & 0xFFFFF, head = (code >> 7) & 1, bside = head ? 0 : 1;      // (head 1 runs on the inlier rows, head 0 on the neighbour rows)
+    const int dead = (int)((unsigned)lrg_ld_coh(lrg_tail_word(A, bside, tile)) >> 16);
+    const long r0 = (long)A.front.tail_row0 + (long)tile * 32;
+    __builtin_amdgcn_s_setprio(LRG_ASYNC_HEAD_PRIO);
+    const int nruns = lrg_fused_tile<32 * 260, 32 * 68, 1, LRG_ASYNC_FD, false, true, true, LrgLdsTeam, false>(A.prob[2 + head], r0, 0, 0, 0x7fffffff, (int)(r0 + 32 - dead), sm, team,
+                                                                                                             nullptr, LrgNoWait(), 0, 1);
+    __builtin_amdgcn_s_setprio(0);
+    lrg_drain_stores();                              // the logits are out before the arrivals the front workgroups poll
+    team.sync();
+    const int *run_inst = reinterpret_cast<const int *>(sm + 32 * 260 + 32 * 68 + 512) + 33;
+    if (tid == 0) {
+        for (int run = 0; run < nruns; ++run) {
+            const int slot = run_inst[run];
+            if (slot < 0) continue;
+            int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
+            const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            if (LRG_DBG(A)) {
+                const long long now = wall_clock64();
+                if (run == 0) { lrg_dbg_add(A, 8 + 2 * LRG_TASK_HEAD, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_HEAD, 1); }
+                if (done == lrg_ld_coh(&sy[6])) lrg_dbg_add(A, 4, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+            }
+        }
+    }
+    team.sync();
+    return team.target;
+}
+
 // ---- the 1-NN fill-in of a finished room (test_region_grow.py:308-316) as tasks of the same launch ----
 // Between launches the fill-ins of the ~13 rooms that finish during a 25 ms launch cost ~2 % of the steady leg (lrg_nn1_fill_batch).  Here the
 // front workgroup that finishes a room lists its unlabeled points, makes the room's labels visible (one release: they were plain stores of its CU) and
@@ -1060,6 +1156,7 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
         else if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task, next_ticket, ticket_word);
         else if (type == LRG_TASK_GEMV && (code & 96)) team.target = lrg_async_task_gemv_batch(kp, code, sm_off, team.target, t_task, t_launch);
         else if (type == LRG_TASK_GEMV) team.target = lrg_async_task_gemv(kp, code, sm_off, team.target, t_task);
+        else if ((code & 127) == 17) team.target = lrg_async_task_head_shared(kp, code, sm_off, team.target, t_task);
         else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task, t_launch, next_ticket, ticket_word);
     }
 }
@@ -1286,7 +1383,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
             const int n_open = (op_in >= 0 ? 1 : 0) + (op_nb >= 0 ? 1 : 0);
             if (tid == 0) {
                 int32_t *sy = A.sync + (long)s * LRG_ASYNC_SYNC_WORDS;
-                C.tgt[i][0] += (nt_in + nt_nb) * A.branch_parts + nsh; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb + sh_in + sh_nb;
+                C.tgt[i][0] += (nt_in + nt_nb) * A.branch_parts + nsh; C.tgt[i][1] += n_gemv; C.tgt[i][2] += nt_in + nt_nb + (A.tail_heads ? nsh : sh_in + sh_nb);
                 if (A.tail) { lrg_st_coh(&sy[9], tb_in); lrg_st_coh(&sy[10], tb_nb); lrg_st_coh(&sy[11], (rin & 31) | ((rnb & 31) << 16)); }
                 lrg_st_coh4(reinterpret_cast<float *>(sy), 16u, make_float4(__int_as_float(C.tgt[i][0]), __int_as_float(C.tgt[i][1]), __int_as_float(C.tgt[i][2]),
                                                                       __int_as_float((nt_in | (sh_in << 12)) | ((nt_nb | (sh_nb << 12)) << 16))));      // (one 16-byte store instead of five dwords)
@@ -1298,7 +1395,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 if (A.work) {
                     atomicAdd(&A.work[0], 1ULL); atomicAdd(&A.work[1], (unsigned long long)(r >> 16));
                     atomicAdd(&A.work[2], (unsigned long long)(r & 0xFFFF)); atomicAdd(&A.work[3], (unsigned long long)(nt_in + nt_nb + n_open));
-                    atomicAdd(&A.work[7], (unsigned long long)(nt_in + nt_nb + sh_in + sh_nb));      // (head tiles: a tail's head tile is the slot's own)
+                    atomicAdd(&A.work[7], (unsigned long long)(nt_in + nt_nb + (A.tail_heads ? 0 : sh_in + sh_nb)));      // (head tiles; shared ones are counted where they are published)
                 }
                 C.state[i] = 1;
                 C.steps[i] += 1;

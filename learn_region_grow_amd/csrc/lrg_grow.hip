@@ -1675,11 +1675,15 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         // LRG_ASYNC_GEMV_BATCH=0 / =1: off / on whatever the slot count; LRG_ASYNC_GEMV_BATCH_US: the patience
         const int batch_env = getenv("LRG_ASYNC_GEMV_BATCH") ? atoi(getenv("LRG_ASYNC_GEMV_BATCH")) : -1;
         const int batch_us10 = getenv("LRG_ASYNC_GEMV_BATCH_US") ? (int)(10.0 * atof(getenv("LRG_ASYNC_GEMV_BATCH_US"))) : 15;
-        const bool fits = (size_t)(LRG_GEMV_BATCH * g.P + 8 * LRG_GEMV_TASK_COLS) <= (size_t)LRG_ASYNC_TILE_FLOATS && (g.P & 127) == 0 && n_slots < LRG_GEMV_NOBODY;
+        const bool fits = (size_t)(LRG_GEMV_BATCH * (g.P + 4)) <= (size_t)LRG_ASYNC_TILE_FLOATS && g.P == 1024 && (g.C & 31) == 0 && n_slots < LRG_GEMV_NOBODY;      // (half ranges of eight k-groups: the paper's 2 x 512 pooled features)
         // (2 176 room jobs, rooms/s without | with: 200 slots 771 | 731, 272: 873 | 800, 320: 888 | 850, 400: 880 | 896 -- a block takes 68 us for ~7.7 slots instead
         //  of 23 us for one, 35 instead of 93 team-us per evaluation, but the pooled stage of a slot's step grows from 71 to 108 us and below ~400 slots the launch is
         //  bound by that latency, not by its teams: profiles/r05_gemv_batch_v1.txt, r05_bench_debug_batch.log)
-        A.gemv_batch = (units == 0 && fits && (batch_env > 0 || (batch_env < 0 && n_slots >= 384))) ? LRG_GEMV_BATCH : 0;
+        // ... and the matrix-core form of the block (this build): 200 slots 773 | 723, 272: 871 | 791, 320: 885 | 837, 400: 884 | 877; with shared head tiles 400: 884-911 | 864,
+        // 544: 906 | 905 (profiles/r05_gemv_batch_v3_mfma_pipelined.txt, r05_tail_heads2.txt).  The block for one slot costs the tile teams' CU nothing but L2 latency
+        // (its few FMAs run beside the other teams' MFMAs); the batch's block costs matrix-pipe time -- 32-row tiles for ~8 slots -- which is what the launch is short of.
+        // Off unless asked for (LRG_ASYNC_GEMV_BATCH=1).
+        A.gemv_batch = (units == 0 && fits && batch_env > 0) ? LRG_GEMV_BATCH : 0;
         A.gemv_batch_ticks = (long long)batch_us10 * 10;
     }
     // With the units, a branch tile leaves its column maxima of the pooled layer as one row of 16-byte stores (pool_rows) and the units take
@@ -1697,7 +1701,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         a.fill_in_launch = 1;
     }
     // Shared tail tiles: the caller's row arrays continue behind the slots' own rows
-    A.tail = nullptr; A.tail_tiles = 0; A.tail_ticks = 0;
+    A.tail = nullptr; A.tail_tiles = 0; A.tail_ticks = 0; A.tail_heads = 0;
     a.tail_cur = nullptr; a.tail_base = nullptr; a.tail_rows = 0; a.tail_row0 = 0;
     if (ab->tail_ctl && ab->tail_rows > 0 && a.rows16 && !ab->pool_rows) {
         if ((ab->tail_rows & 31) || ((uintptr_t)ab->tail_ctl & 63) || (long)b->row_cap < (long)n_slots * row_stride + ab->tail_rows || n_slots >= (1 << 20) ||
@@ -1707,6 +1711,9 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         A.tail_ticks = ab->tail_close_us < 0 ? 0 : ab->tail_close_us > 0 ? (long long)ab->tail_close_us * 100 : 200;
         a.tail_cur = ab->tail_ctl; a.tail_rows = ab->tail_rows; a.tail_row0 = n_slots * row_stride;
         a.tail_base = ab->tail_ctl + 32 + 4 * (size_t)A.tail_tiles;
+        // (the heads of the tails on the shared tiles too -- without the units, whose head tiles start before the pooled product is complete and wait inside;
+        //  LRG_ASYNC_TAIL_HEADS=0: a head tile of the slot's own per tail)
+        A.tail_heads = (A.gemv_units == 0 && !(getenv("LRG_ASYNC_TAIL_HEADS") && atoi(getenv("LRG_ASYNC_TAIL_HEADS")) == 0)) ? 1 : 0;
         LRG_HIP_CHECK(hipMemsetAsync(ab->tail_ctl, 0, (32 + 4 * (size_t)A.tail_tiles) * sizeof(int32_t), (hipStream_t)stream));
     }
     A.pool_rows = nullptr; A.pool_rows_stride = 0;
