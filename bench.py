@@ -77,7 +77,7 @@ def parse():
                          "(learn_region_grow_amd/weights, tools/train_synthetic.py) -- the reference's policy then gives Area-5-like "
                          "dynamics (~100 labeled regions and ~1 500 steps per room); 'random': seeded random weights (growth degenerates "
                          "under 'net': use --policy gt with them)")
-    ap.add_argument('--net-mode', default='fused', choices=['fused', 'streamed'])
+    ap.add_argument('--net-mode', default='fused', choices=['fused', 'streamed', 'streamed-tiles'])
     ap.add_argument('--packed', type=int, default=1, help='1: lrg_grow_step_packed (front kernel + packed rows); 0: the nine-launch lrg_grow_step')
     ap.add_argument('--graph', type=int, default=4, help='packed iterations replayed per host call from a HIP graph (0 = plain launches)')
     ap.add_argument('--fill', type=int, default=1, help='1: finished rooms get their 1-NN fill-in before they are recycled')

@@ -75,6 +75,9 @@ int lrg_pack_weights(const LrgWeights *w, void *packed, size_t packed_bytes, voi
                                   working workgroups, back to back, so they spread evenly over the compute units (skipping
                                   by row count alone leaves the survivors wherever the dead tiles happened to sit).      */
 #define LRG_ROW_TILE 32        /* rows per tile of those lists */
+#define LRG_FWD_STREAM_TILES 32u /* layer-streamed path (no LRG_FWD_FUSED): every layer launch runs on the fused stacks' tile (a 1-layer stack: input rows staged once
+                                 for all column blocks, weights in operand order, output from the accumulators to HBM) instead of lrg_pointwise_mfma_kernel's
+                                 64 x 64 tiles; same layer-by-layer formulation and HBM traffic model (ABI 9)                                                     */
 #define LRG_FWD_POOL_ZEROED 8u /* with LRG_FWD_FUSED: the workspace was zero-filled once by the caller and is only ever used
                                 by calls carrying this flag -- the pooled-feature block is then zero on entry and is
                                 left zero on return (cleared by the head kernel), which saves the per-call memset.

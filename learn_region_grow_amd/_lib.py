@@ -21,6 +21,7 @@ LRG_FWD_FUSE_POOL = 1
 LRG_FWD_FUSED = 2
 LRG_FWD_KEEP_ACTS = 4
 LRG_FWD_POOL_ZEROED = 8
+LRG_FWD_STREAM_TILES = 32
 
 (LRG_IDLE, LRG_ACTIVE, LRG_STOP_NONEIGHBOR, LRG_STOP_NOEXPAND, LRG_STOP_STUCK, LRG_STOP_EMPTY, LRG_STOP_MAXSTEPS,
  LRG_DONE, LRG_WAIT, LRG_PENDING) = range(10)

@@ -50,6 +50,8 @@ struct LrgFusedArgs {
 
 int lrg_fused_branches(const LrgFusedArgs &a, int nprob, hipStream_t st);
 int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st);
+// one layer per launch (lrg_forward, LRG_FWD_STREAM_TILES): 1-layer problems with gout set and no KEEP
+int lrg_fused_layer(const LrgFusedArgs &a, int nprob, hipStream_t st);
 // packed-row variants: P.rows = row capacity (multiple of 32), P.nrows / P.row_inst set
 int lrg_fused_branches_packed(const LrgFusedArgs &a, int nprob, hipStream_t st);
 int lrg_fused_heads_packed(const LrgFusedArgs &a, int nprob, hipStream_t st);

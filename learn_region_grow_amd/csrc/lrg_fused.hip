@@ -11,6 +11,7 @@
 #include "lrg_common.h"
 #include "lrg_fused.h"
 #include "lrg_fused_tile.inl"
+#include "lrg_stream_layer.inl"
 
 #if LRG_TRACE
 __device__ long long *g_lrg_trace = nullptr;
@@ -175,6 +176,55 @@ int lrg_fused_heads(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     // 64 -> 256 -> 128 (-> 2); the last hidden layer is written in place
     if (needs_direct(a, nprob)) return launch_stack<32 * 260, 32 * 68, 1, 4, 2, true>(a, nprob, st);
     return launch_stack<32 * 260, 32 * 68, 1, 4, 3, false>(a, nprob, st);
+}
+
+// ONE layer per launch (lrg_forward's layer-streamed formulation, LRG_FWD_STREAM_TILES).  LrgNet's own layer shapes run on the streaming wavefront kernel
+// (lrg_stream_layer.inl: both MFMA operands from memory in operand order, no LDS, no barrier); any other shape as a 1-layer stack on the fused tile, output from
+// the accumulators to HBM.  Either way the MFMA sequence and the epilogue of the fused stacks: the same bits.
+// LRG_LAYER_VARIANT (measurements, profiles/r05_layer_variants.txt): 0 / 2 = the fused tile for every shape (64-row, two per CU / 32-row, four per CU),
+// 3 = the streaming kernel with its wider column groups, 4 (default) = with the narrower ones.
+int lrg_fused_layer(const LrgFusedArgs &a, int nprob, hipStream_t st) {
+    int K = 0;
+    for (int i = 0; i < nprob; ++i) {
+        if (a.p[i].nlayers != 1 || !a.p[i].L[0].gout || (a.p[i].L[0].flags & (LRG_FL_KEEP | LRG_FL_INPLACE | LRG_FL_POOL)) || a.p[i].fw) return LRG_EINVAL - 30;
+        K = a.p[i].Kin > K ? a.p[i].Kin : K;
+    }
+    static const int v = getenv("LRG_LAYER_VARIANT") ? atoi(getenv("LRG_LAYER_VARIANT")) : 5;
+    if (v >= 3) {
+        const int ng = a.p[0].L[0].ng, N = a.p[0].L[0].N;
+        bool same = true, aligned = true;
+        for (int i = 0; i < nprob; ++i) {
+            same = same && a.p[i].L[0].ng == ng && a.p[i].L[0].N == N && a.p[i].Kin == a.p[0].Kin;
+            same = same && a.p[i].L[0].bias != nullptr;
+            aligned = aligned && a.p[i].ldx % 4 == 0 && a.p[i].Kin == 8 * ng && a.p[i].rows_per_inst % 32 == 0;
+        }
+        if (v >= 5) {      // the persistent form, the weights from LDS (7: every ring eight k-groups deep, refilled a line at a time)
+            if (same && aligned) {
+                if (ng == 8 && N == 64) return lrg_stream_layer_lds_launch<8, 2, 8, 4, false>(a, nprob, st);
+                if (ng == 8 && N == 128) return v == 7 ? lrg_stream_layer_lds_launch<8, 4, 8, 3, false>(a, nprob, st) : lrg_stream_layer_lds_launch<8, 4, 4, 3, false>(a, nprob, st);
+                if (ng == 8 && N == 256) return v == 7 ? lrg_stream_layer_lds_launch<8, 4, 8, 3, false>(a, nprob, st) : lrg_stream_layer_lds_launch<8, 4, 4, 3, false>(a, nprob, st);
+                if (ng == 16 && N == 512) return v == 7 ? lrg_stream_layer_lds_launch<16, 4, 8, 2, false>(a, nprob, st) : lrg_stream_layer_lds_launch<16, 4, 4, 2, false>(a, nprob, st);
+                if (ng == 32 && N == 128) return v == 7 ? lrg_stream_layer_lds_launch<32, 2, 8, 2, false>(a, nprob, st) : lrg_stream_layer_lds_launch<32, 2, 4, 2, false>(a, nprob, st);
+            }
+        }
+        if (same && ng == 2 && N == 64 && a.p[0].rows_per_inst % 32 == 0) return lrg_stream_layer_launch<2, 2, 2, 4, true>(a, nprob, st);
+        if (same && aligned) {
+            if (ng == 8 && N == 64) return lrg_stream_layer_launch<8, 2, 4, 4, false>(a, nprob, st);
+            if (ng == 8 && N == 128) return v == 3 ? lrg_stream_layer_launch<8, 4, 4, 3, false>(a, nprob, st) : lrg_stream_layer_launch<8, 2, 4, 4, false>(a, nprob, st);
+            if (ng == 8 && N == 256) return v == 3 ? lrg_stream_layer_launch<8, 8, 3, 2, false>(a, nprob, st) : lrg_stream_layer_launch<8, 4, 4, 3, false>(a, nprob, st);
+            if (ng == 16 && N == 512) return v == 3 ? lrg_stream_layer_launch<16, 8, 3, 2, false>(a, nprob, st) : lrg_stream_layer_launch<16, 4, 4, 3, false>(a, nprob, st);
+            if (ng == 32 && N == 128) return v == 3 ? lrg_stream_layer_launch<32, 4, 4, 3, false>(a, nprob, st) : lrg_stream_layer_launch<32, 2, 4, 4, false>(a, nprob, st);
+        }
+    }
+    // no layer output stays in LDS, so the even buffer is a stub and four 32-row tiles share a CU (one tile's load / MFMA / store phases do not overlap; the
+    // neighbours' do; two 64-row tiles per CU: 4.78 ms per evaluation of 1088 instances against 4.59)
+    if (v == 0) {
+        if (K <= 128) return launch_stack<64 * 68, 64 * 132, 2, 4, 2, true>(a, nprob, st);      // (the instantiation of the keep-everything parity path)
+        return launch_stack<32 * 68, 32 * 260, 1, 4, 3, true>(a, nprob, st);                    // K = 256: the heads' second layer
+    }
+    if (K <= 64) return launch_stack<64, 32 * 68, 1, 4, 4, true>(a, nprob, st);
+    if (K <= 128) return launch_stack<64, 32 * 132, 1, 4, 4, true>(a, nprob, st);
+    return launch_stack<64, 32 * 260, 1, 4, 4, true>(a, nprob, st);
 }
 
 // Build-time knobs of the packed-row kernels (tools/r02_fd2.sh): depth of the weight ring and workgroups per CU.  Measured on

@@ -995,9 +995,46 @@ int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neig
                                     ws, L, (flags & LRG_FWD_KEEP_ACTS) != 0, (flags & LRG_FWD_POOL_ZEROED) != 0,
                                     (flags & LRG_FWD_TILE_LISTS) != 0 && rows_in != nullptr && !(flags & LRG_FWD_KEEP_ACTS), st);
     if (fuse_pool) LRG_HIP_CHECK(hipMemsetAsync(ws + L.pooled, 0, (size_t)B * L.P * sizeof(float), st));
+    // LRG_FWD_STREAM_TILES: the layer launches on the fused stacks' tile (shapes as for the fused path; else the 64 x 64-tile kernel below)
+    bool stream_tiles = (flags & LRG_FWD_STREAM_TILES) && !fuse_pool && (n_inlier % 64 == 0) && (n_neighbor % 64 == 0);
+    for (int i = 0; stream_tiles && i < nc; ++i)
+        if (w->conv_ch[i] % 64 != 0 || w->conv_ch[i] > 512 || (i + 1 < nc && w->conv_ch[i] > 256)) stream_tiles = false;
+    for (int i = 0; stream_tiles && i < nh - 1; ++i)
+        if (w->head_ch[i] % 64 != 0 || w->head_ch[i] > 512 || (i + 1 < nh - 1 && w->head_ch[i] != 64 && w->head_ch[i] != 128 && w->head_ch[i] != 256)) stream_tiles = false;
+    if (stream_tiles && w->conv_ch[1] != 64 && w->conv_ch[1] != 128) stream_tiles = false;
+    const float *pk = nullptr;
+    LrgPackLayout PL;
+    if (stream_tiles) {
+        if ((rc = pack_layout(w, &PL))) return rc;
+        pk = static_cast<const float *>(w->packed);
+        if (!pk) {
+            if ((rc = pack_weights(w, ws + L.packed, st))) return rc;
+            pk = ws + L.packed;
+        }
+    }
 
     // ---- branches (:106-119): both branches in one launch per layer ----
     for (int i = 0; i < nc; ++i) {
+        const int cin_t = i == 0 ? w->feature_size : w->conv_ch[i - 1];
+        if (stream_tiles) {
+            LrgFusedArgs fa = {};
+            for (int br = 0; br < 2; ++br) {
+                LrgFusedProb &P = fa.p[br];
+                P.x = i == 0 ? (br == 0 ? inlier : neighbor) : ws + L.conv[br][i - 1];
+                P.ldx = cin_t; P.Kin = cin_t;
+                P.rows = rows[br]; P.rows_per_inst = rpi[br];
+                P.nlayers = 1;
+                LrgFusedLayer &F = P.L[0];
+                F.w = pk + PL.conv[br][i];
+                F.bias = br == 0 ? w->inlier_b[i] : w->neighbor_b[i];
+                F.K = cin_t; F.N = w->conv_ch[i]; F.ng = lrg_kgroups(F.K);
+                F.flags = LRG_FL_RELU;
+                F.gout = ws + L.conv[br][i];
+            }
+            rc = lrg_fused_layer(fa, 2, st);
+            if (rc) return rc;
+            continue;
+        }
         LrgLayerArgs a = {};
         const int cin = i == 0 ? w->feature_size : w->conv_ch[i - 1];
         for (int br = 0; br < 2; ++br) {
@@ -1043,6 +1080,26 @@ int lrg_forward_rows(const LrgWeights *w, const float *inlier, const float *neig
     }
     const int hbr[2] = {1, 0};   // branch feeding each head
     for (int i = 0; i < nh - 1; ++i) {
+        if (stream_tiles) {
+            LrgFusedArgs fa = {};
+            for (int hd = 0; hd < 2; ++hd) {
+                const int br = hbr[hd];
+                LrgFusedProb &P = fa.p[hd];
+                P.x = i == 0 ? ws + L.conv[br][1] : ws + L.hid[hd][i - 1];
+                P.Kin = i == 0 ? Cloc : w->head_ch[i - 1]; P.ldx = P.Kin;
+                P.rows = rows[br]; P.rows_per_inst = rpi[br];
+                P.nlayers = 1;
+                LrgFusedLayer &F = P.L[0];
+                F.w = pk + PL.head[hd][i];
+                F.bias = i == 0 ? ws + L.hb[hd] : (hd == 0 ? w->add_b[i] : w->rmv_b[i]);
+                F.K = P.Kin; F.N = w->head_ch[i]; F.ng = lrg_kgroups(F.K);
+                F.flags = LRG_FL_RELU | (i == 0 ? LRG_FL_INST_BIAS : 0);
+                F.gout = ws + L.hid[hd][i];
+            }
+            rc = lrg_fused_layer(fa, 2, st);
+            if (rc) return rc;
+            continue;
+        }
         LrgLayerArgs a = {};
         for (int hd = 0; hd < 2; ++hd) {
             const int br = hbr[hd];

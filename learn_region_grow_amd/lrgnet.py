@@ -35,7 +35,8 @@ class LrgNetHIP:
     def __init__(self, batch_size, seq_len, num_inlier_points, num_neighbor_points, feature_size, lite=0,
                  device='cuda:0', fuse_pool=False, mode='fused', keep_acts=False):
         """mode='fused': whole branch / whole head per 64-row tile in one kernel each (3 launches per evaluation);
-        mode='streamed': one launch per layer, every activation through HBM (the layer-by-layer formulation).
+        mode='streamed': one launch per layer, every activation through HBM (the layer-by-layer formulation);
+        mode='streamed-tiles': the same, every layer launch on the fused stacks' tile (LRG_FWD_STREAM_TILES).
         keep_acts: with 'fused', also copy every intermediate to the workspace so intermediate() works."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -49,9 +50,9 @@ class LrgNetHIP:
         self.conv_channels = CONV_CHANNELS[self.lite]
         self.conv2_channels = CONV2_CHANNELS[self.lite]
         self.fuse_pool = fuse_pool
-        assert mode in ('fused', 'streamed')
+        assert mode in ('fused', 'streamed', 'streamed-tiles')
         self.mode = mode
-        self.forward_flags = (_lib.LRG_FWD_FUSE_POOL if fuse_pool else 0) | (_lib.LRG_FWD_FUSED if mode == 'fused' else 0) | \
+        self.forward_flags = (_lib.LRG_FWD_FUSE_POOL if fuse_pool else 0) | (_lib.LRG_FWD_FUSED if mode == 'fused' else 0) | (_lib.LRG_FWD_STREAM_TILES if mode == 'streamed-tiles' else 0) | \
             (_lib.LRG_FWD_KEEP_ACTS if keep_acts else 0)
         self.weights = {}          # name -> device tensor ([Cin,Cout] / [C])
         self._w = None             # LrgWeights (host struct of device pointers)

@@ -25,7 +25,7 @@ def close(got, want, what):
 
 
 MODES = {'streamed': dict(mode='streamed'), 'streamed+pool': dict(mode='streamed', fuse_pool=True),
-         'fused': dict(mode='fused', keep_acts=True)}
+         'streamed-tiles': dict(mode='streamed-tiles'), 'fused': dict(mode='fused', keep_acts=True)}
 
 
 def make_net(cuda_device, lite, F, ni, nn, mode='streamed'):
@@ -132,13 +132,17 @@ def test_fused_and_streamed_paths_agree(cuda_device):
     xi = torch.from_numpy((rs.randn(9, 512, 13) * 0.5).astype(np.float32)).to(cuda_device)
     xn = torch.from_numpy((rs.randn(9, 512, 13) * 0.5).astype(np.float32)).to(cuda_device)
     outs = {}
-    for mode in ('streamed', 'fused'):
+    for mode in ('streamed', 'fused', 'streamed-tiles'):
         net, _ = make_net(cuda_device, 0, 13, 512, 512, mode)
         add, rmv = net.forward(xi, xn)
         outs[mode] = (add.cpu().numpy(), rmv.cpu().numpy(), net.intermediate('pooled', 0, 9).cpu().numpy().copy())
     close(outs['fused'][0], outs['streamed'][0], 'add')
     close(outs['fused'][1], outs['streamed'][1], 'rmv')
     close(outs['fused'][2], outs['streamed'][2], 'pooled')
+    # one layer per launch on the fused tile: the fused stacks' own MFMA sequence and epilogue, so the pooled features (a max of identical products) are the same bits
+    close(outs['streamed-tiles'][0], outs['streamed'][0], 'add (tiles)')
+    close(outs['streamed-tiles'][1], outs['streamed'][1], 'rmv (tiles)')
+    np.testing.assert_array_equal(outs['streamed-tiles'][2], outs['fused'][2])
 
 
 def test_forward_rows_skips_duplicate_rows_exactly(cuda_device):

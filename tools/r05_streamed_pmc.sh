@@ -3,19 +3,19 @@
 # (`--net-mode streamed`: one lrg_pointwise_mfma_kernel launch per layer, activations through HBM), at B = 68 and B = 1088 instances.
 # Separate --pmc passes (FETCH_SIZE | WRITE_SIZE), durations from a --kernel-trace pass of the same command, counters corrected on a 256 MiB copy
 # (MI355X_MICROARCH.md, HBM section).   usage (GPU box): tools/r05_streamed_pmc.sh <commit> [out.json]
-R=$GRAFT_REPO_ROOT; COMMIT=${1:-unknown}; OUT=${2:-gpurun_out/r05_traffic_streamed.json}
+R=$GRAFT_REPO_ROOT; COMMIT=${1:-unknown}; OUT=${2:-gpurun_out/r05_traffic_streamed.json}; MODE=${MODE:-streamed}   # MODE=streamed-tiles: the layer launches on the fused tile
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pmcs && mkdir -p /tmp/pmcs
 N=10
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmcs/calib_fetch -o cf --output-format csv -- python $R/tools/pmc_calib.py > /tmp/pmcs/cf.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmcs/calib_write -o cw --output-format csv -- python $R/tools/pmc_calib.py > /tmp/pmcs/cw.log 2>&1
 for B in 68 1088; do
-  C="python $R/tools/fwd_only.py $B streamed $((N-1))"
+  C="python $R/tools/fwd_only.py $B $MODE $((N-1))"
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pmcs/kt$B -o kt --output-format csv -- $C > /tmp/pmcs/kt$B.log 2>&1
   timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmcs/fetch$B -o f --output-format csv -- $C > /tmp/pmcs/f$B.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmcs/write$B -o w --output-format csv -- $C > /tmp/pmcs/w$B.log 2>&1
   cp $(find /tmp/pmcs/kt$B -name "*kernel_stats.csv" | head -1) $R/${OUT%.json}_B${B}_kernel_stats.csv 2>/dev/null
 done
-python - /tmp/pmcs "$R/$OUT" "$COMMIT" $N <<'PY'
+python - /tmp/pmcs "$R/$OUT" "$COMMIT" $N $MODE <<'PY'
 import csv, glob, json, os, sys
 root, outp, commit, nfwd = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 def per_kernel(d, counter):
@@ -30,7 +30,7 @@ cf, cw = per_kernel('calib_fetch', 'FETCH_SIZE'), per_kernel('calib_write', 'WRI
 copyk = max(cf, key=lambda k: sum(cf[k]))
 kf = 256 * MiB / (sum(cf[copyk]) / len(cf[copyk]) * 1024)
 kw = 256 * MiB / (sum(cw[copyk]) / len(cw[copyk]) * 1024)
-res = dict(source='tools/r05_streamed_pmc.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE passes of their own over tools/fwd_only.py <B> streamed; durations from a --kernel-trace --stats pass',
+res = dict(source='tools/r05_streamed_pmc.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE passes of their own over tools/fwd_only.py <B> %s; durations' % sys.argv[5] + ' from a --kernel-trace --stats pass',
            commit=commit, fetch_correction=kf, write_correction=kw, hbm_peak_GBps=8000.0, forwards_profiled=nfwd, batches={})
 for B in (68, 1088):
     f, w = per_kernel('fetch%d' % B, 'FETCH_SIZE'), per_kernel('write%d' % B, 'WRITE_SIZE')
