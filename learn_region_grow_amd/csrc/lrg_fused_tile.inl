@@ -149,7 +149,9 @@ __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[RT], const float *ap, in
         for (int t = 0; t < RTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[g % 3][t].z, b.z, acc[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < RTT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[g % 3][t].w, b.w, acc[t], 0, 0, 0);
+#ifndef LRG_EXP_NO_WEIGHT_STREAM      // (experiment switch, --policy gt only: the ring is never refilled -- what streaming every tile's weights from L2 costs at saturation)
         bq[g % FD] = (g + FD < NG) ? wp[(g + FD) * 64] : wpn[(g + FD - NG) * 64];
+#endif
     }
     // pin that order: two groups of LDS reads up front, then per k-group [LDS reads of g+2][4*RTT MFMAs][ring refill]
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * RTT, 0);
