@@ -698,6 +698,30 @@ def main():
                                                 'keep activations in LDS, so this is NOT traffic', 'bytes_per_instance': BYTES_PER_INSTANCE_STEP,
                                         'GBps': S * BYTES_PER_INSTANCE_STEP / (fwd_ms * 1e-3) / 1e9,
                                         'frac_of_hbm_peak': S * BYTES_PER_INSTANCE_STEP / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    # north_star's MLP metric: the SAME evaluation run layer by layer, every activation through HBM (LRG_FWD_STREAM_TILES: csrc/lrg_stream_layer.inl), a side launch
+    # at 1 088 instances, priced with the algorithmic bytes of SURVEY.md 8d (the counters' figure: profiles/r05_traffic_streamed_tiles.json)
+    try:
+        from learn_region_grow_amd.lrgnet import LrgNetHIP
+        Sb = 1088
+        snet = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev, mode='streamed-tiles').load_weights(weights)
+        s_inl = torch.from_numpy((rs.randn(Sb, 512, 13) * 0.5).astype(np.float32)).to(dev)
+        s_nbr = torch.from_numpy((rs.randn(Sb, 512, 13) * 0.5).astype(np.float32)).to(dev)
+        snet.forward(s_inl, s_nbr)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            snet.forward(s_inl, s_nbr)
+        ev1.record()
+        torch.cuda.synchronize()
+        s_ms = ev0.elapsed_time(ev1) / reps
+        roof['dense']['layer_streamed'] = {'note': 'side launch, NOT in the timed loop: one launch per layer, activations through HBM (mode streamed-tiles), %d instances' % Sb,
+                                           'ms_per_evaluation': s_ms, 'algorithmic_bytes': Sb * BYTES_PER_INSTANCE_STEP,
+                                           'GBps': Sb * BYTES_PER_INSTANCE_STEP / (s_ms * 1e-3) / 1e9,
+                                           'frac_of_hbm_peak': Sb * BYTES_PER_INSTANCE_STEP / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           'counters': 'profiles/r05_traffic_streamed_tiles.json (FETCH_SIZE + WRITE_SIZE: 12.16 GB in 3.41 ms under the profiler = 0.446)'}
+        del snet, s_inl, s_nbr
+    except Exception as e:       # (a side figure: never the reason the line is missing)
+        roof['dense']['layer_streamed'] = {'error': repr(e)}
     # HBM traffic / matrix-pipe occupancy of the loop's kernel: PMC passes of their own (tools/pmc_free_run.sh), quoted from the committed
     # file only when it was measured on this ABI and formulation
     roof['traffic'] = None

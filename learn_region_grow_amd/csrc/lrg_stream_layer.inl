@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256, OCC) void lrg_stream_layer_kernel(LrgStreamArg
 // its own -- A through the register ring from HBM (requests run on into the NEXT tile: no prologue bubble between tiles), B by ds_read_b128 one k-group ahead, no
 // barrier after the first.  The column groups of a row tile are workgroups of the same XCD at the same place in their walks: the tile's rows come from HBM once
 // and from that XCD's L2 for the others.
-template <int NG, int CT, int D, int OCC, bool FIRST, int W>
+// RT = 2: a wavefront takes TWO consecutive row tiles at a time -- every B value read from LDS feeds two MFMAs.
+template <int NG, int CT, int D, int OCC, bool FIRST, int W, int RT>
 __global__ __launch_bounds__(64 * W, OCC) void lrg_stream_layer_lds_kernel(LrgStreamArgs a) {
     static_assert(D >= 1 && D <= NG && NG % D == 0, "ring slots are static: the ring's depth divides the layer's k-groups");
     extern __shared__ __attribute__((aligned(16))) float lrg_stream_smem[];
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64 * W, OCC) void lrg_stream_layer_lds_kernel(LrgSt
     const int cg = (int)(unit & ((1u << a.cg_shift) - 1u));
     const int col0 = cg * 32 * CT;
     const int ldx = second ? a.ldx[1] : a.ldx[0];
-    const unsigned ntiles = (unsigned)((second ? a.rows[1] : a.rows[0]) >> 5);
+    const unsigned ntiles = (unsigned)((second ? a.rows[1] : a.rows[0]) >> 5) / (unsigned)RT;      // (units of RT row tiles)
     {
         const float4 *src = reinterpret_cast<const float4 *>(second ? a.w[1] : a.w[0]) + (size_t)(cg * CT) * NG * 64;
         for (int i = tid; i < CT * NG * 64; i += 64 * W) bl[i] = src[i];
@@ -160,24 +161,30 @@ __global__ __launch_bounds__(64 * W, OCC) void lrg_stream_layer_lds_kernel(LrgSt
     const bool inst_bias = (second ? a.inst_bias[1] : a.inst_bias[0]) != 0;
     const bool relu = a.relu != 0;
     const unsigned vx = (unsigned)(li * ldx + 4 * lh) * 4u;          // + 8 g floats
+    const unsigned vx1 = vx + 32u * (unsigned)ldx * 4u;              // (the second tile of a pair)
     const unsigned vy = (unsigned)(4 * lh * N + li) * 4u;
+    const unsigned vy1 = vy + 32u * (unsigned)N * 4u;
     const float4 *bp = bl + lane;                                    // + (c NG + g) 64
-    float4 ar[D];
+    float4 ar[D][RT];
     auto request = [&](const __amdgpu_buffer_rsrc_t &rx, int g, int slot) {
         if constexpr (FIRST) {
+            static_assert(!FIRST || RT == 1, "narrow rows: one tile at a time");
             const int k0 = 8 * g + 4 * lh, K = a.K;
             const float q0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, 32 * g + 0, 0)), q1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, 32 * g + 4, 0)),
                         q2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, 32 * g + 8, 0)), q3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, 32 * g + 12, 0));
-            ar[slot].x = k0 + 0 < K ? q0 : 0.f;
-            ar[slot].y = k0 + 1 < K ? q1 : 0.f;
-            ar[slot].z = k0 + 2 < K ? q2 : 0.f;
-            ar[slot].w = k0 + 3 < K ? q3 : 0.f;
+            ar[slot][0].x = k0 + 0 < K ? q0 : 0.f;
+            ar[slot][0].y = k0 + 1 < K ? q1 : 0.f;
+            ar[slot][0].z = k0 + 2 < K ? q2 : 0.f;
+            ar[slot][0].w = k0 + 3 < K ? q3 : 0.f;
         } else {
-            const lrg_u32x4v u = __builtin_amdgcn_raw_buffer_load_b128(rx, vx, 32 * g, 0);
-            ar[slot] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const lrg_u32x4v u = __builtin_amdgcn_raw_buffer_load_b128(rx, r ? vx1 : vx, 32 * g, 0);
+                ar[slot][r] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+            }
         }
     };
-    auto rsrc_of = [&](unsigned tile) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xbase + (size_t)tile * 32u * (unsigned)ldx), 0, 0x7fffffff, 0x00020000); };
+    auto rsrc_of = [&](unsigned tile) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xbase + (size_t)tile * (32u * RT) * (unsigned)ldx), 0, 0x7fffffff, 0x00020000); };
     {
         const __amdgpu_buffer_rsrc_t rx = rsrc_of(t);
 #pragma unroll
@@ -189,15 +196,17 @@ __global__ __launch_bounds__(64 * W, OCC) void lrg_stream_layer_lds_kernel(LrgSt
         // bias of the lane's column in every block (a per-instance row for a head's first layer: the hoisted pooled product, :128-141)
         float bv[CT];
         {
-            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase + (size_t)(inst_bias ? (t * 32u) / rpi : 0u) * (unsigned)N), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase + (size_t)(inst_bias ? (t * (32u * RT)) / rpi : 0u) * (unsigned)N), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
             for (int c = 0; c < CT; ++c) bv[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)li * 4u, 128 * c, 0));
         }
-        lrg_sf32x16 acc[CT];
+        lrg_sf32x16 acc[RT][CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+        for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
         float4 b[2][CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) b[0][c] = bp[(c * NG) * 64];
@@ -208,15 +217,22 @@ __global__ __launch_bounds__(64 * W, OCC) void lrg_stream_layer_lds_kernel(LrgSt
             if (g + 1 < NG && !(a.dbg & 4))
 #pragma unroll
                 for (int c = 0; c < CT; ++c) b[(g + 1) & 1][c] = bp[(c * NG + g + 1) * 64];
-            const float4 av = ar[s];
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[g & 1][c].x, acc[c], 0, 0, 0);
+            for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[g & 1][c].y, acc[c], 0, 0, 0);
+                for (int r = 0; r < RT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s][r].x, b[g & 1][c].x, acc[r][c], 0, 0, 0);
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[g & 1][c].z, acc[c], 0, 0, 0);
+            for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[g & 1][c].w, acc[c], 0, 0, 0);
+                for (int r = 0; r < RT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s][r].y, b[g & 1][c].y, acc[r][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s][r].z, b[g & 1][c].z, acc[r][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s][r].w, b[g & 1][c].w, acc[r][c], 0, 0, 0);
             // The ring is refilled a 128-byte LINE of every row at a time (four k-groups = 4 x 32 bytes): the four requests go out back to back and the line is
             // fetched once.  One request per k-group touched each line four times a thousand cycles apart -- by then the CU's other wavefronts had pushed it
             // out of the 32 KB L1: four trips to L2 per line, as much L2 traffic as the weights were before they moved to LDS.
@@ -236,11 +252,11 @@ __global__ __launch_bounds__(64 * W, OCC) void lrg_stream_layer_lds_kernel(LrgSt
             }
             // the order inside a k-group: the NEXT group's B reads first (an LDS round trip ahead of their MFMAs, not right in front of them), the MFMAs, the ring's request
             if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, CT, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * CT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * CT * RT, 0);
             if constexpr (LINES) {
-                if ((g & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                if ((g & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x020, 4 * RT, 0);
             } else {
-                __builtin_amdgcn_sched_group_barrier(0x020, FIRST ? 4 : 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, FIRST ? 4 : RT, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -248,27 +264,29 @@ __global__ __launch_bounds__(64 * W, OCC) void lrg_stream_layer_lds_kernel(LrgSt
         // 128-byte row segments each.  (Measured and dropped, profiles/r05_layer_variants.txt: the block through a wave-private LDS patch and out as 16-byte stores
         // of eight row segments per instruction -- 4 stores per block instead of 16 -- is 2-3 % slower; the tile computed transposed, 16-byte stores of 32-byte
         // pieces of 32 rows, 20-40 % slower.)
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(ybase + (size_t)t * 32u * (unsigned)N, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(ybase + (size_t)t * (32u * RT) * (unsigned)N, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+        for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                float v = acc[c][jj] + bv[c];
-                if (relu) v = fmaxf(v, 0.f);
-                if (!(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, vy, (((jj & 3) + 8 * (jj >> 2)) * N + 32 * c) * 4, 0);
-            }
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    float v = acc[r][c][jj] + bv[c];
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (!(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, r ? vy1 : vy, (((jj & 3) + 8 * (jj >> 2)) * N + 32 * c) * 4, 0);
+                }
         if (tn == t) break;
         t = tn;
     }
 }
 
-template <int NG, int CT, int D, int OCC, bool FIRST, int W = 4>
+template <int NG, int CT, int D, int OCC, bool FIRST, int W = 4, int RT = 1>
 static int lrg_stream_layer_lds_launch(const LrgFusedArgs &a, int nprob, hipStream_t st) {
     LrgStreamArgs b = {};
     for (int i = 0; i < nprob; ++i) {
         const LrgFusedProb &P = a.p[i];
         const LrgFusedLayer &L = P.L[0];
-        if (P.rows % 32 != 0 || P.rows_per_inst % 32 != 0 || L.N % (32 * CT) != 0 || L.ng != NG || !L.gout || !L.w || !L.bias) return LRG_EINVAL - 30;
+        if (P.rows % (32 * RT) != 0 || P.rows_per_inst % (32 * RT) != 0 || L.N % (32 * CT) != 0 || L.ng != NG || !L.gout || !L.w || !L.bias) return LRG_EINVAL - 30;
         if (!FIRST && (P.ldx % 4 != 0 || P.Kin != 8 * NG)) return LRG_EINVAL - 31;
         if (i > 0 && (L.N != a.p[0].L[0].N || P.Kin != a.p[0].Kin || (L.flags & LRG_FL_RELU) != (a.p[0].L[0].flags & LRG_FL_RELU))) return LRG_EINVAL - 32;
         if (P.rows == 0 || (P.rows >> 5) >= (1L << 26)) return LRG_EINVAL - 34;
@@ -282,7 +300,7 @@ static int lrg_stream_layer_lds_launch(const LrgFusedArgs &a, int nprob, hipStre
     static const int dbg = getenv("LRG_STREAM_DBG") ? atoi(getenv("LRG_STREAM_DBG")) : 0;
     b.dbg = dbg;
     const size_t lds = (size_t)CT * NG * 1024;
-    auto kern = lrg_stream_layer_lds_kernel<NG, CT, D, OCC, FIRST, W>;
+    auto kern = lrg_stream_layer_lds_kernel<NG, CT, D, OCC, FIRST, W, RT>;
     static bool attr_done[LRG_MAX_DEVICES] = {};      // per instantiation, per device
     const int dev = lrg_current_device();
     if (!attr_done[dev]) {
@@ -296,7 +314,7 @@ static int lrg_stream_layer_lds_launch(const LrgFusedArgs &a, int nprob, hipStre
     if (per_cu > OCC * 4 / W) per_cu = OCC * 4 / W;
     if (per_cu < 1) return LRG_EINVAL - 35;
     long maxt = 0;
-    for (int i = 0; i < nprob; ++i) maxt = (a.p[i].rows >> 5) > maxt ? (a.p[i].rows >> 5) : maxt;
+    for (int i = 0; i < nprob; ++i) maxt = (a.p[i].rows >> 5) / RT > maxt ? (a.p[i].rows >> 5) / RT : maxt;
     int m = 256 * per_cu / (8 * units);
     const int need = (int)((maxt + W * 8 - 1) / (W * 8));      // walks of one tile per wavefront cover everything with this many workgroups per unit and XCD
     if (m > need) m = need;
