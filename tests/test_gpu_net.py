@@ -145,6 +145,29 @@ def test_fused_and_streamed_paths_agree(cuda_device):
     np.testing.assert_array_equal(outs['streamed-tiles'][2], outs['fused'][2])
 
 
+@pytest.mark.parametrize('B,ni,nn', [(1, 64, 64), (3, 64, 192), (5, 256, 128), (2, 512, 512), (37, 128, 64)])
+def test_streaming_layer_kernel_on_ragged_problem_sizes(cuda_device, B, ni, nn):
+    """The layer-streamed evaluation on the streaming wavefront kernel (csrc/lrg_stream_layer.inl: both branches / both heads in one launch per layer, each a
+    problem of its own row count, per-instance bias rows in the heads' first layer) against the round-1 layer kernel: the same logits to fp32 rounding, every
+    intermediate too -- few tiles per column group, row counts that differ between the two problems, instances of one or two tiles."""
+    import torch
+    rs = np.random.RandomState(100 * B + ni + nn)
+    xi = torch.from_numpy((rs.randn(B, ni, 13) * 0.5).astype(np.float32)).to(cuda_device)
+    xn = torch.from_numpy((rs.randn(B, nn, 13) * 0.5).astype(np.float32)).to(cuda_device)
+    outs = {}
+    for mode in ('streamed', 'streamed-tiles'):
+        net, _ = make_net(cuda_device, 0, 13, ni, nn, mode)
+        add, rmv = net.forward(xi, xn)
+        torch.cuda.synchronize()
+        outs[mode] = dict(add=add.cpu().numpy().copy(), rmv=rmv.cpu().numpy().copy(), pooled=net.intermediate('pooled', 0, B).cpu().numpy().copy())
+        for i in range(len(net.conv_channels)):
+            outs[mode]['conv%d' % i] = net.intermediate('conv', i, B).cpu().numpy().copy()
+            outs[mode]['nconv%d' % i] = net.intermediate('neighbor_conv', i, B).cpu().numpy().copy()
+    assert outs['streamed']['add'].shape == (B, nn, 2) and outs['streamed']['rmv'].shape == (B, ni, 2)
+    for k in sorted(outs['streamed']):
+        close(outs['streamed-tiles'][k], outs['streamed'][k], k)
+
+
 def test_forward_rows_skips_duplicate_rows_exactly(cuda_device):
     """Sets padded by duplication (test_region_grow.py:240,:252): evaluating only the distinct leading rows gives
     bit-identical logits for them and the same pooled feature as evaluating all 512 rows."""
