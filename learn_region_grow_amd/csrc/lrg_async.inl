@@ -900,7 +900,7 @@ LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
         if (LRG_DBG(A)) {
             const long long now = wall_clock64();
             lrg_dbg_add(A, 8 + 2 * LRG_TASK_HEAD, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_HEAD, 1);
-            if (done == lrg_ld_coh(&sy[6])) lrg_dbg_add(A, 4, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+            if (done == lrg_ld_coh(&sy[6])) { lrg_dbg_add(A, 4, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8]))); lrg_st_coh(&sy[12], (int)(unsigned)now); }
         }
     }
     return team.target;
@@ -1230,6 +1230,10 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
     __syncthreads();
     for (;;) {
         // a hand-over given up anywhere (or this launch far beyond any sane duration): everybody leaves, the host reports it
+        // (Measured and dropped, profiles/r05_ab_front_wait.txt: wavefront 0 waiting HERE for the first of the evaluations in flight, lane k on slot k's counter,
+        //  instead of passes of this loop -- 17 looks in vain per evaluation became 0.8 and nothing else moved: a result is seen 4.4 us after its last head tile on
+        //  average because the workgroup is inside its OTHER slot's step a fifth of the time (two slots per front workgroup at 68 slots; histogram in
+        //  profiles/r05_bench_debug_68.log), and 68 front workgroups cost more worker CUs than that is worth: profiles/r04_fronts_teams_sweep.txt.)
         if (tid == 0) {
             int ab = lrg_ld_coh(&A.queue[LRG_AQ_ABORT]);
             if (!ab && wall_clock64() - t_launch > A.abort_ticks) { ab = 1; lrg_st_coh(&A.queue[LRG_AQ_ABORT], 1); }
@@ -1314,11 +1318,21 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 __syncthreads();
                 const int ready = C.bc[0];
                 __syncthreads();
-                if (!ready) continue;
+                if (!ready) {
+                    if (LRG_DBG(A) && tid == 0) lrg_dbg_add(A, 28, 1);      // (looks at a result that was not there yet)
+                    continue;
+                }
                 st = 0;
                 if (LRG_DBG(A) && tid == 0) {
-                    lrg_dbg_add(A, 5, (int)((unsigned)wall_clock64() - (unsigned)lrg_ld_coh(&A.sync[(long)s * LRG_ASYNC_SYNC_WORDS + 8])));
+                    const unsigned now = (unsigned)wall_clock64();
+                    lrg_dbg_add(A, 5, (int)(now - (unsigned)lrg_ld_coh(&A.sync[(long)s * LRG_ASYNC_SYNC_WORDS + 8])));
                     lrg_dbg_add(A, 6, 1);
+                    // (how long ago the last head tile arrived, by its own stamp: a histogram in powers of two of 0.5 us)
+                    const int ago = (int)(now - (unsigned)lrg_ld_coh(&A.sync[(long)s * LRG_ASYNC_SYNC_WORDS + 12]));
+                    int b = 0;
+                    for (int lim = 50; b < 7 && ago >= lim; lim *= 2) ++b;
+                    lrg_dbg_add(A, 54 + b, 1);
+                    lrg_dbg_add(A, 62, ago > 0 && ago < 100000 ? ago : 0);
                 }
             }
             // a new evaluation only within the budget of this launch

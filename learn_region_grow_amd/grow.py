@@ -623,7 +623,9 @@ class RegionGrower:
                           team_wait_per_task=d[16] / max(d[17], 1) / 100),
                'front_phase_us': dict(zip(['update', 'commit_seed', 'query', 'sampling', 'gather(+small medians)', 'big medians', 'gather alone', 'one median alone'],
                                           [float(x) / max(d[1], 1) / 100 for x in list(d[21:28]) + [d[20]]])),
-               'tasks_per_evaluation': dict(branch=d[11] / ev, pooled=d[13] / ev, head=d[15] / ev), 'evaluations': float(d[6]), 'front_steps': float(d[1])}
+               'tasks_per_evaluation': dict(branch=d[11] / ev, pooled=d[13] / ev, head=d[15] / ev), 'evaluations': float(d[6]), 'front_steps': float(d[1]),
+               'front_looks_in_vain_per_evaluation': float(d[28]) / ev,
+               'seen_after_last_head_tile': dict(mean_us=d[62] / ev / 100, histogram_us=dict(zip(['<0.5', '<1', '<2', '<4', '<8', '<16', '<32', '>=32'], [float(x) / ev for x in d[54:62]])))}
         if d[32] > 0:      # LRG_TRACE build: mean cycles since the tile began at each stamp
             names = ['staged'] + [x for l in range(5) for x in ('L%d start' % l, 'L%d end' % l)] + \
                     [x for c in range(4) for x in ('pass%d mfma' % c, 'pass%d epilogue' % c)] + ['end']
