@@ -47,6 +47,10 @@ def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
         assert k in rf, k
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
     assert 0 < rf['rows_evaluated_fraction'] <= 1 and rf['dense']['frac'] > 0
+    # north_star's MLP metric, measured live beside the fused figure: the layer-streamed evaluation (csrc/lrg_stream_layer.inl) priced with SURVEY.md 8d's bytes
+    ls = rf['dense']['layer_streamed']
+    assert 'error' not in ls, ls
+    assert ls['algorithmic_bytes'] == 1088 * 10297344 and 0.2 < ls['frac_of_hbm_peak'] < 1.0, ls
     if mode == 'free':
         # the roofline headline can be recomputed from the line alone: algorithmic FLOPs of the timed launches / their time / the peak
         assert abs(rf['algorithmic_flops_in_loop'] / rf['kernel_seconds'] / 1e12 / rf['peak'] - rf['frac']) < 1e-9
