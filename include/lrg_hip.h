@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define LRG_ABI_VERSION 9
+#define LRG_ABI_VERSION 10
 #define LRG_EINVAL (-1000)
 #define LRG_ERESIDENCY (-1100)  /* lrg_grow_async: the launch's workgroups cannot all be resident at once on this stream / device (see there) */
 
@@ -462,6 +462,8 @@ int lrg_step_graph_destroy(void *graph);
  * State between calls is exactly that of lrg_grow_step_packed (a call ends every slot between two evaluations, logits in
  * place), so the two may alternate on the same buffers; results are identical bit for bit.
  * ---------------------------------------------------------------------------------------------- */
+#define LRG_WAVE_AUTO_SLOTS 0     /* wave-branch launches by default up to this many slots in flight: 0 = never (measured slower than the one-kernel launch at every slot count,
+                                     profiles/r06_wave_*.txt: a tile on ONE SIMD at a time is 21-23 us through its two stages against 17-25 us for the four-wavefront team tile) */
 typedef struct LrgAsyncBuffers {
     int32_t *queue;             /* lrg_grow_async_queue_bytes(n_slots) bytes, 256-byte aligned: task ring + control words (cleared by every call) */
     size_t queue_bytes;
@@ -505,7 +507,12 @@ typedef struct LrgAsyncBuffers {
                                    queries saw exactly what the sequential loop (:186-188,:210-217,:227-228) would have shown them.  Same regions, same labels;
                                    for the few-rooms corner (one room or scene per GPU), where a room's chain of dependent steps leaves the chip idle.
                                    n_slots must be a multiple of K; the caller binds whole groups (lrg_bind_group with group_size K); 0 / 1 = off           */
-    int32_t reserved2;
+    int32_t branch_waves;       /* (ABI 10; was `reserved2`) wave-branch launches: the CUs that run tiles as a SECOND kernel (512 threads, up to 256 VGPRs) resident
+                                   beside the front workgroups' and units' kernel, and a branch tile (learn_region_grow_util.py:106-123) as four tasks -- one per
+                                   quarter of the pooled layer's columns -- each run by ONE wavefront that keeps the activations in registers, on a CU that holds
+                                   the kernels of its stage in LDS (csrc/lrg_wave_tile.inl: a PREFIX task = layers 0 - 3, then POOL tasks = a quarter of the pooled
+                                   layer each).  Same results bit for bit.  0 = by the slot count (up to LRG_WAVE_AUTO_SLOTS slots; needs the paper network, rows16,
+                                   no tail_ctl / pool_rows, all CUs); -1 = off; n > 0 = on, n wavefronts per such CU (4 or 8) */
     int32_t start_wait_us;      /* the launch's start rendezvous (all its workgroups must be running at once): how long the front workgroups wait for the
                                    others before the launch gives up with reason 6; 0 = default: the launch budget + 20 ms (a kernel of another stream that
                                    holds CUs for up to one budget is waited out, something that never leaves is reported)  (ABI 9; was `reserved`) */

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(HERE, 'liblrg_hip.so')
 SOURCES = ['lrg_net.hip', 'lrg_fused.hip', 'lrg_grow.hip', 'lrg_grouping.hip', 'lrg_preprocess.hip', 'lrg_train.hip']
 
-LRG_ABI_VERSION = 9       # what this binding was written against (include/lrg_hip.h: LRG_ABI_VERSION; tests/test_capi.py compares them and INTEGRATION.md)
+LRG_ABI_VERSION = 10      # what this binding was written against (include/lrg_hip.h: LRG_ABI_VERSION; tests/test_capi.py compares them and INTEGRATION.md)
 LRG_EINVAL = -1000
 LRG_ERESIDENCY = -1100     # lrg_grow_async: its workgroups cannot all be resident at once on this stream / device
 LRG_MAX_CONV = 5
@@ -92,7 +92,7 @@ class LrgPackedBuffers(ctypes.Structure):
 class LrgAsyncBuffers(ctypes.Structure):
     _fields_ = [('queue', _fp), ('queue_bytes', ctypes.c_size_t), ('sync', _fp), ('front_workgroups', ctypes.c_int32), ('teams', ctypes.c_int32),
                 ('compute_units', ctypes.c_int32), ('poll_sleep', ctypes.c_int32), ('branch_parts', ctypes.c_int32), ('gemv_units', ctypes.c_int32), ('room_queue', _fp), ('work', _fp),
-                ('fill_list', _fp), ('fill_best', _fp), ('fill_sync', _fp), ('fill_label_base', _fp), ('fill_out_base', _fp), ('fill_rooms', ctypes.c_int32), ('fill_wgs', ctypes.c_int32), ('rows16', ctypes.c_int32), ('speculate', ctypes.c_int32), ('reserved2', ctypes.c_int32), ('start_wait_us', ctypes.c_int32),
+                ('fill_list', _fp), ('fill_best', _fp), ('fill_sync', _fp), ('fill_label_base', _fp), ('fill_out_base', _fp), ('fill_rooms', ctypes.c_int32), ('fill_wgs', ctypes.c_int32), ('rows16', ctypes.c_int32), ('speculate', ctypes.c_int32), ('branch_waves', ctypes.c_int32), ('start_wait_us', ctypes.c_int32),
                 ('pool_rows', _fp), ('pool_rows_bytes', ctypes.c_size_t), ('debug_ticks', _fp),
                 ('tail_ctl', _fp), ('tail_rows', ctypes.c_int32), ('tail_close_us', ctypes.c_int32)]
 

@@ -36,6 +36,9 @@
 #ifndef LRG_WORKER_POLL_SLEEP
 #define LRG_WORKER_POLL_SLEEP 8    // s_sleep argument (x 64 cycles) between two looks of an idle team at its ring entry (x LrgAsyncBuffers.poll_sleep)
 #endif
+#ifndef LRG_WAIT_POOLED_SLEEP
+#define LRG_WAIT_POOLED_SLEEP 2     // s_sleep argument (x 64 cycles) between two looks of a head tile's wavefronts at their slot's pooled-product counter
+#endif
 #ifndef LRG_ASYNC_FD
 #define LRG_ASYNC_FD 4              // depth of the tile teams' weight ring (k-groups in flight)
 #endif
@@ -53,6 +56,10 @@
 #define LRG_AQ_FHEAD 144
 #define LRG_AQ_RING 192          // ring 0, then ring 1 (qmask + 1 entries each), then the units' ring (gmask + 1 entries), then the fill-in ring (fmask + 1)
 #define LRG_ASYNC_FILL_RING 8192 // entries of the fill-in ring: one per 256 candidate points of a finished room (a 131 072-point scene: 512)
+// behind the fill-in ring: the wave rings' control words (ring t = side * 4 + quarter: [32 t] entries reserved, [32 t + 16] tickets taken) and the eight rings
+#define LRG_AQ_WAVE(A) (LRG_AQ_RING + 2 * ((A).qmask + 1) + ((A).gmask + 1) + LRG_ASYNC_FILL_RING)
+#define LRG_AQ_WAVE_RING(A, t) (LRG_AQ_WAVE(A) + 256 + (t) * ((A).wmask + 1))
+#define LRG_WORKER_THREADS 512   // workgroup of lrg_grow_async_worker_kernel
 #define LRG_TASK_FILL 4
 #define LRG_ASYNC_SYNC_WORDS 16  // per slot: 0 branch tiles done, 1 pooled-product blocks done, 2 head tiles done (arrival counters); 4 .. 7 one 16-byte word written by
                                  //           the front workgroup: the three targets and inlier | neighbour << 16 tiles of the evaluation in flight; 8 a debug stamp
@@ -118,6 +125,20 @@ struct LrgAsyncArgs {
     int pool_rows_stride;        // 2 * 16 * (P / 2)
     int poll_sleep;              // s_sleep(8) repeats between two polls of an idle team (1 = ~0.25 us)
     int branch_parts;            // tasks per branch tile (1, 2, 4): they share the column blocks of the pooled layer (lrg_fused_tile)
+    // Wave-branch mode (round 6; lrg_wave_tile.inl): the launch is TWO kernels resident together -- lrg_grow_async_kernel with the front workgroups and the
+    // pooled-product units only, and lrg_grow_async_worker_kernel (512 threads, up to 256 VGPRs) with `wave_wgs` wave-branch CUs and the head teams' CUs behind them.
+    // A branch tile is a PREFIX task (layers 0 - 3, by one wavefront of a CU that holds those kernels of both branches in LDS) that publishes the tile's POOL tasks
+    // (a quarter of the pooled layer each -- or half a quarter: wave_split 4 / 8 -- by one wavefront of a CU that holds its (side, half) of that kernel in LDS).
+    // Rings of their own: 0 .. 3 = POOL tasks of (side, half), 4 = PREFIX tasks.  0: off -- one kernel, branch tiles by the tile teams.
+    int wave_wgs;                // wave-branch CUs: workgroups 0 .. wave_a_wgs - 1 of the worker kernel run PREFIX tasks, wave_a_wgs .. wave_wgs - 1 POOL tasks of
+    int wave_a_wgs;              //   (side, half) = (w - wave_a_wgs) & 3
+    int wave_waves;              // wavefronts per wave-branch CU that run branch tasks (4: one per SIMD)
+    int wave_split;              // POOL tasks per tile: 4 (a quarter = two pairs of column blocks each) or 8 (one pair each)
+    int wave_fill;               // 1: wavefronts 4 .. 7 of the first fill_wgs wave-branch CUs are a fill-in team (VALU work beside the MFMA-bound branch waves)
+    int wmask;                   // entries of one wave ring - 1 (power of two)
+    float *h3[2];                // [row_cap, 128] per side: layer 3's output rows, from the PREFIX to the POOL tasks
+    int worker_base;             // blockIdx.x of the first worker workgroup in the kernel that runs the tile teams (n_front + gemv_units, or wave_wgs in the worker kernel)
+    int total_wgs;               // workgroups of the launch in all (both kernels): what the start rendezvous waits for
     int max_steps;               // evaluations per slot in this launch
     long long start_ticks;       // ... the front workgroups wait at most this long for all workgroups of the launch to have started (reason 6)
     long long budget_ticks;      // wall_clock64 ticks (100 MHz) after which no new evaluation is started
@@ -289,6 +310,7 @@ __device__ __forceinline__ int lrg_uniform(int v) { return __builtin_amdgcn_read
 // the launch's dynamic LDS: roles get OFFSETS into it (a float * parameter would be a generic pointer, and every LDS access of a
 // tile a flat instruction)
 extern __shared__ __attribute__((aligned(16))) float lrg_async_smem[];
+#include "lrg_wave_tile.inl"
 #define LRG_ASYNC_ROLE __device__ __noinline__
 // The tile tasks are inlined into the worker's loop (round 4).  As functions of their own (round 3) every call saved and restored the callee-saved registers the
 // tile code uses -- 54 / 72 dwords per lane and task through scratch memory: ~0.6 MB of writes and as many reads per evaluation, which is what the write counter of
@@ -852,7 +874,7 @@ struct LrgWaitPooled {
                 if (lrg_ld_coh(&queue[LRG_AQ_ABORT])) break;
                 if (wall_clock64() - t_launch > abort_ticks) { lrg_st_coh(&queue[LRG_AQ_ABORT], 5); break; }
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(LRG_WAIT_POOLED_SLEEP);
         }
     }
 };
@@ -1096,18 +1118,20 @@ __device__ __noinline__ void lrg_async_fill_publish(lrg_kargs_ptr kp_, int room_
 // (the caller then parks the slot as idle: a finished room is published once, not again by the next launch that finds the slot still bound to it)
 
 // ---- a worker team: tasks until every front workgroup is done ----
-LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t_launch) {
+// role_: 0 = by the team's place in its workgroup (below); 1 = a fill-in team (wave-branch mode: wavefronts 4 .. 7 of a wave-branch CU); 2 = ring 1 (wave-branch
+// mode: every team of the head teams' CUs -- pooled blocks and head tiles; the branch tiles have rings and wavefronts of their own)
+LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t_launch, int role_) {
     const lrg_kargs_ptr kp = lrg_uniform(kp_);
-    const int sm_off = lrg_uniform(sm_off_);
+    const int sm_off = lrg_uniform(sm_off_), role = lrg_uniform(role_);
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
     float *sm = lrg_async_smem + sm_off + LRG_ASYNC_CTL_FLOATS;      // (sm_off: the team's region, control words first)
     LrgLdsTeam team = lrg_async_team(A, sm, 0);
     const int tid = team.tid();
     int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);       // [0] task of this round
-    const int team_no = lrg_uniform((int)threadIdx.x >> 8), wg_no = (int)blockIdx.x - A.n_front - A.gemv_units;
+    const int team_no = lrg_uniform((int)threadIdx.x >> 8), wg_no = (int)blockIdx.x - A.worker_base;
     // (small teams have the LDS of a branch tile only: ring 0; beside them every other team runs the rest)
-    const bool secondary = A.head_ring == 1 && (A.small_teams ? team_no >= lrg_async_small_teams(A, wg_no) : 2 * team_no + (wg_no & 1) >= A.ring0_halves);
-    const bool filler = A.fill_list && wg_no < A.fill_wgs && team_no == A.teams - 1 + A.fill_extra;      // this team serves the fill-in ring only (fill_extra: a team MORE on these workgroups)
+    const bool secondary = role == 2 || (role == 0 && A.head_ring == 1 && (A.small_teams ? team_no >= lrg_async_small_teams(A, wg_no) : 2 * team_no + (wg_no & 1) >= A.ring0_halves));
+    const bool filler = role == 1 || (role == 0 && A.fill_list && wg_no < A.fill_wgs && team_no == A.teams - 1 + A.fill_extra);      // this team serves the fill-in ring only (fill_extra: a team MORE on these workgroups)
     // (at 68 slots two branch tiles on a CU slow each other: 809 k -> 783 k instance-steps/s with some second teams on ring 0; at 272 slots
     //  with three teams a single branch team per CU is what every slot queues for: 257 us from publishing to the last branch tile)
     const int ring = secondary ? 1 : 0;      // (more than one team per workgroup: the first teams run the branch tiles, the others the rest)
@@ -1161,6 +1185,107 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
     }
 }
 
+// ---- a wavefront of a wave-branch CU (round 6, lrg_wave_tile.inl): branch tasks (tile, the CU's quarter of the pooled layer) of the CU's side until every front
+//      workgroup is done.  The CU's kernels are in LDS (lrg_wave_load_kernels, before the workgroup's only barrier); every wavefront is a worker of its own: its
+//      ticket, its ring entry, its task, its arrival -- nothing is shared with the wavefronts beside it but the LDS they read ----
+__device__ __forceinline__ void lrg_wave_load_prefix_kernels(const LrgFusedProb &P, int wa, int tid, int nthreads) {      // layers 0 - 3 of one branch
+    const int offs[4] = {LRG_WA_W0, LRG_WA_W1, LRG_WA_W2, LRG_WA_W3}, n4[4] = {256, 1024, 1024, 2048};
+    const int boff[4] = {LRG_WA_B0, LRG_WA_B1, LRG_WA_B2, LRG_WA_B3}, bn[4] = {LRG_WB_C0, LRG_WB_C1, LRG_WB_C2, LRG_WB_C3};
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const float4 *src = reinterpret_cast<const float4 *>(P.L[l].w);
+        float4 *dst = reinterpret_cast<float4 *>(lrg_async_smem + wa + offs[l]);
+        for (int i = tid; i < n4[l]; i += nthreads) dst[i] = src[i];
+        for (int i = tid; i < bn[l]; i += nthreads) lrg_async_smem[wa + boff[l] + i] = P.L[l].bias[i];
+    }
+}
+__device__ __forceinline__ void lrg_wave_load_pool_kernels(const LrgFusedProb &P, int q, int wp, int tid, int nthreads) {      // quarter q of the pooled layer
+    const float4 *src = reinterpret_cast<const float4 *>(P.L[4].w) + (long)q * 4096;      // (the quarter's four column blocks are contiguous in the image)
+    float4 *dst = reinterpret_cast<float4 *>(lrg_async_smem + wp + LRG_WP_W4);
+    for (int i = tid; i < 4096; i += nthreads) dst[i] = src[i];
+    for (int i = tid; i < 128; i += nthreads) lrg_async_smem[wp + LRG_WP_B4 + i] = P.L[4].bias[q * 128 + i];
+}
+
+// a wavefront's next task from wave ring `rg` (lane 0 polls; every lane gets the code: < 0 = leave)
+__device__ __forceinline__ int lrg_async_wave_take(const LrgAsyncArgs &A, int rg, int &next_ticket, long long t_launch, long long &t_task, int lane) {
+    int code = 0;
+    if (lane == 0) {
+        const long long t_wait = LRG_DBG(A) ? wall_clock64() : 0;
+        int *ticket_word = &A.queue[LRG_AQ_WAVE(A) + 32 * rg + 16];
+        const int t = next_ticket >= 0 ? next_ticket : __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        next_ticket = -1;
+        int32_t *e = A.queue + LRG_AQ_WAVE_RING(A, rg) + (t & A.wmask);
+        for (unsigned spin = 0;; ++spin) {
+            code = lrg_ld_coh(e);
+            if (code) break;
+            if ((spin & 7) == 7) {
+                if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT]) || lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front) { code = -1; break; }
+                if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 2); code = -1; break; }
+            }
+            for (int q = 0; q < A.poll_sleep; ++q) __builtin_amdgcn_s_sleep(LRG_WORKER_POLL_SLEEP);
+        }
+        if (code > 0) lrg_st_coh(e, 0);
+        t_task = wall_clock64();
+        if (LRG_DBG(A)) { lrg_dbg_add(A, 16, t_task - t_wait); lrg_dbg_add(A, 17, 1); }
+    }
+    return __builtin_amdgcn_readfirstlane(code);
+}
+
+// (both inlined into lrg_grow_async_worker_kernel: a function of its own is compiled for any workgroup size -- 128 VGPRs -- and the tiles need ~150)
+// PREFIX tasks: code = LRG_TASK(BRANCH, slot, side, tile)
+__device__ __forceinline__ void lrg_async_wave_prefix_worker(lrg_kargs_ptr kp, long long t_launch) {
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    const int lane = (int)threadIdx.x & 63;
+    int next_ticket = -1;
+    __builtin_amdgcn_s_setprio(2);      // (a fill-in team may share the SIMD: the MFMA-bound wave issues first)
+    for (;;) {
+        long long t_task = 0;
+        const int code = lrg_async_wave_take(A, 4, next_ticket, t_launch, t_task, lane);
+        if (code < 0) return;
+        const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 15;
+        const LrgFusedProb &P = A.prob[side];
+        const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
+        lrg_wave_prefix_tile(P.x, P.center, P.L[1].gout, A.h3[side], r0, slot, side * LRG_WA_SIDE, lane);
+        // the tile's POOL tasks: wave_split / 2 entries in each of the side's two rings, reserved while the rows drain (lanes 0 / 1: the halves)
+        const int per_ring = A.wave_split >> 1;
+        int base = 0;
+        if (lane < 2) base = __hip_atomic_fetch_add(&A.queue[LRG_AQ_WAVE(A) + 32 * (side * 2 + lane)], per_ring, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (LRG_TICKET_EARLY && lane == 2) next_ticket = __hip_atomic_fetch_add(&A.queue[LRG_AQ_WAVE(A) + 32 * 4 + 16], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        next_ticket = __shfl(next_ticket, 2);
+        lrg_drain_stores();                              // conv[1] and layer-3 rows are out before anybody is told
+        const int half = lane / per_ring, j = lane - half * per_ring;
+        const int b = __shfl(base, half & 1);
+        if (lane < A.wave_split) {
+            const int q = half * 2 + (A.wave_split == 8 ? j >> 1 : j), pair = A.wave_split == 8 ? j & 1 : 0;
+            lrg_st_coh(&A.queue[LRG_AQ_WAVE_RING(A, side * 2 + half) + ((b + j) & A.wmask)], LRG_TASK(LRG_TASK_BRANCH, slot, side, idx) | (q << 5) | (pair << 4));
+        }
+        if (LRG_DBG(A) && lane == 0) { lrg_dbg_add(A, 8 + 2 * LRG_TASK_FILL, wall_clock64() - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_FILL, 1); }      // (index 4's pair: PREFIX tasks)
+    }
+}
+
+// POOL tasks of ring `rg` = side * 2 + half: code = LRG_TASK(BRANCH, slot, side, tile) | quarter << 5 | pair << 4
+__device__ __forceinline__ void lrg_async_wave_pool_worker(lrg_kargs_ptr kp, int rg, long long t_launch) {
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    const int lane = (int)threadIdx.x & 63;
+    const int side = rg >> 1;
+    const LrgFusedProb &P = A.prob[side];
+    int next_ticket = -1;
+    __builtin_amdgcn_s_setprio(2);
+    for (;;) {
+        long long t_task = 0;
+        const int code = lrg_async_wave_take(A, rg, next_ticket, t_launch, t_task, lane);
+        if (code < 0) return;
+        const int slot = (code >> 8) & 0xFFFFF, idx = code & 15, q = (code >> 5) & 3, pair = (code >> 4) & 1;
+        const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
+        const int p_lo = A.wave_split == 8 ? pair : 0, p_hi = A.wave_split == 8 ? pair + 1 : 2;
+        lrg_wave_pool_tile(A.h3[side], P.pool + (long)slot * P.pool_stride, r0, q, (q & 1) * LRG_WP_QUARTER, p_lo, p_hi, lane);
+        if (LRG_TICKET_EARLY && lane == 0) next_ticket = __hip_atomic_fetch_add(&A.queue[LRG_AQ_WAVE(A) + 32 * rg + 16], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        next_ticket = __shfl(next_ticket, 0);
+        lrg_drain_stores();                              // the pooled maxima are out before the arrival
+        lrg_async_branch_arrive(A, slot, lane, t_task, true);
+    }
+}
+
 struct LrgAsyncFrontCtl {
     int state[LRG_ASYNC_MAX_SERVED];     // 0 to be served, 1 evaluation in flight, 2 finished for this launch; speculation: 3 no seed left for the slot while the
                                          // group's room is not finished (parked until the group is rebound), 4 region pending (served when it is the room's
@@ -1168,6 +1293,7 @@ struct LrgAsyncFrontCtl {
     int steps[LRG_ASYNC_MAX_SERVED];
     int tgt[LRG_ASYNC_MAX_SERVED][3];    // running targets of the slot's three arrival counters
     int bc[4];                           // broadcasts of thread 0
+    int wb[8];                           // wave-branch mode: the evaluation's first entry in each of the eight wave rings
 };
 
 // ---- one slot's front step, a function of its own: the register allocation of lrg_front_greedy_kernel (no spills) instead of the
@@ -1220,7 +1346,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
     // (LrgAsyncBuffers.start_wait_us: a kernel that leaves within a budget is waited out) and reported (reason 6), not by the hand-overs'
     // bounds seconds later.
     if (tid == 0) {
-        const int all = (int)gridDim.x;
+        const int all = A.total_wgs;      // (both kernels of a wave-branch launch)
         for (unsigned spin = 0; lrg_ld_coh(&A.queue[LRG_AQ_ARRIVED]) < all; ++spin) {
             if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) break;
             if ((spin & 15) == 15 && wall_clock64() - t_launch > A.start_ticks) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 6); break; }
@@ -1413,11 +1539,17 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
                 }
                 C.state[i] = 1;
                 C.steps[i] += 1;
-                C.bc[3] = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL], (nt_in + nt_nb) * A.branch_parts + n_open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!A.wave_wgs) C.bc[3] = __hip_atomic_fetch_add(&A.queue[LRG_AQ_TAIL], (nt_in + nt_nb) * A.branch_parts + n_open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // (wave-branch mode: the tiles' PREFIX tasks, one reservation in ring 4 -- beside thread 0's stores, by the second wavefront)
+            if (A.wave_wgs && tid == 64) C.wb[0] = __hip_atomic_fetch_add(&A.queue[LRG_AQ_WAVE(A) + 32 * 4], nt_in + nt_nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lrg_drain_stores();
             __syncthreads();
-            if (tid < 128) {                                     // (up to 32 tiles x 4 parts)
+            if (A.wave_wgs) {
+                if (tid < nt_in + nt_nb)                         // (up to 32 tiles)
+                    lrg_st_coh(&A.queue[LRG_AQ_WAVE_RING(A, 4) + ((C.wb[0] + tid) & A.wmask)],
+                               tid < nt_in ? LRG_TASK(LRG_TASK_BRANCH, s, 0, tid) : LRG_TASK(LRG_TASK_BRANCH, s, 1, tid - nt_in));
+            } else if (tid < 128) {                              // (up to 32 tiles x 4 parts)
                 const int nt = nt_in + nt_nb, t = tid / A.branch_parts, part = tid - t * A.branch_parts;
                 if (tid < nt * A.branch_parts)
                     lrg_st_coh(&A.queue[LRG_AQ_RING + ((C.bc[3] + tid) & A.qmask)],      // (ring 0)
@@ -1465,16 +1597,67 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgAs
     }
     if ((int)blockIdx.x >= K.A.n_front) {
         // worker workgroup: teams of four consecutive wavefronts (one per SIMD), each on its own part of the LDS
+        // (a wave-branch launch has none of these in this kernel: its grid ends with the units)
         const int t = tid >> 8;
-        if (t >= K.A.teams + (((int)blockIdx.x - K.A.n_front - K.A.gemv_units < K.A.fill_wgs && K.A.fill_list) ? K.A.fill_extra : 0)) return;
-        const int small = lrg_async_small_teams(K.A, (int)blockIdx.x - K.A.n_front - K.A.gemv_units);
+        if (t >= K.A.teams + (((int)blockIdx.x - K.A.worker_base < K.A.fill_wgs && K.A.fill_list) ? K.A.fill_extra : 0)) return;
+        const int small = lrg_async_small_teams(K.A, (int)blockIdx.x - K.A.worker_base);
         const int sm_off = t < small ? t * LRG_ASYNC_SMALL_TEAM_FLOATS : small * LRG_ASYNC_SMALL_TEAM_FLOATS + (t - small) * LRG_ASYNC_TEAM_FLOATS;
         int *word = reinterpret_cast<int *>(lrg_async_smem + sm_off);
         if ((tid & 255) == 0) { word[4] = 0; word[5] = 0; }  // the team's barrier counter, its 'at work' flag
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // the only workgroup-wide barrier of a worker: before any team has started
-        lrg_async_worker(kp, sm_off, t_launch);
+        lrg_async_worker(kp, sm_off, t_launch, 0);
         return;
     }
     lrg_async_front(kp, t_launch);
+}
+
+// ---- the second kernel of a wave-branch launch (round 6): the CUs that run tiles, as a kernel of their own shape ----
+// One launch used to give every role the front step's shape -- 1 024 threads, 128 VGPRs -- and the tile code inherited it (spills in the tile tasks, no room for a
+// wavefront that keeps a tile's activations in registers: lrg_wave_tile.inl needs ~176).  This kernel is 512 threads (eight wavefronts, up to 256 VGPRs each) and is
+// launched on a side stream right before lrg_grow_async_kernel, which then holds the front workgroups and the pooled-product units only; the two are resident together
+// (one workgroup per CU in both: the front kernel fills its CUs' register files, this one's LDS allows no second workgroup on a CU; the host sizes both grids per
+// XCD, tools/two_kernel_rendezvous.hip) and talk through the same rings and arrival counters as the roles of the single launch did.  Every workgroup of both kernels
+// reports in; the front workgroups wait for all of them (bounded: reason 6).
+//   workgroups 0 .. wave_a_wgs - 1: PREFIX CUs; wave_a_wgs .. wave_wgs - 1: POOL CUs of (side, half) = (w - wave_a_wgs) & 3 -- wavefronts 0 .. wave_waves - 1 run
+//                                  branch tasks; wavefronts 4 .. 7 of the first fill_wgs are a fill-in team (wave_fill)
+//   the others: two tile teams each on ring 1 (pooled blocks where there are no units, head tiles)
+__global__ __launch_bounds__(LRG_WORKER_THREADS) void lrg_grow_async_worker_kernel(LrgAsyncKArgs K) {
+    const int tid = threadIdx.x;
+    const long long t_launch = wall_clock64();
+#if defined(__HIP_DEVICE_COMPILE__)
+    lrg_kargs_ptr kp = (lrg_kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    lrg_kargs_ptr kp = nullptr;
+#endif
+    if (tid == 0) __hip_atomic_fetch_add(&K.A.queue[LRG_AQ_ARRIVED], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int w = (int)blockIdx.x;
+    if (w < K.A.wave_wgs) {
+        const int rg = w < K.A.wave_a_wgs ? 4 : (w - K.A.wave_a_wgs) & 3;
+        if (rg == 4) {
+            lrg_wave_load_prefix_kernels(K.A.prob[0], 0, tid, LRG_WORKER_THREADS);
+            lrg_wave_load_prefix_kernels(K.A.prob[1], LRG_WA_SIDE, tid, LRG_WORKER_THREADS);
+        } else {
+            lrg_wave_load_pool_kernels(K.A.prob[rg >> 1], 2 * (rg & 1), 0, tid, LRG_WORKER_THREADS);
+            lrg_wave_load_pool_kernels(K.A.prob[rg >> 1], 2 * (rg & 1) + 1, LRG_WP_QUARTER, tid, LRG_WORKER_THREADS);
+        }
+        const bool fill_team = K.A.wave_fill && K.A.fill_list && w < K.A.fill_wgs && tid >= 256;
+        int *word = reinterpret_cast<int *>(lrg_async_smem + LRG_WB_FLOATS);      // the fill-in team's region: control words first
+        if (tid == 256) { word[4] = 0; word[5] = 0; }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // the CU's kernels are in place; from here on every wavefront (and the fill-in team) goes its own way
+        if (fill_team) { lrg_async_worker(kp, LRG_WB_FLOATS, t_launch, 1); return; }
+        if ((tid >> 6) >= K.A.wave_waves) return;
+        if (rg == 4) lrg_async_wave_prefix_worker(kp, t_launch);
+        else lrg_async_wave_pool_worker(kp, rg, t_launch);
+        return;
+    }
+    const int t = tid >> 8;
+    if (t >= K.A.teams) return;
+    const int sm_off = t * LRG_ASYNC_TEAM_FLOATS;
+    int *word = reinterpret_cast<int *>(lrg_async_smem + sm_off);
+    if ((tid & 255) == 0) { word[4] = 0; word[5] = 0; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    lrg_async_worker(kp, sm_off, t_launch, 2);
 }

@@ -73,3 +73,5 @@ struct LrgGemvArgs {
 int lrg_packed_problems(const LrgWeights *w, const float *x_in, const float *x_nb, const float *center, const int32_t *row_inst_in,
                         const int32_t *row_inst_nb, int32_t *nrows, int n_inst, int row_cap, float *add_logits, float *rmv_logits,
                         void *workspace, size_t workspace_bytes, LrgFusedArgs *branches, LrgGemvArgs *gemv, LrgFusedArgs *heads);
+// float offsets in the packed workspace of the two [row_cap, conv_ch[n_conv - 2]] row arrays a wave-branch launch hands from its PREFIX to its POOL tasks
+int lrg_packed_conv3_view(const LrgWeights *w, int n_inst, int row_cap, size_t offset_floats[2]);

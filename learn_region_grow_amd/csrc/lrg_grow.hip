@@ -1557,10 +1557,37 @@ static size_t async_unit_ring_entries(int n_slots) {         // the pooled-produ
     while (ring < (size_t)n_slots * 2) ring <<= 1;
     return ring;
 }
+static size_t async_wave_ring_entries(int n_slots) {         // one of the eight (side, quarter) rings of a wave-branch launch: a slot has at most 16 tiles per side outstanding
+    size_t ring = 2048;
+    while (ring < (size_t)n_slots * 32) ring <<= 1;
+    return ring;
+}
 size_t lrg_grow_async_queue_bytes(int n_slots) {
     if (n_slots <= 0) return 0;
-    // (two task rings: branch tiles | pooled blocks and head tiles; then the units' ring; then the fill-in ring)
-    return (LRG_AQ_RING + 2 * async_ring_entries(n_slots) + async_unit_ring_entries(n_slots) + LRG_ASYNC_FILL_RING) * sizeof(int32_t);
+    // (two task rings: branch tiles | pooled blocks and head tiles; then the units' ring; then the fill-in ring; then the wave rings' control words and the eight wave rings)
+    return (LRG_AQ_RING + 2 * async_ring_entries(n_slots) + async_unit_ring_entries(n_slots) + LRG_ASYNC_FILL_RING + 256 + 8 * async_wave_ring_entries(n_slots)) * sizeof(int32_t);
+}
+
+// the network lrg_wave_tile.inl is written for: 9 .. 16 features, branch layers 64, 64, 64, 128, 512 (the LrgNet of the paper, lite 0)
+static bool lrg_wave_branch_fits(const LrgWeights *w) {
+    return w->feature_size > 8 && w->feature_size <= LRG_WB_K0 && w->n_conv == 5 && w->conv_ch[0] == LRG_WB_C0 && w->conv_ch[1] == LRG_WB_C1 && w->conv_ch[2] == LRG_WB_C2 &&
+           w->conv_ch[3] == LRG_WB_C3 && w->conv_ch[4] == LRG_WB_C4;
+}
+
+// the side stream and the two events of a wave-branch launch (per device; created once)
+// (a ring of event pairs: a launch's events are not recorded again while an earlier launch's waits on them may still be queued -- callers run a few launches ahead)
+#define LRG_SIDE_EVENTS 64
+struct LrgSideStream { hipStream_t stream; hipEvent_t start[LRG_SIDE_EVENTS], done[LRG_SIDE_EVENTS]; unsigned next; bool ok; };
+static LrgSideStream *lrg_side_stream() {
+    static LrgSideStream side[LRG_MAX_DEVICES] = {};
+    LrgSideStream *s = &side[lrg_current_device()];
+    if (!s->ok) {
+        if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 0; i < LRG_SIDE_EVENTS; ++i)
+            if (hipEventCreateWithFlags(&s->start[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        s->ok = true;
+    }
+    return s;
 }
 
 size_t lrg_grow_async_tail_bytes(int n_slots, int tail_rows) {
@@ -1727,6 +1754,52 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         }
         a.pooled = nullptr;          // (nobody accumulates into it)
     }
+    // Wave-branch mode (round 6, lrg_wave_tile.inl / lrg_grow_async_worker_kernel): the tile CUs as a second kernel of 512 threads, a branch tile as four
+    // one-wavefront tasks on CUs that keep the kernels of their (side, quarter) in LDS.  Where a step is a chain of latencies -- up to LRG_WAVE_AUTO_SLOTS slots;
+    // LrgAsyncBuffers.branch_waves: -1 off, 0 by the slot count, n = on with n wavefronts per wave-branch CU.  Needs the rows at a 64-byte stride, the paper's
+    // network, no shared tail tiles / per-tile pool rows, and the whole chip (the two grids are sized per XCD: a CU-masked launch keeps the one-kernel form).
+    A.wave_wgs = 0; A.wave_a_wgs = 0; A.wave_waves = 0; A.wave_split = 4; A.wave_fill = 0; A.wmask = (int)async_wave_ring_entries(n_slots) - 1; A.h3[0] = A.h3[1] = nullptr;
+    int worker_wgs = 0;                                      // workgroups of the worker kernel (wave-branch mode)
+    {
+        static const int wave_env = getenv("LRG_ASYNC_WAVES") ? atoi(getenv("LRG_ASYNC_WAVES")) : 0;
+        const int want = wave_env ? wave_env : ab->branch_waves;
+        const bool can = a.rows16 && !A.tail && !A.pool_rows && lrg_wave_branch_fits(weights) && A.prob[0].nlayers == 5 && A.prob[0].L[1].gout && A.prob[0].pool &&
+                         (ab->compute_units <= 0 || ab->compute_units >= prop.multiProcessorCount) && (wgs % 32) == 0 && wgs >= 64 && n_slots < (1 << 20);
+        if (can && (want > 0 || (want == 0 && n_slots <= LRG_WAVE_AUTO_SLOTS))) {
+            // Both kernels' workgroups go round the 8 XCDs in turn, and inside an XCD round its 4 shader engines (8 CUs each) -- a workgroup whose engine has no CU
+            // free WAITS for one instead of going elsewhere, and where a kernel's round starts depends on what was dispatched before.  So the grids are sized per
+            // shader engine for ANY alignment of the two rounds: the front kernel's F = n_front + units workgroups put at most f = ceil(ceil(F / 8) / 4) on one
+            // engine, the worker kernel may then have 8 - f per engine: W = 32 x (8 - f).  (Sized per XCD only -- 21 + 232 workgroups -- 7 of 10 launches gave up at the
+            // start rendezvous with every workgroup arrived in the end: the last worker workgroups had waited for CUs that front workgroups held, tools/r06_wave_rendezvous.py;
+            // tools/two_kernel_rendezvous.hip, profiles/r03_side_stream: "a kernel of another stream is only placed when EVERY shader engine has a CU to spare".)
+            // Front workgroups are added while the engines they already claim have room and there are slots for them.
+            const int engines = 32, per_engine = wgs / engines;
+            static const int fronts_env = getenv("LRG_ASYNC_WAVE_FRONTS") ? atoi(getenv("LRG_ASYNC_WAVE_FRONTS")) : 0;
+            if (ab->front_workgroups <= 0 && !a.spec_k && fronts_env > 0) n_front = min(fronts_env, n_slots);
+            int f = ((n_front + A.gemv_units + 7) / 8 + 3) / 4;
+            if (ab->front_workgroups <= 0 && !a.spec_k && fronts_env <= 0) n_front = max(n_front, min(n_slots, engines * f - A.gemv_units));
+            const int F = n_front + A.gemv_units;
+            f = ((F + 7) / 8 + 3) / 4;
+            worker_wgs = engines * (per_engine - f);
+            static const int wwgs_env = getenv("LRG_ASYNC_WAVE_WGS") ? atoi(getenv("LRG_ASYNC_WAVE_WGS")) : 0;
+            static const int awgs_env = getenv("LRG_ASYNC_WAVE_A_WGS") ? atoi(getenv("LRG_ASYNC_WAVE_A_WGS")) : 0;
+            static const int split_env = getenv("LRG_ASYNC_WAVE_SPLIT") ? atoi(getenv("LRG_ASYNC_WAVE_SPLIT")) : 0;
+            // (per evaluation ~7 tiles: PREFIX tasks ~7 x 10 us of one wavefront, POOL tasks ~28 x 9 us, four wavefronts to a CU; head tiles ~7 x 13-17 us of a team, two
+            //  to a CU -- and the pooled blocks where there are no units: 62 % | 55 % of the worker CUs run branch tasks, a fifth of those the PREFIX tasks)
+            int wave_wgs = wwgs_env > 0 ? wwgs_env : worker_wgs * (A.gemv_units ? 62 : 55) / 100;
+            wave_wgs = max(8, min(wave_wgs / 4 * 4, worker_wgs - 8));
+            int a_wgs = awgs_env > 0 ? awgs_env : (wave_wgs + 2) / 5;
+            a_wgs = max(1, min(a_wgs, wave_wgs - 4));
+            a_wgs += (wave_wgs - a_wgs) % 4;                 // (POOL CUs: a multiple of four -- the (side, half) kinds)
+            size_t c3[2];
+            if (worker_wgs >= 24 && lrg_packed_conv3_view(weights, n_slots, b->row_cap, c3) == 0) {
+                A.wave_wgs = wave_wgs; A.wave_a_wgs = a_wgs;
+                A.wave_waves = want > 0 ? min(want, 8) : 4;
+                A.wave_split = split_env == 8 ? 8 : 4;
+                A.h3[0] = static_cast<float *>(b->workspace) + c3[0]; A.h3[1] = static_cast<float *>(b->workspace) + c3[1];
+            }
+        }
+    }
     // Teams per worker CU: two -- the first runs branch tiles, the second head tiles (a tile beside another takes 1.2 x as long, but
     // the head tiles wait inside for the pooled-product units, and at 68 slots the teams are what a step queues for: 1 / 2 / 3 teams
     // 751 / 806 / 771 k instance-steps/s with 34 front workgroups, profiles/r03_units_sweep.log); one while the slots are few (nothing
@@ -1735,8 +1808,17 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.room_queue = ab->room_queue; A.work = reinterpret_cast<unsigned long long *>(ab->work); A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
     A.qmask = (int)async_ring_entries(n_slots) - 1;
     A.gmask = (int)async_unit_ring_entries(n_slots) - 1;
-    A.n_slots = n_slots; A.n_front = n_front; A.teams = teams;
-    if (A.fill_list) {
+    A.n_slots = n_slots; A.n_front = n_front; A.teams = A.wave_wgs ? 2 : teams;
+    A.worker_base = n_front + A.gemv_units; A.total_wgs = A.wave_wgs ? n_front + A.gemv_units + worker_wgs : wgs;
+    if (A.fill_list && A.wave_wgs) {
+        // the fill-in teams: wavefronts 4 .. 7 of wave-branch CUs (VALU work beside the MFMA-bound branch wavefronts of the same SIMDs), unless those run branch tasks too
+        if (A.wave_waves <= 4) {
+            A.wave_fill = 1;
+            A.fill_wgs = ab->fill_wgs > 0 ? min(ab->fill_wgs, A.wave_wgs) : min(64, A.wave_wgs);
+        } else {
+            A.fill_list = nullptr; a.fill_in_launch = 0;      // (the host fills in between launches)
+        }
+    } else if (A.fill_list) {
         const int workers = wgs - n_front - A.gemv_units;
         // (16 / 32 / 64 / 103 such workgroups at 68 rooms in flight: 852 / 858 / 857 / 857 k instance-steps/s, 6: 804 k -- a big room's ~170 tasks queue for
         //  them; without the in-launch fill-in 852 k: profiles/r04_fill_in_launch_ab.txt)
@@ -1757,6 +1839,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // few slots, most teams idle: a branch tile as two tasks that share its pooled layer (tile 22.8 -> 18.4 us; eight 100 k-point scenes
     // 75.9 k -> 78.1 k instance-steps/s, four tasks 75.0 k; 68 rooms: 559 k -> 505 k, the teams are busy there: profiles/r03_parts_perf.log)
     A.branch_parts = ab->branch_parts > 0 ? (ab->branch_parts >= 4 ? 4 : ab->branch_parts >= 2 ? 2 : 1) : (n_slots <= 46 ? 2 : 1);      // (end of round 4, profiles/r04_teams_units_sweep.txt: 16 / 24 / 39 / 44 / 52 / 68 slots, 2 against 1 part: +8 / +6 / +2.3 / +1.5 / -2 / -17 %)
+    if (A.wave_wgs) { A.branch_parts = A.wave_split; A.head_ring = 1; A.small_teams = 0; A.small_alt = 0; A.fill_extra = 0; }      // (a branch tile = its four quarters; ring 1 for everything else)
     A.max_steps = max_steps;
     A.budget_ticks = budget_us > 0 ? (long long)budget_us * 100 : (1LL << 60);      // wall_clock64: 100 MHz
     A.abort_ticks = (budget_us > 0 ? (long long)budget_us * 100 : 0) + 400000000LL;  // ... + 4 s without an end: something is broken
@@ -1772,11 +1855,15 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     static_assert((3 * LRG_ASYNC_TEAM_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "three tile teams and a fill team per CU");
     static_assert((2 * LRG_ASYNC_SMALL_TEAM_FLOATS + 2 * LRG_ASYNC_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "four tile teams per CU");
     const size_t unit_lds = A.gemv_units ? (size_t)LRG_GEMV_UNIT_FLOATS(A.gemv.P) * sizeof(float) + 16 : 0;
-    const size_t lds = (max(max(front_lds, team_lds), unit_lds) + 15) & ~(size_t)15;
+    const size_t lds = (max(max(front_lds, A.wave_wgs ? (size_t)0 : team_lds), unit_lds) + 15) & ~(size_t)15;
+    // (wave-branch mode, the worker kernel: a wave-branch CU's kernels + its fill-in team | two tile teams)
+    const size_t worker_lds = (max((size_t)(LRG_WB_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS), (size_t)2 * LRG_ASYNC_TEAM_FLOATS) * sizeof(float) + 15) & ~(size_t)15;
+    static_assert((LRG_WB_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "a wave-branch CU: the kernels of its (side, quarter) and a fill-in team");
     static bool attr_done[LRG_MAX_DEVICES] = {};
     const int dev = lrg_current_device();
     if (!attr_done[dev]) {
         LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_grow_async_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LRG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(lrg_grow_async_worker_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev] = true;
     }
     // Residency: front workgroups, units and tile teams wait for each other, so the launch is only correct when ALL its workgroups run at
@@ -1788,15 +1875,37 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         int per_cu = 0;
         LRG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(lrg_grow_async_kernel), LRG_FRONT_THREADS, lds));
         if (per_cu < 1) return LRG_ERESIDENCY;
+        if (A.wave_wgs) {
+            LRG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(lrg_grow_async_worker_kernel), LRG_WORKER_THREADS, worker_lds));
+            if (per_cu < 1) return LRG_ERESIDENCY;
+        }
         uint32_t cumask[32] = {};
         const uint32_t words = (uint32_t)min(32, (prop.multiProcessorCount + 31) / 32);
         if (hipExtStreamGetCUMask(st, words, cumask) == hipSuccess) {
             int visible = 0;
             for (uint32_t i = 0; i < words; ++i) visible += __builtin_popcount(cumask[i]);
-            if (visible > 0 && visible < wgs) return LRG_ERESIDENCY;      // (no bit set: no mask reported)
+            if (visible > 0 && visible < (A.wave_wgs ? prop.multiProcessorCount : wgs)) return LRG_ERESIDENCY;      // (no bit set: no mask reported)
         } else {
             (void)hipGetLastError();
         }
+    }
+    if (A.wave_wgs) {
+        // Two kernels, resident together: the worker kernel on the side stream between two events of the caller's stream (it starts after everything the caller
+        // enqueued before this call -- the memsets above included -- and the caller's stream goes on only when it has left), the front kernel on the caller's stream.
+        LrgSideStream *side = lrg_side_stream();
+        if (!side) return LRG_ERESIDENCY;
+        LrgAsyncKArgs KW = K;
+        KW.A.worker_base = A.wave_wgs;                       // (the tile teams' workgroups are numbered from the first one behind the wave-branch CUs)
+        const unsigned ev = side->next++ % LRG_SIDE_EVENTS;
+        LRG_HIP_CHECK(hipEventRecord(side->start[ev], st));
+        LRG_HIP_CHECK(hipStreamWaitEvent(side->stream, side->start[ev], 0));
+        hipLaunchKernelGGL(lrg_grow_async_worker_kernel, dim3(worker_wgs), dim3(LRG_WORKER_THREADS), worker_lds, side->stream, KW);
+        LRG_LAUNCH_CHECK();
+        LRG_HIP_CHECK(hipEventRecord(side->done[ev], side->stream));
+        hipLaunchKernelGGL(lrg_grow_async_kernel, dim3(n_front + A.gemv_units), dim3(LRG_FRONT_THREADS), lds, st, K);
+        LRG_LAUNCH_CHECK();
+        LRG_HIP_CHECK(hipStreamWaitEvent(st, side->done[ev], 0));
+        return 0;
     }
     hipLaunchKernelGGL(lrg_grow_async_kernel, dim3(wgs), dim3(LRG_FRONT_THREADS), lds, st, K);
     LRG_LAUNCH_CHECK();

@@ -662,6 +662,7 @@ struct LrgPackedLayout {
     size_t pooled;       // [n_inst, 2*C_last]
     size_t hb[2];        // [n_inst, head_ch[0]] hoisted pooled product of the add / remove head
     size_t packed;       // lrg_pack_weights image when the caller supplies none
+    size_t conv3[2];     // the last layer before the pooled one, [row_cap, conv_ch[n_conv - 2]] per side: from the PREFIX to the POOL tasks of a wave-branch launch (lrg_wave_tile.inl)
     size_t total;
     int P;
 };
@@ -681,7 +682,16 @@ static int packed_layout(const LrgWeights *w, int n_inst, int row_cap, LrgPacked
     if (rc) return rc;
     L->packed = off;
     off = lrg_align_up(off + PL.total, 64);
+    for (int br = 0; br < 2; ++br) { L->conv3[br] = off; off = lrg_align_up(off + (size_t)row_cap * w->conv_ch[w->n_conv - 2], 64); }
     L->total = off;
+    return 0;
+}
+
+int lrg_packed_conv3_view(const LrgWeights *w, int n_inst, int row_cap, size_t offset_floats[2]) {
+    LrgPackedLayout L;
+    int rc = packed_layout(w, n_inst, row_cap, &L);
+    if (rc) return rc;
+    offset_floats[0] = L.conv3[0]; offset_floats[1] = L.conv3[1];
     return 0;
 }
 

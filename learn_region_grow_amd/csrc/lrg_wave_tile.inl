@@ -1,0 +1,247 @@
+// A 32-row tile of one LrgNet branch (learn_region_grow_util.py:106-123: five 1x1 convolutions 13 -> 64 -> 64 -> 64 -> 128 -> 512, bias, ReLU, max-pool) by single
+// wavefronts, activations in registers.  Round 6; included by lrg_async.inl.
+//
+// lrg_fused_tile.inl runs such a tile on a team of four wavefronts that hand every layer's output to each other through LDS: a team barrier, an LDS round trip and an
+// epilogue of ~600 instructions per pass with ONE wave per SIMD -- 52 k cycles for 23 k cycles of MFMA issue under load (profiles/r05_bench_debug_68.log), and the
+// branch stage is the longest piece of a slot's step.  Here the product is computed TRANSPOSED, H_l^T = W_l^T H_(l-1)^T:
+//
+//   v_mfma_f32_32x32x2_f32   A = the layer's kernel (row i = output channel, from LDS in lrg_pack_weights' operand order: the lane's float4 of k-group g holds
+//                                k = 8g + 4h + 0..3 of column 32 cb + lane % 32 -- the image the team tiles read as their B operand, unchanged),
+//                            B = the activations (column j = point = lane % 32),
+//                            D: lane (point j, half h) holds channels 32 cb + 8 (r >> 2) + 4 h + (r & 3), r = 0 .. 15.
+//
+// So register 4 (g & 3) + s of output block g >> 2 of a lane holds, in lane half h, channel 8g + 4h + s: exactly the B operand of instruction s of k-group g of the
+// NEXT layer ("lane half h feeds logical k = 8g + 4h + s", lrg_fused_tile.inl: tile_mfma).  Bias and ReLU are applied to the accumulators in place and the next
+// layer's MFMAs read them: no LDS round trip, no barrier, nothing shared between wavefronts.  Same sums in the same order as the team tile -- per output a chain of
+// FMAs over k = 8g + 0, 4, 1, 5, 2, 6, 3, 7 (the instruction adds lane half 0, then lane half 1: tools/mfma_order_check.py), products commute -- so conv[1], the pooled
+// maxima and everything downstream are the team tile's bit for bit (tools/wave_tile_probe.hip against a host chain; tests/test_gpu_free_run.py against the lock-step
+// iterations).
+//
+// What a wavefront cannot hold is the pooled layer's kernel (128 x 512 floats), and what a CU's LDS cannot hold is all of a branch (331 KB).  Two stages:
+//   PREFIX task (tile): layers 0 - 3 (272 MFMAs) on a CU that keeps the four kernels of BOTH branches in LDS (2 x 69 KB); conv[1] (for the heads, :130,:134) and the
+//     128-channel output go to HBM rows (write-through, 16-byte stores), then the wavefront publishes the tile's four POOL tasks.
+//   POOL task (tile, quarter of the pooled layer's 512 columns): the tile's 128 channels back into registers (sixteen 16-byte loads per lane = the B operands), 2 x 2
+//     column blocks of 128 MFMAs each from a CU that keeps its (side, half) of the pooled layer's kernel in LDS (128 KB), the max over the tile's points, one
+//     atomicMax instruction per pair of blocks.  The last POOL task of a slot's evaluation publishes its pooled product and head tiles (lrg_async_branch_arrive).
+// A k-group's kernel operand is one ds_read_b128 per 4 MFMAs (256 cycles); the matrix pipe of the wave's SIMD is what a task waits for.
+// (First form of the round, profiles/r06_wave_probe.txt: ONE stage, a task = (tile, quarter) that ran layers 0 - 3 again -- 528 MFMAs, 46 k cycles = 19.5 us a task,
+//  62 % more matrix work per tile; bit-identical too, but with 68 rooms in flight the wave-branch CUs, the head teams and the units were all above 80 % busy and the
+//  step got no shorter: 850 k against 879 k instance-steps/s.)
+//
+// The max-pool (:122-123) of a block of 32 channels: max over the 32 lanes of a half of max(acc + bias, 0) = max(max_lanes(acc) + bias, 0) (rounding is monotone), by a
+// TRANSPOSING reduction on the DPP network -- at every level half of the registers are exchanged for the partner lane's other half, 16 registers x 32 lanes -> one
+// register in which lane t of a row of 16 holds channel register t: 46 instructions instead of 80, and the 64 maxima of two blocks end up in 64 different lanes: ONE
+// atomicMax instruction (on the non-negative float bits, as in the team tile) per pair of blocks.
+#pragma once
+#include "lrg_fused_tile.inl"
+
+// LDS of a PREFIX CU, in floats from the start of the launch's dynamic LDS: side s at s * LRG_WA_SIDE
+#define LRG_WA_W0 0                    // layer 0: 2 column blocks x 2 k-groups x 64 lanes x 4
+#define LRG_WA_W1 1024                 // layer 1: 2 x 8 x 256
+#define LRG_WA_W2 5120                 // layer 2: 2 x 8 x 256
+#define LRG_WA_W3 9216                 // layer 3: 4 x 8 x 256
+#define LRG_WA_B0 17408                // biases: 64, 64, 64, 128
+#define LRG_WA_B1 17472
+#define LRG_WA_B2 17536
+#define LRG_WA_B3 17600
+#define LRG_WA_SIDE 17728
+#define LRG_WA_FLOATS (2 * LRG_WA_SIDE)
+// LDS of a POOL CU of (side, half): quarter q of the pooled layer (q = 2 half + 0 / 1) at (q & 1) * LRG_WP_QUARTER
+#define LRG_WP_W4 0                    // 4 column blocks x 16 k-groups x 256
+#define LRG_WP_B4 16384                // 128
+#define LRG_WP_QUARTER 16512
+#define LRG_WP_FLOATS (2 * LRG_WP_QUARTER)
+#define LRG_WB_FLOATS (LRG_WA_FLOATS > LRG_WP_FLOATS ? LRG_WA_FLOATS : LRG_WP_FLOATS)      // (the fill-in team of such a CU lives behind it)
+
+#ifndef LRG_WB_SMEM
+#define LRG_WB_SMEM lrg_async_smem
+#endif
+
+// the shape this file is written for (checked on the host: lrg_wave_branch_fits)
+#define LRG_WB_K0 16
+#define LRG_WB_C0 64
+#define LRG_WB_C1 64
+#define LRG_WB_C2 64
+#define LRG_WB_C3 128
+#define LRG_WB_C4 512
+
+__device__ __forceinline__ float4 lrg_wb_lds4(int off_floats) { return *reinterpret_cast<const float4 *>(&LRG_WB_SMEM[off_floats]); }
+
+// acc0 / acc1 (two 32-channel output blocks of a layer) over NG k-groups; h = the previous layer's output blocks (NG / 4 of them); w0 / w1 = float offset of the
+// lane's float4 of k-group 0 of the two blocks' kernels.  The operands of group g + 1 are requested before the MFMAs of group g.
+template <int NG, int NBI>
+__device__ __forceinline__ void lrg_wb_mfma2(f32x16 &acc0, f32x16 &acc1, const f32x16 (&h)[NBI], int w0, int w1) {
+    static_assert(NBI * 4 == NG, "four k-groups per input block");
+    float4 a0 = lrg_wb_lds4(w0), a1 = lrg_wb_lds4(w1);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float4 n0 = a0, n1 = a1;
+        if (g + 1 < NG) { n0 = lrg_wb_lds4(w0 + (g + 1) * 256); n1 = lrg_wb_lds4(w1 + (g + 1) * 256); }
+        const f32x16 &hb = h[g >> 2];
+        const int r = 4 * (g & 3);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, hb[r + 0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, hb[r + 0], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, hb[r + 1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, hb[r + 1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, hb[r + 2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, hb[r + 2], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, hb[r + 3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, hb[r + 3], acc1, 0, 0, 0);
+        a0 = n0; a1 = n1;
+        __builtin_amdgcn_sched_barrier(0);      // (nothing moves across a k-group: left to itself the scheduler requests a whole pass's operands up front -- 128 VGPRs)
+    }
+}
+
+// bias + ReLU on an output block in place: the lane's channels are 8 j + 4 h + (0 .. 3), j = 0 .. 3 -- four float4 of the bias row
+__device__ __forceinline__ void lrg_wb_bias_relu(f32x16 &a, int bias_off /* floats: bias of the block's channel 0 + 4 h */) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 b = lrg_wb_lds4(bias_off + 8 * j);
+        a[4 * j + 0] = fmaxf(a[4 * j + 0] + b.x, 0.f);
+        a[4 * j + 1] = fmaxf(a[4 * j + 1] + b.y, 0.f);
+        a[4 * j + 2] = fmaxf(a[4 * j + 2] + b.z, 0.f);
+        a[4 * j + 3] = fmaxf(a[4 * j + 3] + b.w, 0.f);
+    }
+}
+
+// ---- the transposing max over the 32 lanes of each wave half ----
+// one level: the lanes whose bit `sel` is clear keep x and take the partner's x, the others keep y and take the partner's y (partner = DPP control CTRL, which maps
+// a lane with the bit clear to one with it set and back)
+template <int CTRL>
+__device__ __forceinline__ float lrg_wb_level(float x, float y, bool hi) {
+    const float keep = hi ? y : x, send = hi ? x : y;
+    const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, false));
+    return fmaxf(keep, recv);
+}
+// 16 registers x 16 lanes of a row -> one register: lane t of the row holds the maximum over the row's lanes of register t
+__device__ __forceinline__ float lrg_wb_rowmax16(const f32x16 &a, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float l1[8];          // registers r and r + 4 (r = 0 .. 3, 8 .. 11): partner lane t ^ 7 (row_half_mirror), selected by lane bit 2
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2);
+        l1[i] = lrg_wb_level<0x141>(a[r], a[r + 4], b2);
+    }
+    float l2[4];          // r and r + 1: partner t ^ 1 (quad_perm 1, 0, 3, 2), lane bit 0.  l1[i]: r = (i & 3) + 8 (i >> 2)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l2[i] = lrg_wb_level<0xB1>(l1[2 * i], l1[2 * i + 1], b0);
+    float l3[2];          // r and r + 2: partner t ^ 2 (quad_perm 2, 3, 0, 1), lane bit 1.  l2[i]: r = 2 (i & 1) + 8 (i >> 1)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) l3[i] = lrg_wb_level<0x4E>(l2[2 * i], l2[2 * i + 1], b1);
+    // r and r + 8: partner t ^ 8 (row_ror 8), lane bit 3
+    return lrg_wb_level<0x128>(l3[0], l3[1], b3);
+}
+
+// PREFIX task: rows r0 .. r0 + 31 of `x` (64-byte stride, uncentred) of slot `slot`, layers 0 - 3 with the kernels at LDS offset `wa` (the side's).
+//   x, center: as LrgFusedProb (write-through by the front workgroup: read past the L1); conv1: layer 1's HBM copy [rows, 64]; h3: layer 3's [rows, 128]
+__device__ __forceinline__ void lrg_wave_prefix_tile(const float *x, const float *center, float *conv1, float *h3out, long r0, int slot, int wa, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    // ---- the rows: lane (point li, half lh) holds k = 8g + 4 lh + 0..3 of its point for g = 0, 1 (columns past the feature count are zeros on both sides) ----
+    f32x16 h0[1];
+    {
+        const float4 x0 = lrg_ld_coh4(x + r0 * 16, (unsigned)(li * 16 + 4 * lh) * 4u), x1 = lrg_ld_coh4(x + r0 * 16, (unsigned)(li * 16 + 8 + 4 * lh) * 4u);
+        const float4 c0 = lrg_ld_coh4(center + (long)slot * 16, (unsigned)(4 * lh) * 4u), c1 = lrg_ld_coh4(center + (long)slot * 16, (unsigned)(8 + 4 * lh) * 4u);
+        h0[0][0] = __fsub_rn(x0.x, c0.x); h0[0][1] = __fsub_rn(x0.y, c0.y); h0[0][2] = __fsub_rn(x0.z, c0.z); h0[0][3] = __fsub_rn(x0.w, c0.w);
+        h0[0][4] = __fsub_rn(x1.x, c1.x); h0[0][5] = __fsub_rn(x1.y, c1.y); h0[0][6] = __fsub_rn(x1.z, c1.z); h0[0][7] = __fsub_rn(x1.w, c1.w);
+#pragma unroll
+        for (int i = 8; i < 16; ++i) h0[0][i] = 0.f;
+    }
+    const int lw = wa + 4 * lane;                  // the lane's float4 within a k-group's 256 floats
+    const int lb = wa + 4 * lh;                    // the lane's first channel within a block's group of 8
+    f32x16 ha[2], hb[2];
+    // ---- layer 0: K = 16 (two k-groups), 64 channels ----
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ha[0][i] = 0.f; ha[1][i] = 0.f; }
+        float4 a0 = lrg_wb_lds4(LRG_WA_W0 + lw), a1 = lrg_wb_lds4(LRG_WA_W0 + 2 * 256 + lw);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float4 n0 = a0, n1 = a1;
+            if (g == 0) { n0 = lrg_wb_lds4(LRG_WA_W0 + 256 + lw); n1 = lrg_wb_lds4(LRG_WA_W0 + 3 * 256 + lw); }
+            const int r = 4 * g;
+            ha[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, h0[0][r + 0], ha[0], 0, 0, 0);
+            ha[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, h0[0][r + 0], ha[1], 0, 0, 0);
+            ha[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, h0[0][r + 1], ha[0], 0, 0, 0);
+            ha[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, h0[0][r + 1], ha[1], 0, 0, 0);
+            ha[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, h0[0][r + 2], ha[0], 0, 0, 0);
+            ha[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, h0[0][r + 2], ha[1], 0, 0, 0);
+            ha[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, h0[0][r + 3], ha[0], 0, 0, 0);
+            ha[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, h0[0][r + 3], ha[1], 0, 0, 0);
+            a0 = n0; a1 = n1;
+        }
+        lrg_wb_bias_relu(ha[0], LRG_WA_B0 + lb);
+        lrg_wb_bias_relu(ha[1], LRG_WA_B0 + 32 + lb);
+    }
+    // ---- layer 1: 64 -> 64, and its copy for the heads (conv[1], :130,:134) ----
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { hb[0][i] = 0.f; hb[1][i] = 0.f; }
+        lrg_wb_mfma2<8, 2>(hb[0], hb[1], ha, LRG_WA_W1 + lw, LRG_WA_W1 + 8 * 256 + lw);
+        lrg_wb_bias_relu(hb[0], LRG_WA_B1 + lb);
+        lrg_wb_bias_relu(hb[1], LRG_WA_B1 + 32 + lb);
+        float *gb = conv1 + r0 * LRG_WB_C1;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                lrg_st_coh4(gb, (unsigned)(li * LRG_WB_C1 + 32 * b + 8 * j + 4 * lh) * 4u, make_float4(hb[b][4 * j], hb[b][4 * j + 1], hb[b][4 * j + 2], hb[b][4 * j + 3]));
+    }
+    // ---- layer 2: 64 -> 64 ----
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ha[0][i] = 0.f; ha[1][i] = 0.f; }
+        lrg_wb_mfma2<8, 2>(ha[0], ha[1], hb, LRG_WA_W2 + lw, LRG_WA_W2 + 8 * 256 + lw);
+        lrg_wb_bias_relu(ha[0], LRG_WA_B2 + lb);
+        lrg_wb_bias_relu(ha[1], LRG_WA_B2 + 32 + lb);
+    }
+    // ---- layer 3: 64 -> 128, two blocks at a time, out to the tile's rows for the POOL tasks ----
+    float *gh = h3out + r0 * LRG_WB_C3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        f32x16 c0, c1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; }
+        lrg_wb_mfma2<8, 2>(c0, c1, ha, LRG_WA_W3 + (2 * p) * 8 * 256 + lw, LRG_WA_W3 + (2 * p + 1) * 8 * 256 + lw);
+        lrg_wb_bias_relu(c0, LRG_WA_B3 + 64 * p + lb);
+        lrg_wb_bias_relu(c1, LRG_WA_B3 + 64 * p + 32 + lb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lrg_st_coh4(gh, (unsigned)(li * LRG_WB_C3 + 64 * p + 8 * j + 4 * lh) * 4u, make_float4(c0[4 * j], c0[4 * j + 1], c0[4 * j + 2], c0[4 * j + 3]));
+            lrg_st_coh4(gh, (unsigned)(li * LRG_WB_C3 + 64 * p + 32 + 8 * j + 4 * lh) * 4u, make_float4(c1[4 * j], c1[4 * j + 1], c1[4 * j + 2], c1[4 * j + 3]));
+        }
+    }
+}
+
+// POOL task: the tile's layer-3 rows h3in[r0 .. r0 + 31][128], quarter `q` of the pooled layer's columns (its kernel at LDS offset `wp`), block pairs p_lo .. p_hi - 1
+// of the quarter's two; pool: the slot's pooled feature for this side ([512] floats, zero before the evaluation's first tile)
+__device__ __forceinline__ void lrg_wave_pool_tile(const float *h3in, float *pool, long r0, int q, int wp, int p_lo, int p_hi, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 h3[4];
+    {
+        const float *gh = h3in + r0 * LRG_WB_C3;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = lrg_ld_coh4(gh, (unsigned)(li * LRG_WB_C3 + 32 * b + 8 * j + 4 * lh) * 4u);
+                h3[b][4 * j] = v.x; h3[b][4 * j + 1] = v.y; h3[b][4 * j + 2] = v.z; h3[b][4 * j + 3] = v.w;
+            }
+    }
+    const int lw = wp + 4 * lane;
+    const bool row1 = (lane & 16) != 0;
+    for (int p = p_lo; p < p_hi; ++p) {
+        f32x16 c0, c1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; }
+        lrg_wb_mfma2<16, 4>(c0, c1, h3, LRG_WP_W4 + (2 * p) * 16 * 256 + lw, LRG_WP_W4 + (2 * p + 1) * 16 * 256 + lw);
+        const float m0 = lrg_wb_rowmax16(c0, lane), m1 = lrg_wb_rowmax16(c1, lane);
+        // rows 0 / 1 of a half hold the maxima over lanes 0-15 / 16-31 of the same channels: the even row keeps block 2p, the odd row block 2p + 1
+        const float keep = row1 ? m1 : m0, send = row1 ? m0 : m1;
+        const float m = fmaxf(keep, __shfl_xor(send, 16));
+        const int t = lane & 15;
+        const int ch = 32 * (2 * p + (row1 ? 1 : 0)) + 8 * (t >> 2) + 4 * lh + (t & 3);      // within the quarter
+        const float v = fmaxf(m + LRG_WB_SMEM[wp + LRG_WP_B4 + ch], 0.f);
+        const int bits = __float_as_int(v);
+        if (bits > 0) atomicMax(reinterpret_cast<int *>(pool + q * 128 + ch), bits);
+    }
+}

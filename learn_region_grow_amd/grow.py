@@ -54,7 +54,7 @@ class RegionGrower:
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
                  skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np', free_run=None,
                  free_run_steps=1 << 20, free_run_budget_us=5000, free_run_fronts=0, free_run_teams=0, free_run_fill_cus=None, free_run_units=0,
-                 speculate=0, free_run_tail_rows=None):
+                 speculate=0, free_run_tail_rows=None, free_run_waves=0):
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
         graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*).
@@ -130,6 +130,7 @@ class RegionGrower:
         self.free_run_fill_cus = free_run_fill_cus
         self.free_run_units = int(free_run_units)      # 0 = pooled-product units where they fit, -1 = the tile teams' 128-column blocks
         self.free_run_tail_rows = free_run_tail_rows   # shared tail tiles: rows per side (None = by the slot count, 0 = off)
+        self.free_run_waves = int(free_run_waves)      # wave-branch launches (LrgAsyncBuffers.branch_waves): 0 = by the slot count, -1 = off, n = on with n wavefronts per wave-branch CU
         self.debug_hook = None      # tests: called once per active slot per legacy iteration with the step's data
         self._rooms_loaded = False
 
@@ -402,6 +403,7 @@ class RegionGrower:
                 ab.poll_sleep = int(os.environ.get('LRG_FREE_RUN_POLL', '0'))
                 ab.branch_parts = int(os.environ.get('LRG_FREE_RUN_PARTS', '0'))
                 ab.gemv_units = self.free_run_units or int(os.environ.get('LRG_FREE_RUN_UNITS', '0'))          # -1: the pooled product as tasks of the tile teams
+                ab.branch_waves = self.free_run_waves or int(os.environ.get('LRG_FREE_RUN_WAVES', '0'))
                 ab.rows16 = 1 if (9 <= F <= 16 and os.environ.get('LRG_FREE_RUN_ROWS16', '1') != '0') else 0
                 # LRG_FREE_RUN_POOL_ROWS=1: a branch tile leaves its column maxima as ONE row of 16-byte stores and the pooled-product units take
                 # the maximum over a slot's tiles while loading (no atomicMax per column, no zeroing by the front workgroup).  Same labels;

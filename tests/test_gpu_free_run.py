@@ -38,7 +38,29 @@ def test_free_run_equals_lock_step(net, steps, fronts, teams, in_flight, units):
     rooms = _rooms()
     kw = dict(rooms_in_flight=in_flight, rng='counter', seed=123, policy='net')
     want = RegionGrower(net, free_run=False, **kw).run(rooms)
-    gr = RegionGrower(net, free_run=True, free_run_steps=steps, free_run_fronts=fronts, free_run_teams=teams, free_run_units=units, **kw)
+    # (free_run_waves=-1: the one-kernel launch whose tile teams run the branch tiles; the wave-branch launches have a test of their own below)
+    gr = RegionGrower(net, free_run=True, free_run_steps=steps, free_run_fronts=fronts, free_run_teams=teams, free_run_units=units, free_run_waves=-1, **kw)
+    got = gr.run(rooms)
+    assert gr.free_run
+    for g, w in zip(got, want):
+        same_regions(g.regions, w.regions)
+        np.testing.assert_array_equal(g.cluster_label, w.cluster_label)
+        np.testing.assert_array_equal(g.filled_label, w.filled_label)
+
+
+@pytest.mark.parametrize('steps,fronts,in_flight,units,waves', [(64, 0, 5, 0, 4), (1, 0, 5, 0, 4), (7, 2, 5, 0, 4), (64, 0, 9, 0, 8), (64, 0, 30, 0, 4), (64, 0, 68, 0, 4),
+                                                                 (64, 3, 5, -1, 4), (16, 0, 100, -1, 4), (64, 0, 140, 0, 8), (64, 0, 200, 0, 4)])
+def test_wave_branch_launches_equal_lock_step(net, steps, fronts, in_flight, units, waves):
+    """Round 6 (csrc/lrg_wave_tile.inl): the launch as two kernels resident together -- front workgroups and units | the CUs that run tiles -- and a branch tile
+    (learn_region_grow_util.py:106-123) as four one-wavefront tasks with the activations in registers, on CUs that hold the kernels of their (side, quarter) in LDS.
+    The same sums in the same order as the team tiles: regions and labels equal the lock-step iterations' exactly.  waves: 4 = four wavefronts per wave-branch CU and a
+    fill-in team beside them, 8 = eight (the fill-in between launches).  An option (LrgAsyncBuffers.branch_waves), off by default: measured slower than the one-kernel
+    launch at every slot count."""
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = _rooms()
+    kw = dict(rooms_in_flight=in_flight, rng='counter', seed=123, policy='net')
+    want = RegionGrower(net, free_run=False, **kw).run(rooms)
+    gr = RegionGrower(net, free_run=True, free_run_steps=steps, free_run_fronts=fronts, free_run_units=units, free_run_waves=waves, **kw)
     got = gr.run(rooms)
     assert gr.free_run
     for g, w in zip(got, want):
