@@ -1331,6 +1331,7 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
     const int row_stride = A.front.row_stride;
     const int n_gemv = A.gemv_units ? A.gemv_units : 2 * ((A.gemv.C + LRG_GEMV_TASK_COLS - 1) / LRG_GEMV_TASK_COLS);
     if (tid < LRG_ASYNC_MAX_SERVED) { C.state[tid] = tid < n_served ? 0 : 2; C.steps[tid] = 0; C.tgt[tid][0] = C.tgt[tid][1] = C.tgt[tid][2] = 0; }
+    if (tid == 0) reinterpret_cast<LrgFrontShared *>(smem)->upd[0] = 0;      // (the mask update's flag: zero between two updates; the rendezvous' barrier below is ahead of the first)
     // a slot's rows have a fixed place in the row arrays: their tags are written once per launch
     for (int i = 0; i < n_served; ++i) {
         const int s = s_first + i * s_step;

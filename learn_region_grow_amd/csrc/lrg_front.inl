@@ -783,6 +783,8 @@ struct LrgFrontShared {
     int off[2];
     int tail[4];             // shared tail tiles: [0] / [1] first shared row of the inlier / neighbour tail (-1: none), [2] / [3] rows of a failed reservation that lie
                              // inside the shared rows (dead rows of the last shared tile, for the serving loop to account)
+    int upd[4];              // the mask update: [0] != 0 = some sample slot's re-derived voxel is not its own point's (the update then takes the general form).  Zero
+                             // between two updates: cleared by whoever declares the struct, and again by every update after it has been read
 };
 
 // ---- speculation (LrgFrontArgs.spec_k = K > 1): several regions of ONE room in flight ----
@@ -1014,6 +1016,20 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     uint32_t pv0[4];
     int al0 = 0;                     // bit k: entry k is still a member after the update
     if (status == LRG_ACTIVE) {
+        // The update by the slot's own lists (round 6).  A sample slot's point is entry `pos` of the list its side was sampled from (:238-240,:250-252) -- known
+        // before the evaluation, like the point's voxel word -- and the voxel the reference re-derives from the centred row, rint(((x - c) + c) / res) (:271-276),
+        // is that point's own voxel unless the float32 round trip through the centre moves x across a voxel boundary.  So where no taken slot's voxel moved
+        // (checked for all of them: SH.upd[0]), an add switches on the slot's own candidate -- not in the mask, by the box query (:226-228): elected among the copies
+        // of its row by a flag in LDS, no atomic on the mask's word and no voxel look-up -- and a remove switches off the slot's own member and marks its list
+        // position in a bitmap in LDS, from which the survivors' count and bounding box (:292-293) follow without reading the mask back.  Behind the logits' trip
+        // the update is LDS work and fire-and-forget stores: four dependent memory round trips less (grid look-up, atomicOr, mask read-back, added points'
+        // voxel words; 7.3 -> ~3 us of the front step).  Same mask, same lists, bit for bit; a moved voxel (rare) takes the general form below for that step.
+        unsigned *bm_rm = reinterpret_cast<unsigned *>(sh_flags);        // bit i: entry i of the old index list was removed by this step
+        {
+            const int bm_words = (nc0 + 31) >> 5;                          // (<= 4096 words: rooms up to 131 072 points)
+            for (int w = tid; w < bm_words; w += LRG_FRONT_THREADS) bm_rm[w] = 0u;
+            if (tid < 512) sh_tab[tid] = 0;                                // per neighbour row: its point was switched on (copies of a row draw for themselves, :266)
+        }
         if (tid == 0) { sh_i[0] = 0; sh_i[1] = 0; sh_i[5] = 0; sh_i[6] = 0; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) id0[k] = spec ? lrg_ld_coh(&cur_idx[min(tid + k * LRG_FRONT_THREADS, nc0 - 1)]) : cur_idx[min(tid + k * LRG_FRONT_THREADS, nc0 - 1)];
@@ -1029,16 +1045,23 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         }
         int idx = -1;
         int correct = 0;
+        bool take = false;
+        int pos = 0, own = -1;                        // the source row's position in the list it was sampled from (the gather's arithmetic), and the point there
+        float px = 0.f, py = 0.f, pz = 0.f;
         if (mine) {
+            // (a padded set's rows are its members in order, a full set's the prefix of the permutation)
+            pos = nside < Nside ? srow : (int)lrg_sample_position((uint32_t)srow, (uint32_t)nside, (uint32_t)Nside, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
+                                                                  (uint32_t)seed0, (uint32_t)restart0, (uint32_t)step0, k0, k1);
+            const int32_t *lst = half ? cur_idx : cand_idx;
+            own = spec ? lrg_ld_coh(&lst[pos]) : lst[pos];
             const float4 u = (half ? a.upd_in : a.upd_nb)[(long)s * Nside + srow];
-            const float px = u.x, py = u.y, pz = u.z;
+            px = u.x; py = u.y; pz = u.z;
             const float *lgp = (half ? a.rmv_logits : a.add_logits) + 2 * row;
             float lg[2];
             if constexpr (ASYNC) { const float2 t = lrg_ld_coh2(lgp); lg[0] = t.x; lg[1] = t.y; }      // (written by a tile team of this launch)
             else { lg[0] = lgp[0]; lg[1] = lgp[1]; }
             const int gtf = u.w != 0.f;
             correct = (lg[1] > lg[0] ? 1 : 0) == gtf;                                        // add_acc / remove_acc (util:174-180)
-            bool take;
             if (prm.policy == 2) take = gtf != 0;                                            // :268-269
             else {
                 const float conf = lrg_conf(lg);                                             // :262-263
@@ -1049,22 +1072,87 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
 #ifdef LRG_SPEC_TRACE
             if (spec && j == 0) LRG_SPEC_EV(a, 5 + half, s, seed0, ((long long)__float_as_uint(lg[0]) << 32) | __float_as_uint(lg[1]), ((long long)take << 40) | ((long long)(row & 0xFFFFF) << 20) | (srow & 0xFFFFF));
 #endif
-            if (take) {
-                // the rows are stored uncentred: (x - c) + c in float32, as the reference centres (:243,:246) and un-centres
-                // (:271,:275) the row -- not x itself
-                const int vx = lrg_voxel_of(__fadd_rn(__fsub_rn(px, c0), c0), prm.resolution);   // :271-272 / :275-276
-                const int vy = lrg_voxel_of(__fadd_rn(__fsub_rn(py, c1), c1), prm.resolution);
-                const int vz = lrg_voxel_of(pz, prm.resolution);
-                idx = lrg_voxel_index(VI, vx, vy, vz);
-            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) pv0[k] = pvox[id0[k]];
+        const uint32_t pv_own = mine ? pvox[max(own, 0)] : 0u;                                 // (the slot's own point's voxel word: the test below, an added point's share of the new bounding box)
+        // the voxel the reference looks up: the rows are stored uncentred, so (x - c) + c in float32, as it centres (:243,:246) and un-centres (:271,:275) the row
+        int vx = 0, vy = 0, vz = 0;
+        if (mine && take) {
+            vx = lrg_voxel_of(__fadd_rn(__fsub_rn(px, c0), c0), prm.resolution);              // :271-272 / :275-276
+            vy = lrg_voxel_of(__fadd_rn(__fsub_rn(py, c1), c1), prm.resolution);
+            vz = lrg_voxel_of(pz, prm.resolution);
+#ifndef LRG_UPDATE_GENERAL      // (build switch: every update in the general form, as up to round 5)
+            if (vx - ox != LRG_PVX(pv_own) || vy - oy != LRG_PVY(pv_own) || vz - oz != LRG_PVZ(pv_own)) SH.upd[0] = 1;      // (whoever stores, stores 1; the room's grid holds `own` in that voxel)
+#else
+            SH.upd[0] = 1;
+#endif
+        }
         {
             const int wsum = lrg_wave_sum_i32(correct);          // a wavefront lies in one half (512 = 8 wavefronts)
             __syncthreads();
             if (lane == 0 && wsum) atomicAdd(&sh_i[5 + half], wsum);
         }
+        const bool by_lists = SH.upd[0] == 0;                     // (workgroup-uniform: written before the barrier, cleared behind the next ones)
+        int cnt = 0;
+        int mn0 = INT_MAX, mn1 = INT_MAX, mn2 = INT_MAX, mx0 = INT_MIN, mx1 = INT_MIN, mx2 = INT_MIN;
+        if (by_lists) {
+            if (mine && take) {
+                if (!half) {                                                                  // :283-285
+                    if (atomicOr(&sh_tab[srow], 1) == 0) {
+                        cur[own] = 1;
+                        sh_i[0] = 1;
+                        const int k = atomicAdd(&sh_i[1], 1);
+                        sh_src[0][k] = own; sh_src[1][k] = (int)pv_own;
+                    }
+                } else {                                                                      // :286-287
+                    atomicOr(&bm_rm[pos >> 5], 1u << (pos & 31));
+                    cur[own] = 0;
+                }
+            }
+            __syncthreads();
+            // members and bounding box of the new mask (:292-293): the old members whose list position was not removed + the points switched on
+            // (a candidate is no member: nothing is added and removed in the same step here)
+            const int nadd = sh_i[1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid + k * LRG_FRONT_THREADS;
+                if (i < nc0 && !((bm_rm[i >> 5] >> (i & 31)) & 1u)) {
+                    al0 |= 1 << k;
+                    ++cnt;
+                    const int x = LRG_PVX(pv0[k]), y = LRG_PVY(pv0[k]), z = LRG_PVZ(pv0[k]);
+                    mn0 = min(mn0, x); mn1 = min(mn1, y); mn2 = min(mn2, z);
+                    mx0 = max(mx0, x); mx1 = max(mx1, y); mx2 = max(mx2, z);
+                }
+            }
+            for (int i0 = 4 * LRG_FRONT_THREADS; i0 < nc0; i0 += 4 * LRG_FRONT_THREADS) {       // regions above 4096 points
+                int id[4];
+                uint32_t pv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) id[k] = cur_idx[min(i0 + k * LRG_FRONT_THREADS + tid, nc0 - 1)];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pv[k] = pvox[id[k]];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * LRG_FRONT_THREADS + tid;
+                    if (i < nc0 && !((bm_rm[i >> 5] >> (i & 31)) & 1u)) {
+                        ++cnt;
+                        const int x = LRG_PVX(pv[k]), y = LRG_PVY(pv[k]), z = LRG_PVZ(pv[k]);
+                        mn0 = min(mn0, x); mn1 = min(mn1, y); mn2 = min(mn2, z);
+                        mx0 = max(mx0, x); mx1 = max(mx1, y); mx2 = max(mx2, z);
+                    }
+                }
+            }
+            for (int k = tid; k < nadd; k += LRG_FRONT_THREADS) {
+                const uint32_t pv = (uint32_t)sh_src[1][k];
+                ++cnt;
+                const int x = LRG_PVX(pv), y = LRG_PVY(pv), z = LRG_PVZ(pv);
+                mn0 = min(mn0, x); mn1 = min(mn1, y); mn2 = min(mn2, z);
+                mx0 = max(mx0, x); mx1 = max(mx1, y); mx2 = max(mx2, z);
+            }
+        } else {
+        // ---- the general form: the voxel's point from the room's grid / hash, a word-wide atomicOr electing the slot that switches a point on, the mask read back ----
+        if (mine && take) idx = lrg_voxel_index(VI, vx, vy, vz);
         if (!half && idx >= 0) {                                                             // :283-285
             unsigned *w = reinterpret_cast<unsigned *>(cur + (idx & ~3));
             const unsigned bit = 1u << (8 * (idx & 3));
@@ -1075,8 +1163,6 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         __syncthreads();
         // members and bounding box of the new mask (:292-293): surviving old members + surviving new ones
         const int nadd = sh_i[1];
-        int cnt = 0;
-        int mn0 = INT_MAX, mn1 = INT_MAX, mn2 = INT_MAX, mx0 = INT_MIN, mx1 = INT_MIN, mx2 = INT_MIN;
         {
             int al[4];
 #pragma unroll
@@ -1117,9 +1203,11 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
                 mx0 = max(mx0, x); mx1 = max(mx1, y); mx2 = max(mx2, z);
             }
         }
+        }      // (general form)
         lrg_block_bbox(cnt, mn0, mn1, mn2, mx0, mx1, mx2, red);
         if (tid == 0) {
             const int upd = sh_i[0];
+            SH.upd[0] = 0;                       // (read by everybody before the barriers of the reduction above)
             S->pad = 0;
             S->step = step0 + 1;
             S->steps_total = steps_total0 + 1;                                               // :288
@@ -1735,6 +1823,8 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_front_greedy_kernel(Lrg
 #if LRG_FRONT_EXCLUSIVE
     asm volatile("" ::: "v127");         // the kernel is accounted 128 VGPRs: four of its waves fill a SIMD's register file, a CU to itself
 #endif
+    if (threadIdx.x == 0) SH.upd[0] = 0;
+    __syncthreads();
     (void)lrg_front_greedy_slot<false>(SH, slots, rooms, n_slots, prm, a, big, (int)blockIdx.x);
 }
 
