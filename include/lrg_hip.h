@@ -524,7 +524,7 @@ typedef struct LrgAsyncBuffers {
                                    launch, for tools/free_run_perf.py (layout: csrc/lrg_async.inl, LrgAsyncArgs.dbg)            */
     /* Shared tail tiles (ABI 9; tail_ctl non-NULL, tail_rows > 0, rows16): a slot's rows beyond its last full 32-row tile (16 of ~91 rows per side on
        average: as padded tiles of the slot's own they were 18 % of all tile rows) go to `tail_rows` rows per side that ALL slots share -- rows
-       [n_slots * row_stride, + tail_rows) of the row arrays (buffers->row_cap and the workspace must cover them) -- so that the tails of several slots fill one
+       [n_slots * row_stride, + tail_rows) of the row arrays (buffers->row_cap and the workspace must cover them and 32 rows more) -- so that the tails of several slots fill one
        branch tile.  Same results bit for bit (the shared tile is lrg_forward_packed's tile: runs of rows, per-run max-pool).  When a launch runs out of
        shared rows the slots pad tiles of their own again.                                                                                        */
     int32_t *tail_ctl;          /* lrg_grow_async_tail_bytes(n_slots, tail_rows) bytes, 64-byte aligned (cleared by every call)                    */

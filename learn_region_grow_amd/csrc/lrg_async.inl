@@ -1286,6 +1286,32 @@ __device__ __forceinline__ void lrg_async_wave_pool_worker(lrg_kargs_ptr kp, int
     }
 }
 
+// A slot that leaves the launch between two evaluations: the logits of its tail rows (in the shared rows, lrg_async.inl "shared tail tiles") are copied to the rows of
+// its own that the tail would have had without sharing, and its tail bases are cleared -- the next launch hands the shared rows out again from row 0 (its cursors are
+// cleared by the host), and the slot's first turn there reads the logits of its last evaluation.  All threads of the slot's front workgroup.
+__device__ __forceinline__ void lrg_async_tail_logits_home(const LrgAsyncArgs &A, int s) {
+    const LrgFrontArgs &a = A.front;
+    const int tid = threadIdx.x;
+    if (!a.tail_base) return;
+    const int side = tid >> 6, k = tid & 63;                 // (wavefront 0: the inlier side's remove logits, wavefront 1: the neighbour side's add logits)
+    if (side < 2) {
+        const int tb = a.tail_base[2 * s + side];
+        if (tb >= 0) {
+            const int rows = a.slot_rows[4 * s + side], first_tail = rows & ~31, tl = rows & 31;
+            float *lg = const_cast<float *>(side ? a.add_logits : a.rmv_logits);
+            if (k < tl) {
+                const float2 v = lrg_ld_coh2(lg + 2 * ((long)a.tail_row0 + tb + k));
+                lrg_st_coh2(lg + 2 * ((long)s * a.row_stride + first_tail + k), v.x, v.y);
+            }
+        }
+    }
+    lrg_drain_stores();
+    __syncthreads();
+    if (tid < 2) a.tail_base[2 * s + tid] = -1;
+    lrg_drain_stores();
+    __syncthreads();
+}
+
 struct LrgAsyncFrontCtl {
     int state[LRG_ASYNC_MAX_SERVED];     // 0 to be served, 1 evaluation in flight, 2 finished for this launch; speculation: 3 no seed left for the slot while the
                                          // group's room is not finished (parked until the group is rebound), 4 region pending (served when it is the room's
@@ -1470,7 +1496,16 @@ __device__ __forceinline__ void lrg_async_front(lrg_kargs_ptr kp, long long t_la
             __syncthreads();
             const int stop = C.bc[1];
             __syncthreads();
-            if (stop) { if (tid == 0) C.state[i] = 2; continue; }
+            if (stop) {
+                // (shared tail tiles: the slot leaves the launch with the logits of its tail rows in rows that the NEXT launch hands out again from row 0 -- its
+                //  first turn there would read them while other slots' head tiles may already write into them.  They go home, to the slot's own rows, before it
+                //  leaves: its next update finds them there, tail_base = -1.)
+#ifndef LRG_EXP_NO_TAIL_HOME      // (experiment switch: the hazard as it was up to round 5 -- tests/test_gpu_free_run.py::test_shared_tail_tiles_across_short_launches fails with it)
+                if (A.tail) lrg_async_tail_logits_home(A, s);
+#endif
+                if (tid == 0) C.state[i] = 2;
+                continue;
+            }
             const long long t_front = LRG_DBG(A) ? wall_clock64() : 0;
             const int r = __builtin_amdgcn_readfirstlane(spec_k ? lrg_async_front_step<true>(kp, s) : lrg_async_front_step<false>(kp, s));
             if (r == 0) {

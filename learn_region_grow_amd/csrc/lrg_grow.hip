@@ -1552,9 +1552,9 @@ static size_t async_ring_entries(int n_slots) {
     while (ring < (size_t)n_slots * 512) ring <<= 1;
     return ring;
 }
-static size_t async_unit_ring_entries(int n_slots) {         // the pooled-product units' ring: a slot has one entry outstanding at most
-    size_t ring = 256;
-    while (ring < (size_t)n_slots * 2) ring <<= 1;
+static size_t async_unit_ring_entries(int n_slots) {         // the pooled-product units' ring: a slot has one entry outstanding at most -- and with batched pooled
+    size_t ring = 256;                                       // products (LRG_GEMV_BATCH) a closed batch takes LRG_GEMV_BATCH positions whatever it holds: live batches
+    while (ring < (size_t)n_slots * 2 * LRG_GEMV_BATCH) ring <<= 1;      // span up to LRG_GEMV_BATCH x n_slots positions (twice that: nobody wraps onto an unread entry)
     return ring;
 }
 static size_t async_wave_ring_entries(int n_slots) {         // one of the eight (side, quarter) rings of a wave-branch launch: a slot has at most 16 tiles per side outstanding
@@ -1731,7 +1731,8 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     A.tail = nullptr; A.tail_tiles = 0; A.tail_ticks = 0; A.tail_heads = 0;
     a.tail_cur = nullptr; a.tail_base = nullptr; a.tail_rows = 0; a.tail_row0 = 0;
     if (ab->tail_ctl && ab->tail_rows > 0 && a.rows16 && !ab->pool_rows) {
-        if ((ab->tail_rows & 31) || ((uintptr_t)ab->tail_ctl & 63) || (long)b->row_cap < (long)n_slots * row_stride + ab->tail_rows || n_slots >= (1 << 20) ||
+        // (+ 32 rows: a slot's own head tile on its tail rows stages a full tile from the tail's first row, tail_heads == 0)
+        if ((ab->tail_rows & 31) || ((uintptr_t)ab->tail_ctl & 63) || (long)b->row_cap < (long)n_slots * row_stride + ab->tail_rows + 32 || n_slots >= (1 << 20) ||
             ab->tail_rows / 32 >= (1 << 20))
             return LRG_EINVAL - 9;
         A.tail = ab->tail_ctl; A.tail_tiles = ab->tail_rows / 32;

@@ -344,7 +344,7 @@ class RegionGrower:
                 env = os.environ.get('LRG_FREE_RUN_TAIL_ROWS', '')
                 want = int(env) if env else (self.free_run_tail_rows if self.free_run_tail_rows is not None else (min(1 << 20, 4096 * S) if (S >= 224 and not self.speculate) else 0))
                 self.tail_rows = max(0, want) // 32 * 32
-            cap_rows += self.tail_rows
+            cap_rows += self.tail_rows + (32 if self.tail_rows else 0)      # (+ a tile: a head tile on a slot's tail rows stages 32 rows from the tail's first)
             self.row_cap = cap_rows
             # (room for rows at a 64-byte stride: the free-running kernel gathers and stages its rows in 16-byte pieces, LrgAsyncBuffers.rows16; the
             #  lock-step launches use the first cap_rows x F floats of the same arrays)

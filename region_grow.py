@@ -252,12 +252,21 @@ def main(argv=None):
         elif args.shared_stream:
             kw['rooms_in_flight'] = 1
             results = RegionGrower(net, **kw).run(rooms, legacy_shared_seed=args.seed)
-        elif args.rng == 'counter' and max(1, args.restarts) == 1 and spec_k > 1 and RegionGrower.free_run_applies(net, rooms, in_flight * spec_k, **{k: v for k, v in kw.items() if k != 'rooms_in_flight'}):
-            results = RegionGrower(net, speculate=spec_k, **kw).run(rooms)
-        elif args.rng == 'counter' and args.lanes != 1:
-            results = LanedRegionGrower(net, lanes=args.lanes, **kw).run(rooms)
         else:
-            results = RegionGrower(net, **kw).run(rooms)
+            results = None
+            # (speculation only where no lane count was asked for: an explicit --lanes N > 1 means lock-step lanes)
+            if (args.rng == 'counter' and max(1, args.restarts) == 1 and spec_k > 1 and args.lanes in (0, 1) and
+                    RegionGrower.free_run_applies(net, rooms, in_flight * spec_k, **{k: v for k, v in kw.items() if k != 'rooms_in_flight'})):
+                try:
+                    results = RegionGrower(net, speculate=spec_k, **kw).run(rooms)
+                except ValueError as e:      # (the host's check and the device's voxel words disagreed: the plain growers take the rooms)
+                    say('speculation not applicable (%s): growing without it' % e)
+                    results = None
+            if results is None:
+                if args.rng == 'counter' and args.lanes != 1:
+                    results = LanedRegionGrower(net, lanes=args.lanes, **kw).run(rooms)
+                else:
+                    results = RegionGrower(net, **kw).run(rooms)
         t_grow = time.time() - t0
         # ---- per-room evaluation where the room was grown; lines, metrics and labels to rank 0 ----
         local_out = []

@@ -229,6 +229,39 @@ def test_shared_tail_tiles_equal_lock_step(net, monkeypatch, in_flight, tail_row
     assert work[3] * 32 >= work[1] + work[2]          # (tiles run x 32 rows cover the rows evaluated)
 
 
+def test_shared_tail_tiles_across_short_launches(net):
+    """Every launch hands the shared rows out again from row 0, and a slot enters a launch with the logits of its last evaluation still to be read: they are
+    copied to the slot's own rows before it leaves a launch (lrg_async_tail_logits_home), so that the next launch's tails cannot land on them.  Provoked here with
+    launches of ONE evaluation per slot that alternate between 64 front workgroups (the tails reserved in any order) and 4 (sixteen slots each: a workgroup's last
+    slots take their first turn ~300 us into the launch, when the tails of 40 evaluations have been written from row 0 on): with the hazard compiled back in
+    (-DLRG_EXP_NO_TAIL_HOME) rooms come out with other labels; as built, regions and labels are the lock-step iterations'."""
+    import torch
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = [small_room(700 + i, 420 + 37 * (i % 9), room_id=40 + i) for i in range(64)]
+    kw = dict(rooms_in_flight=64, rng='counter', seed=5, policy='net')
+    want = RegionGrower(net, free_run=False, **kw).run(rooms)
+    gr = RegionGrower(net, free_run=True, free_run_steps=1, free_run_tail_rows=2048, free_run_waves=-1, **kw)
+    gr.load_rooms(rooms)
+    assert gr.free_run and gr.async_buffers.tail_ctl
+    for g in range(64):
+        gr.bind(g, g)
+    for k in range(100000):
+        gr.async_buffers.front_workgroups = 64 if k % 2 == 0 else 4
+        gr.enqueue_free_run()
+        if k % 16 == 15:
+            torch.cuda.synchronize()
+            assert int(gr.d_stats[3].item()) == 0
+            if int(gr.d_stats[1].item()) >= 64:
+                break
+    for r in range(64):
+        gr.fill(r)
+    got = gr.collect()
+    for g, w in zip(got, want):
+        same_regions(g.regions, w.regions)
+        np.testing.assert_array_equal(g.cluster_label, w.cluster_label)
+        np.testing.assert_array_equal(g.filled_label, w.filled_label)
+
+
 def test_shared_tail_tiles_with_speculation(net, monkeypatch):
     from learn_region_grow_amd.grow import RegionGrower
     rooms = _rooms()
