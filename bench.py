@@ -237,7 +237,9 @@ def cpu_baseline_all_cores(rooms, weights, seconds, policy, gpu_room_steps):
     out = dict(value=steps / busy, unit='instance-steps/s', cores=workers, cores_busy=workers + n_small, kind='port', rooms_finished=finished, wall_seconds=wall,
                per_core=steps / busy / workers)
     if known:
-        out['rooms_per_sec'] = (steps / busy) / float(np.mean(known))
+        # (extrapolated: the step rate of the sample over the mean steps the GPU run took for these rooms -- kept beside the measured figure below)
+        out['rooms_per_sec_extrapolated_set_mean'] = (steps / busy) / float(np.mean(known))
+        out['rooms_per_sec'] = out['rooms_per_sec_extrapolated_set_mean']
         out['rooms_per_sec_extrapolated'] = True
     done_small = [(i, r) for i, r in zip(small, res_small) if r[2] is not None]
     if done_small:
@@ -251,6 +253,10 @@ def cpu_baseline_all_cores(rooms, weights, seconds, policy, gpu_room_steps):
                                            what='the %d smallest rooms of the set, each grown to its end and filled in by one single-threaded process: '
                                                 'rooms/s per core = rooms / the sum of their seconds; x the %d cores in use = the box' % (n_small, workers + n_small))
         out['rooms_finished'] = finished + len(done_small)
+        # the headline key is the MEASURED figure (whole rooms, grown to the end and filled in); the extrapolated one for the set's mean room stays beside it
+        out['rooms_per_sec'] = out['measured_small_rooms']['rooms_per_sec_box']
+        out['rooms_per_sec_extrapolated'] = False
+        out['rooms_per_sec_what'] = 'measured on the %d smallest rooms of the set (an upper bound for the set); rooms_per_sec_extrapolated_set_mean is the step rate over the mean steps per room' % len(done_small)
     out['sample'] = ('%d rooms (evenly over the set\'s sizes: %d .. %d points), one single-threaded process each, oracle.grow_ref (faithful=True, policy=%s) for '
                      '%.0f s or to the room\'s end: %d steps, longest worker %.1f s, %d rooms grown to the end; rooms/s = step rate / the mean steps the GPU run '
                      'took for these rooms' % (workers, min(len(rooms[i]['points']) for i in picks), max(len(rooms[i]['points']) for i in picks), policy,
@@ -344,6 +350,18 @@ def _respawn_under_torchrun(args):
 def _lib_auto_slots():
     from learn_region_grow_amd import _lib
     return _lib.LRG_FREE_RUN_AUTO_SLOTS
+
+
+def kernel_sources_sha16():
+    """Digest of the kernel sources (csrc/*.hip, *.inl, *.h and the C-ABI header): what a committed counter file was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, 'learn_region_grow_amd', 'csrc', '*.*')) + [os.path.join(REPO, 'include', 'lrg_hip.h')]):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 class _Leg:
@@ -637,7 +655,7 @@ def main():
                      'speculation': ({'depth': args.speculate, 'regions_voided': dw[4], 'evaluations_voided': dw[5], 'steps_voided': dw[6],
                                       'note': 'algorithmic_flops_in_loop counts every evaluation executed, voided ones included (work done, not work kept); '
                                               '`value` counts kept steps only'} if args.speculate > 1 else None),
-                     'reproduce': 'rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps %d --warmup %d  (profiles/r04_bench_kernel_stats.csv)'
+                     'reproduce': 'rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps %d --warmup %d  (profiles/r06_bench_kernel_stats.csv)'
                                   % (args.steps, args.warmup)})
     else:
         reps = 20
@@ -674,7 +692,7 @@ def main():
                                'lanes\' last iteration), HIP events on the launch stream',
                      'achieved': ach, 'frac': ach / FP32_MATRIX_PEAK_TFLOPS, 'algorithmic_flops_in_loop': flops,
                      'flops_per_launch': flops, 'avg_us': 1e3 * loop_ms, 'packed_rows': [int(rows[0]), int(rows[1])],
-                     'rows_evaluated_fraction': float(rows.sum()) / (S * 1024.0),
+                     'rows_evaluated_fraction': float(rows.sum()) / (max(act, 1) * 1024.0), 'slots_evaluated': int(act),
                      'flops_definition': 'distinct rows evaluated x (165 504 + 98 816 FLOP per row) + active slots x 1 048 576'})
     # the dense evaluation (all 512 + 512 rows of S instances): the formulation SURVEY.md 8d prices, a side launch outside the timed loop
     reps = 10
@@ -725,8 +743,8 @@ def main():
     # HBM traffic / matrix-pipe occupancy of the loop's kernel: PMC passes of their own (tools/pmc_free_run.sh), quoted from the committed
     # file only when it was measured on this ABI and formulation
     roof['traffic'] = None
-    tpath = os.path.join(REPO, 'profiles', 'r05_pmc_free_run.json' if leg.free else 'r02_traffic_loop.json')
-    for older in ('r04_pmc_free_run.json', 'r03_pmc_free_run.json'):
+    tpath = os.path.join(REPO, 'profiles', 'r06_pmc_free_run.json' if leg.free else 'r02_traffic_loop.json')
+    for older in ('r05_pmc_free_run.json', 'r04_pmc_free_run.json', 'r03_pmc_free_run.json'):
         if leg.free and not os.path.exists(tpath):
             tpath = os.path.join(REPO, 'profiles', older)
     if os.path.exists(tpath):
@@ -737,7 +755,10 @@ def main():
             roof['traffic_quoted_from'] = {'file': 'profiles/' + os.path.basename(tpath), 'measured_at_commit': tj.get('commit'), 'abi': tj.get('abi'),
                                            'launch_ms': tj.get('launch_ms'), 'hbm_GBps': tj.get('hbm_GBps'), 'frac_of_hbm_peak': tj.get('frac_of_hbm_peak'),
                                            'mfma_util_chipwide': tj.get('mfma_util_chipwide'),
-                                           'note': 'rocprofv3 --pmc passes of their own over the same command; bytes per launch of %.0f ms' % args.step_ms}
+                                           'kernel_sources_sha16_then': tj.get('kernel_sources_sha16'), 'kernel_sources_sha16_now': kernel_sources_sha16(),
+                                           'stale': tj.get('kernel_sources_sha16') != kernel_sources_sha16(),
+                                           'note': 'rocprofv3 --pmc passes of their own over the same command; bytes per launch of %.0f ms; stale = the kernel '
+                                                   'sources (csrc/*, include/lrg_hip.h) changed since the counters were read' % args.step_ms}
         elif not leg.free:
             roof['traffic'] = tj.get('hbm_bytes_per_iteration')
             roof['traffic_quoted_from'] = {'file': 'profiles/' + os.path.basename(tpath), 'note': 'round-2 measurement of the five lock-step launches, per iteration'}
@@ -777,7 +798,19 @@ def main():
             crc = zlib.crc32(np.ascontiguousarray(gathered[j], dtype=np.int32).tobytes(), crc) if gathered[j] is not None else crc
         for k, v in fl.room_steps().items():
             room_steps.setdefault(mine[k] % len(base), v)
+        leg_roof = None
+        if wk is not None:
+            # the launches' algorithmic FLOPs by the device counters (as for the headline: distinct rows, pooled products) over the WHOLE leg's wall clock -- bind,
+            # launches, fill-ins, the start and the tail where slots run dry included: a lower bound of the kernel's own fraction
+            fl_flops = lrg_dist.allreduce_sum([float((wk[1] + wk[2]) * (FLOPS_PER_BRANCH_ROW + FLOPS_PER_HEAD_ROW) + wk[0] * FLOPS_POOLED_GEMM)], device=coll_dev,
+                                               force_collective=force_coll)[0]
+            leg_roof = {'bound': 'mfma', 'peak': FP32_MATRIX_PEAK_TFLOPS * world, 'unit': 'TFLOP/s', 'achieved': fl_flops / tf_grow / 1e12,
+                        'frac': fl_flops / tf_grow / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * world), 'algorithmic_flops': fl_flops, 'seconds': tf_grow,
+                        'evaluations': float(wk[0]), 'rows_evaluated_fraction': float(wk[1] + wk[2]) / max(float(wk[0]) * 1024.0, 1.0),
+                        'rows_in_tiles_fraction': float(wk[1] + wk[2]) / max(float(wk[3]) * 32.0, 1.0),
+                        'note': 'device counters of the launches (rank 0 x ranks) over the grow time of the leg (launches + binding + fill-ins), not over kernel time'}
         out = {'rooms': int(f_rooms), 'seconds': el, 'rooms_per_sec': f_rooms / el, 'instance_steps': f_steps, 'instance_steps_per_sec': f_steps / el,
+               'roofline': leg_roof,
                'scaling': 'strong', 'slots_per_gpu': fl.slots, 'waves_per_rank': R / float(world) / max(fl.slots, 1),
                'waves_per_rank_at_8_gpus': R / 8.0 / max(n_slots, 1), 'formulation': 'free-running launches' if fl.free else 'lock-step iterations',
                'lanes': fl.lanes, 'grow_seconds_rank0': tf_grow, 'gather_seconds_rank0': tf1 - tg0, 'rccl_ranks': world,
@@ -826,7 +859,8 @@ def main():
             pick = max(tried, key=lambda k: tried[k]['rooms_per_sec'] if tried[k]['all_rooms_labeled_after_gather'] else -1.0)
             best = dict(tried[pick])
             best['sweep'] = {str(k): {'rooms_per_sec': tried[k]['rooms_per_sec'], 'instance_steps_per_sec': tried[k]['instance_steps_per_sec'],
-                                      'formulation': tried[k]['formulation'], 'lanes': tried[k]['lanes']} for k in sorted(tried)}
+                                      'formulation': tried[k]['formulation'], 'lanes': tried[k]['lanes'],
+                                      'roofline_frac': (tried[k]['roofline'] or {}).get('frac')} for k in sorted(tried)}
 
     if rank == 0:
         out = {

@@ -70,6 +70,22 @@ def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
     assert d['preprocessing_p0']['gpu_rooms_per_sec'] > 0
     if mode == 'free':
         assert d['steady_more_rooms_in_flight']['9']['value'] > 0
+        # the fixed-work legs of the free-running launches carry a roofline of their own (device counters over the leg's grow time): the best frac is in the line
+        assert 0 < fw['roofline']['frac'] < 1 and 0 < fw['roofline']['rows_evaluated_fraction'] <= 1 and set(fb['sweep']['3']) >= {'roofline_frac'}
+    # the measured CPU figure is the headline key of the baseline, the extrapolated one beside it
+    if 'measured_small_rooms' in cb:
+        assert cb['rooms_per_sec'] == cb['measured_small_rooms']['rooms_per_sec_box'] and not cb['rooms_per_sec_extrapolated']
+
+
+def test_bench_line_with_restarts_counts_rows_per_slot(cuda_device, tmp_path):
+    """test_random_restart.py's loop, 4 restarts per seed batched per launch: rows_evaluated_fraction is per SLOT (rooms x restarts), so it stays <= 1
+    (round 5 divided by the rooms: 2.65 in the 16-restart record)."""
+    r, lines = run_bench(['--gpus', '1', '--steps', '2', '--warmup', '1', '--iters-per-step', '8', '--rooms', '4', '--restarts', '4', '--fixed-rooms', '0',
+                          '--best-slots', '', '--steady-slots', '', '--cpu-seconds', '0', '--p0-rooms', '0', '--one-room-ks', '', '--cache', str(tmp_path / 'cache')])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(lines[0])
+    rf = d['roofline']
+    assert d['config']['restarts'] == 4 and 0 < rf['rows_evaluated_fraction'] <= 1 and 0 < rf['slots_evaluated'] <= 16
 
 
 def test_bench_two_ranks_started_by_the_script_itself(cuda_device, tmp_path):

@@ -3,7 +3,7 @@
 # rocprofv3 --pmc passes of their own (FETCH_SIZE | WRITE_SIZE | SQ counters), the byte counters corrected on a 256 MiB copy as
 # MI355X_MICROARCH.md prescribes (tools/pmc_calib.py), the launch duration from a --kernel-trace pass of the same command.
 #   usage (GPU box): tools/pmc_free_run.sh <commit> [out.json]
-R=$GRAFT_REPO_ROOT; COMMIT=${1:-unknown}; OUT=${2:-gpurun_out/r05_pmc_free_run.json}
+R=$GRAFT_REPO_ROOT; COMMIT=${1:-unknown}; OUT=${2:-gpurun_out/r06_pmc_free_run.json}
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pmcf && mkdir -p /tmp/pmcf
 B="python $R/bench.py --gpus 1 --steps 6 --warmup 4 --cpu-seconds 0 --p0-rooms 0 --fixed-rooms 0 --one-room-ks= --steady-slots="
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pmcf/kt -o kt --output-format csv -- $B > /tmp/pmcf/kt.log 2>&1
@@ -44,8 +44,9 @@ for r in csv.DictReader(open(ks[0])):
     if K in r['Name']:
         launch_ms = float(r['AverageNs']) * 1e-6
 from learn_region_grow_amd import _lib
+import bench
 res = dict(source='tools/pmc_free_run.sh: rocprofv3 --pmc passes of their own over `bench.py --gpus 1 --steps 6 --warmup 4` (68 rooms in flight, 25 ms launches)',
-           commit=commit, abi=_lib.load().lrg_abi_version(), kernel=K, launches_profiled=len(f), fetch_correction=kf, write_correction=kw,
+           commit=commit, abi=_lib.load().lrg_abi_version(), kernel_sources_sha16=bench.kernel_sources_sha16(), kernel=K, launches_profiled=len(f), fetch_correction=kf, write_correction=kw,
            read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr, launch_ms=launch_ms,
            hbm_GBps=(rd + wr) / (launch_ms * 1e-3) / 1e9 if launch_ms else None,
            frac_of_hbm_peak=(rd + wr) / (launch_ms * 1e-3) / 1e9 / 8000.0 if launch_ms else None,
