@@ -1782,6 +1782,10 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
             const int F = n_front + A.gemv_units;
             f = ((F + 7) / 8 + 3) / 4;
             worker_wgs = engines * (per_engine - f);
+            // (test hook: that many worker workgroups MORE than the shader engines hold -- a launch that can never be resident as a whole: its front workgroups
+            //  give up at the start rendezvous with reason 6, the workgroups that start after that find the abort word and leave;
+            //  tests/test_gpu_free_run.py::test_wave_branch_launch_that_cannot_be_resident_gives_up_cleanly)
+            if (getenv("LRG_ASYNC_WAVE_EXTRA_WGS")) worker_wgs += max(0, atoi(getenv("LRG_ASYNC_WAVE_EXTRA_WGS")));
             static const int wwgs_env = getenv("LRG_ASYNC_WAVE_WGS") ? atoi(getenv("LRG_ASYNC_WAVE_WGS")) : 0;
             static const int awgs_env = getenv("LRG_ASYNC_WAVE_A_WGS") ? atoi(getenv("LRG_ASYNC_WAVE_A_WGS")) : 0;
             static const int split_env = getenv("LRG_ASYNC_WAVE_SPLIT") ? atoi(getenv("LRG_ASYNC_WAVE_SPLIT")) : 0;

@@ -1,0 +1,120 @@
+"""GPU: run-to-run determinism as a gate (round 6; the round-5 review's item 4).
+
+Rooms are independent (test_region_grow.py:110-183) and the random stream is keyed by (seed, room), so every repetition of a
+configuration must give the SAME labels, whatever the order in which the launch's workgroups happened to serve the slots -- and the
+same labels as the lock-step iterations.  Round 5's race ("uniform" loads racing thread 0's stores: a label checksum that differed in
+2 of 16 runs of an unchanged path) was found by a tool (tools/r05_crc_repeat.sh), not by the suite, which ran every configuration
+once or twice.  Here every formulation of the benchmark configuration is repeated with SHORT launches (many launch boundaries, many
+first turns) and must give ONE checksum, that of the lock-step iterations:
+  * 68 Area-5-shaped rooms in flight, free-running launches (what bench.py times), trained weights, Bernoulli policy;
+  * 272 room jobs in 272 slots with shared tail tiles (the many-slots shape of the fixed-work legs);
+  * 8 rooms with three regions per room in flight (speculation);
+  * the wave-branch launches (two kernels resident together, LrgAsyncBuffers.branch_waves);
+  * the 68-room configuration once more while a second stream keeps every CU busy with dense evaluations."""
+import threading
+import zlib
+
+import numpy as np
+import pytest
+
+from learn_region_grow_amd import synthetic, workloads
+
+pytestmark = pytest.mark.gpu
+CACHE = '/tmp/lrg_cache'
+REPEATS = 8
+
+
+@pytest.fixture(scope='module')
+def net(cuda_device):
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    return LrgNetHIP(1, 1, 512, 512, 13, 0, device=cuda_device, mode='fused').load_weights(synthetic.load_trained_weights())
+
+
+@pytest.fixture(scope='module')
+def rooms():
+    return workloads.area5_rooms(68, seed_base=1000, cache_dir=CACHE)
+
+
+def crc_of(results):
+    crc = 0
+    for r in results:
+        crc = zlib.crc32(np.ascontiguousarray(r.filled_label, dtype=np.int32).tobytes(), crc)
+        crc = zlib.crc32(np.ascontiguousarray(r.cluster_label, dtype=np.int32).tobytes(), crc)
+    return crc
+
+
+def lock_step(net, jobs, in_flight, **kw):
+    from learn_region_grow_amd.grow import LanedRegionGrower
+    return crc_of(LanedRegionGrower(net, lanes=1, free_run=False, rooms_in_flight=in_flight, rng='counter', seed=0, policy='net', **kw).run(jobs))
+
+
+def repeat(make, jobs, n=REPEATS):
+    return [crc_of(make().run(jobs)) for _ in range(n)]
+
+
+def test_benchmark_configuration_repeats_to_one_checksum(net, rooms):
+    from learn_region_grow_amd.grow import RegionGrower
+    want = lock_step(net, rooms, 68)
+    got = repeat(lambda: RegionGrower(net, rooms_in_flight=68, rng='counter', seed=0, policy='net', free_run=True, free_run_budget_us=1500), rooms)
+    assert set(got) == {want}, (want, got)
+
+
+def test_many_slots_with_shared_tails_repeat_to_one_checksum(net, rooms):
+    from learn_region_grow_amd.grow import RegionGrower
+    jobs = [dict(rooms[j % 68], room_id=100000 + j) for j in range(272)]
+    want = lock_step(net, jobs, 272)
+    made = []
+
+    def make():
+        gr = RegionGrower(net, rooms_in_flight=272, rng='counter', seed=0, policy='net', free_run=True, free_run_budget_us=1500)
+        made.append(gr)
+        return gr
+    got = repeat(make, jobs, 6)
+    assert all(g.free_run and g.tail_rows > 0 for g in made)
+    assert set(got) == {want}, (want, got)
+
+
+def test_speculation_repeats_to_one_checksum(net, rooms):
+    from learn_region_grow_amd.grow import RegionGrower
+    jobs = rooms[:8]
+    want = lock_step(net, jobs, 8)
+    got = repeat(lambda: RegionGrower(net, rooms_in_flight=8, rng='counter', seed=0, policy='net', speculate=3, free_run_budget_us=1500), jobs)
+    assert set(got) == {want}, (want, got)
+
+
+def test_wave_branch_launches_repeat_to_one_checksum(net, rooms):
+    from learn_region_grow_amd.grow import RegionGrower
+    want = lock_step(net, rooms, 68)
+    got = repeat(lambda: RegionGrower(net, rooms_in_flight=68, rng='counter', seed=0, policy='net', free_run=True, free_run_budget_us=1500, free_run_waves=4), rooms, 4)
+    assert set(got) == {want}, (want, got)
+
+
+def test_benchmark_configuration_repeats_to_one_checksum_on_a_busy_chip(net, rooms):
+    """The free-running launch beside a stream that keeps every CU busy with dense evaluations: its workgroups are not all resident from the start (the launch's
+    start rendezvous waits the hog's kernels out), slots are served in another order -- same checksum."""
+    import torch
+    from learn_region_grow_amd.grow import RegionGrower
+    from learn_region_grow_amd.lrgnet import LrgNetHIP
+    want = lock_step(net, rooms, 68)
+    dev = net.device
+    rs = np.random.RandomState(0)
+    xi = torch.from_numpy((rs.randn(68, 512, 13) * 0.5).astype(np.float32)).to(dev)
+    xn = torch.from_numpy((rs.randn(68, 512, 13) * 0.5).astype(np.float32)).to(dev)
+    hog_net = LrgNetHIP(1, 1, 512, 512, 13, 0, device=dev).load_weights(synthetic.load_trained_weights())
+    hog_stream = torch.cuda.Stream(device=dev)
+    stop = threading.Event()
+
+    def hog():
+        with torch.cuda.stream(hog_stream):
+            while not stop.is_set():
+                for _ in range(8):
+                    hog_net.forward(xi, xn)
+                hog_stream.synchronize()
+    th = threading.Thread(target=hog)
+    th.start()
+    try:
+        got = repeat(lambda: RegionGrower(net, rooms_in_flight=68, rng='counter', seed=0, policy='net', free_run=True), rooms, 3)
+    finally:
+        stop.set()
+        th.join()
+    assert set(got) == {want}, (want, got)

@@ -69,6 +69,31 @@ def test_wave_branch_launches_equal_lock_step(net, steps, fronts, in_flight, uni
         np.testing.assert_array_equal(g.filled_label, w.filled_label)
 
 
+def test_wave_branch_launch_that_cannot_be_resident_gives_up_cleanly(net, monkeypatch):
+    """The two kernels of a wave-branch launch wait for each other, so all their workgroups must run at once.  With 64 worker workgroups more than the shader
+    engines hold (a test hook) the launch can never be resident as a whole: its front workgroups give up at the start rendezvous within start_wait_us (reason 6),
+    the late workgroups find the abort word and leave, the host raises instead of returning labels -- and the next launch on the same device is unharmed."""
+    import time
+    from learn_region_grow_amd import _lib
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = _rooms()
+    kw = dict(rooms_in_flight=5, rng='counter', seed=123, policy='net')
+    want = RegionGrower(net, free_run=False, **kw).run(rooms)
+    monkeypatch.setenv('LRG_ASYNC_WAVE_EXTRA_WGS', '64')
+    gr = RegionGrower(net, free_run=True, free_run_waves=4, **kw)
+    gr.load_rooms(rooms)
+    gr.async_buffers.start_wait_us = 30000
+    t0 = time.time()
+    with pytest.raises(_lib.LrgHipError, match='gave up'):
+        gr.grow_loaded()
+    assert time.time() - t0 < 20.0                      # (bounded by the rendezvous, not by the hand-overs' multi-second limits)
+    monkeypatch.delenv('LRG_ASYNC_WAVE_EXTRA_WGS')
+    got = RegionGrower(net, free_run=True, free_run_waves=4, **kw).run(rooms)
+    for g, w in zip(got, want):
+        same_regions(g.regions, w.regions)
+        np.testing.assert_array_equal(g.filled_label, w.filled_label)
+
+
 def test_free_run_matches_oracle(net):
     from learn_region_grow_amd.grow import RegionGrower
     rooms = _rooms()[:4]
