@@ -462,8 +462,9 @@ int lrg_step_graph_destroy(void *graph);
  * State between calls is exactly that of lrg_grow_step_packed (a call ends every slot between two evaluations, logits in
  * place), so the two may alternate on the same buffers; results are identical bit for bit.
  * ---------------------------------------------------------------------------------------------- */
-#define LRG_WAVE_AUTO_SLOTS 0     /* wave-branch launches by default up to this many slots in flight: 0 = never (measured slower than the one-kernel launch at every slot count,
-                                     profiles/r06_wave_*.txt: a tile on ONE SIMD at a time is 21-23 us through its two stages against 17-25 us for the four-wavefront team tile) */
+#define LRG_REG_TILE_AUTO_MIN 25   /* register-tile launches (branch_waves = 1) by default from this many ... */
+#define LRG_REG_TILE_AUTO_MAX 112  /* ... to this many slots in flight: 16 / 34 / 68 / 100 slots +3 / +6 / +3.4 / +4.9 % over the one-kernel launch, 136 / 192: -3 / -26 % (two teams per
+                                      CU are too few there), eight 100 k-point scenes x 3 regions: -3 % (profiles/r06_reg_tiles_slots.txt) */
 typedef struct LrgAsyncBuffers {
     int32_t *queue;             /* lrg_grow_async_queue_bytes(n_slots) bytes, 256-byte aligned: task ring + control words (cleared by every call) */
     size_t queue_bytes;
@@ -507,12 +508,14 @@ typedef struct LrgAsyncBuffers {
                                    queries saw exactly what the sequential loop (:186-188,:210-217,:227-228) would have shown them.  Same regions, same labels;
                                    for the few-rooms corner (one room or scene per GPU), where a room's chain of dependent steps leaves the chip idle.
                                    n_slots must be a multiple of K; the caller binds whole groups (lrg_bind_group with group_size K); 0 / 1 = off           */
-    int32_t branch_waves;       /* (ABI 10; was `reserved2`) wave-branch launches: the CUs that run tiles as a SECOND kernel (512 threads, up to 256 VGPRs) resident
-                                   beside the front workgroups' and units' kernel, and a branch tile (learn_region_grow_util.py:106-123) as four tasks -- one per
-                                   quarter of the pooled layer's columns -- each run by ONE wavefront that keeps the activations in registers, on a CU that holds
-                                   the kernels of its stage in LDS (csrc/lrg_wave_tile.inl: a PREFIX task = layers 0 - 3, then POOL tasks = a quarter of the pooled
-                                   layer each).  Same results bit for bit.  0 = by the slot count (up to LRG_WAVE_AUTO_SLOTS slots; needs the paper network, rows16,
-                                   no tail_ctl / pool_rows, all CUs); -1 = off; n > 0 = on, n wavefronts per such CU (4 or 8) */
+    int32_t branch_waves;       /* (ABI 10; was `reserved2`) two-kernel launches: the CUs that run tiles as a SECOND kernel (512 threads, up to 256 VGPRs) resident beside the
+                                   front workgroups' and units' kernel (csrc/lrg_wave_tile.inl; same results bit for bit in every form):
+                                     1 = REGISTER TILES: a branch tile (learn_region_grow_util.py:106-123) by a team of four wavefronts that each run layers 0 - 2 in
+                                         registers, meet once in LDS behind layer 3 and take a quarter of the pooled layer each; the other team of the CU runs head tiles;
+                                     4 / 8 = one-wavefront tasks: a PREFIX task (layers 0 - 3) and four POOL tasks (a quarter of the pooled layer) per tile, on CUs that
+                                         hold the kernels of their stage in LDS, that many wavefronts per such CU (measured slower at every slot count: kept as an option);
+                                     0 = by the slot count: register tiles from LRG_REG_TILE_AUTO_MIN to LRG_REG_TILE_AUTO_MAX slots; -1 = one kernel, team tiles.
+                                   Needs the paper's network (13 -> 64 -> 64 -> 64 -> 128 -> 512), rows16, no tail_ctl / pool_rows, all CUs of the device. */
     int32_t start_wait_us;      /* the launch's start rendezvous (all its workgroups must be running at once): how long the front workgroups wait for the
                                    others before the launch gives up with reason 6; 0 = default: the launch budget + 20 ms (a kernel of another stream that
                                    holds CUs for up to one budget is waited out, something that never leaves is reported)  (ABI 9; was `reserved`) */

@@ -137,6 +137,8 @@ struct LrgAsyncArgs {
     int wave_fill;               // 1: wavefronts 4 .. 7 of the first fill_wgs wave-branch CUs are a fill-in team (VALU work beside the MFMA-bound branch waves)
     int wmask;                   // entries of one wave ring - 1 (power of two)
     float *h3[2];                // [row_cap, 128] per side: layer 3's output rows, from the PREFIX to the POOL tasks
+    int reg_tiles;               // 1: the worker kernel's workgroups are all alike -- team 0 runs the branch tiles of ring 0 as REGISTER TILES (lrg_team_branch_tile_reg: a team
+                                 // of four wavefronts per tile, layers 0 - 2 per wavefront in registers, one barrier), team 1 the pooled blocks and head tiles of ring 1
     int worker_base;             // blockIdx.x of the first worker workgroup in the kernel that runs the tile teams (n_front + gemv_units, or wave_wgs in the worker kernel)
     int total_wgs;               // workgroups of the launch in all (both kernels): what the start rendezvous waits for
     int max_steps;               // evaluations per slot in this launch
@@ -1648,6 +1650,66 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgAs
     lrg_async_front(kp, t_launch);
 }
 
+// ---- team 0 of a register-tile CU (LrgAsyncArgs.reg_tiles): branch tiles of ring 0, one per turn of the team (inlined into the worker kernel: ~200 VGPRs) ----
+#define LRG_RT_TEAM0_FLOATS (LRG_ASYNC_CTL_FLOATS + LRG_RT_XCH_FLOATS)
+__device__ __forceinline__ void lrg_async_reg_tile_team(lrg_kargs_ptr kp, long long t_launch) {
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    float *sm = lrg_async_smem + LRG_RT_WEIGHT_FLOATS + LRG_ASYNC_CTL_FLOATS;
+    LrgLdsTeam team = lrg_async_team(A, sm, 0);
+    const int tid = team.tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
+    int *ticket_word = &A.queue[LRG_AQ_HEAD];
+    int next_ticket = -1;
+    for (;;) {
+        long long t_task = 0;
+        if (tid == 0) {
+            const long long t_wait = LRG_DBG(A) ? wall_clock64() : 0;
+            const int t = next_ticket >= 0 ? next_ticket : __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            next_ticket = -1;
+            int *e = &A.queue[LRG_AQ_RING + (t & A.qmask)];
+            int code = 0;
+            for (unsigned spin = 0;; ++spin) {
+                code = lrg_ld_coh(e);
+                if (code) break;
+                if ((spin & 7) == 7) {
+                    if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT]) || lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front) { code = -1; break; }
+                    if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 2); code = -1; break; }
+                }
+                for (int q = 0; q < A.poll_sleep; ++q) __builtin_amdgcn_s_sleep(LRG_WORKER_POLL_SLEEP);
+            }
+            if (code > 0) lrg_st_coh(e, 0);
+            word[0] = code;
+            t_task = wall_clock64();
+            if (LRG_DBG(A)) { lrg_dbg_add(A, 16, t_task - t_wait); lrg_dbg_add(A, 17, 1); }
+        }
+        team.sync();
+        const int code = word[0];                            // (thread 0 writes the next one behind the barriers of the tile)
+        if (code < 0) return;
+        const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 31;
+        const LrgFusedProb &P = A.prob[side];
+        const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
+        lrg_team_branch_tile_reg(P.x, P.center, P.L[1].gout, P.pool + (long)slot * P.pool_stride, P.L[3].w, P.L[4].w, r0, slot, side * LRG_RT_SIDE,
+                                 LRG_RT_WEIGHT_FLOATS + LRG_ASYNC_CTL_FLOATS, team, wave, lane);
+        if (LRG_TICKET_EARLY && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lrg_drain_stores();                                  // conv[1] rows and the pooled maxima are out before the arrival
+        team.sync();
+        if (tid < 64) lrg_async_branch_arrive(A, slot, lane, t_task, true);
+    }
+}
+__device__ __forceinline__ void lrg_rt_load_kernels(const LrgFusedProb &P, int ws, int tid, int nthreads) {      // layers 0 - 2 and every layer's bias of one branch
+    const int offs[3] = {LRG_RT_W0, LRG_RT_W1, LRG_RT_W2}, n4[3] = {256, 1024, 1024};
+    const int boff[5] = {LRG_RT_B0, LRG_RT_B1, LRG_RT_B2, LRG_RT_B3, LRG_RT_B4}, bn[5] = {LRG_WB_C0, LRG_WB_C1, LRG_WB_C2, LRG_WB_C3, LRG_WB_C4};
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+        if (l < 3) {
+            const float4 *src = reinterpret_cast<const float4 *>(P.L[l].w);
+            float4 *dst = reinterpret_cast<float4 *>(lrg_async_smem + ws + offs[l]);
+            for (int i = tid; i < n4[l]; i += nthreads) dst[i] = src[i];
+        }
+        for (int i = tid; i < bn[l]; i += nthreads) lrg_async_smem[ws + boff[l] + i] = P.L[l].bias[i];
+    }
+}
+
 // ---- the second kernel of a wave-branch launch (round 6): the CUs that run tiles, as a kernel of their own shape ----
 // One launch used to give every role the front step's shape -- 1 024 threads, 128 VGPRs -- and the tile code inherited it (spills in the tile tasks, no room for a
 // wavefront that keeps a tile's activations in registers: lrg_wave_tile.inl needs ~176).  This kernel is 512 threads (eight wavefronts, up to 256 VGPRs each) and is
@@ -1686,6 +1748,19 @@ __global__ __launch_bounds__(LRG_WORKER_THREADS) void lrg_grow_async_worker_kern
         if ((tid >> 6) >= K.A.wave_waves) return;
         if (rg == 4) lrg_async_wave_prefix_worker(kp, t_launch);
         else lrg_async_wave_pool_worker(kp, rg, t_launch);
+        return;
+    }
+    if (K.A.reg_tiles) {
+        // a register-tile CU: [the kernels of layers 0 - 2 and the biases of both branches][team 0: control words, layer-3 exchange][team 1: a tile team's region]
+        lrg_rt_load_kernels(K.A.prob[0], 0, tid, LRG_WORKER_THREADS);
+        lrg_rt_load_kernels(K.A.prob[1], LRG_RT_SIDE, tid, LRG_WORKER_THREADS);
+        const int sm_off = (tid >> 8) ? LRG_RT_WEIGHT_FLOATS + LRG_RT_TEAM0_FLOATS : LRG_RT_WEIGHT_FLOATS;
+        int *word = reinterpret_cast<int *>(lrg_async_smem + sm_off);
+        if ((tid & 255) == 0) { word[4] = 0; word[5] = 0; }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid >> 8) lrg_async_worker(kp, sm_off, t_launch, (K.A.fill_list && w < K.A.fill_wgs) ? 1 : 2);      // (the fill-in ring on a few of them, ring 1 on the others)
+        else lrg_async_reg_tile_team(kp, t_launch);
         return;
     }
     const int t = tid >> 8;

@@ -1755,18 +1755,20 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         }
         a.pooled = nullptr;          // (nobody accumulates into it)
     }
-    // Wave-branch mode (round 6, lrg_wave_tile.inl / lrg_grow_async_worker_kernel): the tile CUs as a second kernel of 512 threads, a branch tile as four
-    // one-wavefront tasks on CUs that keep the kernels of their (side, quarter) in LDS.  Where a step is a chain of latencies -- up to LRG_WAVE_AUTO_SLOTS slots;
-    // LrgAsyncBuffers.branch_waves: -1 off, 0 by the slot count, n = on with n wavefronts per wave-branch CU.  Needs the rows at a 64-byte stride, the paper's
-    // network, no shared tail tiles / per-tile pool rows, and the whole chip (the two grids are sized per XCD: a CU-masked launch keeps the one-kernel form).
-    A.wave_wgs = 0; A.wave_a_wgs = 0; A.wave_waves = 0; A.wave_split = 4; A.wave_fill = 0; A.wmask = (int)async_wave_ring_entries(n_slots) - 1; A.h3[0] = A.h3[1] = nullptr;
+    // Two-kernel launches (round 6, lrg_wave_tile.inl / lrg_grow_async_worker_kernel): the tile CUs as a second kernel of 512 threads and up to 256 VGPRs, resident
+    // beside the front workgroups' and units' kernel.  LrgAsyncBuffers.branch_waves: 1 = REGISTER TILES (a branch tile by a team of four wavefronts, layers 0 - 2 per
+    // wavefront in registers, one barrier: the default from LRG_REG_TILE_AUTO_MIN to LRG_REG_TILE_AUTO_MAX slots), 4 / 8 = one-wavefront PREFIX / POOL tasks on CUs that
+    // keep the kernels of their stage in LDS, -1 = one kernel.  Needs the rows at a 64-byte stride, the paper's network, no shared tail tiles / per-tile pool rows, and the
+    // whole chip (the two grids are sized per shader engine: a CU-masked launch keeps the one-kernel form).
+    A.wave_wgs = 0; A.wave_a_wgs = 0; A.wave_waves = 0; A.wave_split = 4; A.wave_fill = 0; A.wmask = (int)async_wave_ring_entries(n_slots) - 1; A.h3[0] = A.h3[1] = nullptr; A.reg_tiles = 0;
     int worker_wgs = 0;                                      // workgroups of the worker kernel (wave-branch mode)
     {
         static const int wave_env = getenv("LRG_ASYNC_WAVES") ? atoi(getenv("LRG_ASYNC_WAVES")) : 0;
-        const int want = wave_env ? wave_env : ab->branch_waves;
+        int want = wave_env ? wave_env : ab->branch_waves;
+        if (want == 0 && n_slots >= LRG_REG_TILE_AUTO_MIN && n_slots <= LRG_REG_TILE_AUTO_MAX) want = 1;      // (register tiles where they win: include/lrg_hip.h)
         const bool can = a.rows16 && !A.tail && !A.pool_rows && lrg_wave_branch_fits(weights) && A.prob[0].nlayers == 5 && A.prob[0].L[1].gout && A.prob[0].pool &&
                          (ab->compute_units <= 0 || ab->compute_units >= prop.multiProcessorCount) && (wgs % 32) == 0 && wgs >= 64 && n_slots < (1 << 20);
-        if (can && (want > 0 || (want == 0 && n_slots <= LRG_WAVE_AUTO_SLOTS))) {
+        if (can && want > 0) {
             // Both kernels' workgroups go round the 8 XCDs in turn, and inside an XCD round its 4 shader engines (8 CUs each) -- a workgroup whose engine has no CU
             // free WAITS for one instead of going elsewhere, and where a kernel's round starts depends on what was dispatched before.  So the grids are sized per
             // shader engine for ANY alignment of the two rounds: the front kernel's F = n_front + units workgroups put at most f = ceil(ceil(F / 8) / 4) on one
@@ -1797,7 +1799,11 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
             a_wgs = max(1, min(a_wgs, wave_wgs - 4));
             a_wgs += (wave_wgs - a_wgs) % 4;                 // (POOL CUs: a multiple of four -- the (side, half) kinds)
             size_t c3[2];
-            if (worker_wgs >= 24 && lrg_packed_conv3_view(weights, n_slots, b->row_cap, c3) == 0) {
+            if (want == 1) {
+                // REGISTER TILES (LrgAsyncBuffers.branch_waves = 1): every worker workgroup alike -- team 0 the branch tiles (four wavefronts per tile, activations in
+                // registers where that is free: lrg_team_branch_tile_reg), team 1 the pooled blocks and head tiles
+                if (worker_wgs >= 24) A.reg_tiles = 1;
+            } else if (worker_wgs >= 24 && lrg_packed_conv3_view(weights, n_slots, b->row_cap, c3) == 0) {
                 A.wave_wgs = wave_wgs; A.wave_a_wgs = a_wgs;
                 A.wave_waves = want > 0 ? min(want, 8) : 4;
                 A.wave_split = split_env == 8 ? 8 : 4;
@@ -1813,9 +1819,18 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     A.queue = ab->queue; A.sync = ab->sync; A.big = b->slot_big; A.room_queue = ab->room_queue; A.work = reinterpret_cast<unsigned long long *>(ab->work); A.dbg = reinterpret_cast<unsigned long long *>(ab->debug_ticks);
     A.qmask = (int)async_ring_entries(n_slots) - 1;
     A.gmask = (int)async_unit_ring_entries(n_slots) - 1;
-    A.n_slots = n_slots; A.n_front = n_front; A.teams = A.wave_wgs ? 2 : teams;
-    A.worker_base = n_front + A.gemv_units; A.total_wgs = A.wave_wgs ? n_front + A.gemv_units + worker_wgs : wgs;
-    if (A.fill_list && A.wave_wgs) {
+    const bool two_kernels = A.wave_wgs || A.reg_tiles;
+    A.n_slots = n_slots; A.n_front = n_front; A.teams = two_kernels ? 2 : teams;
+    A.worker_base = n_front + A.gemv_units; A.total_wgs = two_kernels ? n_front + A.gemv_units + worker_wgs : wgs;
+    if (A.fill_list && A.reg_tiles) {
+        // both teams of a register-tile CU run tiles: the second team of the first fill_wgs of them serves the fill-in ring instead of ring 1 (LRG_ASYNC_RT_FILL_WGS / LrgAsyncBuffers.fill_wgs).
+        // Default 0: the host fills finished rooms in between launches -- 68 rooms in flight, 0 / 8 / 16 / 32 such workgroups: 931 / 892 / 918 / 920 k instance-steps/s
+        // (profiles/r06_reg_tiles_sweep.txt): a head team less per CU costs more than the fill-ins between two launches
+        static const int rt_fill_env = getenv("LRG_ASYNC_RT_FILL_WGS") ? atoi(getenv("LRG_ASYNC_RT_FILL_WGS")) : -1;
+        const int want_fill = ab->fill_wgs > 0 ? ab->fill_wgs : rt_fill_env >= 0 ? rt_fill_env : 0;
+        A.fill_wgs = min(want_fill, worker_wgs / 4);
+        if (A.fill_wgs < 1) { A.fill_list = nullptr; a.fill_in_launch = 0; }
+    } else if (A.fill_list && A.wave_wgs) {
         // the fill-in teams: wavefronts 4 .. 7 of wave-branch CUs (VALU work beside the MFMA-bound branch wavefronts of the same SIMDs), unless those run branch tasks too
         if (A.wave_waves <= 4) {
             A.wave_fill = 1;
@@ -1844,7 +1859,8 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // few slots, most teams idle: a branch tile as two tasks that share its pooled layer (tile 22.8 -> 18.4 us; eight 100 k-point scenes
     // 75.9 k -> 78.1 k instance-steps/s, four tasks 75.0 k; 68 rooms: 559 k -> 505 k, the teams are busy there: profiles/r03_parts_perf.log)
     A.branch_parts = ab->branch_parts > 0 ? (ab->branch_parts >= 4 ? 4 : ab->branch_parts >= 2 ? 2 : 1) : (n_slots <= 46 ? 2 : 1);      // (end of round 4, profiles/r04_teams_units_sweep.txt: 16 / 24 / 39 / 44 / 52 / 68 slots, 2 against 1 part: +8 / +6 / +2.3 / +1.5 / -2 / -17 %)
-    if (A.wave_wgs) { A.branch_parts = A.wave_split; A.head_ring = 1; A.small_teams = 0; A.small_alt = 0; A.fill_extra = 0; }      // (a branch tile = its four quarters; ring 1 for everything else)
+    if (A.wave_wgs) { A.branch_parts = A.wave_split; A.head_ring = 1; A.small_teams = 0; A.small_alt = 0; A.fill_extra = 0; }
+    if (A.reg_tiles) { A.branch_parts = 1; A.head_ring = 1; A.small_teams = 0; A.small_alt = 0; A.fill_extra = 0; }      // (a branch tile = its four quarters; ring 1 for everything else)
     A.max_steps = max_steps;
     A.budget_ticks = budget_us > 0 ? (long long)budget_us * 100 : (1LL << 60);      // wall_clock64: 100 MHz
     A.abort_ticks = (budget_us > 0 ? (long long)budget_us * 100 : 0) + 400000000LL;  // ... + 4 s without an end: something is broken
@@ -1860,9 +1876,10 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     static_assert((3 * LRG_ASYNC_TEAM_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "three tile teams and a fill team per CU");
     static_assert((2 * LRG_ASYNC_SMALL_TEAM_FLOATS + 2 * LRG_ASYNC_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "four tile teams per CU");
     const size_t unit_lds = A.gemv_units ? (size_t)LRG_GEMV_UNIT_FLOATS(A.gemv.P) * sizeof(float) + 16 : 0;
-    const size_t lds = (max(max(front_lds, A.wave_wgs ? (size_t)0 : team_lds), unit_lds) + 15) & ~(size_t)15;
+    const size_t lds = (max(max(front_lds, two_kernels ? (size_t)0 : team_lds), unit_lds) + 15) & ~(size_t)15;
     // (wave-branch mode, the worker kernel: a wave-branch CU's kernels + its fill-in team | two tile teams)
-    const size_t worker_lds = (max((size_t)(LRG_WB_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS), (size_t)2 * LRG_ASYNC_TEAM_FLOATS) * sizeof(float) + 15) & ~(size_t)15;
+    const size_t worker_lds = (max(max((size_t)(LRG_WB_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS), (size_t)2 * LRG_ASYNC_TEAM_FLOATS),
+                                   (size_t)(LRG_RT_WEIGHT_FLOATS + LRG_RT_TEAM0_FLOATS + LRG_ASYNC_TEAM_FLOATS)) * sizeof(float) + 15) & ~(size_t)15;
     static_assert((LRG_WB_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "a wave-branch CU: the kernels of its (side, quarter) and a fill-in team");
     static bool attr_done[LRG_MAX_DEVICES] = {};
     const int dev = lrg_current_device();
@@ -1880,7 +1897,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         int per_cu = 0;
         LRG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(lrg_grow_async_kernel), LRG_FRONT_THREADS, lds));
         if (per_cu < 1) return LRG_ERESIDENCY;
-        if (A.wave_wgs) {
+        if (two_kernels) {
             LRG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(lrg_grow_async_worker_kernel), LRG_WORKER_THREADS, worker_lds));
             if (per_cu < 1) return LRG_ERESIDENCY;
         }
@@ -1889,12 +1906,12 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         if (hipExtStreamGetCUMask(st, words, cumask) == hipSuccess) {
             int visible = 0;
             for (uint32_t i = 0; i < words; ++i) visible += __builtin_popcount(cumask[i]);
-            if (visible > 0 && visible < (A.wave_wgs ? prop.multiProcessorCount : wgs)) return LRG_ERESIDENCY;      // (no bit set: no mask reported)
+            if (visible > 0 && visible < (two_kernels ? prop.multiProcessorCount : wgs)) return LRG_ERESIDENCY;      // (no bit set: no mask reported)
         } else {
             (void)hipGetLastError();
         }
     }
-    if (A.wave_wgs) {
+    if (two_kernels) {
         // Two kernels, resident together: the worker kernel on the side stream between two events of the caller's stream (it starts after everything the caller
         // enqueued before this call -- the memsets above included -- and the caller's stream goes on only when it has left), the front kernel on the caller's stream.
         LrgSideStream *side = lrg_side_stream();

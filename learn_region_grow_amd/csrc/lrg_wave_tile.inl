@@ -245,3 +245,187 @@ __device__ __forceinline__ void lrg_wave_pool_tile(const float *h3in, float *poo
         if (bits > 0) atomicMax(reinterpret_cast<int *>(pool + q * 128 + ch), bits);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+// REGISTER TILE: the same 32-row branch tile by a TEAM of four wavefronts (one per SIMD, as lrg_fused_tile's), activations in registers where that is free.
+// One wavefront per tile is one SIMD's matrix pipe per tile: 21-23 us through PREFIX and POOL against 17 (idle) / 25 us (loaded) for the team tile, whose passes
+// spread over four pipes (profiles/r06_wave_sweep_*.txt).  The team tile's time, by its cycle stamps (profiles/r04_delay_and_stamps.txt: 52 k cycles for 23 k of MFMA
+// issue), is barriers, LDS round trips and epilogues of the NARROW layers: 25 k cycles before the pooled layer starts, for 272 MFMAs of which every wave issues a
+// quarter or a half.  Here:
+//   layers 0 - 2 (13 -> 64 -> 64 -> 64, 144 MFMAs): every wavefront computes them for ITSELF, in registers (kernels from LDS) -- 9 k cycles of matrix pipe on four
+//     pipes at once, no barrier, no LDS round trip, instead of three passes of ~5 k cycles each with two waves idle;
+//   layer 3 (64 -> 128): wavefront w computes column block w (its kernel columns prefetched from L2 at the task's start), the four blocks meet in LDS -- the tile's ONE
+//     barrier -- and every wavefront takes all 128 channels back as its B operands;
+//   layer 4 (128 -> 512, pooled): wavefront w computes column blocks 4w .. 4w + 3, the kernel columns requested from L2 one whole block (sixteen k-groups) ahead;
+//     the max over the points by the transposing DPP reduction, one atomicMax instruction per pair of blocks.
+// ~190 VGPRs: a tile of lrg_grow_async_worker_kernel (512 threads) only.  Same sums in the same order: bit-identical to the team tile.
+#define LRG_RT_W0 0                    // per side: layer 0 (1024 floats), 1, 2 (4096 each); biases of layers 0 - 4 (64, 64, 64, 128, 512)
+#define LRG_RT_W1 1024
+#define LRG_RT_W2 5120
+#define LRG_RT_B0 9216
+#define LRG_RT_B1 9280
+#define LRG_RT_B2 9344
+#define LRG_RT_B3 9408
+#define LRG_RT_B4 9536
+#define LRG_RT_SIDE 10048
+#define LRG_RT_WEIGHT_FLOATS (2 * LRG_RT_SIDE)
+#define LRG_RT_XCH_LD 132              // floats between two points' rows of the layer-3 exchange (128 + 4: conflict-free 16-byte accesses)
+#define LRG_RT_XCH_FLOATS (32 * LRG_RT_XCH_LD)
+
+// 16 bytes of a kernel image through a buffer descriptor on a wave-uniform base: the lane's offset in ONE register, the k-group's in a scalar -- as global loads every
+// one of a tile's 72 kernel loads had a 64-bit address of its own in registers (offsets beyond the instruction's 4 KB immediate), and the tile spilled
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float4 lrg_rt_ldw(const __amdgpu_buffer_rsrc_t &r, unsigned lane_off, unsigned group_off) {
+    const lrg_u32x4v u = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, group_off, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+#else
+struct lrg_rt_host_rsrc {};
+#define __amdgpu_buffer_rsrc_t lrg_rt_host_rsrc
+#define __builtin_amdgcn_make_buffer_rsrc(...) lrg_rt_host_rsrc()
+__device__ __forceinline__ float4 lrg_rt_ldw(const lrg_rt_host_rsrc &, unsigned, unsigned) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+#endif
+// one 32-channel block over NG k-groups, kernel operands from registers (a[g]), activations h (NG / 4 blocks)
+template <int NG, int NBI>
+__device__ __forceinline__ void lrg_rt_mfma1(f32x16 &acc, const f32x16 (&h)[NBI], const float4 (&a)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x16 &hb = h[g >> 2];
+        const int r = 4 * (g & 3);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, hb[r + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, hb[r + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, hb[r + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, hb[r + 3], acc, 0, 0, 0);
+    }
+}
+
+// wn: the wavefront's number in its team (0 .. 3); ws: LDS offset (floats) of the side's kernels (LRG_RT_*); xch: LDS offset of the team's exchange buffer;
+// w3 / w4: the packed images of layers 3 and 4 in global memory (lrg_pack_weights layout)
+template <class TEAM>
+__device__ __forceinline__ void lrg_team_branch_tile_reg(const float *x, const float *center, float *conv1, float *pool, const float *w3, const float *w4, long r0, int slot,
+                                                         int ws, int xch, const TEAM &team, int wn, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    // ---- what comes from memory, requested first: the rows, the centre, this wavefront's columns of layer 3 and its first block of layer 4 ----
+    const float4 x0 = lrg_ld_coh4(x + r0 * 16, (unsigned)(li * 16 + 4 * lh) * 4u), x1 = lrg_ld_coh4(x + r0 * 16, (unsigned)(li * 16 + 8 + 4 * lh) * 4u);
+    const float4 c0 = lrg_ld_coh4(center + (long)slot * 16, (unsigned)(4 * lh) * 4u), c1 = lrg_ld_coh4(center + (long)slot * 16, (unsigned)(8 + 4 * lh) * 4u);
+    float4 a3[8], wa[16];
+    // (block wn of layer 3: 8 k-groups of 1 KB; blocks 4 wn .. 4 wn + 3 of layer 4: 16 k-groups each)
+    const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w3) + (long)(wn * 8) * 256, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r4 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w4) + (long)(4 * wn * 16) * 256, 0, 0x7fffffff, 0x00020000);
+    const unsigned lo = (unsigned)lane * 16u;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) a3[g] = lrg_rt_ldw(r3, lo, (unsigned)g * 1024u);
+    f32x16 h0[1];
+    h0[0][0] = __fsub_rn(x0.x, c0.x); h0[0][1] = __fsub_rn(x0.y, c0.y); h0[0][2] = __fsub_rn(x0.z, c0.z); h0[0][3] = __fsub_rn(x0.w, c0.w);
+    h0[0][4] = __fsub_rn(x1.x, c1.x); h0[0][5] = __fsub_rn(x1.y, c1.y); h0[0][6] = __fsub_rn(x1.z, c1.z); h0[0][7] = __fsub_rn(x1.w, c1.w);
+#pragma unroll
+    for (int i = 8; i < 16; ++i) h0[0][i] = 0.f;
+    const int lw = ws + 4 * lane, lb = ws + 4 * lh;
+    f32x16 ha[2], hb[2];
+    // ---- layer 0 ----
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ha[0][i] = 0.f; ha[1][i] = 0.f; }
+        float4 a0 = lrg_wb_lds4(LRG_RT_W0 + lw), a1 = lrg_wb_lds4(LRG_RT_W0 + 2 * 256 + lw);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float4 n0 = a0, n1 = a1;
+            if (g == 0) { n0 = lrg_wb_lds4(LRG_RT_W0 + 256 + lw); n1 = lrg_wb_lds4(LRG_RT_W0 + 3 * 256 + lw); }
+            const int r = 4 * g;
+            ha[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, h0[0][r + 0], ha[0], 0, 0, 0);
+            ha[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, h0[0][r + 0], ha[1], 0, 0, 0);
+            ha[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, h0[0][r + 1], ha[0], 0, 0, 0);
+            ha[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, h0[0][r + 1], ha[1], 0, 0, 0);
+            ha[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, h0[0][r + 2], ha[0], 0, 0, 0);
+            ha[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, h0[0][r + 2], ha[1], 0, 0, 0);
+            ha[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, h0[0][r + 3], ha[0], 0, 0, 0);
+            ha[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, h0[0][r + 3], ha[1], 0, 0, 0);
+            a0 = n0; a1 = n1;
+        }
+        lrg_wb_bias_relu(ha[0], LRG_RT_B0 + lb);
+        lrg_wb_bias_relu(ha[1], LRG_RT_B0 + 32 + lb);
+    }
+    // ---- layer 1 (+ conv[1] for the heads, by the team's first wavefront) ----
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { hb[0][i] = 0.f; hb[1][i] = 0.f; }
+        lrg_wb_mfma2<8, 2>(hb[0], hb[1], ha, LRG_RT_W1 + lw, LRG_RT_W1 + 8 * 256 + lw);
+        lrg_wb_bias_relu(hb[0], LRG_RT_B1 + lb);
+        lrg_wb_bias_relu(hb[1], LRG_RT_B1 + 32 + lb);
+        if (wn == 0) {
+            float *gb = conv1 + r0 * LRG_WB_C1;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    lrg_st_coh4(gb, (unsigned)(li * LRG_WB_C1 + 32 * b + 8 * j + 4 * lh) * 4u, make_float4(hb[b][4 * j], hb[b][4 * j + 1], hb[b][4 * j + 2], hb[b][4 * j + 3]));
+        }
+    }
+    // ---- layer 2 ----
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ha[0][i] = 0.f; ha[1][i] = 0.f; }
+        lrg_wb_mfma2<8, 2>(ha[0], ha[1], hb, LRG_RT_W2 + lw, LRG_RT_W2 + 8 * 256 + lw);
+        lrg_wb_bias_relu(ha[0], LRG_RT_B2 + lb);
+        lrg_wb_bias_relu(ha[1], LRG_RT_B2 + 32 + lb);
+    }
+    // ---- layer 3: this wavefront's column block, then all four through LDS ----
+    // (the first block of layer 4's kernel columns starts its trip here: behind layers 0 - 2, whose 96 live registers it would have sat beside, and ahead of this
+    //  layer's 32 MFMAs, the exchange and the barrier -- ~4 k cycles)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) wa[g] = lrg_rt_ldw(r4, lo, (unsigned)g * 1024u);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 h3[4];
+    {
+        f32x16 c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = 0.f;
+        lrg_rt_mfma1<8, 2>(c, ha, a3);
+        lrg_wb_bias_relu(c, LRG_RT_B3 + 32 * wn + lb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4 *>(&LRG_WB_SMEM[xch + li * LRG_RT_XCH_LD + 32 * wn + 8 * j + 4 * lh]) = make_float4(c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]);
+    }
+    team.sync();
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = lrg_wb_lds4(xch + li * LRG_RT_XCH_LD + 32 * b + 8 * j + 4 * lh);
+            h3[b][4 * j] = v.x; h3[b][4 * j + 1] = v.y; h3[b][4 * j + 2] = v.z; h3[b][4 * j + 3] = v.w;
+        }
+    // ---- layer 4: column blocks 4 wn .. 4 wn + 3; a k-group's kernel operand is replaced by the NEXT block's right behind its last MFMA (sixteen k-groups = 4 k
+    //      cycles of lead over a trip to L2: one load per four MFMAs in the stream, 64 registers instead of the 128 of two whole blocks -- which spilled) ----
+    const bool row1 = (lane & 16) != 0;
+    const int t = lane & 15;
+    float m_even = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x16 c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const f32x16 &hb4 = h3[g >> 2];
+            const int r = 4 * (g & 3);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g].x, hb4[r + 0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g].y, hb4[r + 1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g].z, hb4[r + 2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g].w, hb4[r + 3], c, 0, 0, 0);
+            if (q < 3) wa[g] = lrg_rt_ldw(r4, lo, (unsigned)((q + 1) * 16 + g) * 1024u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float m = lrg_wb_rowmax16(c, lane);
+        if (!(q & 1)) m_even = m;
+        else {
+            // rows 0 / 1 of a half hold the maxima over lanes 0-15 / 16-31 of the same channels: the even row keeps block q - 1, the odd row block q
+            const float keep = row1 ? m : m_even, send = row1 ? m_even : m;
+            const float mm = fmaxf(keep, __shfl_xor(send, 16));
+            const int ch = 32 * (4 * wn + q - 1 + (row1 ? 1 : 0)) + 8 * (t >> 2) + 4 * lh + (t & 3);
+            const float v = fmaxf(mm + LRG_WB_SMEM[ws + LRG_RT_B4 + ch], 0.f);
+            const int bits = __float_as_int(v);
+            if (bits > 0) atomicMax(reinterpret_cast<int *>(pool + ch), bits);
+        }
+    }
+}

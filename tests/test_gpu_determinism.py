@@ -82,10 +82,12 @@ def test_speculation_repeats_to_one_checksum(net, rooms):
     assert set(got) == {want}, (want, got)
 
 
-def test_wave_branch_launches_repeat_to_one_checksum(net, rooms):
+@pytest.mark.parametrize('waves', [4, 1])
+def test_wave_branch_launches_repeat_to_one_checksum(net, rooms, waves):
+    """waves 4: one-wavefront PREFIX / POOL tasks; 1: register tiles (a team of four wavefronts per branch tile) -- both as two kernels resident together."""
     from learn_region_grow_amd.grow import RegionGrower
     want = lock_step(net, rooms, 68)
-    got = repeat(lambda: RegionGrower(net, rooms_in_flight=68, rng='counter', seed=0, policy='net', free_run=True, free_run_budget_us=1500, free_run_waves=4), rooms, 4)
+    got = repeat(lambda: RegionGrower(net, rooms_in_flight=68, rng='counter', seed=0, policy='net', free_run=True, free_run_budget_us=1500, free_run_waves=waves), rooms, 4)
     assert set(got) == {want}, (want, got)
 
 

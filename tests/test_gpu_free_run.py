@@ -49,12 +49,14 @@ def test_free_run_equals_lock_step(net, steps, fronts, teams, in_flight, units):
 
 
 @pytest.mark.parametrize('steps,fronts,in_flight,units,waves', [(64, 0, 5, 0, 4), (1, 0, 5, 0, 4), (7, 2, 5, 0, 4), (64, 0, 9, 0, 8), (64, 0, 30, 0, 4), (64, 0, 68, 0, 4),
-                                                                 (64, 3, 5, -1, 4), (16, 0, 100, -1, 4), (64, 0, 140, 0, 8), (64, 0, 200, 0, 4)])
+                                                                 (64, 3, 5, -1, 4), (16, 0, 100, -1, 4), (64, 0, 140, 0, 8), (64, 0, 200, 0, 4),
+                                                                 (64, 0, 5, 0, 1), (1, 0, 5, 0, 1), (7, 2, 9, -1, 1), (64, 0, 30, 0, 1), (64, 0, 68, 0, 1), (16, 0, 200, 0, 1)])
 def test_wave_branch_launches_equal_lock_step(net, steps, fronts, in_flight, units, waves):
     """Round 6 (csrc/lrg_wave_tile.inl): the launch as two kernels resident together -- front workgroups and units | the CUs that run tiles -- and a branch tile
     (learn_region_grow_util.py:106-123) as four one-wavefront tasks with the activations in registers, on CUs that hold the kernels of their (side, quarter) in LDS.
     The same sums in the same order as the team tiles: regions and labels equal the lock-step iterations' exactly.  waves: 4 = four wavefronts per wave-branch CU and a
-    fill-in team beside them, 8 = eight (the fill-in between launches).  An option (LrgAsyncBuffers.branch_waves), off by default: measured slower than the one-kernel
+    fill-in team beside them, 8 = eight (the fill-in between launches); 1 = REGISTER TILES: the same two kernels, a branch tile by a team of four wavefronts that keep
+    layers 0 - 2 in registers and meet once (lrg_team_branch_tile_reg).  An option (LrgAsyncBuffers.branch_waves), off by default: measured slower than the one-kernel
     launch at every slot count."""
     from learn_region_grow_amd.grow import RegionGrower
     rooms = _rooms()

@@ -41,6 +41,31 @@ __global__ __launch_bounds__(512) void probe_kernel(Args a) {
             for (int i = tid; i < 128; i += 512) lrg_async_smem[qq * LRG_WP_QUARTER + LRG_WP_B4 + i] = a.b[4][q * 128 + i];
         }
     }
+    if (a.stage == 2) {
+        // REGISTER TILE: the workgroup = one team of four wavefronts per tile; both halves of the kernels' LDS hold the probe's one branch
+        const int sizes[3] = {1024, 4096, 4096}, offs[3] = {LRG_RT_W0, LRG_RT_W1, LRG_RT_W2};
+        const int bs[5] = {64, 64, 64, 128, 512}, bo[5] = {LRG_RT_B0, LRG_RT_B1, LRG_RT_B2, LRG_RT_B3, LRG_RT_B4};
+        for (int side = 0; side < 2; ++side) {
+            for (int l = 0; l < 3; ++l)
+                for (int i = tid; i < sizes[l] / 4; i += blockDim.x) reinterpret_cast<float4 *>(lrg_async_smem + side * LRG_RT_SIDE + offs[l])[i] = reinterpret_cast<const float4 *>(a.w[l])[i];
+            for (int l = 0; l < 5; ++l)
+                for (int i = tid; i < bs[l]; i += blockDim.x) lrg_async_smem[side * LRG_RT_SIDE + bo[l] + i] = a.b[l][i];
+        }
+        __syncthreads();
+        LrgWgTeam team;
+        const long long t0 = (long long)__builtin_readcyclecounter();
+        for (int it = 0; it < a.iters; ++it) {
+            const int tile = (blockIdx.x + it * 7) % a.n_tiles;
+            const long r0 = (long)tile * 32;
+            lrg_team_branch_tile_reg(a.x, a.center, a.conv1, a.pool + (r0 / a.rows_per_slot) * 512, a.w[3], a.w[4], r0, (int)(r0 / a.rows_per_slot), (tile & 1) * LRG_RT_SIDE,
+                                     LRG_RT_WEIGHT_FLOATS, team, wave, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // (as the task does before its arrival; the exchange buffer is free again)
+        }
+        const long long t1 = (long long)__builtin_readcyclecounter();
+        if (lane == 0) a.cycles[blockIdx.x * 16 + wave] = t1 - t0;
+        return;
+    }
     __syncthreads();
     if (wave >= a.waves) return;
     const long long t0 = (long long)__builtin_readcyclecounter();
@@ -162,6 +187,28 @@ int main(int argc, char **argv) {
             if (memcmp(&gp[i], &pool_ref[i], 4)) { printf("  pool[%zu,%zu] gpu %.9g ref %.9g\n", i / 512, i % 512, gp[i], pool_ref[i]); ++shown; }
     }
     badp += bad3;
+    // ---- the register tile (a team of four wavefronts per tile) ----
+    CK(hipMemset(conv1, 0xFF, (size_t)rows * 64 * 4)); CK(hipMemset(pool, 0, (size_t)n_slots * 512 * 4));
+    a.stage = 2; a.iters = 1;
+    hipLaunchKernelGGL(probe_kernel, dim3(n_tiles), dim3(256), (LRG_RT_WEIGHT_FLOATS + LRG_RT_XCH_FLOATS) * 4, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(g1.data(), conv1, g1.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gp.data(), pool, gp.size() * 4, hipMemcpyDeviceToHost));
+    size_t rb1 = 0, rbp = 0;
+    for (size_t i = 0; i < g1.size(); ++i) rb1 += memcmp(&g1[i], &h[1][i], 4) != 0;
+    for (size_t i = 0; i < gp.size(); ++i) rbp += memcmp(&gp[i], &pool_ref[i], 4) != 0;
+    printf("register tile (team of four): conv[1] %zu of %zu differ; pooled %zu of %zu\n", rb1, g1.size(), rbp, gp.size());
+    badp += rb1 + rbp;
+    for (int grid : {1, 200}) {
+        a.iters = 50;
+        hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(256), (LRG_RT_WEIGHT_FLOATS + LRG_RT_XCH_FLOATS) * 4, 0, a);
+        CK(hipDeviceSynchronize());
+        std::vector<long long> c((size_t)grid * 16);
+        CK(hipMemcpy(c.data(), cyc, c.size() * 8, hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (int g = 0; g < grid; ++g) sum += (double)c[g * 16] / a.iters;
+        printf("REGISTER TILE, grid %3d, one team per CU: %8.0f counter ticks per tile (the team tile of lrg_fused_tile.inl: ~52 000)\n", grid, sum / grid);
+    }
 
     // ---- timing (counter ticks of the shader clock; a PREFIX task is 272 x 64 = 17 408 cycles of MFMA issue, a POOL task 256 x 64 = 16 384) ----
     int dev = 0;
