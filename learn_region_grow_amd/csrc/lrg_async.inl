@@ -1696,6 +1696,72 @@ __device__ __forceinline__ void lrg_async_reg_tile_team(lrg_kargs_ptr kp, long l
         if (tid < 64) lrg_async_branch_arrive(A, slot, lane, t_task, true);
     }
 }
+// ---- team 1 of a register-tile CU: ring 1 -- head tiles as REGISTER HEAD TILES (lrg_team_head_tile_reg), pooled blocks where there are no units (inlined into
+//      the worker kernel: ~240 VGPRs) ----
+#define LRG_RT_TEAM1_FLOATS (LRG_ASYNC_CTL_FLOATS + LRG_RH_FLOATS)
+__device__ __forceinline__ void lrg_async_reg_head_team(lrg_kargs_ptr kp, long long t_launch) {
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    const int sm_off = LRG_RT_WEIGHT_FLOATS + LRG_RT_TEAM0_FLOATS;
+    float *sm = lrg_async_smem + sm_off + LRG_ASYNC_CTL_FLOATS;
+    LrgLdsTeam team = lrg_async_team(A, sm, 0);
+    const int tid = team.tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
+    int *ticket_word = &A.queue[LRG_AQ_HEAD + LRG_AQ_SECOND];
+    int next_ticket = -1;
+    for (;;) {
+        long long t_task = 0;
+        if (tid == 0) {
+            const long long t_wait = LRG_DBG(A) ? wall_clock64() : 0;
+            const int t = next_ticket >= 0 ? next_ticket : __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            next_ticket = -1;
+            int *e = &A.queue[LRG_AQ_RING + (A.qmask + 1) + (t & A.qmask)];
+            int code = 0;
+            for (unsigned spin = 0;; ++spin) {
+                code = lrg_ld_coh(e);
+                if (code) break;
+                if ((spin & 7) == 7) {
+                    if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT]) || lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front) { code = -1; break; }
+                    if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 2); code = -1; break; }
+                }
+                for (int q = 0; q < A.poll_sleep; ++q) __builtin_amdgcn_s_sleep(LRG_WORKER_POLL_SLEEP);
+            }
+            if (code > 0) lrg_st_coh(e, 0);
+            word[0] = code;
+            t_task = wall_clock64();
+            if (LRG_DBG(A)) { lrg_dbg_add(A, 16, t_task - t_wait); lrg_dbg_add(A, 17, 1); }
+        }
+        team.sync();
+        const int code = word[0];
+        if (code < 0) return;
+        if (((code >> 28) & 7) == LRG_TASK_GEMV) {            // (no units: a 128-column block of a slot's pooled product -- the team tiles' task as it is)
+            team.target = lrg_async_task_gemv(kp, code, sm_off, team.target, t_task);
+            continue;
+        }
+        const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 127;
+        int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
+        const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
+        __builtin_amdgcn_s_setprio(LRG_ASYNC_HEAD_PRIO);
+        if (A.gemv_units) {
+            LrgWaitPooled wait;
+            wait.sy = sy; wait.queue = A.queue; wait.t_launch = t_launch; wait.abort_ticks = A.abort_ticks;
+            lrg_team_head_tile_reg(A.prob[2 + side], r0, slot, sm_off + LRG_ASYNC_CTL_FLOATS, team, wait, wave, lane);
+        } else {
+            lrg_team_head_tile_reg(A.prob[2 + side], r0, slot, sm_off + LRG_ASYNC_CTL_FLOATS, team, LrgNoWait(), wave, lane);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (LRG_TICKET_EARLY && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lrg_drain_stores();                                  // the logits are out before the arrival the front workgroup polls
+        team.sync();
+        if (tid == 0) {
+            const int done = __hip_atomic_fetch_add(&sy[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            if (LRG_DBG(A)) {
+                const long long now = wall_clock64();
+                lrg_dbg_add(A, 8 + 2 * LRG_TASK_HEAD, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_HEAD, 1);
+                if (done == lrg_ld_coh(&sy[6])) { lrg_dbg_add(A, 4, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8]))); lrg_st_coh(&sy[12], (int)(unsigned)now); }
+            }
+        }
+    }
+}
 __device__ __forceinline__ void lrg_rt_load_kernels(const LrgFusedProb &P, int ws, int tid, int nthreads) {      // layers 0 - 2 and every layer's bias of one branch
     const int offs[3] = {LRG_RT_W0, LRG_RT_W1, LRG_RT_W2}, n4[3] = {256, 1024, 1024};
     const int boff[5] = {LRG_RT_B0, LRG_RT_B1, LRG_RT_B2, LRG_RT_B3, LRG_RT_B4}, bn[5] = {LRG_WB_C0, LRG_WB_C1, LRG_WB_C2, LRG_WB_C3, LRG_WB_C4};
@@ -1759,8 +1825,10 @@ __global__ __launch_bounds__(LRG_WORKER_THREADS) void lrg_grow_async_worker_kern
         if ((tid & 255) == 0) { word[4] = 0; word[5] = 0; }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (tid >> 8) lrg_async_worker(kp, sm_off, t_launch, (K.A.fill_list && w < K.A.fill_wgs) ? 1 : 2);      // (the fill-in ring on a few of them, ring 1 on the others)
-        else lrg_async_reg_tile_team(kp, t_launch);
+        if (!(tid >> 8)) lrg_async_reg_tile_team(kp, t_launch);
+        else if (K.A.fill_list && w < K.A.fill_wgs) lrg_async_worker(kp, sm_off, t_launch, 1);      // (the fill-in ring on a few of them)
+        else if (K.A.reg_tiles == 2) lrg_async_worker(kp, sm_off, t_launch, 2);                    // (LRG_ASYNC_RT_TEAM_HEADS=1: the head tiles as team tiles)
+        else lrg_async_reg_head_team(kp, t_launch);
         return;
     }
     const int t = tid >> 8;

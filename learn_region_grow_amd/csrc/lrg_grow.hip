@@ -1802,7 +1802,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
             if (want == 1) {
                 // REGISTER TILES (LrgAsyncBuffers.branch_waves = 1): every worker workgroup alike -- team 0 the branch tiles (four wavefronts per tile, activations in
                 // registers where that is free: lrg_team_branch_tile_reg), team 1 the pooled blocks and head tiles
-                if (worker_wgs >= 24) A.reg_tiles = 1;
+                if (worker_wgs >= 24) A.reg_tiles = (getenv("LRG_ASYNC_RT_TEAM_HEADS") && atoi(getenv("LRG_ASYNC_RT_TEAM_HEADS"))) ? 2 : 1;      // (2: register branch tiles, team head tiles)
             } else if (worker_wgs >= 24 && lrg_packed_conv3_view(weights, n_slots, b->row_cap, c3) == 0) {
                 A.wave_wgs = wave_wgs; A.wave_a_wgs = a_wgs;
                 A.wave_waves = want > 0 ? min(want, 8) : 4;
@@ -1879,7 +1879,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     const size_t lds = (max(max(front_lds, two_kernels ? (size_t)0 : team_lds), unit_lds) + 15) & ~(size_t)15;
     // (wave-branch mode, the worker kernel: a wave-branch CU's kernels + its fill-in team | two tile teams)
     const size_t worker_lds = (max(max((size_t)(LRG_WB_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS), (size_t)2 * LRG_ASYNC_TEAM_FLOATS),
-                                   (size_t)(LRG_RT_WEIGHT_FLOATS + LRG_RT_TEAM0_FLOATS + LRG_ASYNC_TEAM_FLOATS)) * sizeof(float) + 15) & ~(size_t)15;
+                                   (size_t)(LRG_RT_WEIGHT_FLOATS + LRG_RT_TEAM0_FLOATS + max((int)LRG_ASYNC_TEAM_FLOATS, (int)LRG_RT_TEAM1_FLOATS))) * sizeof(float) + 15) & ~(size_t)15;
     static_assert((LRG_WB_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "a wave-branch CU: the kernels of its (side, quarter) and a fill-in team");
     static bool attr_done[LRG_MAX_DEVICES] = {};
     const int dev = lrg_current_device();

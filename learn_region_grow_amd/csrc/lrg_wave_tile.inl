@@ -429,3 +429,137 @@ __device__ __forceinline__ void lrg_team_branch_tile_reg(const float *x, const f
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+// REGISTER HEAD TILE: a 32-row tile of a head stack (learn_region_grow_util.py:138-162: conv[1] (64) + the hoisted pooled product -> 256 -> 128 -> 2) by a team of four
+// wavefronts.  The team tile (lrg_fused_tile) stages the rows in LDS, runs the 64 -> 256 layer as two passes of which only the FIRST one's MFMAs run before it waits for
+// the slot's pooled product, and meets at four barriers: 13 us from the pooled product to the logits (profiles/r06_bench_debug_68_update_by_lists.log).  Here:
+//   conv[1] rows straight into registers as B operands; layer 0: wavefront w computes column blocks 2w, 2w + 1 (kernel columns from L2, requested with the rows) --
+//     ALL of the layer's MFMAs before the wait; behind it only the pooled product's 8 values per lane, ReLU and the exchange (LDS, barrier);
+//   layer 1 (256 -> 128): wavefront w computes column block w, B operands from the exchange buffer two k-groups ahead, kernel columns from L2 sixteen k-groups ahead;
+//   the 2-wide last layer from a second buffer in LDS: lrg_fused_tile's own arithmetic (eight lanes per row, a fixed butterfly), so the same bits.
+// Same sums in the same order as the team tile: bit-identical logits.
+#define LRG_RH_H0_LD 260
+#define LRG_RH_H1_LD 132
+#define LRG_RH_H0 0                                  // [32][260] layer 0's output
+#define LRG_RH_H1 (32 * LRG_RH_H0_LD)                // [32][132] layer 1's output
+#define LRG_RH_FW (LRG_RH_H1 + 32 * LRG_RH_H1_LD)    // [128][2] the last layer's kernel
+#define LRG_RH_FLOATS (LRG_RH_FW + 256)
+
+template <class TEAM, class WAIT>
+__device__ __forceinline__ void lrg_team_head_tile_reg(const LrgFusedProb &P, long r0, int slot, int sm, const TEAM &team, const WAIT &wait_pooled, int wn, int lane) {
+    const int li = lane & 31, lh = lane >> 5, tid = 64 * wn + lane;
+    const unsigned lo = (unsigned)lane * 16u;
+    // ---- requested first: the conv[1] rows, this wavefront's two column blocks of layer 0, its first sixteen k-groups of layer 1, layer 1's bias ----
+    f32x16 hin[2];
+    {
+        const float *gx = P.x + r0 * 64;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = lrg_ld_coh4(gx, (unsigned)(li * 64 + 32 * b + 8 * j + 4 * lh) * 4u);
+                hin[b][4 * j] = v.x; hin[b][4 * j + 1] = v.y; hin[b][4 * j + 2] = v.z; hin[b][4 * j + 3] = v.w;
+            }
+    }
+    const __amdgpu_buffer_rsrc_t q0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.L[0].w) + (long)(2 * wn * 8) * 256, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t q1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.L[1].w) + (long)(wn * 32) * 256, 0, 0x7fffffff, 0x00020000);
+    float4 a0[8], a1[8], wr[16], b1[4];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { a0[g] = lrg_rt_ldw(q0, lo, (unsigned)g * 1024u); a1[g] = lrg_rt_ldw(q0, lo, (unsigned)(8 + g) * 1024u); }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) wr[g] = lrg_rt_ldw(q1, lo, (unsigned)g * 1024u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float *bp1 = P.L[1].bias + 32 * wn + 8 * j + 4 * lh;
+        b1[j] = make_float4(bp1[0], bp1[1], bp1[2], bp1[3]);
+    }
+    LRG_WB_SMEM[sm + LRG_RH_FW + tid] = P.fw[tid];                     // (256 floats: one per thread of the team)
+    // ---- layer 0: 64 -> this wavefront's 64 of 256 columns, all of it before the pooled product is needed ----
+    f32x16 c0, c1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const f32x16 &hb = hin[g >> 2];
+        const int r = 4 * (g & 3);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[g].x, hb[r + 0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[g].x, hb[r + 0], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[g].y, hb[r + 1], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[g].y, hb[r + 1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[g].z, hb[r + 2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[g].z, hb[r + 2], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[g].w, hb[r + 3], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[g].w, hb[r + 3], c1, 0, 0, 0);
+    }
+    // ---- the slot's pooled product (the hoisted part of layer 0, :128-141) as a per-slot bias, then ReLU; the blocks meet in LDS ----
+    wait_pooled();
+    {
+        const float *hbp = P.L[0].bias + (long)slot * 256;
+        float4 hv[8];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[4 * b + j] = lrg_ld_coh4(hbp, (unsigned)(32 * (2 * wn + b) + 8 * j + 4 * lh) * 4u);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x16 &c = b ? c1 : c0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // (the team tile adds the per-slot bias, then its -- zero -- layer bias, then takes the ReLU: the same three operations)
+                const float4 h = hv[4 * b + j];
+                const float v0 = fmaxf(__fadd_rn(__fadd_rn(c[4 * j + 0], h.x), 0.f), 0.f), v1 = fmaxf(__fadd_rn(__fadd_rn(c[4 * j + 1], h.y), 0.f), 0.f);
+                const float v2 = fmaxf(__fadd_rn(__fadd_rn(c[4 * j + 2], h.z), 0.f), 0.f), v3 = fmaxf(__fadd_rn(__fadd_rn(c[4 * j + 3], h.w), 0.f), 0.f);
+                *reinterpret_cast<float4 *>(&LRG_WB_SMEM[sm + LRG_RH_H0 + li * LRG_RH_H0_LD + 32 * (2 * wn + b) + 8 * j + 4 * lh]) = make_float4(v0, v1, v2, v3);
+            }
+        }
+    }
+    team.sync();
+    // ---- layer 1: 256 -> this wavefront's 32 of 128 columns ----
+    {
+        f32x16 c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = 0.f;
+        const int bp = sm + LRG_RH_H0 + li * LRG_RH_H0_LD + 4 * lh;
+        float4 br[3];
+        br[0] = lrg_wb_lds4(bp); br[1] = lrg_wb_lds4(bp + 8);
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            if (g + 2 < 32) br[(g + 2) % 3] = lrg_wb_lds4(bp + 8 * (g + 2));
+            const float4 a = wr[g & 15], bq = br[g % 3];
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, c, 0, 0, 0);
+            if (g + 16 < 32) wr[g & 15] = lrg_rt_ldw(q1, lo, (unsigned)(g + 16) * 1024u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4 *>(&LRG_WB_SMEM[sm + LRG_RH_H1 + li * LRG_RH_H1_LD + 32 * wn + 8 * j + 4 * lh]) =
+                make_float4(fmaxf(c[4 * j + 0] + b1[j].x, 0.f), fmaxf(c[4 * j + 1] + b1[j].y, 0.f), fmaxf(c[4 * j + 2] + b1[j].z, 0.f), fmaxf(c[4 * j + 3] + b1[j].w, 0.f));
+    }
+    team.sync();
+    // ---- the 2-wide last layer, no ReLU (:145-149, :158-162): lrg_fused_tile's arithmetic -- eight lanes per row, each every eighth float4 of the row, the partial
+    //      sums combined by xor-shuffles in a fixed order ----
+    {
+        const float *act = &LRG_WB_SMEM[sm + LRG_RH_H1], *fw = &LRG_WB_SMEM[sm + LRG_RH_FW];
+        const int row = tid >> 3, q = tid & 7;
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = 4 * q; k < 128; k += 32) {
+            const float4 a = *reinterpret_cast<const float4 *>(act + row * LRG_RH_H1_LD + k);
+            const float4 w01 = *reinterpret_cast<const float4 *>(fw + 2 * k);
+            const float4 w23 = *reinterpret_cast<const float4 *>(fw + 2 * k + 4);
+            s0 = fmaf(a.x, w01.x, s0); s1 = fmaf(a.x, w01.y, s1);
+            s0 = fmaf(a.y, w01.z, s0); s1 = fmaf(a.y, w01.w, s1);
+            s0 = fmaf(a.z, w23.x, s0); s1 = fmaf(a.z, w23.y, s1);
+            s0 = fmaf(a.w, w23.z, s0); s1 = fmaf(a.w, w23.w, s1);
+        }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); }
+        // two rows' logits per 16-byte write-through store
+        const float t0 = s0 + P.fb[0], t1 = s1 + P.fb[1];
+        const float u0 = __shfl_down(t0, 8), u1 = __shfl_down(t1, 8);
+        if (q == 0 && !(row & 1)) lrg_st_coh4(P.fout + r0 * 2, (unsigned)row * 8u, make_float4(t0, t1, u0, u1));
+    }
+}

@@ -20,6 +20,7 @@ struct Args {
     float *conv1, *h3, *pool;     // pool: [slots][512]
     long long *cycles;       // [workgroups][16]
     int n_tiles, rows_per_slot, iters, waves, stage;
+    LrgFusedProb head;       // stage 3: the register head tile's problem (x = conv[1] rows, L[0] / L[1], fw / fb / fout)
 };
 
 // stage 0: PREFIX tasks (layers 0 - 3 -> conv[1], layer-3 rows); stage 1: POOL tasks (workgroup & 1 = the half of the pooled layer's columns it holds)
@@ -40,6 +41,22 @@ __global__ __launch_bounds__(512) void probe_kernel(Args a) {
             for (int i = tid; i < 4096; i += 512) reinterpret_cast<float4 *>(lrg_async_smem + qq * LRG_WP_QUARTER + LRG_WP_W4)[i] = reinterpret_cast<const float4 *>(a.w[4] + (long)q * 16384)[i];
             for (int i = tid; i < 128; i += 512) lrg_async_smem[qq * LRG_WP_QUARTER + LRG_WP_B4 + i] = a.b[4][q * 128 + i];
         }
+    }
+    if (a.stage == 3) {
+        // REGISTER HEAD TILE: one team of four wavefronts per tile
+        LrgWgTeam team;
+        struct { __device__ void operator()() const {} } nowait;
+        const long long t0 = (long long)__builtin_readcyclecounter();
+        for (int it = 0; it < a.iters; ++it) {
+            const int tile = (blockIdx.x + it * 7) % a.n_tiles;
+            const long r0 = (long)tile * 32;
+            lrg_team_head_tile_reg(a.head, r0, (int)(r0 / a.rows_per_slot), 0, team, nowait, wave, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        const long long t1 = (long long)__builtin_readcyclecounter();
+        if (lane == 0) a.cycles[blockIdx.x * 16 + wave] = t1 - t0;
+        return;
     }
     if (a.stage == 2) {
         // REGISTER TILE: the workgroup = one team of four wavefronts per tile; both halves of the kernels' LDS hold the probe's one branch
@@ -229,6 +246,68 @@ int main(int argc, char **argv) {
                 printf("%s, grid %3d, %2d waves per CU: %8.0f counter ticks per task (max %8.0f)\n", stage ? "POOL  " : "PREFIX", grid, waves, sum / (grid * waves), mx);
             }
         }
+    // ---- the register head tile: conv[1] rows (the branch reference's) + a per-slot pooled product -> 256 -> 128 -> 2 ----
+    {
+        std::vector<float> hw0((size_t)64 * 256), hw1((size_t)256 * 128), hbias1(128), fw(256), fb(2), hbv((size_t)n_slots * 256), pk0, pk1;
+        for (auto &v : hw0) v = rnd() * 0.2f;
+        for (auto &v : hw1) v = rnd() * 0.1f;
+        for (auto &v : hbias1) v = rnd() * 0.1f;
+        for (auto &v : fw) v = rnd() * 0.2f;
+        for (auto &v : fb) v = rnd() * 0.1f;
+        for (auto &v : hbv) v = rnd() * 0.5f;
+        pack(hw0, 64, 256, pk0); pack(hw1, 256, 128, pk1);
+        // host: the MFMA chain per layer, then lrg_fused_tile's last layer (eight partial chains over k = 4q + 32m + i, butterfly over q)
+        std::vector<float> g0((size_t)rows * 256), g1h((size_t)rows * 128), lref((size_t)rows * 2);
+        const std::vector<float> &cin = h[1];
+        for (int n = 0; n < rows; ++n) {
+            for (int c = 0; c < 256; ++c) {
+                float acc = 0.f;
+                for (int g = 0; g < 8; ++g) for (int s2 = 0; s2 < 4; ++s2) for (int hh = 0; hh < 2; ++hh) { const int k = 8 * g + 4 * hh + s2; acc = fmaf(hw0[(size_t)k * 256 + c], cin[(size_t)n * 64 + k], acc); }
+                g0[(size_t)n * 256 + c] = fmaxf((acc + hbv[(size_t)(n / rows_per_slot) * 256 + c]) + 0.f, 0.f);
+            }
+            for (int c = 0; c < 128; ++c) {
+                float acc = 0.f;
+                for (int g = 0; g < 32; ++g) for (int s2 = 0; s2 < 4; ++s2) for (int hh = 0; hh < 2; ++hh) { const int k = 8 * g + 4 * hh + s2; acc = fmaf(hw1[(size_t)k * 128 + c], g0[(size_t)n * 256 + k], acc); }
+                g1h[(size_t)n * 128 + c] = fmaxf(acc + hbias1[c], 0.f);
+            }
+            float part[8][2];
+            for (int q = 0; q < 8; ++q) {
+                float s0 = 0.f, s1 = 0.f;
+                for (int k = 4 * q; k < 128; k += 32)
+                    for (int i = 0; i < 4; ++i) { s0 = fmaf(g1h[(size_t)n * 128 + k + i], fw[2 * (k + i)], s0); s1 = fmaf(g1h[(size_t)n * 128 + k + i], fw[2 * (k + i) + 1], s1); }
+                part[q][0] = s0; part[q][1] = s1;
+            }
+            for (int o = 0; o < 2; ++o) {
+                const float t01 = part[0][o] + part[1][o], t23 = part[2][o] + part[3][o], t45 = part[4][o] + part[5][o], t67 = part[6][o] + part[7][o];
+                lref[(size_t)n * 2 + o] = ((t01 + t23) + (t45 + t67)) + fb[o];
+            }
+        }
+        auto up = [&](const std::vector<float> &v) { float *dd; CK(hipMalloc(&dd, v.size() * 4)); CK(hipMemcpy(dd, v.data(), v.size() * 4, hipMemcpyHostToDevice)); return dd; };
+        LrgFusedProb &H = a.head;
+        memset(&H, 0, sizeof(H));
+        H.x = up(cin); H.L[0].w = up(pk0); H.L[0].bias = up(hbv); H.L[1].w = up(pk1); H.L[1].bias = up(hbias1); H.fw = up(fw); H.fb = up(fb);
+        float *lout; CK(hipMalloc(&lout, (size_t)rows * 2 * 4)); CK(hipMemset(lout, 0xFF, (size_t)rows * 2 * 4)); H.fout = lout;
+        a.stage = 3; a.iters = 1;
+        hipLaunchKernelGGL(probe_kernel, dim3(n_tiles), dim3(256), LRG_RH_FLOATS * 4, 0, a);
+        CK(hipDeviceSynchronize());
+        std::vector<float> lg((size_t)rows * 2);
+        CK(hipMemcpy(lg.data(), lout, lg.size() * 4, hipMemcpyDeviceToHost));
+        size_t bl = 0;
+        for (size_t i = 0; i < lg.size(); ++i) bl += memcmp(&lg[i], &lref[i], 4) != 0;
+        printf("register head tile: logits %zu of %zu differ from the host chain\n", bl, lg.size());
+        for (size_t i = 0, shown = 0; i < lg.size() && shown < 6; ++i) if (memcmp(&lg[i], &lref[i], 4)) { printf("  logit[%zu,%zu] gpu %.9g ref %.9g\n", i / 2, i % 2, lg[i], lref[i]); ++shown; }
+        badp += bl;
+        for (int grid : {1, 200}) {
+            a.iters = 50;
+            hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(256), LRG_RH_FLOATS * 4, 0, a);
+            CK(hipDeviceSynchronize());
+            std::vector<long long> c((size_t)grid * 16);
+            CK(hipMemcpy(c.data(), cyc, c.size() * 8, hipMemcpyDeviceToHost));
+            double sum = 0;
+            for (int g = 0; g < grid; ++g) sum += (double)c[g * 16] / a.iters;
+            printf("REGISTER HEAD TILE, grid %3d, one team per CU: %8.0f counter ticks per tile\n", grid, sum / grid);
+        }
+    }
     (void)ghz;
     (void)argc; (void)argv;
     return (bad1 || badp) ? 1 : 0;
