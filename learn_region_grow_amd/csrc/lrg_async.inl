@@ -137,6 +137,7 @@ struct LrgAsyncArgs {
     int wave_fill;               // 1: wavefronts 4 .. 7 of the first fill_wgs wave-branch CUs are a fill-in team (VALU work beside the MFMA-bound branch waves)
     int wmask;                   // entries of one wave ring - 1 (power of two)
     float *h3[2];                // [row_cap, 128] per side: layer 3's output rows, from the PREFIX to the POOL tasks
+    int unit_pairs;              // 1: the pooled-product units run their tasks on half-teams of two wavefronts (lrg_async_gemv_unit2)
     int reg_tiles;               // 1: the worker kernel's workgroups are all alike -- team 0 runs the branch tiles of ring 0 as REGISTER TILES (lrg_team_branch_tile_reg: a team
                                  // of four wavefronts per tile, layers 0 - 2 per wavefront in registers, one barrier), team 1 the pooled blocks and head tiles of ring 1
     int worker_base;             // blockIdx.x of the first worker workgroup in the kernel that runs the tile teams (n_front + gemv_units, or wave_wgs in the worker kernel)
@@ -844,6 +845,149 @@ LRG_ASYNC_ROLE void lrg_async_gemv_unit(lrg_kargs_ptr kp_, int unit_, long long 
                 const float v0 = __shfl(sum, 4 * (lane & 7)), v1 = __shfl(sum, 4 * (lane & 7) + 1), v2 = __shfl(sum, 4 * (lane & 7) + 2), v3 = __shfl(sum, 4 * (lane & 7) + 3);
                 if (lane < LRG_GEMV_UNIT_COLS / 4) lrg_st_coh4(g.hb[z] + (long)slot * g.C + col0, (unsigned)lane * 16u, make_float4(v0, v1, v2, v3));
             }
+            lrg_drain_stores();
+            if (lane == 0) {
+                int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
+                if (LRG_DBG(A)) {
+                    const int done = __hip_atomic_fetch_add(&sy[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                    const long long now = wall_clock64();
+                    lrg_dbg_add(A, 8 + 2 * LRG_TASK_GEMV, now - t_task); lrg_dbg_add(A, 9 + 2 * LRG_TASK_GEMV, 1);
+                    if (done == lrg_ld_coh(&sy[5])) lrg_dbg_add(A, 3, (int)((unsigned)now - (unsigned)lrg_ld_coh(&sy[8])));
+                } else {
+                    __hip_atomic_fetch_add(&sy[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
+// ---- a pooled-product unit of HALF-TEAMS (round 6): eight tasks in flight per unit instead of four ----
+// With the register tiles a step is ~69 us and sixteen units x four teams x 3.3 us a task are 81 % busy at 0.99 M evaluations a second: a slot's pooled product
+// queues for the slowest of its sixteen units (15 us from the last branch tile to the last sum, profiles/r06_bench_debug_68_reg_tiles.log).  A task's 3.3 us are
+// latencies (the ring entry, the slot's pooled row, two barriers, the store, the arrival), not arithmetic, and a fifth team has no place: four staged rows are all the
+// LDS holds beside the unit's 128 KB slice.  Here a task is run by TWO wavefronts: the row comes in ONE trip (16 bytes of either half per thread) and is staged half
+// at a time (2 KB); a lane owns a column and TWO of the eight K ranges (256 FMAs).  Eight half-teams = sixteen wavefronts: twice the tasks in flight on the same LDS.
+// (First form: no staging, the row's values read chunk by chunk with write-through-coherent loads one chunk ahead -- sixteen dependent trips to the memory side per
+//  task: 15 us a task, 530 k instance-steps/s.)  The sums are those of lrg_async_gemv_unit bit for bit (per K range a chain
+// over k = 8g + 0, 4, 1, 5, 2, 6, 3, 7; the eight partial sums in order; the bias last).
+#define LRG_GEMV_UNIT2_TEAM_FLOATS(P) ((P) / 2 + 8 * LRG_GEMV_UNIT_COLS + 32)      // half a pooled row, partial sums, task words + barrier counter
+#define LRG_GEMV_UNIT2_FLOATS(P) ((P) * LRG_GEMV_UNIT_COLS + 8 * LRG_GEMV_UNIT2_TEAM_FLOATS(P) + 4)
+struct LrgLdsPair {          // two wavefronts meeting at a counter in LDS (LrgLdsTeam's scheme)
+    int *cnt;
+    mutable int target;
+    int *gave_up;
+    __device__ __forceinline__ void sync() const {
+        target += 2;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0) {
+            __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            long long t_long = 0;
+            for (unsigned spin = 1; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spin) {
+                if ((spin & 4095u) == 0) {
+                    const long long now = (long long)wall_clock64();
+                    if (!t_long) t_long = now;
+                    else if (now - t_long > 500000000LL) { if (gave_up) __hip_atomic_store(gave_up, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+};
+
+LRG_ASYNC_ROLE void lrg_async_gemv_unit2(lrg_kargs_ptr kp_, int unit_, long long t_launch) {
+    const lrg_kargs_ptr kp = lrg_uniform(kp_);
+    const int unit = lrg_uniform(unit_);
+    const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
+    const LrgGemvArgs &g = A.gemv;
+    const int P = g.P, kq = P >> 3;
+    const int upz = g.C / LRG_GEMV_UNIT_COLS;
+    const int z = unit / upz, col0 = (unit - z * upz) * LRG_GEMV_UNIT_COLS;
+    float *wl = lrg_async_smem;                                // [P][32] this unit's columns of head z's pooled kernel
+    {
+        const float *w = g.w[z] + col0;
+        for (int i = threadIdx.x; i < P * (LRG_GEMV_UNIT_COLS / 4); i += LRG_FRONT_THREADS) {
+            const int row = i >> 3, q = i & 7;
+            *reinterpret_cast<float4 *>(wl + row * LRG_GEMV_UNIT_COLS + 4 * q) = *reinterpret_cast<const float4 *>(w + (long)row * g.ldw + 4 * q);
+        }
+    }
+    const int ht = lrg_uniform((int)threadIdx.x >> 7);
+    float *prow_lds = lrg_async_smem + P * LRG_GEMV_UNIT_COLS + ht * LRG_GEMV_UNIT2_TEAM_FLOATS(P);      // [P / 2] half of the slot's pooled row
+    float *part = prow_lds + P / 2;                                                                 // [8][32] partial sums
+    int *word = reinterpret_cast<int *>(part + 8 * LRG_GEMV_UNIT_COLS);                            // [0], [1] the task of even / odd rounds, [4] barrier counter
+    int *ctl = reinterpret_cast<int *>(lrg_async_smem + P * LRG_GEMV_UNIT_COLS + 8 * LRG_GEMV_UNIT2_TEAM_FLOATS(P));      // [0] the unit's next ring entry
+    if ((threadIdx.x & 127) == 0) { word[0] = 0; word[1] = 0; word[4] = 0; }
+    if (threadIdx.x < 4) ctl[threadIdx.x] = 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    LrgLdsPair pair;
+    pair.cnt = &word[4]; pair.target = 0; pair.gave_up = &A.queue[LRG_AQ_ABORT];
+    const int tid = (int)threadIdx.x & 127, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const float bias = g.bias[z] ? g.bias[z][col0 + c] : 0.f;
+    const int32_t *ring = A.queue + LRG_AQ_RING + 2 * (A.qmask + 1);
+    for (int round = 0;; round ^= 1) {
+        long long t_task = 0;
+        if (wave == 0) {
+            int slot = -2;
+            int i = 0;
+            if (lane == 0) i = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            i = __shfl(i, 0);
+            const int32_t *e = ring + (i & A.gmask);
+            const int tag = lrg_gemv_ring_tag(i, A.gmask);
+            for (unsigned spin = 0; slot == -2; ++spin) {
+                const int code = lrg_ld_coh(e);
+                if ((code >> 20) == tag) { slot = code & 0xFFFFF; break; }
+                if ((spin & 7) == 7) {
+                    if (lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front || lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) slot = -1;
+                    else if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) { lrg_st_coh(&A.queue[LRG_AQ_ABORT], 4); slot = -1; }
+                }
+                if (slot == -2) __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) word[round] = slot;
+        }
+        pair.sync();
+        const int entry = word[round];
+        if (entry < 0) return;
+        const int slot = entry & 0xFFF;
+        if (LRG_DBG(A)) t_task = wall_clock64();
+        // the slot's pooled row: ONE trip -- every thread of the pair takes 16 bytes of either half (four K ranges each) -- and half a row at a time in LDS: eight
+        // staged HALF rows are what fits beside the slice.  Ranges 2 wave + h (first half) and 4 + 2 wave + h (second): each a chain of kq FMAs.
+        const float4 ph0 = lrg_ld_coh4(g.pooled + (long)slot * P, (unsigned)tid * 16u), ph1 = lrg_ld_coh4(g.pooled + (long)slot * P, (unsigned)(128 + tid) * 16u);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass) pair.sync();                                   // (everybody is done with the first half)
+            *reinterpret_cast<float4 *>(prow_lds + 4 * tid) = pass ? ph1 : ph0;
+            pair.sync();
+            const int rl = 2 * wave + h, r = 4 * pass + rl;
+            const float *w = wl + (r * kq) * LRG_GEMV_UNIT_COLS + c;
+            const float *p = prow_lds + rl * kq;
+            float acc = 0.f;
+            for (int kb = 0; kb < kq; kb += 16) {
+                float wv[16];
+                float4 pv[4];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = w[(kb + u) * LRG_GEMV_UNIT_COLS];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pv[u] = *reinterpret_cast<const float4 *>(p + kb + 4 * u);
+                const float pk[16] = {pv[0].x, pv[0].y, pv[0].z, pv[0].w, pv[1].x, pv[1].y, pv[1].z, pv[1].w,
+                                      pv[2].x, pv[2].y, pv[2].z, pv[2].w, pv[3].x, pv[3].y, pv[3].z, pv[3].w};
+#pragma unroll
+                for (int uu = 0; uu < 16; ++uu) {
+                    const int u = (uu & 8) | ((uu & 1) << 2) | ((uu >> 1) & 3);      // k = 8g + 0, 4, 1, 5, 2, 6, 3, 7 (lrg_async_gemv)
+                    acc = fmaf(pk[u], wv[u], acc);
+                }
+            }
+            part[r * LRG_GEMV_UNIT_COLS + c] = acc;
+        }
+        pair.sync();
+        // the sums and the arrival by the second wavefront: the first is back at the ring while these stores drain
+        if (wave == 1) {
+            float sum = part[lane & (LRG_GEMV_UNIT_COLS - 1)];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) sum += part[q * LRG_GEMV_UNIT_COLS + (lane & (LRG_GEMV_UNIT_COLS - 1))];
+            sum += bias;
+            const float v0 = __shfl(sum, 4 * (lane & 7)), v1 = __shfl(sum, 4 * (lane & 7) + 1), v2 = __shfl(sum, 4 * (lane & 7) + 2), v3 = __shfl(sum, 4 * (lane & 7) + 3);
+            if (lane < LRG_GEMV_UNIT_COLS / 4) lrg_st_coh4(g.hb[z] + (long)slot * g.C + col0, (unsigned)lane * 16u, make_float4(v0, v1, v2, v3));
             lrg_drain_stores();
             if (lane == 0) {
                 int32_t *sy = A.sync + (long)slot * LRG_ASYNC_SYNC_WORDS;
@@ -1630,7 +1774,9 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgAs
 #endif
     if (tid == 0) __hip_atomic_fetch_add(&K.A.queue[LRG_AQ_ARRIVED], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody waits for the result)
     if ((int)blockIdx.x >= K.A.n_front && (int)blockIdx.x < K.A.n_front + K.A.gemv_units) {
-        lrg_async_gemv_unit(kp, (int)blockIdx.x - K.A.n_front, t_launch);
+        // (half-teams: eight tasks in flight per unit; not with per-tile pool rows, whose maximum is taken while the row is staged)
+        if (K.A.unit_pairs && !K.A.pool_rows) lrg_async_gemv_unit2(kp, (int)blockIdx.x - K.A.n_front, t_launch);
+        else lrg_async_gemv_unit(kp, (int)blockIdx.x - K.A.n_front, t_launch);
         return;
     }
     if ((int)blockIdx.x >= K.A.n_front) {

@@ -1694,10 +1694,14 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     {
         const LrgGemvArgs &g = A.gemv;
         int units = (g.C % LRG_GEMV_UNIT_COLS == 0) ? 2 * g.C / LRG_GEMV_UNIT_COLS : 0;
-        if (ab->gemv_units < 0 || (ab->gemv_units == 0 && n_slots > 148) || (size_t)LRG_GEMV_UNIT_FLOATS(g.P) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
+        if (ab->gemv_units < 0 || (ab->gemv_units == 0 && n_slots > 148) || (size_t)max((int)LRG_GEMV_UNIT_FLOATS(g.P), (int)LRG_GEMV_UNIT2_FLOATS(g.P)) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
             n_front + units > wgs / 2 + wgs / 4 || n_slots >= (1 << 20))
             units = 0;
         A.gemv_units = units;
+        // (half-teams in the units, lrg_async_gemv_unit2: eight tasks in flight per unit, each a little longer.  68 / 100 / 136 slots with register tiles: 992 -> 975,
+        //  1 147 -> 1 189, 1 156 -> 1 206 k instance-steps/s (profiles/r06_unit_pairs.txt): on from 84 slots, where the units' capacity is what a slot queues for;
+        //  LRG_ASYNC_UNIT_PAIRS=0 / 1 forces)
+        A.unit_pairs = getenv("LRG_ASYNC_UNIT_PAIRS") ? (atoi(getenv("LRG_ASYNC_UNIT_PAIRS")) ? 1 : 0) : (units && n_slots >= 84 ? 1 : 0);
         // without the units: the pooled products in batches (lrg_async.inl, LRG_GEMV_BATCH) where slots become ready faster than a batch's patience --
         // LRG_ASYNC_GEMV_BATCH=0 / =1: off / on whatever the slot count; LRG_ASYNC_GEMV_BATCH_US: the patience
         const int batch_env = getenv("LRG_ASYNC_GEMV_BATCH") ? atoi(getenv("LRG_ASYNC_GEMV_BATCH")) : -1;
@@ -1875,7 +1879,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
                              (size_t)A.fill_extra * LRG_ASYNC_FILL_TEAM_FLOATS) * sizeof(float);
     static_assert((3 * LRG_ASYNC_TEAM_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "three tile teams and a fill team per CU");
     static_assert((2 * LRG_ASYNC_SMALL_TEAM_FLOATS + 2 * LRG_ASYNC_TEAM_FLOATS) * sizeof(float) <= 160 * 1024, "four tile teams per CU");
-    const size_t unit_lds = A.gemv_units ? (size_t)LRG_GEMV_UNIT_FLOATS(A.gemv.P) * sizeof(float) + 16 : 0;
+    const size_t unit_lds = A.gemv_units ? (size_t)max((int)LRG_GEMV_UNIT_FLOATS(A.gemv.P), (int)LRG_GEMV_UNIT2_FLOATS(A.gemv.P)) * sizeof(float) + 16 : 0;
     const size_t lds = (max(max(front_lds, two_kernels ? (size_t)0 : team_lds), unit_lds) + 15) & ~(size_t)15;
     // (wave-branch mode, the worker kernel: a wave-branch CU's kernels + its fill-in team | two tile teams)
     const size_t worker_lds = (max(max((size_t)(LRG_WB_FLOATS + LRG_ASYNC_FILL_TEAM_FLOATS), (size_t)2 * LRG_ASYNC_TEAM_FLOATS),
