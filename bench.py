@@ -755,7 +755,7 @@ def main():
             roof['traffic_quoted_from'] = {'file': 'profiles/' + os.path.basename(tpath), 'measured_at_commit': tj.get('commit'), 'abi': tj.get('abi'),
                                            'launch_ms': tj.get('launch_ms'), 'hbm_GBps': tj.get('hbm_GBps'), 'frac_of_hbm_peak': tj.get('frac_of_hbm_peak'),
                                            'mfma_util_chipwide': tj.get('mfma_util_chipwide'),
-                                           'kernel_sources_sha16_then': tj.get('kernel_sources_sha16'), 'kernel_sources_sha16_now': kernel_sources_sha16(),
+                                           'formulation_measured': tj.get('formulation'), 'kernel_sources_sha16_then': tj.get('kernel_sources_sha16'), 'kernel_sources_sha16_now': kernel_sources_sha16(),
                                            'stale': tj.get('kernel_sources_sha16') != kernel_sources_sha16(),
                                            'note': 'rocprofv3 --pmc passes of their own over the same command; bytes per launch of %.0f ms; stale = the kernel '
                                                    'sources (csrc/*, include/lrg_hip.h) changed since the counters were read' % args.step_ms}

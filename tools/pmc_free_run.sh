@@ -5,6 +5,9 @@
 #   usage (GPU box): tools/pmc_free_run.sh <commit> [out.json]
 R=$GRAFT_REPO_ROOT; COMMIT=${1:-unknown}; OUT=${2:-gpurun_out/r06_pmc_free_run.json}
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pmcf && mkdir -p /tmp/pmcf
+# (counter collection serialises kernels: the two kernels of a register-tile launch -- resident together, waiting for each other -- cannot run under it; the counters are
+#  read on the ONE-kernel formulation of the same loop, LRG_FREE_RUN_WAVES=-1, and the file says so)
+export LRG_FREE_RUN_WAVES=-1
 B="python $R/bench.py --gpus 1 --steps 6 --warmup 4 --cpu-seconds 0 --p0-rooms 0 --fixed-rooms 0 --one-room-ks= --steady-slots="
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pmcf/kt -o kt --output-format csv -- $B > /tmp/pmcf/kt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmcf/fetch -o f --output-format csv -- $B > /tmp/pmcf/f.log 2>&1
@@ -30,14 +33,21 @@ copyk = max(cf, key=lambda k: sum(cf[k]))
 kf = 256 * MiB / (sum(cf[copyk]) / len(cf[copyk]) * 1024)
 kw = 256 * MiB / (sum(cw[copyk]) / len(cw[copyk]) * 1024)
 K = 'lrg_grow_async_kernel'
-def mine(d):
-    return [v for k, vs in d.items() if K in k for v in vs]
-f, w = mine(per_kernel('fetch', 'FETCH_SIZE')), mine(per_kernel('write', 'WRITE_SIZE'))
-# (the launches of the timed steps: the longest ones -- warm-up and timed steps have the same budget, so: all of them but the first)
-f, w = f[1:], w[1:]
-rd, wr = sum(f) / len(f) * 1024 * kf, sum(w) / len(w) * 1024 * kw
-sq = {c: mine(per_kernel('sq', c))[1:] for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES')}
-mf, gui = sum(sq['SQ_VALU_MFMA_BUSY_CYCLES']) / len(sq['SQ_VALU_MFMA_BUSY_CYCLES']), sum(sq['GRBM_GUI_ACTIVE']) / len(sq['GRBM_GUI_ACTIVE'])
+KW = 'lrg_grow_async_worker_kernel'      # (a two-kernel launch: the CUs that run tiles are a kernel of their own, resident beside the front workgroups' -- per launch = the sum of the two)
+def mine(d, name=K):
+    return [v for k, vs in d.items() if name in k for v in vs]
+def per_launch(d):
+    a, b = mine(d, K)[1:], mine(d, KW)[1:]      # (the launches of the timed steps: all of them but the first)
+    return (sum(a) / len(a) if a else 0.0) + (sum(b) / len(b) if b else 0.0), len(a), len(b)
+fs, ws = per_kernel('fetch', 'FETCH_SIZE'), per_kernel('write', 'WRITE_SIZE')
+rd_kb, nf, nfw = per_launch(fs)
+wr_kb, _, _ = per_launch(ws)
+f = mine(fs)[1:]
+rd, wr = rd_kb * 1024 * kf, wr_kb * 1024 * kw
+sqd = {c: per_kernel('sq', c) for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES')}
+sq = {c: [per_launch(sqd[c])[0]] for c in sqd}
+mf = sq['SQ_VALU_MFMA_BUSY_CYCLES'][0]
+gui = max(sum(mine(sqd['GRBM_GUI_ACTIVE'], K)[1:]) / max(1, len(mine(sqd['GRBM_GUI_ACTIVE'], K)[1:])), 1.0)      # (the front kernel spans the launch)
 launch_ms = None
 ks = glob.glob(os.path.join(root, 'kt', '**', '*kernel_stats.csv'), recursive=True)
 for r in csv.DictReader(open(ks[0])):
@@ -45,8 +55,8 @@ for r in csv.DictReader(open(ks[0])):
         launch_ms = float(r['AverageNs']) * 1e-6
 from learn_region_grow_amd import _lib
 import bench
-res = dict(source='tools/pmc_free_run.sh: rocprofv3 --pmc passes of their own over `bench.py --gpus 1 --steps 6 --warmup 4` (68 rooms in flight, 25 ms launches)',
-           commit=commit, abi=_lib.load().lrg_abi_version(), kernel_sources_sha16=bench.kernel_sources_sha16(), kernel=K, launches_profiled=len(f), fetch_correction=kf, write_correction=kw,
+res = dict(formulation='one kernel, team tiles (LRG_FREE_RUN_WAVES=-1): rocprofv3 serialises kernels under --pmc, the two kernels of the default register-tile launch cannot be resident together there', source='tools/pmc_free_run.sh: rocprofv3 --pmc passes of their own over `bench.py --gpus 1 --steps 6 --warmup 4` (68 rooms in flight, 25 ms launches)',
+           commit=commit, abi=_lib.load().lrg_abi_version(), kernel_sources_sha16=bench.kernel_sources_sha16(), kernel=K + (' + ' + KW if nfw else ''), launches_profiled=len(f), worker_kernel_launches_profiled=nfw, fetch_correction=kf, write_correction=kw,
            read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr, launch_ms=launch_ms,
            hbm_GBps=(rd + wr) / (launch_ms * 1e-3) / 1e9 if launch_ms else None,
            frac_of_hbm_peak=(rd + wr) / (launch_ms * 1e-3) / 1e9 / 8000.0 if launch_ms else None,
