@@ -463,8 +463,8 @@ int lrg_step_graph_destroy(void *graph);
  * place), so the two may alternate on the same buffers; results are identical bit for bit.
  * ---------------------------------------------------------------------------------------------- */
 #define LRG_REG_TILE_AUTO_MIN 25   /* register-tile launches (branch_waves = 1) by default from this many ... */
-#define LRG_REG_TILE_AUTO_MAX 140  /* ... to this many slots in flight: 16 / 34 / 68 / 100 slots +3 / +6 / +3.4 / +4.9 % over the one-kernel launch, 136 / 192: -3 / -26 % (two teams per
-                                      CU are too few there), eight 100 k-point scenes x 3 regions: -3 % (profiles/r06_reg_tiles_slots.txt) */
+#define LRG_REG_TILE_AUTO_MAX 176  /* ... to this many slots in flight: 16 (x 3 regions) / 34 / 68 / 100 / 136 / 160 slots +6 / +11.5 / +9.6 / +9.1 / +4 / +4.6 % over the one-kernel launch,
+                                      192: -1.7 % (two teams per CU are too few there), eight 100 k-point scenes x 3 regions: -0.7 % (profiles/r06_reg_tiles_slots.txt) */
 typedef struct LrgAsyncBuffers {
     int32_t *queue;             /* lrg_grow_async_queue_bytes(n_slots) bytes, 256-byte aligned: task ring + control words (cleared by every call) */
     size_t queue_bytes;

@@ -137,6 +137,7 @@ struct LrgAsyncArgs {
     int wave_fill;               // 1: wavefronts 4 .. 7 of the first fill_wgs wave-branch CUs are a fill-in team (VALU work beside the MFMA-bound branch waves)
     int wmask;                   // entries of one wave ring - 1 (power of two)
     float *h3[2];                // [row_cap, 128] per side: layer 3's output rows, from the PREFIX to the POOL tasks
+    int rt_bb_every;             // register tiles: every so-manyth worker CU runs branch tiles on BOTH its teams (0: none)
     int unit_pairs;              // 1: the pooled-product units run their tasks on half-teams of two wavefronts (lrg_async_gemv_unit2)
     int reg_tiles;               // 1: the worker kernel's workgroups are all alike -- team 0 runs the branch tiles of ring 0 as REGISTER TILES (lrg_team_branch_tile_reg: a team
                                  // of four wavefronts per tile, layers 0 - 2 per wavefront in registers, one barrier), team 1 the pooled blocks and head tiles of ring 1
@@ -1798,9 +1799,9 @@ __global__ __launch_bounds__(LRG_FRONT_THREADS) void lrg_grow_async_kernel(LrgAs
 
 // ---- team 0 of a register-tile CU (LrgAsyncArgs.reg_tiles): branch tiles of ring 0, one per turn of the team (inlined into the worker kernel: ~200 VGPRs) ----
 #define LRG_RT_TEAM0_FLOATS (LRG_ASYNC_CTL_FLOATS + LRG_RT_XCH_FLOATS)
-__device__ __forceinline__ void lrg_async_reg_tile_team(lrg_kargs_ptr kp, long long t_launch) {
+__device__ __forceinline__ void lrg_async_reg_tile_team(lrg_kargs_ptr kp, long long t_launch, int region) {      // region: LDS offset (floats) of the team's control words
     const LrgAsyncArgs &A = LRG_ASYNC_KARGS().A;
-    float *sm = lrg_async_smem + LRG_RT_WEIGHT_FLOATS + LRG_ASYNC_CTL_FLOATS;
+    float *sm = lrg_async_smem + region + LRG_ASYNC_CTL_FLOATS;
     LrgLdsTeam team = lrg_async_team(A, sm, 0);
     const int tid = team.tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int *word = reinterpret_cast<int *>(sm - LRG_ASYNC_CTL_FLOATS);
@@ -1835,7 +1836,7 @@ __device__ __forceinline__ void lrg_async_reg_tile_team(lrg_kargs_ptr kp, long l
         const LrgFusedProb &P = A.prob[side];
         const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
         lrg_team_branch_tile_reg(P.x, P.center, P.L[1].gout, P.pool + (long)slot * P.pool_stride, P.L[3].w, P.L[4].w, r0, slot, side * LRG_RT_SIDE,
-                                 LRG_RT_WEIGHT_FLOATS + LRG_ASYNC_CTL_FLOATS, team, wave, lane);
+                                 region + LRG_ASYNC_CTL_FLOATS, team, wave, lane);
         if (LRG_TICKET_EARLY && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lrg_drain_stores();                                  // conv[1] rows and the pooled maxima are out before the arrival
         team.sync();
@@ -1971,8 +1972,9 @@ __global__ __launch_bounds__(LRG_WORKER_THREADS) void lrg_grow_async_worker_kern
         if ((tid & 255) == 0) { word[4] = 0; word[5] = 0; }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (!(tid >> 8)) lrg_async_reg_tile_team(kp, t_launch);
+        if (!(tid >> 8)) lrg_async_reg_tile_team(kp, t_launch, LRG_RT_WEIGHT_FLOATS);
         else if (K.A.fill_list && w < K.A.fill_wgs) lrg_async_worker(kp, sm_off, t_launch, 1);      // (the fill-in ring on a few of them)
+        else if (K.A.rt_bb_every > 0 && w % K.A.rt_bb_every == K.A.rt_bb_every - 1) lrg_async_reg_tile_team(kp, t_launch, sm_off);      // (a CU with two branch teams)
         else if (K.A.reg_tiles == 2) lrg_async_worker(kp, sm_off, t_launch, 2);                    // (LRG_ASYNC_RT_TEAM_HEADS=1: the head tiles as team tiles)
         else lrg_async_reg_head_team(kp, t_launch);
         return;

@@ -1694,7 +1694,13 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     {
         const LrgGemvArgs &g = A.gemv;
         int units = (g.C % LRG_GEMV_UNIT_COLS == 0) ? 2 * g.C / LRG_GEMV_UNIT_COLS : 0;
-        if (ab->gemv_units < 0 || (ab->gemv_units == 0 && n_slots > 148) || (size_t)max((int)LRG_GEMV_UNIT_FLOATS(g.P), (int)LRG_GEMV_UNIT2_FLOATS(g.P)) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
+        // (register-tile launches keep the units up to their last slot count: 160 slots with units and every fourth worker CU on two branch teams 1.26 M against 1.20 M
+        //  instance-steps/s for the one-kernel launch without units, profiles/r06_reg_tiles_slots.txt)
+        static const int wave_env0 = getenv("LRG_ASYNC_WAVES") ? atoi(getenv("LRG_ASYNC_WAVES")) : 0;
+        const int want0 = wave_env0 ? wave_env0 : ab->branch_waves;
+        const bool reg_candidate = (want0 == 1 || (want0 == 0 && n_slots >= LRG_REG_TILE_AUTO_MIN && n_slots <= LRG_REG_TILE_AUTO_MAX)) && ab->rows16 && !tails_on && !ab->pool_rows &&
+                                   lrg_wave_branch_fits(weights) && !(ab->compute_units > 0 && ab->compute_units < prop.multiProcessorCount);
+        if (ab->gemv_units < 0 || (ab->gemv_units == 0 && n_slots > (reg_candidate ? LRG_REG_TILE_AUTO_MAX : 148)) || (size_t)max((int)LRG_GEMV_UNIT_FLOATS(g.P), (int)LRG_GEMV_UNIT2_FLOATS(g.P)) * sizeof(float) + 16 > 160 * 1024 || n_slots > LRG_GEMV_UNIT_MAX_SLOTS || (((uintptr_t)g.pooled) & 15) || (g.P & 127) ||
             n_front + units > wgs / 2 + wgs / 4 || n_slots >= (1 << 20))
             units = 0;
         A.gemv_units = units;
@@ -1765,6 +1771,8 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // keep the kernels of their stage in LDS, -1 = one kernel.  Needs the rows at a 64-byte stride, the paper's network, no shared tail tiles / per-tile pool rows, and the
     // whole chip (the two grids are sized per shader engine: a CU-masked launch keeps the one-kernel form).
     A.wave_wgs = 0; A.wave_a_wgs = 0; A.wave_waves = 0; A.wave_split = 4; A.wave_fill = 0; A.wmask = (int)async_wave_ring_entries(n_slots) - 1; A.h3[0] = A.h3[1] = nullptr; A.reg_tiles = 0;
+    // (every fourth register-tile CU with two branch teams from 120 slots: a slot's branch tiles queue for their teams there -- 68 slots -2.5 %, 100: +0.3 %, 136: +3.6 %, 160: +4.6 %)
+    A.rt_bb_every = getenv("LRG_ASYNC_RT_BB_EVERY") ? atoi(getenv("LRG_ASYNC_RT_BB_EVERY")) : (n_slots >= 120 ? 4 : 0);
     int worker_wgs = 0;                                      // workgroups of the worker kernel (wave-branch mode)
     {
         static const int wave_env = getenv("LRG_ASYNC_WAVES") ? atoi(getenv("LRG_ASYNC_WAVES")) : 0;
