@@ -1778,7 +1778,8 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         static const int wave_env = getenv("LRG_ASYNC_WAVES") ? atoi(getenv("LRG_ASYNC_WAVES")) : 0;
         int want = wave_env ? wave_env : ab->branch_waves;
         if (want == 0 && n_slots >= LRG_REG_TILE_AUTO_MIN && n_slots <= LRG_REG_TILE_AUTO_MAX) want = 1;      // (register tiles where they win: include/lrg_hip.h)
-        const bool can = a.rows16 && !A.tail && !A.pool_rows && lrg_wave_branch_fits(weights) && A.prob[0].nlayers == 5 && A.prob[0].L[1].gout && A.prob[0].pool &&
+        const bool can = a.rows16 && !A.tail && !A.pool_rows && !A.gemv_batch && lrg_wave_branch_fits(weights) &&      // (batched pooled products: tasks of the one-kernel launch's teams)
+                         A.prob[0].nlayers == 5 && A.prob[0].L[1].gout && A.prob[0].pool &&
                          (ab->compute_units <= 0 || ab->compute_units >= prop.multiProcessorCount) && (wgs % 32) == 0 && wgs >= 64 && n_slots < (1 << 20);
         if (can && want > 0) {
             // Both kernels' workgroups go round the 8 XCDs in turn, and inside an XCD round its 4 shader engines (8 CUs each) -- a workgroup whose engine has no CU
