@@ -462,7 +462,7 @@ int lrg_step_graph_destroy(void *graph);
  * State between calls is exactly that of lrg_grow_step_packed (a call ends every slot between two evaluations, logits in
  * place), so the two may alternate on the same buffers; results are identical bit for bit.
  * ---------------------------------------------------------------------------------------------- */
-#define LRG_REG_TILE_AUTO_MIN 25   /* register-tile launches (branch_waves = 1) by default from this many ... */
+#define LRG_REG_TILE_AUTO_MIN 1    /* register-tile launches (branch_waves = 1) by default from this many (up to 24 slots a branch tile is two tasks: one room +14 %, x 3 regions +7 %, 16 rooms +3 %) ... */
 #define LRG_REG_TILE_AUTO_MAX 176  /* ... to this many slots in flight: 16 (x 3 regions) / 34 / 68 / 100 / 136 / 160 slots +6 / +11.5 / +9.6 / +9.1 / +4 / +4.6 % over the one-kernel launch,
                                       192: -1.7 % (two teams per CU are too few there), eight 100 k-point scenes x 3 regions: -0.7 % (profiles/r06_reg_tiles_slots.txt) */
 typedef struct LrgAsyncBuffers {

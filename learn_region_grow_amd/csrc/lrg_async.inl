@@ -1832,11 +1832,15 @@ __device__ __forceinline__ void lrg_async_reg_tile_team(lrg_kargs_ptr kp, long l
         team.sync();
         const int code = word[0];                            // (thread 0 writes the next one behind the barriers of the tile)
         if (code < 0) return;
-        const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 31;
+        const int slot = (code >> 8) & 0xFFFFF, side = (code >> 7) & 1, idx = code & 31, part = (code >> 5) & 3;
         const LrgFusedProb &P = A.prob[side];
         const long r0 = (long)slot * A.front.row_stride + (long)idx * 32;
-        lrg_team_branch_tile_reg(P.x, P.center, P.L[1].gout, P.pool + (long)slot * P.pool_stride, P.L[3].w, P.L[4].w, r0, slot, side * LRG_RT_SIDE,
-                                 region + LRG_ASYNC_CTL_FLOATS, team, wave, lane);
+        if (A.branch_parts == 2)
+            lrg_team_branch_tile_reg<2>(P.x, P.center, P.L[1].gout, P.pool + (long)slot * P.pool_stride, P.L[3].w, P.L[4].w, r0, slot, side * LRG_RT_SIDE,
+                                        region + LRG_ASYNC_CTL_FLOATS, team, wave, lane, part);
+        else
+            lrg_team_branch_tile_reg<1>(P.x, P.center, P.L[1].gout, P.pool + (long)slot * P.pool_stride, P.L[3].w, P.L[4].w, r0, slot, side * LRG_RT_SIDE,
+                                        region + LRG_ASYNC_CTL_FLOATS, team, wave, lane, 0);
         if (LRG_TICKET_EARLY && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lrg_drain_stores();                                  // conv[1] rows and the pooled maxima are out before the arrival
         team.sync();

@@ -1582,7 +1582,13 @@ static LrgSideStream *lrg_side_stream() {
     static LrgSideStream side[LRG_MAX_DEVICES] = {};
     LrgSideStream *s = &side[lrg_current_device()];
     if (!s->ok) {
-        if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        // HIP streams are mapped onto a few hardware queues (four per priority level), round robin by creation, and kernels of two streams that share a queue never run
+        // side by side: with a side stream of the callers' own priority every fourth new caller stream landed on its queue -- the worker kernel waited out its 4 s for a
+        // front kernel queued BEHIND it (3 of 12 growers, tools/r06_spec_soak.py).  The side stream is created at the HIGHEST priority: a queue of another pool than any
+        // stream of default priority.  (A caller that launches from a highest-priority stream of its own can still collide: found out by the start rendezvous, reason 6 / 2.)
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) return nullptr;
         for (int i = 0; i < LRG_SIDE_EVENTS; ++i)
             if (hipEventCreateWithFlags(&s->start[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         s->ok = true;
@@ -1873,7 +1879,12 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // 75.9 k -> 78.1 k instance-steps/s, four tasks 75.0 k; 68 rooms: 559 k -> 505 k, the teams are busy there: profiles/r03_parts_perf.log)
     A.branch_parts = ab->branch_parts > 0 ? (ab->branch_parts >= 4 ? 4 : ab->branch_parts >= 2 ? 2 : 1) : (n_slots <= 46 ? 2 : 1);      // (end of round 4, profiles/r04_teams_units_sweep.txt: 16 / 24 / 39 / 44 / 52 / 68 slots, 2 against 1 part: +8 / +6 / +2.3 / +1.5 / -2 / -17 %)
     if (A.wave_wgs) { A.branch_parts = A.wave_split; A.head_ring = 1; A.small_teams = 0; A.small_alt = 0; A.fill_extra = 0; }
-    if (A.reg_tiles) { A.branch_parts = 1; A.head_ring = 1; A.small_teams = 0; A.small_alt = 0; A.fill_extra = 0; }      // (a branch tile = its four quarters; ring 1 for everything else)
+    if (A.reg_tiles) {
+        // (a register branch tile as two tasks where CUs idle: LrgAsyncBuffers.branch_parts >= 2 / LRG_ASYNC_RT_PARTS, by default up to 24 slots)
+        static const int rt_parts_env = getenv("LRG_ASYNC_RT_PARTS") ? atoi(getenv("LRG_ASYNC_RT_PARTS")) : 0;
+        A.branch_parts = rt_parts_env > 0 ? (rt_parts_env >= 2 ? 2 : 1) : ab->branch_parts > 0 ? (ab->branch_parts >= 2 ? 2 : 1) : (n_slots <= 24 ? 2 : 1);
+        A.head_ring = 1; A.small_teams = 0; A.small_alt = 0; A.fill_extra = 0;
+    }      // (a branch tile = its four quarters; ring 1 for everything else)
     A.max_steps = max_steps;
     A.budget_ticks = budget_us > 0 ? (long long)budget_us * 100 : (1LL << 60);      // wall_clock64: 100 MHz
     A.abort_ticks = (budget_us > 0 ? (long long)budget_us * 100 : 0) + 400000000LL;  // ... + 4 s without an end: something is broken

@@ -301,9 +301,12 @@ __device__ __forceinline__ void lrg_rt_mfma1(f32x16 &acc, const f32x16 (&h)[NBI]
 
 // wn: the wavefront's number in its team (0 .. 3); ws: LDS offset (floats) of the side's kernels (LRG_RT_*); xch: LDS offset of the team's exchange buffer;
 // w3 / w4: the packed images of layers 3 and 4 in global memory (lrg_pack_weights layout)
-template <class TEAM>
+// part / nparts (1 or 2): the tile as two tasks on two teams that each run layers 0 - 3 and HALF of every wavefront's column blocks of the pooled layer (blocks
+// 4 wn + 2 part, + 1): where CUs idle (few slots in flight) the pooled layer's 20 k cycles are what a tile's latency is made of; part 0 alone stores conv[1].
+template <int NPARTS, class TEAM>
 __device__ __forceinline__ void lrg_team_branch_tile_reg(const float *x, const float *center, float *conv1, float *pool, const float *w3, const float *w4, long r0, int slot,
-                                                         int ws, int xch, const TEAM &team, int wn, int lane) {
+                                                         int ws, int xch, const TEAM &team, int wn, int lane, int part = 0) {
+    static_assert(NPARTS == 1 || NPARTS == 2, "one or two tasks per tile");
     const int li = lane & 31, lh = lane >> 5;
     // ---- what comes from memory, requested first: the rows, the centre, this wavefront's columns of layer 3 and its first block of layer 4 ----
     const float4 x0 = lrg_ld_coh4(x + r0 * 16, (unsigned)(li * 16 + 4 * lh) * 4u), x1 = lrg_ld_coh4(x + r0 * 16, (unsigned)(li * 16 + 8 + 4 * lh) * 4u);
@@ -311,7 +314,9 @@ __device__ __forceinline__ void lrg_team_branch_tile_reg(const float *x, const f
     float4 a3[8], wa[16];
     // (block wn of layer 3: 8 k-groups of 1 KB; blocks 4 wn .. 4 wn + 3 of layer 4: 16 k-groups each)
     const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w3) + (long)(wn * 8) * 256, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r4 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w4) + (long)(4 * wn * 16) * 256, 0, 0x7fffffff, 0x00020000);
+    const int q_lo = NPARTS == 2 ? 2 * part : 0;
+    constexpr int q_n = NPARTS == 2 ? 2 : 4;      // this task's column blocks of the wavefront's four
+    const __amdgpu_buffer_rsrc_t r4 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w4) + (long)((4 * wn + q_lo) * 16) * 256, 0, 0x7fffffff, 0x00020000);
     const unsigned lo = (unsigned)lane * 16u;
 #pragma unroll
     for (int g = 0; g < 8; ++g) a3[g] = lrg_rt_ldw(r3, lo, (unsigned)g * 1024u);
@@ -352,7 +357,7 @@ __device__ __forceinline__ void lrg_team_branch_tile_reg(const float *x, const f
         lrg_wb_mfma2<8, 2>(hb[0], hb[1], ha, LRG_RT_W1 + lw, LRG_RT_W1 + 8 * 256 + lw);
         lrg_wb_bias_relu(hb[0], LRG_RT_B1 + lb);
         lrg_wb_bias_relu(hb[1], LRG_RT_B1 + 32 + lb);
-        if (wn == 0) {
+        if (wn == 0 && part == 0) {
             float *gb = conv1 + r0 * LRG_WB_C1;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -401,7 +406,7 @@ __device__ __forceinline__ void lrg_team_branch_tile_reg(const float *x, const f
     const int t = lane & 15;
     float m_even = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < q_n; ++q) {
         f32x16 c;
 #pragma unroll
         for (int i = 0; i < 16; ++i) c[i] = 0.f;
@@ -413,7 +418,7 @@ __device__ __forceinline__ void lrg_team_branch_tile_reg(const float *x, const f
             c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g].y, hb4[r + 1], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g].z, hb4[r + 2], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g].w, hb4[r + 3], c, 0, 0, 0);
-            if (q < 3) wa[g] = lrg_rt_ldw(r4, lo, (unsigned)((q + 1) * 16 + g) * 1024u);
+            if (q + 1 < q_n) wa[g] = lrg_rt_ldw(r4, lo, (unsigned)((q + 1) * 16 + g) * 1024u);
             __builtin_amdgcn_sched_barrier(0);
         }
         const float m = lrg_wb_rowmax16(c, lane);
@@ -422,7 +427,7 @@ __device__ __forceinline__ void lrg_team_branch_tile_reg(const float *x, const f
             // rows 0 / 1 of a half hold the maxima over lanes 0-15 / 16-31 of the same channels: the even row keeps block q - 1, the odd row block q
             const float keep = row1 ? m : m_even, send = row1 ? m_even : m;
             const float mm = fmaxf(keep, __shfl_xor(send, 16));
-            const int ch = 32 * (4 * wn + q - 1 + (row1 ? 1 : 0)) + 8 * (t >> 2) + 4 * lh + (t & 3);
+            const int ch = 32 * (4 * wn + q_lo + q - 1 + (row1 ? 1 : 0)) + 8 * (t >> 2) + 4 * lh + (t & 3);
             const float v = fmaxf(mm + LRG_WB_SMEM[ws + LRG_RT_B4 + ch], 0.f);
             const int bits = __float_as_int(v);
             if (bits > 0) atomicMax(reinterpret_cast<int *>(pool + ch), bits);

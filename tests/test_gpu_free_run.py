@@ -96,6 +96,26 @@ def test_wave_branch_launch_that_cannot_be_resident_gives_up_cleanly(net, monkey
         np.testing.assert_array_equal(g.filled_label, w.filled_label)
 
 
+def test_two_kernel_launches_from_any_stream(net, cuda_device):
+    """HIP streams share a few hardware queues, round robin by creation, and kernels of two streams on one queue never run side by side: the side stream of a
+    two-kernel launch must not share the caller's queue (it is created at the highest priority: another pool).  With a side stream of default priority every fourth
+    new caller stream made the worker kernel wait out its 4 s for a front kernel queued behind it.  Nine growers on nine fresh streams: all finish, with the labels."""
+    import time
+    import torch
+    from learn_region_grow_amd.grow import RegionGrower
+    rooms = _rooms()[:3]
+    kw = dict(rooms_in_flight=3, rng='counter', seed=123, policy='net')
+    want = RegionGrower(net, free_run=False, **kw).run(rooms)
+    t0 = time.time()
+    for k in range(9):
+        with torch.cuda.stream(torch.cuda.Stream(device=cuda_device)):
+            got = RegionGrower(net, free_run=True, free_run_waves=1, **kw).run(rooms)
+            torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g.filled_label, w.filled_label)
+    assert time.time() - t0 < 30.0
+
+
 def test_free_run_matches_oracle(net):
     from learn_region_grow_amd.grow import RegionGrower
     rooms = _rooms()[:4]

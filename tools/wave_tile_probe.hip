@@ -74,7 +74,7 @@ __global__ __launch_bounds__(512) void probe_kernel(Args a) {
         for (int it = 0; it < a.iters; ++it) {
             const int tile = (blockIdx.x + it * 7) % a.n_tiles;
             const long r0 = (long)tile * 32;
-            lrg_team_branch_tile_reg(a.x, a.center, a.conv1, a.pool + (r0 / a.rows_per_slot) * 512, a.w[3], a.w[4], r0, (int)(r0 / a.rows_per_slot), (tile & 1) * LRG_RT_SIDE,
+            lrg_team_branch_tile_reg<1>(a.x, a.center, a.conv1, a.pool + (r0 / a.rows_per_slot) * 512, a.w[3], a.w[4], r0, (int)(r0 / a.rows_per_slot), (tile & 1) * LRG_RT_SIDE,
                                      LRG_RT_WEIGHT_FLOATS, team, wave, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                  // (as the task does before its arrival; the exchange buffer is free again)
