@@ -1541,6 +1541,10 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
     }
 
     // =========================== (3) dilated voxel-box query with ordered compaction (:221-235) ===========================
+    // (round 6: where the grid query's two index lists are short -- <= 2048 entries each, the bitmaps in the first half of the flag bytes -- they are ALSO kept in LDS
+    //  behind the bitmaps, for the sampling and the wave medians of this same step: a trip to L2 less in each)
+    bool lds_lists = false;
+    int *lds_cur = reinterpret_cast<int *>(sh_flags + 16384), *lds_cand = lds_cur + 2048;
     if (!lists_ready) {
         const int nchunk = (n + LRG_SCAN_CHUNK - 1) / LRG_SCAN_CHUNK;
         const int lo0 = max(sh_box[0] - 1 - ox, 0), lo1 = max(sh_box[1] - 1 - oy, 0), lo2 = max(sh_box[2] - 1 - oz, 0);     // :222-225
@@ -1611,11 +1615,12 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
                 totc += wt_c[w]; tote += wt_e[w];
             }
             int pc = oc + (incl & 0xFFFF) - pcn, pe = oe + (int)((unsigned)incl >> 16) - pen;
+            lds_lists = nwords <= 2048 && totc <= 2048 && tote <= 2048;       // (workgroup-uniform)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int base = (tid * wpt + q) << 5;
-                for (unsigned m = mc[q]; m; m &= m - 1) cur_idx[pc++] = base + __ffs((int)m) - 1;
-                for (unsigned m = me[q]; m; m &= m - 1) cand_idx[pe++] = base + __ffs((int)m) - 1;
+                for (unsigned m = mc[q]; m; m &= m - 1) { const int v = base + __ffs((int)m) - 1; if (lds_lists) lds_cur[pc] = v; cur_idx[pc++] = v; }
+                for (unsigned m = me[q]; m; m &= m - 1) { const int v = base + __ffs((int)m) - 1; if (lds_lists) lds_cand[pe] = v; cand_idx[pe++] = v; }
             }
         } else {
         // LRG_QUERY_TRIP chunks per trip (4 points per thread and chunk: 3 loads per 4 points), all loads of a trip in flight
@@ -1750,7 +1755,7 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
             const int pos = nn < kk ? j : (int)lrg_sample_position((uint32_t)j, (uint32_t)nn, (uint32_t)kk, half ? LRG_PURPOSE_INLIER : LRG_PURPOSE_NEIGHBOR,
                                                                    (uint32_t)cur_seed, (uint32_t)cur_restart, (uint32_t)cur_step, k0, k1);
             // (a fresh seed: the lists were stored a moment ago by other threads -- the seed and its neighbours are still at hand in a register / in LDS)
-            sh_src[half ? 0 : 1][j] = lists_ready ? (half ? cur_seed : sh_list[pos]) : (half ? cur_idx : cand_idx)[pos];
+            sh_src[half ? 0 : 1][j] = lists_ready ? (half ? cur_seed : sh_list[pos]) : lds_lists ? (half ? lds_cur : lds_cand)[pos] : (half ? cur_idx : cand_idx)[pos];
         }
     }
     if (tid == 0) {
@@ -1788,9 +1793,10 @@ __device__ __forceinline__ int lrg_front_greedy_slot(LrgFrontShared &SH, LrgSlot
         const int ch = lrg_centred_channel(wave, F);
         if (ch >= 0) {
             const LrgChanSrc cs = lrg_chan_src(R, wave, ch, F);
+            const int32_t *mlist = lds_lists ? lds_cur : cur_idx;                            // (the list's copy in LDS where there is one)
             const float m = lists_ready ? cs.base[(long)cur_seed * cs.stride]                  // (a fresh seed: the median of one point is that point, :241)
-                          : nc <= 256 ? lrg_median_wave_r<4>(cs.base, cur_idx, cs.stride, nc)
-                          : nc <= 1024 ? lrg_median_wave_r<16>(cs.base, cur_idx, cs.stride, nc)
+                          : nc <= 256 ? lrg_median_wave_r<4>(cs.base, mlist, cs.stride, nc)
+                          : nc <= 1024 ? lrg_median_wave_r<16>(cs.base, mlist, cs.stride, nc)
                                        : lrg_median_wave_r64(cs.base, cur_idx, cs.stride, nc);
             if (lane == 0) sh_c[ch] = m;
         }
