@@ -117,7 +117,8 @@ def test_cli_region_lines_and_timing_table(cuda_device, tmp_path):
     table = lines[-7:]
     assert [t.split()[0] for t in table] == ['feature', 'net', 'neighbor', 'inlier', 'iter_net', 'iter_neighbor', 'iter_inlier']
     shares = [float(t.split()[-1]) for t in table]
-    assert abs(sum(shares) - 100.0) < 0.5 and all(x > 0 for x in shares)
+    # (one decimal: a per-iteration bucket of ~50 us beside per-room buckets of seconds may print as 0.0 when a room's feature computation was slow)
+    assert abs(sum(shares) - 100.0) < 0.5 and all(x >= 0 for x in shares) and sum(1 for x in shares if x > 0) >= 4
 
 
 def test_cli_two_ranks_equal_one(cuda_device, tmp_path):
