@@ -98,6 +98,7 @@ def parse():
                     help='--gpus 1: 1 = a one-rank RCCL process group is brought up and the fixed-work leg\'s label gather goes through its all_gather '
                          '(the nccl branch of learn_region_grow_amd/dist.py executed on the device); 0 = the single-rank short cut')
     ap.add_argument('--cache', default=os.environ.get('LRG_CACHE', '/tmp/lrg_cache'))
+    ap.add_argument('--named-configs', type=int, default=1, help='1: the ScanNet-shaped (8 rooms in flight) and KITTI-shaped (8 scenes in flight) configurations as short runs of their own, reported as named_configs')
     ap.add_argument('--p0-rooms', type=int, default=4, help='rooms of the preprocessing (P0) side measurement (0 = skip)')
     return ap.parse_args()
 
@@ -943,6 +944,25 @@ def main():
                 except Exception as e:      # (informational leg: never fails the line)
                     sweep[str(sl)] = {'error': repr(e)[:200]}
             out['steady_more_rooms_in_flight'] = sweep
+        if world == 1 and args.named_configs and args.workload == 'area5' and args.restarts == 1:
+            # BASELINE configs 3 and 5 in the driver's own line (round-5 review: "the driver's line carries no KITTI or ScanNet figure"): eight ScanNet-shaped rooms and
+            # eight Semantic-KITTI-shaped scenes in flight on this GPU, each a short run of this script of its own (steady leg + the rooms / scenes from reset to labels)
+            named = {}
+            for wl, fixed_n in (('scannet', 39), ('kitti', 8)):
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--workload', wl, '--rooms', '8', '--steps', str(max(4, args.steps // 2)),
+                                        '--warmup', str(args.warmup), '--step-ms', str(args.step_ms), '--fixed-rooms', str(fixed_n), '--best-slots', '', '--steady-slots', '',
+                                        '--one-room-ks', '', '--named-configs', '0', '--cpu-seconds', '0', '--p0-rooms', '0', '--policy', args.policy, '--weights', args.weights,
+                                        '--cache', args.cache], capture_output=True, text=True, timeout=600)
+                    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+                    fwk = d.get('fixed_work') or {}
+                    named[wl] = {'workload': d['config']['workload'], 'value': d['value'], 'unit': d['unit'], 'formulation': d['config']['formulation'],
+                                 'speculation_depth': d['config'].get('speculation_depth'), 'roofline_frac': d['roofline']['frac'],
+                                 'fixed_work_rooms_per_sec': fwk.get('rooms_per_sec'), 'fixed_work_rooms': fwk.get('rooms'), 'labels_crc32': fwk.get('labels_crc32'),
+                                 'all_rooms_labeled_after_gather': fwk.get('all_rooms_labeled_after_gather')}
+                except Exception as e:      # (informational legs: never fail the line)
+                    named[wl] = {'error': repr(e)[:200]}
+            out['named_configs'] = named
         if world == 1 and args.one_room_ks and args.restarts == 1 and packed:
             ks = [int(x) for x in args.one_room_ks.split(',') if x.strip()]
             by_size = sorted(range(len(base)), key=lambda i: len(base[i]['points']))

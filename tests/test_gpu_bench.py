@@ -27,7 +27,7 @@ def run_bench(argv, env=None, timeout=1200):
 @pytest.mark.parametrize('mode,lanes,graph', [('free', 0, 0), ('lockstep', 1, 0), ('lockstep', 2, 4)])
 def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
     r, lines = run_bench(['--gpus', '1', '--steps', '3', '--warmup', '2', '--iters-per-step', '16', '--step-ms', '2', '--rooms', '6', '--fixed-rooms', '12',
-                          '--best-slots', '3,6', '--steady-slots', '9' if mode == 'free' else '', '--cpu-seconds', '3', '--cpu-box-seconds', '2', '--p0-rooms', '1', '--mode', mode, '--lanes', str(lanes), '--graph', str(graph),
+                          '--best-slots', '3,6', '--steady-slots', '9' if mode == 'free' else '', '--named-configs', '1' if mode == 'free' else '0', '--cpu-seconds', '3', '--cpu-box-seconds', '2', '--p0-rooms', '1', '--mode', mode, '--lanes', str(lanes), '--graph', str(graph),
                           '--cache', str(tmp_path / 'cache')])
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1
@@ -70,6 +70,10 @@ def test_bench_line(cuda_device, tmp_path, mode, lanes, graph):
     assert d['preprocessing_p0']['gpu_rooms_per_sec'] > 0
     if mode == 'free':
         assert d['steady_more_rooms_in_flight']['9']['value'] > 0
+        # BASELINE configs 3 and 5 in the line: ScanNet-shaped rooms and KITTI-shaped scenes, eight in flight, as runs of the script of their own
+        for wl in ('scannet', 'kitti'):
+            nc = d['named_configs'][wl]
+            assert 'error' not in nc and nc['value'] > 0 and nc['fixed_work_rooms_per_sec'] > 0 and nc['all_rooms_labeled_after_gather'], nc
         # the fixed-work legs of the free-running launches carry a roofline of their own (device counters over the leg's grow time): the best frac is in the line
         assert 0 < fw['roofline']['frac'] < 1 and 0 < fw['roofline']['rows_evaluated_fraction'] <= 1 and set(fb['sweep']['3']) >= {'roofline_frac'}
     # the measured CPU figure is the headline key of the baseline, the extrapolated one beside it
@@ -81,7 +85,7 @@ def test_bench_line_with_restarts_counts_rows_per_slot(cuda_device, tmp_path):
     """test_random_restart.py's loop, 4 restarts per seed batched per launch: rows_evaluated_fraction is per SLOT (rooms x restarts), so it stays <= 1
     (round 5 divided by the rooms: 2.65 in the 16-restart record)."""
     r, lines = run_bench(['--gpus', '1', '--steps', '2', '--warmup', '1', '--iters-per-step', '8', '--rooms', '4', '--restarts', '4', '--fixed-rooms', '0',
-                          '--best-slots', '', '--steady-slots', '', '--cpu-seconds', '0', '--p0-rooms', '0', '--one-room-ks', '', '--cache', str(tmp_path / 'cache')])
+                          '--best-slots', '', '--steady-slots', '', '--named-configs', '0', '--cpu-seconds', '0', '--p0-rooms', '0', '--one-room-ks', '', '--cache', str(tmp_path / 'cache')])
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads(lines[0])
     rf = d['roofline']
@@ -91,7 +95,7 @@ def test_bench_line_with_restarts_counts_rows_per_slot(cuda_device, tmp_path):
 def test_bench_two_ranks_started_by_the_script_itself(cuda_device, tmp_path):
     """`python bench.py --gpus 2` with no torch.distributed environment: the script starts its two ranks (here both on cuda:0,
     collectives over gloo: LRG_BENCH_ONE_DEVICE=1), shards the fixed work over them and gathers every room's labels."""
-    common = ['--steps', '2', '--warmup', '1', '--step-ms', '2', '--rooms', '4', '--fixed-rooms', '8', '--best-slots', '', '--steady-slots', '', '--cpu-seconds', '0',
+    common = ['--steps', '2', '--warmup', '1', '--step-ms', '2', '--rooms', '4', '--fixed-rooms', '8', '--best-slots', '', '--steady-slots', '', '--named-configs', '0', '--cpu-seconds', '0',
               '--p0-rooms', '0', '--cache', str(tmp_path / 'cache')]
     # (both ranks share the one device here: lock-step launches -- two free-running launches side by side on one chip each assume that all
     #  their workgroups are resident at once, DESIGN.md section 4; on a multi-GPU node every rank has a device to itself)
@@ -111,7 +115,7 @@ def test_bench_two_ranks_started_by_the_script_itself(cuda_device, tmp_path):
     assert d1['fixed_work']['labels_crc32'] == d2['fixed_work']['labels_crc32']      # the gathered labels of all rooms equal the one-rank run's
     assert abs(d2['fixed_work']['waves_per_rank'] - 1.0) < 1e-9 and abs(d1['fixed_work']['waves_per_rank'] - 2.0) < 1e-9      # 8 jobs, 4 slots, 2 / 1 ranks
     # the default sizing of the leg: the same R for every N, and four waves of rooms per slot and rank at N = 8
-    r3, l3 = run_bench(['--gpus', '1', '--steps', '1', '--warmup', '1', '--step-ms', '2', '--rooms', '3', '--best-slots', '', '--steady-slots', '', '--cpu-seconds', '0',
+    r3, l3 = run_bench(['--gpus', '1', '--steps', '1', '--warmup', '1', '--step-ms', '2', '--rooms', '3', '--best-slots', '', '--steady-slots', '', '--named-configs', '0', '--cpu-seconds', '0',
                         '--p0-rooms', '0', '--cache', str(tmp_path / 'cache')])
     assert r3.returncode == 0, r3.stderr[-3000:]
     d3 = json.loads(l3[0])
@@ -120,6 +124,6 @@ def test_bench_two_ranks_started_by_the_script_itself(cuda_device, tmp_path):
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus(cuda_device, tmp_path):
-    r, lines = run_bench(['--gpus', '4', '--steps', '1', '--warmup', '0', '--cache', str(tmp_path / 'cache')],
+    r, lines = run_bench(['--gpus', '4', '--steps', '1', '--warmup', '0', '--named-configs', '0', '--cache', str(tmp_path / 'cache')],
                          env={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'}, timeout=300)
     assert r.returncode != 0 and not lines and '--gpus 4' in (r.stderr + r.stdout)

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pmcf && mkdir -p /tmp/pmcf
 # (counter collection serialises kernels: the two kernels of a register-tile launch -- resident together, waiting for each other -- cannot run under it; the counters are
 #  read on the ONE-kernel formulation of the same loop, LRG_FREE_RUN_WAVES=-1, and the file says so)
 export LRG_FREE_RUN_WAVES=-1
-B="python $R/bench.py --gpus 1 --steps 6 --warmup 4 --cpu-seconds 0 --p0-rooms 0 --fixed-rooms 0 --one-room-ks= --steady-slots="
+B="python $R/bench.py --gpus 1 --steps 6 --warmup 4 --cpu-seconds 0 --p0-rooms 0 --named-configs 0 --fixed-rooms 0 --one-room-ks= --steady-slots="
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pmcf/kt -o kt --output-format csv -- $B > /tmp/pmcf/kt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmcf/fetch -o f --output-format csv -- $B > /tmp/pmcf/f.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmcf/write -o w --output-format csv -- $B > /tmp/pmcf/w.log 2>&1
