@@ -14,8 +14,8 @@
 // NEXT layer ("lane half h feeds logical k = 8g + 4h + s", lrg_fused_tile.inl: tile_mfma).  Bias and ReLU are applied to the accumulators in place and the next
 // layer's MFMAs read them: no LDS round trip, no barrier, nothing shared between wavefronts.  Same sums in the same order as the team tile -- per output a chain of
 // FMAs over k = 8g + 0, 4, 1, 5, 2, 6, 3, 7 (the instruction adds lane half 0, then lane half 1: tools/mfma_order_check.py), products commute -- so conv[1], the pooled
-// maxima and everything downstream are the team tile's bit for bit (tools/wave_tile_probe.hip against a host chain; tests/test_gpu_free_run.py against the lock-step
-// iterations).
+// maxima and everything downstream are the team tile's bit for bit (tools/wave_tile_probe.hip against a host chain: tests/test_gpu_wave_tile.py; regions and labels
+// against the lock-step iterations: tests/test_gpu_free_run.py).
 //
 // What a wavefront cannot hold is the pooled layer's kernel (128 x 512 floats), and what a CU's LDS cannot hold is all of a branch (331 KB).  Two stages:
 //   PREFIX task (tile): layers 0 - 3 (272 MFMAs) on a CU that keeps the four kernels of BOTH branches in LDS (2 x 69 KB); conv[1] (for the heads, :130,:134) and the
