@@ -783,7 +783,7 @@ def main():
     def fixed_work(R, n_slots, measure_fill=False):
         jobs = jobs_of(R, 100000)
         sizes = [len(j['points']) for j in jobs]
-        mine = sorted(lrg_dist.shard_rooms_lpt(sizes, world)[rank], key=lambda j: -sizes[j])      # largest first: the small rooms fill the tail
+        mine = lrg_dist.queue_order(lrg_dist.shard_rooms_lpt(sizes, world)[rank], sizes, n_slots)      # passes over the sizes, the smallest rooms last (dist.queue_order)
         my_jobs = [jobs[j] for j in mine]
         fl = _Leg(net, my_jobs, min(n_slots, max(1, len(my_jobs))), args.mode, args, grow_kw, 0, dev, step_us)
         barrier()
@@ -825,7 +825,7 @@ def main():
                'lanes': fl.lanes, 'grow_seconds_rank0': tf_grow, 'gather_seconds_rank0': tf1 - tg0, 'rccl_ranks': world,
                'collective_backend': backend, 'collective_executed': bool(world > 1 or force_coll), 'collective_error': collective_error,
                'all_rooms_labeled_after_gather': bool(ok), 'labels_crc32': int(crc), 'given_up': int(st[3]),
-               'what': '%d room jobs = the %d geometries x %d random-stream keys, LPT-sharded by point count over %d rank(s), reset -> grow -> '
+               'what': '%d room jobs = the %d geometries x %d random-stream keys, LPT-sharded by point count over %d rank(s), queued in passes over the sizes with the smallest rooms last (dist.queue_order), reset -> grow -> '
                        '1-NN fill-in -> all_gather of the labels' % (R, len(base), (R + len(base) - 1) // len(base), world)}
         if measure_fill and fl.free and rank == 0:
             # P14 (the 1-NN fill-in, test_region_grow.py:308-316; "k-NN at scale" of configs[4]) priced by itself: the fill-ins of this leg's rooms

@@ -109,6 +109,7 @@ struct LrgAsyncArgs {
     int small_teams;             // the first so many teams of a worker workgroup run branch tiles only, on the smaller LDS region (four teams per workgroup)
     int small_alt;               // 1: ... and one more of them on the odd workgroups
     int fill_extra;              // 1: ... and that team is one more than the other workgroups have (where LDS and threads allow: up to three tile teams)
+    int fill_hybrid;             // 1: four tile teams per CU, the fill-in team is one of them: it takes a fill-in task when one is waiting and ring 1's next task otherwise
     // Shared tail tiles (nullable: tail == nullptr -> every slot pads its own last tile).  A slot's rows beyond its last full 32-row tile -- 16 of 91 rows per side
     // on average: 18 % of all tile rows were such padding -- are reserved from a cursor per side in rows that all slots share (LrgFrontArgs.tail_*), so that the
     // tails of several slots fill one BRANCH tile: the tile code's packed form (runs of rows of one slot each: per-run max-pool, lrg_forward_packed's arithmetic bit
@@ -461,7 +462,7 @@ LRG_ASYNC_TASK int lrg_async_task_branch(lrg_kargs_ptr kp_, int code_, int sm_of
     lrg_exp_delay(LRG_EXP_DELAY_BRANCH);
     // the team's next ticket is on its way while this task's stores drain (an agent-scope atomic with a result is a round trip of its own: taken at the
     // loop's head it was ~1 us between a finished tile and the first look at the next task)
-    if (LRG_TICKET_EARLY && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (LRG_TICKET_EARLY && ticket_word && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lrg_drain_stores();                              // conv[1] rows and the pooled maxima are out before the arrival
     team.sync();
     if (tid < 64) lrg_async_branch_arrive(A, slot, lane, t_task, true);
@@ -1061,7 +1062,7 @@ LRG_ASYNC_TASK int lrg_async_task_head(lrg_kargs_ptr kp_, int code_, int sm_off_
 #endif
     __builtin_amdgcn_s_setprio(0);
     lrg_exp_delay(LRG_EXP_DELAY_HEAD);
-    if (LRG_TICKET_EARLY && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (LRG_TICKET_EARLY && ticket_word && tid == 0) next_ticket = __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lrg_drain_stores();                              // the logits are out before the arrival the front workgroup polls
     team.sync();
     if (tid == 0) {
@@ -1282,38 +1283,61 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
     // (at 68 slots two branch tiles on a CU slow each other: 809 k -> 783 k instance-steps/s with some second teams on ring 0; at 272 slots
     //  with three teams a single branch team per CU is what every slot queues for: 257 us from publishing to the last branch tile)
     const int ring = secondary ? 1 : 0;      // (more than one team per workgroup: the first teams run the branch tiles, the others the rest)
-    int *ticket_word = &A.queue[filler ? LRG_AQ_FHEAD : LRG_AQ_HEAD + ring * LRG_AQ_SECOND];
+    // (fill_hybrid: a fill-in team that is a tile team like the others -- a fill-in task when one is waiting [reserved - handed out > 0: the ticket by compare-and-swap, so
+    //  that no ticket is taken for a task that does not exist], ring 1's next task otherwise.  A room's ~40-170 fill-in tasks a millisecond left 64 teams of four
+    //  hundred idle 98 % of the time while ring 1's tasks queued for theirs.)
+    const bool hybrid = filler && role == 0 && A.fill_hybrid && secondary;
+    int *ticket_word = &A.queue[filler && !hybrid ? LRG_AQ_FHEAD : LRG_AQ_HEAD + ring * LRG_AQ_SECOND];
+    int *early_word = hybrid ? nullptr : ticket_word;
     int next_ticket = -1;                    // (thread 0: the ticket a tile task took while its stores drained)
+    bool draining = false;                   // (hybrid, thread 0: every front workgroup has left -- the fill-in tasks that are left, then out)
     for (;;) {
         long long t_task = 0;
         if (tid == 0) {
             const long long t_wait = LRG_DBG(A) ? wall_clock64() : 0;
-            const int t = next_ticket >= 0 ? next_ticket : __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            next_ticket = -1;
-            int *slot = filler ? &A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (A.gmask + 1) + (t & (LRG_ASYNC_FILL_RING - 1))]
-                               : &A.queue[LRG_AQ_RING + ring * (A.qmask + 1) + (t & A.qmask)];
-            int code = 0;
-            for (unsigned spin = 0;; ++spin) {
-                code = lrg_ld_coh(slot);
-                if (code) break;
-                if ((spin & 7) == 7) {
-                    if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) { code = -1; break; }
-                    if (lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front) {
-                        // Every front workgroup has left, so nothing more is published.  A tile team's entries are all taken by then (the front
-                        // workgroups waited for their results); nobody waits for a fill-in, so a filler leaves only when its ticket lies beyond the
-                        // FINAL reservation count -- an entry reserved before the last front workgroup left is written (write-through, drained before
-                        // FRONTS_DONE was raised) and is waited for here instead of being given up on a stale look at the slot.
-                        if (!filler || t - lrg_ld_coh(&A.queue[LRG_AQ_FTAIL]) >= 0) { code = -1; break; }
-                    }
-                    if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) {
-                        lrg_st_coh(&A.queue[LRG_AQ_ABORT], 2);
-                        code = -1;
-                        break;
-                    }
+            bool fill_task = filler && !hybrid;
+            int t = 0, code = 0;
+            if (hybrid) {      // (its tile tasks take no ticket ahead -- early_word below -- so that none is held while it fills in)
+                for (;;) {
+                    int head = lrg_ld_coh(&A.queue[LRG_AQ_FHEAD]);
+                    const int tail = lrg_ld_coh(&A.queue[LRG_AQ_FTAIL]);
+                    if (tail - head <= 0) break;
+                    if (__hip_atomic_compare_exchange_strong(&A.queue[LRG_AQ_FHEAD], &head, head + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fill_task = true; t = head; break; }
                 }
-                for (int q = 0; q < A.poll_sleep; ++q) __builtin_amdgcn_s_sleep(LRG_WORKER_POLL_SLEEP);
+                if (!fill_task && draining) code = -1;
             }
-            if (code > 0) lrg_st_coh(slot, 0);
+            if (code == 0) {
+                if (!hybrid || !fill_task) {      // (a team of one ring: its ticket word; hybrid: ring 1's, unless the compare-and-swap above took a fill-in ticket)
+                    t = next_ticket >= 0 ? next_ticket : __hip_atomic_fetch_add(ticket_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    next_ticket = -1;
+                }
+                int *slot = fill_task ? &A.queue[LRG_AQ_RING + 2 * (A.qmask + 1) + (A.gmask + 1) + (t & (LRG_ASYNC_FILL_RING - 1))]
+                                      : &A.queue[LRG_AQ_RING + ring * (A.qmask + 1) + (t & A.qmask)];
+                for (unsigned spin = 0;; ++spin) {
+                    code = lrg_ld_coh(slot);
+                    if (code) break;
+                    if ((spin & 7) == 7) {
+                        if (lrg_ld_coh(&A.queue[LRG_AQ_ABORT])) { code = -1; break; }
+                        if (lrg_ld_coh(&A.queue[LRG_AQ_FRONTS_DONE]) >= A.n_front) {
+                            // Every front workgroup has left, so nothing more is published.  A tile team's entries are all taken by then (the front
+                            // workgroups waited for their results); nobody waits for a fill-in, so a filler leaves only when its ticket lies beyond the
+                            // FINAL reservation count -- an entry reserved before the last front workgroup left is written (write-through, drained before
+                            // FRONTS_DONE was raised) and is waited for here instead of being given up on a stale look at the slot.
+                            // (hybrid: a compare-and-swap ticket is never beyond the count; on a tile ticket it turns to what is left of the fill-in ring)
+                            if (hybrid && !fill_task) { code = -2; break; }
+                            if (!fill_task || t - lrg_ld_coh(&A.queue[LRG_AQ_FTAIL]) >= 0) { code = -1; break; }
+                        }
+                        if ((spin & 1023) == 1023 && wall_clock64() - t_launch > A.abort_ticks) {
+                            lrg_st_coh(&A.queue[LRG_AQ_ABORT], 2);
+                            code = -1;
+                            break;
+                        }
+                    }
+                    for (int q = 0; q < A.poll_sleep; ++q) __builtin_amdgcn_s_sleep(LRG_WORKER_POLL_SLEEP);
+                }
+                if (code > 0) lrg_st_coh(slot, 0);
+            }
+            if (code == -2) { draining = true; code = 0; }
             word[0] = code;
             t_task = wall_clock64();
             if (LRG_DBG(A)) { lrg_dbg_add(A, 16, t_task - t_wait); lrg_dbg_add(A, 17, 1); }
@@ -1321,14 +1345,15 @@ LRG_ASYNC_ROLE void lrg_async_worker(lrg_kargs_ptr kp_, int sm_off_, long long t
         team.sync();
         const int code = word[0];                            // (no barrier behind the read: thread 0 writes the next task only after the barriers
         if (code < 0) return;                                //  INSIDE this one, which every wavefront reaches after it has read the word)
+        if (code == 0) { team.sync(); continue; }            // (hybrid fill-in team, the launch's end: once more round the fill-in ring)
         const int type = (code >> 28) & 7;
         if (type == LRG_TASK_FILL) team.target = lrg_async_task_fill(kp, code, sm_off, team.target);
         else if (type == LRG_TASK_BRANCH && (code & 31) == 16) team.target = lrg_async_task_branch_shared(kp, code, sm_off, team.target, t_task, t_launch);
-        else if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task, next_ticket, ticket_word);
+        else if (type == LRG_TASK_BRANCH) team.target = lrg_async_task_branch(kp, code, sm_off, team.target, t_task, next_ticket, early_word);
         else if (type == LRG_TASK_GEMV && (code & 96)) team.target = lrg_async_task_gemv_batch(kp, code, sm_off, team.target, t_task, t_launch);
         else if (type == LRG_TASK_GEMV) team.target = lrg_async_task_gemv(kp, code, sm_off, team.target, t_task);
         else if ((code & 127) == 17) team.target = lrg_async_task_head_shared(kp, code, sm_off, team.target, t_task);
-        else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task, t_launch, next_ticket, ticket_word);
+        else team.target = lrg_async_task_head(kp, code, sm_off, team.target, t_task, t_launch, next_ticket, early_word);
     }
 }
 

@@ -1734,7 +1734,7 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
     // be acknowledged before the tile may report in), no zeroing of the pooled feature by the front workgroup.
     // In-launch fill-in (lrg_async.inl): the caller's arenas for the lists of unlabeled points and the best (distance, index) words, laid out like
     // the label arena; 13 features (the compiled-in search); one team each of up to sixteen worker workgroups serves the fill-in ring.
-    A.fill_list = nullptr; A.fill_best = nullptr; A.fill_sync = nullptr; A.fill_label_base = nullptr; A.fill_out_base = nullptr; A.fill_wgs = 0; A.fill_extra = 0;
+    A.fill_list = nullptr; A.fill_best = nullptr; A.fill_sync = nullptr; A.fill_label_base = nullptr; A.fill_out_base = nullptr; A.fill_wgs = 0; A.fill_extra = 0; A.fill_hybrid = 0;
     a.fill_in_launch = 0;
     if (ab->fill_list && ab->fill_best && ab->fill_sync && ab->fill_label_base && ab->fill_out_base && params->feature_size == 13 && ab->fill_rooms > 0 &&
         ab->fill_rooms <= (1 << 18) && max_points <= 1024 * LRG_NN1_C) {
@@ -1864,6 +1864,9 @@ int lrg_grow_async(LrgSlot *slots, LrgRoom *rooms, int n_slots, int max_points, 
         A.fill_wgs = ab->fill_wgs > 0 ? min(ab->fill_wgs, workers / 2) : min(64, workers / 3);      // (end of round 4, 2 176 rooms: 32 / 64 / 96 such workgroups 581 / 587 / 587 rooms/s at 68 slots, 839 / 856 / 844 at 272)
         if (A.fill_wgs < 1) { A.fill_list = nullptr; a.fill_in_launch = 0; }      // (too few workgroups: the host fills in)
         A.fill_extra = (A.fill_list && teams <= 3) ? 1 : 0;      // (a fourth team of 256 threads beside three tile teams; its LDS region is 16 KB)
+        // four tile teams: the fill-in team is the CU's fourth tile team and serves ring 1 while no fill-in task waits (LRG_ASYNC_FILL_HYBRID=0: the fill-in ring only)
+        static const int hybrid_env = getenv("LRG_ASYNC_FILL_HYBRID") ? atoi(getenv("LRG_ASYNC_FILL_HYBRID")) : 1;
+        A.fill_hybrid = (A.fill_list && teams == 4 && hybrid_env) ? 1 : 0;
     }
     {
         static const int r0_env = getenv("LRG_ASYNC_RING0_HALVES") ? atoi(getenv("LRG_ASYNC_RING0_HALVES")) : 0;

@@ -21,6 +21,40 @@ def shard_rooms_lpt(sizes, world_size):
     return [sorted(s) for s in shards]
 
 
+def queue_order(ids, sizes, slots):
+    """The order in which a rank's room jobs `ids` (sizes[i] = point count of job i) wait for one of its `slots` (S1, the batched scheduler: rooms are
+    independent, test_region_grow.py:110-183, so any order gives the same labels).  Two things decide how long the jobs take together:
+    (a) a job must not START so late that it is still running when everything else is done (largest-first, LPT, is the extreme answer);
+    (b) a large room's step costs more than a small room's, and not the same workgroups: with the jobs simply sorted by size a launch first holds ONLY large
+        rooms and later only small ones -- 0.45 M, then 1.8 M instance-steps/s at 400 slots -- where a mix keeps front workgroups and tile teams both busy
+        (1.55 M throughout, profiles/r06_fixed_trace_400*.txt).
+    So every job gets a deadline -- the last queue position from which it would still be done with the rest: a job of s points runs for about
+    slots x s / sum(sizes) of the whole (steps grow with the point count, and a slot's step takes slots / throughput), and the deadline leaves that much, and a
+    quarter more, behind it -- and the positions are filled from the LAST one backwards, each with a job drawn evenly from those whose deadline allows it.  Small
+    rooms end up spread over the whole queue, large ones over its front part, and the last positions fall to the smallest by themselves.  Deterministic (a
+    golden-ratio sequence, no random state)."""
+    desc = sorted(ids, key=lambda i: (-sizes[i], i))
+    slots = max(1, int(slots))
+    n = len(desc)
+    if n <= 2 * slots:
+        return desc
+    total = float(sum(sizes[i] for i in desc)) or 1.0
+    # (the first `slots` positions all start at once: a deadline inside them is as good as position 0)
+    deadline = [max(slots - 1, int((1.0 - 1.25 * slots * sizes[i] / total) * n)) for i in desc]      # non-decreasing along desc (sizes fall)
+    order = [None] * n
+    pool = []                      # jobs that may stand at the position being filled
+    nxt = n - 1                    # desc[nxt]: the next job to become eligible (smallest first: the latest deadlines)
+    for p in range(n - 1, -1, -1):
+        while nxt >= 0 and deadline[nxt] >= p:
+            pool.append(desc[nxt])
+            nxt -= 1
+        if not pool:               # (no job may be this late: the one that minds least)
+            pool.append(desc[nxt])
+            nxt -= 1
+        order[p] = pool.pop(int((((n - p) * 0.6180339887498949) % 1.0) * len(pool)))
+    return order
+
+
 def _short_cut(world, force_collective):
     """A single rank needs no exchange -- unless the caller wants the collectives of an initialised process group executed
     all the same (`force_collective`: the one-rank RCCL run of tests/test_gpu_dist.py and of bench.py at --gpus 1, which is

@@ -758,6 +758,8 @@ class RegionGrower:
         if last:
             self._in_fill_stream = False
         self.rooms_finished += n
+        if getattr(self, '_trace_done', None) is not None:
+            self._trace_done.extend(int(r) for r in self.done_rooms)
         self.done_rooms = []
         return n
 
@@ -769,9 +771,18 @@ class RegionGrower:
             with torch.cuda.stream(main):
                 return self._grow_loaded_free_run(fill)
         self.free_run_begin()
+        trace = [] if os.environ.get('LRG_FREE_RUN_TRACE') == '1' else None      # (per launch: seconds, rooms reported finished, steps the device had counted)
+        self._trace_done = [] if trace is not None else None
+        t0 = time.perf_counter()
         while self.rooms_finished < self.n_rooms:
             self.free_run_step(fill)
+            if trace is not None:
+                trace.append((round(time.perf_counter() - t0, 4), self.rooms_finished, getattr(self, 'last_stats', (0, 0, 0))[2]))
         torch.cuda.current_stream(self.dev).synchronize()
+        if trace is not None:
+            import sys
+            sys.stderr.write('LRG_FREE_RUN_TRACE %d slots %d rooms: %s\n' % (self.S, self.n_rooms, trace))
+            sys.stderr.write('LRG_FREE_RUN_LAST %d slots: %s\n' % (self.S, [(r, int(self.room_n[r])) for r in self._trace_done[-60:]]))      # (queue position, points)
         self.wait_fills()
         if fill:
             self.verify_fills_in_launch()

@@ -18,6 +18,26 @@ def test_lpt_sharding_is_a_balanced_partition():
         assert shards == lrg_dist.shard_rooms_lpt(AREA5_POINTS, world)   # deterministic
 
 
+def test_queue_order_is_a_deterministic_permutation_that_starts_long_jobs_early():
+    """dist.queue_order: every job once; a job's position leaves it the time it needs (as far as the jobs allow); the last positions are the smallest rooms;
+    the rooms in flight at any time are a mix of sizes (not the size-sorted queue's)."""
+    sizes = [AREA5_POINTS[j % len(AREA5_POINTS)] for j in range(2176)]
+    ids = list(range(0, 2176, 2))                                    # (a rank's shard: not all ids, not contiguous)
+    total = float(sum(sizes[i] for i in ids))
+    for slots in (68, 400):
+        order = lrg_dist.queue_order(ids, sizes, slots)
+        assert sorted(order) == ids
+        assert order == lrg_dist.queue_order(list(reversed(ids)), sizes, slots)
+        n = len(order)
+        late = [p for p, i in enumerate(order) if p > max(slots - 1, int((1.0 - 1.25 * slots * sizes[i] / total) * n))]
+        assert all(sizes[order[p]] <= np.percentile([sizes[i] for i in ids], 35) for p in late)      # only small rooms stand behind their deadline
+        assert max(sizes[i] for i in order[-slots // 2:]) <= np.percentile([sizes[i] for i in ids], 50)
+        first = [sizes[i] for i in order[:slots]]
+        assert max(first) == max(sizes[i] for i in ids) and min(first) < np.percentile([sizes[i] for i in ids], 50)      # the largest AND small ones at the start
+    few = lrg_dist.queue_order([3, 1, 2], [5, 9, 7, 1], 68)
+    assert few == [1, 2, 3]                                          # fewer jobs than two rounds of slots: largest first
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
