@@ -551,6 +551,7 @@ def main():
         n_jobs = max(2 * slots, int((args.warmup + args.steps) * args.step_ms * 1e-3 * 1500) + slots)
         leg = _Leg(net, jobs_of(n_jobs, 1000000 * (rank + 1)), slots, 'free', args, grow_kw, rank, dev, step_us)
         gr = leg.gr
+        gr.room_order_mode = 'loaded'      # (the set's geometries in turn, as in every round so far: the timed window sees the same rooms)
         with torch.cuda.stream(leg.stream):
             gr.free_run_begin()
 

@@ -54,7 +54,7 @@ class RegionGrower:
                  resolution=0.1, cluster_threshold=10, max_region_steps=0, advance_rounds=1, pipeline_depth=4,
                  skip_duplicate_rows=True, poll_every=4, packed=None, graph_iterations=0, scoring='np', free_run=None,
                  free_run_steps=1 << 20, free_run_budget_us=5000, free_run_fronts=0, free_run_teams=0, free_run_fill_cus=None, free_run_units=0,
-                 speculate=0, free_run_tail_rows=None, free_run_waves=0):
+                 speculate=0, free_run_tail_rows=None, free_run_waves=0, room_order='queue'):
         """packed: True / False / None (= whenever it applies: counter stream, fused network, rooms up to 131072 points):
         one iteration = lrg_grow_step_packed (4 launches, network on the packed distinct rows) instead of lrg_grow_step.
         graph_iterations: > 0 replays that many packed iterations per host call from a HIP graph (lrg_step_graph_*).
@@ -130,6 +130,7 @@ class RegionGrower:
         self.free_run_fill_cus = free_run_fill_cus
         self.free_run_units = int(free_run_units)      # 0 = pooled-product units where they fit, -1 = the tile teams' 128-column blocks
         self.free_run_tail_rows = free_run_tail_rows   # shared tail tiles: rows per side (None = by the slot count, 0 = off)
+        self.room_order_mode = room_order              # 'queue': dist.queue_order where rooms wait for slots (more than two rounds of them); 'loaded': as loaded
         self.free_run_waves = int(free_run_waves)      # wave-branch launches (LrgAsyncBuffers.branch_waves): 0 = by the slot count, -1 = off, n = on with n wavefronts per wave-branch CU
         self.debug_hook = None      # tests: called once per active slot per legacy iteration with the step's data
         self._rooms_loaded = False
@@ -713,13 +714,22 @@ class RegionGrower:
         self.a_roomq = torch.from_numpy(q).to(self.dev)
         self.async_buffers.room_queue = self.a_roomq.data_ptr()
 
+    def room_order(self):
+        """The order in which the loaded rooms take slots: as loaded while they are few; with more than two rounds of slots, long rooms early and sizes mixed
+        (dist.queue_order -- rooms are independent and the random stream is keyed by the room, so the labels do not depend on it)."""
+        if self.n_rooms <= 2 * self.n_groups or self.room_order_mode == 'loaded' or os.environ.get('LRG_ROOM_ORDER', '') == 'loaded':
+            return list(range(self.n_rooms))
+        from .dist import queue_order
+        return queue_order(list(range(self.n_rooms)), [int(n) for n in self.room_n[:self.n_rooms]], self.n_groups)
+
     def free_run_begin(self):
         """Free-running launches over ALL loaded rooms: the first S rooms bound by the host, the rest handed out on the device."""
         self.reset_state()
+        order = self.room_order()
         first = min(self.n_groups, self.n_rooms)
         for g in range(self.n_groups):
-            self.bind(g, g if g < first else -1)
-        self.set_room_queue(list(range(first, self.n_rooms)))
+            self.bind(g, order[g] if g < first else -1)
+        self.set_room_queue(order[first:])
         self.rooms_finished = 0
 
     def verify_fills_in_launch(self):
@@ -795,7 +805,7 @@ class RegionGrower:
         if self.free_run:
             return self._grow_loaded_free_run(fill)
         self.reset_state()
-        queue = list(range(self.n_rooms))
+        queue = self.room_order()
         for g in range(self.n_groups):
             self.bind(g, queue.pop(0) if queue else -1)
         finished = 0
