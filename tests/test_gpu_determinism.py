@@ -7,7 +7,7 @@ same labels as the lock-step iterations.  Round 5's race ("uniform" loads racing
 once or twice.  Here every formulation of the benchmark configuration is repeated with SHORT launches (many launch boundaries, many
 first turns) and must give ONE checksum, that of the lock-step iterations:
   * 68 Area-5-shaped rooms in flight, free-running launches (what bench.py times), trained weights, Bernoulli policy;
-  * 272 room jobs in 272 slots with shared tail tiles (the many-slots shape of the fixed-work legs);
+  * 272 room jobs in 272 slots with shared tail tiles (the many-slots shape of the fixed-work legs: four teams per worker CU, fill-in teams that take tile tasks);
   * 8 rooms with three regions per room in flight (speculation);
   * the wave-branch launches (two kernels resident together, LrgAsyncBuffers.branch_waves);
   * the 68-room configuration once more while a second stream keeps every CU busy with dense evaluations."""
@@ -71,6 +71,8 @@ def test_many_slots_with_shared_tails_repeat_to_one_checksum(net, rooms):
         return gr
     got = repeat(make, jobs, 6)
     assert all(g.free_run and g.tail_rows > 0 for g in made)
+    # (four teams per worker CU here: the fill-in teams take ring 1's tasks between fill-ins -- every room was filled in by its launch, none again by the host)
+    assert all(g.fill_in_launch and getattr(g, 'fills_redone', 0) == 0 for g in made)
     assert set(got) == {want}, (want, got)
 
 
