@@ -780,6 +780,7 @@ def main():
     # fixed-work leg(s): R room jobs over all ranks, reset -> final labels (grow + fill-in) -> RCCL gather
     # ------------------------------------------------------------------------------------------------------------------
     room_steps = {}
+    coll_warm = []
 
     def fixed_work(R, n_slots, measure_fill=False):
         jobs = jobs_of(R, 100000)
@@ -787,6 +788,13 @@ def main():
         mine = lrg_dist.queue_order(lrg_dist.shard_rooms_lpt(sizes, world)[rank], sizes, n_slots)      # passes over the sizes, the smallest rooms last (dist.queue_order)
         my_jobs = [jobs[j] for j in mine]
         fl = _Leg(net, my_jobs, min(n_slots, max(1, len(my_jobs))), args.mode, args, grow_kw, 0, dev, step_us)
+        if not coll_warm:
+            # the communicator's first all_gather / all_reduce set up its connections and load its kernels (0.1 s on one rank): once, ahead of the timed region, as
+            # the steady leg has its warm-up steps
+            coll_warm.append(1)
+            lrg_dist.gather_flat_labels([rank], [256 * 1024], torch.ones(256 * 1024, dtype=torch.int32, device=dev), world, device=coll_dev, force_collective=force_coll)
+            lrg_dist.allreduce_max(0.0, device=coll_dev, force_collective=force_coll)
+            lrg_dist.allreduce_sum([0.0, 0.0], device=coll_dev, force_collective=force_coll)
         barrier()
         tf0 = time.perf_counter()
         fl.grow_all()
