@@ -966,7 +966,7 @@ class RegionGrower:
             self._grow_loaded_free_run(fill)          # (binds the first rooms itself, the rest wait in the device-side queue)
             torch.cuda.synchronize()
             return self.collect(fill)
-        queue = list(range(self.n_rooms))
+        queue = list(range(self.n_rooms)) if self.rng == 'legacy' else self.room_order()      # (legacy streams are consumed in the loaded order: the reference's)
         for g in range(self.n_groups):
             self.bind(g, queue.pop(0) if queue else -1)
         finished = 0

@@ -339,3 +339,25 @@ def test_batched_pooled_products_equal_lock_step(net, monkeypatch, in_flight, pa
         same_regions(g.regions, w.regions)
         np.testing.assert_array_equal(g.cluster_label, w.cluster_label)
         np.testing.assert_array_equal(g.filled_label, w.filled_label)
+
+
+def test_room_order_does_not_change_the_labels(net):
+    """More rooms than two rounds of slots: they take slots in dist.queue_order (long rooms early, sizes mixed) instead of as loaded -- rooms are independent
+    (test_region_grow.py:110-183) and the random stream is keyed by the room, so regions and labels are those of the loaded order and of the lock-step iterations;
+    with four teams per worker CU forced, the fill-in teams take ring 1's tasks between fill-ins here too."""
+    from learn_region_grow_amd.grow import RegionGrower
+    base = _rooms()
+    rooms = [dict(base[j % len(base)], room_id=500 + j) for j in range(23)]
+    kw = dict(rooms_in_flight=4, rng='counter', seed=7, policy='net')
+    want = RegionGrower(net, free_run=False, room_order='loaded', **kw).run(rooms)
+    made = []
+    for order, free, teams in (('queue', True, 0), ('loaded', True, 0), ('queue', False, 0), ('queue', True, 4)):
+        gr = RegionGrower(net, free_run=free, room_order=order, free_run_budget_us=1500, free_run_teams=teams, **kw)
+        got = gr.run(rooms)
+        made.append(gr)
+        for a, b in zip(want, got):
+            same_regions(a.regions, b.regions)
+            np.testing.assert_array_equal(a.cluster_label, b.cluster_label)
+            np.testing.assert_array_equal(a.filled_label, b.filled_label)
+    assert made[0].room_order() != list(range(len(rooms))) and sorted(made[0].room_order()) == list(range(len(rooms)))
+    assert made[1].room_order() == list(range(len(rooms)))
